@@ -1,0 +1,135 @@
+/*
+ * witch_hip.h - C ABI of libwitch_hip.so: MI355X-native query-vs-eHMM scoring,
+ * weighting/top-k and optimal-accuracy alignment for WITCH.
+ *
+ * Every entry point replaces a piece of the reference's HMMER-subprocess path
+ * (paths relative to the c5shen/WITCH checkout):
+ *
+ *   wh_ehmm_load   <- HMMSubset.__init__ reading NSEQ + the HMM text files that
+ *                     hmmsearch/hmmalign parse      witch_msa/gcmm/loader.py:17-65
+ *   wh_score*      <- SearchAlgorithm.search / subset_frag_chunk_hmmsearch running
+ *                     "hmmsearch --cpu 1 --noali -E 99999999 --max" per (HMM, chunk)
+ *                     and evalHMMSearchOutput        witch_msa/gcmm/algorithm.py:273-336,482-544,579-605
+ *   wh_topk*       <- readAndRankBitscoreMP + calculateWeights/writeWeights
+ *                                                    witch_msa/gcmm/loader.py:299-332, weighting.py:58-74,121-169
+ *                     and the 0.999 cumulative-weight cut   witch_msa/gcmm/aligner.py:58-63
+ *   wh_align*      <- getBackbones running "hmmalign -o OUT HMM QUERY" per chosen HMM
+ *                     and decoding the Stockholm row witch_msa/gcmm/aligner.py:96-142
+ *
+ * Conventions: plain pointers and sizes; the caller owns every input and output
+ * buffer; the library owns wh_ehmm handles and its device workspace.  Functions
+ * return 0 on success or a negative WH_E* code; wh_last_error() gives the message of
+ * the calling thread's last failure.  Calls on one handle must not overlap.
+ * "*_dev" variants take DEVICE pointers and a hipStream_t (passed as void*) and only
+ * enqueue work; the plain variants take HOST pointers and block.
+ *
+ * Data contract:
+ *   decibits  int32  [nq x H]  bit-score x 10 exactly as hmmsearch's "%6.1f" prints it
+ *   flags     uint8  [nq x H]  WH_FLAG_* (REPORTED = the pair is listed by hmmsearch)
+ *   top-k     int32 idx[nq x k] (the caller's hmm_index values, -1 padded),
+ *             double w[nq x k] (0 padded), n_kept[nq], n_used[nq] (0.999 prefix length)
+ *             ordered by (-weight, -decibits, +hmm_index)
+ *   cols      int32, CSR over the residues of each pair: 0-based match column or -1
+ */
+#ifndef WITCH_HIP_H
+#define WITCH_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WH_OK          0
+#define WH_EINVAL     -1   /* bad argument                                   */
+#define WH_EIO        -2   /* cannot open / parse an HMM file                */
+#define WH_ENODEV     -3   /* no usable HIP device                           */
+#define WH_EHIP       -4   /* a HIP runtime call failed                      */
+#define WH_ERANGE     -5   /* model or query longer than this build supports */
+#define WH_ENOMEM     -6
+
+#define WH_ALPH_DNA    0
+#define WH_ALPH_RNA    1
+#define WH_ALPH_AMINO  2
+
+#define WH_FLAG_REPORTED  1   /* pair appears in hmmsearch's per-sequence table          */
+#define WH_FLAG_MULTI     2   /* a region was multidomain (HMMER's stochastic class)     */
+#define WH_FLAG_OVERRIDE  4   /* reconstruction score overrode the Forward score         */
+#define WH_FLAG_TRUNC     8   /* more envelopes than WH_MAX_ENVELOPES; extra ones dropped */
+
+#define WH_MAX_ENVELOPES 8
+
+typedef struct wh_ehmm wh_ehmm;
+
+/* Optional per-pair diagnostics (tests compare them with the oracle stage by stage). */
+typedef struct wh_pair_detail {
+  float   fwd_bits;        /* (Forward - null1) / ln 2, multihit local               */
+  float   seq_score;       /* final float32 score before the deci-bit print          */
+  float   pre_score;       /* score before the null2 correction                      */
+  float   seqbias_nats;
+  int32_t nregions;
+  int32_t nenv;
+  int32_t env_i[WH_MAX_ENVELOPES];
+  int32_t env_j[WH_MAX_ENVELOPES];
+  float   envsc[WH_MAX_ENVELOPES];      /* nats */
+  float   domcorr[WH_MAX_ENVELOPES];    /* nats */
+} wh_pair_detail;
+
+const char *wh_version(void);
+const char *wh_last_error(void);
+
+/* Select the HIP device for the calling process (one process per GPU). */
+int wh_init(int device);
+int wh_device_info(char *name, int name_len, int *cu_count, int64_t *hbm_bytes);
+
+/* Digitise text residues with HMMER/Easel's alphabet rules (case-insensitive, U->T,
+ * X->N for nucleic acids).  Codes >= K are degenerate; 255 marks an illegal character. */
+int wh_digitize(int alphabet, const char *text, int64_t n, uint8_t *out);
+
+/* Parse n HMMER3/f text models, configure the local profiles and upload them.
+ * hmm_index[i] is the caller's label for model i (WITCH's A_0_<idx>); nseq may be NULL
+ * (then NSEQ from each file header is used, as loader.py:48-53 does). */
+wh_ehmm *wh_ehmm_load(const char *const *hmm_paths, const int32_t *hmm_index, const int32_t *nseq, int n);
+void     wh_ehmm_free(wh_ehmm *e);
+int      wh_ehmm_count(const wh_ehmm *e);
+int      wh_ehmm_alphabet(const wh_ehmm *e);
+int      wh_ehmm_info(const wh_ehmm *e, int32_t *M, int32_t *nseq, int32_t *hmm_index);
+/* MAP annotation of model h: alignment column (1-based) of match state k=1..M, 0 if absent. */
+int      wh_ehmm_map(const wh_ehmm *e, int h, int32_t *map_cols);
+int      wh_ehmm_max_query_len(const wh_ehmm *e);
+
+/* All-vs-all scoring: nq queries (digital residues, CSR offsets[nq+1]) x H models. */
+int wh_score(wh_ehmm *e, const uint8_t *residues, const int64_t *offsets, int64_t nq,
+             int32_t *decibits, uint8_t *flags, float *fwd_bits, wh_pair_detail *detail);
+int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets, int64_t nq,
+                 int64_t total_residues, int32_t max_len,
+                 int32_t *d_decibits, uint8_t *d_flags, float *d_fwd_bits, wh_pair_detail *d_detail,
+                 void *stream);
+
+/* Weights over the reported models of each query, deterministic top-k and 0.999 prefix. */
+int wh_topk(wh_ehmm *e, const int32_t *decibits, const uint8_t *flags, int64_t nq, int k,
+            int32_t *idx, double *w, int32_t *n_kept, int32_t *n_used);
+int wh_topk_dev(wh_ehmm *e, const int32_t *d_decibits, const uint8_t *d_flags, int64_t nq, int k,
+                int32_t *d_idx, double *d_w, int32_t *d_n_kept, int32_t *d_n_used, void *stream);
+
+/* Optimal-accuracy alignment of query pair_q[p] against model position pair_h[p]
+ * (0..H-1, the position in the load order, not the hmm_index label).
+ * cols is CSR: pair p writes cols[col_offsets[p] .. col_offsets[p] + len(query)). */
+int wh_align(wh_ehmm *e, const uint8_t *residues, const int64_t *offsets, int64_t nq,
+             const int64_t *pair_q, const int32_t *pair_h, int64_t npairs,
+             const int64_t *col_offsets, int32_t *cols);
+int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets, int64_t nq,
+                 int64_t total_residues, int32_t max_len,
+                 const int64_t *d_pair_q, const int32_t *d_pair_h, int64_t npairs,
+                 const int64_t *d_col_offsets, int32_t *d_cols, void *stream);
+
+/* Duration (ms) and launch count of the kernels of the last *_dev/plain call, measured
+ * with HIP events on the stream the kernels ran on: which = 0 score, 1 topk, 2 align. */
+int wh_last_kernel_ms(wh_ehmm *e, int which, double *ms, int *launches);
+/* When enabled, every kernel launch is bracketed by HIP events (bench/roofline use). */
+int wh_set_timing(wh_ehmm *e, int enabled);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WITCH_HIP_H */

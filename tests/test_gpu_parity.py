@@ -1,0 +1,206 @@
+"""GPU parity tests: the HIP path (through the C ABI of libwitch_hip.so) against the CPU
+oracle on the same inputs, and against the committed HMMER / reference-Python golden
+vectors.  Run on a real MI355X with ``pytest -m gpu``.
+
+Tolerances (BASELINE.json north_star / SURVEY.md section 8.0):
+  * Forward log-odds: |GPU - oracle(float64)| <= 1e-4 bit
+  * region/envelope coordinates, reported mask, multidomain flag: identical
+  * deci-bit scores: identical, except where the oracle's float32 score lies within
+    BOUNDARY_EPS bit of a "%6.1f" rounding boundary (then at most one deci-bit apart)
+  * top-k models, order, n_used: identical; weights rel 1e-12 vs the numpy restatement
+  * aligned columns: identical
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+BOUNDARY_EPS = 2e-3   # bits; float32 ulp at 100+ bits is 8e-6, null2 sums differ by a few ulp
+
+
+def _need_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+def _load(case):
+    from witch_amd.ehmm import EHMM, pack_queries
+    e = EHMM(case.hmm_paths, hmm_index=case.hmm_index, nseq=case.nseq)
+    seqs = [e.digitize(s) for s in case.qseqs]
+    res, offs = pack_queries(seqs)
+    return e, seqs, res, offs
+
+
+def _near_boundary(score):
+    frac = abs(float(score)) * 10.0
+    return abs((frac % 1.0) - 0.5) < BOUNDARY_EPS * 10.0
+
+
+def test_score_against_oracle_and_golden(golden_case, orc):
+    _need_gpu()
+    case = golden_case
+    e, seqs, res, offs = _load(case)
+    deci, flags, fwd, det = e.score(res, offs, want_fwd=True, want_detail=True)
+    ohm = [orc.OracleHMM(p) for p in case.hmm_paths]
+    od, of, ofwd, osc = orc.score_batch(ohm, res, offs)
+    # Forward log-odds within 1e-4 bit of the float64 restatement
+    finite = np.isfinite(ofwd)
+    assert np.max(np.abs(fwd[finite] - ofwd[finite])) <= 1e-4, np.max(np.abs(fwd[finite] - ofwd[finite]))
+    # reported / multidomain / override flags identical
+    mism = np.argwhere((flags & 7) != (of & 7))
+    assert len(mism) == 0, (case.name, mism[:5], flags[tuple(mism[0])], of[tuple(mism[0])])
+    # envelopes identical (stage-by-stage detail)
+    H = e.H
+    for qi in range(len(seqs)):
+        for hj in range(H):
+            r = ohm[hj].score(seqs[qi])
+            d = det[qi * H + hj]
+            assert d.nregions == r.nregions, (case.name, qi, hj)
+            assert d.nenv == min(r.nenv, 8)
+            for t in range(d.nenv):
+                assert (d.env_i[t], d.env_j[t]) == (r.env_i[t], r.env_j[t]), (case.name, qi, hj, t)
+                assert abs(d.envsc[t] - r.envsc[t]) <= 2e-4 * max(1.0, abs(r.envsc[t]) / 50), (case.name, qi, hj, d.envsc[t], r.envsc[t])
+                assert abs(d.domcorr[t] - r.domcorr[t]) <= 1e-3, (case.name, qi, hj, d.domcorr[t], r.domcorr[t])
+    # deci-bits
+    rep = (of & 1) == 1
+    diff = (deci != od) & rep
+    n_diff = int(diff.sum())
+    for qi, hj in np.argwhere(diff):
+        assert abs(int(deci[qi, hj]) - int(od[qi, hj])) == 1, (case.name, qi, hj, deci[qi, hj], od[qi, hj])
+        assert _near_boundary(osc[qi, hj]), (case.name, qi, hj, osc[qi, hj], deci[qi, hj], od[qi, hj])
+    # and directly against HMMER's printed scores for the single-domain class
+    n_exact = n_pairs = 0
+    for hj, hf in enumerate(case.hmm_files):
+        S = case.g["search"][hf]
+        for qi, qn in enumerate(case.qnames):
+            if flags[qi, hj] & 2:
+                continue
+            assert bool(flags[qi, hj] & 1) == (qn in S), (case.name, hf, qn)
+            if qn in S:
+                n_pairs += 1
+                g = int(round(S[qn]["score"] * 10))
+                if g == deci[qi, hj]:
+                    n_exact += 1
+                else:
+                    assert abs(g - int(deci[qi, hj])) == 1 and _near_boundary(osc[qi, hj]), (case.name, hf, qn, g, deci[qi, hj])
+    print("\n[%s] GPU vs oracle: %d/%d reported pairs differ (all at a rounding boundary); "
+          "GPU vs HMMER print (single-domain): %d/%d exact" % (case.name, n_diff, int(rep.sum()), n_exact, n_pairs))
+    assert n_exact >= 0.98 * n_pairs
+    e.close()
+
+
+def test_topk_against_restatement_and_reference(golden_case, orc):
+    _need_gpu()
+    case = golden_case
+    e, seqs, res, offs = _load(case)
+    deci, flags = e.score(res, offs)
+    k = case.k
+    idx, w, nk, nu = e.topk(deci, flags, k)
+    size_of = dict(zip(case.hmm_index, case.nseq))
+    for qi, qn in enumerate(case.qnames):
+        ranked = orc.rank_bitscores(case.hmm_index, deci[qi], flags[qi] & 1)
+        if not ranked:
+            assert nk[qi] == 0 and nu[qi] == 0
+            continue
+        idxs = [r[0] for r in ranked]
+        bits = [r[1] for r in ranked]
+        ref = orc.calculate_weights(idxs, bits, [size_of[i] for i in idxs], k)
+        assert nk[qi] == len(ref)
+        got_w = w[qi, :nk[qi]]
+        ref_w = np.array([x[1] for x in ref])
+        assert np.allclose(got_w, ref_w, rtol=1e-12, atol=0), (case.name, qn, got_w, ref_w)
+        # identical order except inside groups of weights equal to 1e-12 (float64 noise in numpy's formula)
+        got_i = idx[qi, :nk[qi]].tolist()
+        ref_i = [x[0] for x in ref]
+        if got_i != ref_i:
+            for a, b, wa, wb in zip(got_i, ref_i, got_w, ref_w):
+                if a != b:
+                    assert abs(wa - wb) <= 1e-12 * max(wa, wb), (case.name, qn, got_i, ref_i)
+        assert nu[qi] == orc.adaptive_cut(list(zip(got_i, got_w))), (case.name, qn)
+    e.close()
+
+
+def test_align_against_oracle_and_reference(golden_case, orc):
+    _need_gpu()
+    case = golden_case
+    e, seqs, res, offs = _load(case)
+    pos_of = {idx: i for i, idx in enumerate(case.hmm_index)}
+    pq, ph, gold = [], [], []
+    for qi, qn in enumerate(case.qnames):
+        if qn not in case.g["align"]:
+            continue
+        for idx, cols in case.g["align"][qn]["cols"].items():
+            pq.append(qi)
+            ph.append(pos_of[int(idx)])
+            gold.append(cols)
+    # plus every (query, model 0) pair, including unrelated / very short queries
+    for qi in range(len(seqs)):
+        pq.append(qi)
+        ph.append(0)
+        gold.append(None)
+    cols, co = e.align(res, offs, pq, ph)
+    ohm = [orc.OracleHMM(p) for p in case.hmm_paths]
+    n_gold = n_bad = 0
+    for p in range(len(pq)):
+        got = cols[co[p]:co[p + 1]].tolist()
+        want = ohm[ph[p]].align(seqs[pq[p]]).tolist()
+        assert got == want, (case.name, "vs oracle", pq[p], ph[p], [(i, a, b) for i, (a, b) in enumerate(zip(got, want)) if a != b][:5])
+        if gold[p] is not None:
+            n_gold += 1
+            n_bad += got != gold[p]
+    assert n_bad == 0, (case.name, n_bad, n_gold)
+    e.close()
+
+
+def test_device_tensor_entry_points_match_host_entry_points():
+    _need_gpu()
+    import torch
+    from tests.conftest import load_case
+    case = load_case("dna_synth")
+    e, seqs, res, offs = _load(case)
+    deci, flags = e.score(res, offs)
+    rt = torch.from_numpy(res).cuda()
+    ot = torch.from_numpy(offs).cuda()
+    maxlen = int(np.max(np.diff(offs)))
+    d2, f2 = e.score_t(rt, ot, maxlen)
+    torch.cuda.synchronize()
+    assert np.array_equal(d2.cpu().numpy(), deci) and np.array_equal(f2.cpu().numpy(), flags)
+    idx, w, nk, nu = e.topk(deci, flags, 3)
+    i2, w2, nk2, nu2 = e.topk_t(d2, f2, 3)
+    torch.cuda.synchronize()
+    assert np.array_equal(i2.cpu().numpy(), idx) and np.array_equal(w2.cpu().numpy(), w)
+    assert np.array_equal(nk2.cpu().numpy(), nk) and np.array_equal(nu2.cpu().numpy(), nu)
+    e.close()
+
+
+def test_edge_cases_empty_and_ragged():
+    _need_gpu()
+    from tests.conftest import load_case
+    from witch_amd.ehmm import EHMM, pack_queries
+    case = load_case("dna_synth")
+    e = EHMM(case.hmm_paths)
+    # no queries at all
+    d, f = e.score(np.zeros(0, np.uint8), np.zeros(1, np.int64))
+    assert d.shape == (0, e.H)
+    # an empty query between two normal ones: HMMER silently skips length-0 sequences
+    seqs = [e.digitize(case.qseqs[0]), np.zeros(0, np.uint8), e.digitize(case.qseqs[1])]
+    res, offs = pack_queries(seqs)
+    d, f = e.score(res, offs)
+    assert f[1].sum() == 0 and d[1].sum() == 0
+    d0, f0 = e.score(*pack_queries([seqs[0]]))
+    assert np.array_equal(d[0], d0[0]) and np.array_equal(f[0], f0[0])
+    idx, w, nk, nu = e.topk(d, f, 4)
+    assert nk[1] == 0 and nu[1] == 0 and (idx[1] == -1).all()
+    cols, co = e.align(res, offs, [1, 0], [0, 0])
+    assert co.tolist() == [0, 0, len(seqs[0])]
+    # illegal residue codes are rejected loudly
+    with pytest.raises(Exception):
+        e.score(np.array([200], np.uint8), np.array([0, 1], np.int64))
+    e.close()

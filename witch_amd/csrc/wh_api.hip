@@ -1,0 +1,518 @@
+// C ABI of libwitch_hip.so (declared in include/witch_hip.h): handle management, device
+// workspace, kernel launches and optional HIP-event timing.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <array>
+#include <cstring>
+#include <map>
+#include <memory>
+
+#include "wh_launch.h"
+
+namespace wh {
+const char *last_error();
+}
+
+using namespace wh;
+
+#define HIPCHK(expr)                                                                  \
+  do {                                                                                \
+    hipError_t _e = (expr);                                                           \
+    if (_e != hipSuccess) {                                                           \
+      set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return WH_EHIP;                                                                 \
+    }                                                                                 \
+  } while (0)
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return WH_OK;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    size_t want = bytes + bytes / 8 + 256;
+    if (hipMalloc(&p, want) != hipSuccess) {
+      set_error("hipMalloc of %zu bytes failed", want);
+      return WH_ENOMEM;
+    }
+    cap = want;
+    return WH_OK;
+  }
+  void release() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
+};
+
+struct KernelTimer {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  double ms = 0.0;
+  int launches = 0;
+  bool pending = false;
+};
+
+struct wh_ehmm {
+  int device = 0;
+  int alphabet = 0, K = 0, Kp = 0;
+  int cu_count = 256;
+  std::vector<HostHMM> hmms;
+  std::vector<DevHMM> dev;          // host copy of the descriptors
+  std::map<int, std::vector<int32_t>> by_q;   // Q class -> model positions
+  DevBuf d_hmms, d_tables, d_nseq, d_index, d_lists, d_counter, d_scratch;
+  // staging for the host-pointer entry points
+  DevBuf s_res, s_off, s_deci, s_flags, s_fwd, s_det, s_idx, s_w, s_nk, s_nu, s_pq, s_ph, s_co, s_cols, s_pos;
+  DevBuf d_order, d_items;
+  uint32_t degen[32];
+  bool timing = false;
+  KernelTimer timers[3];
+  int max_M = 0;
+};
+
+static int g_device = -1;
+
+extern "C" {
+
+const char *wh_version(void) { return "witch_hip 0.1.0 (gfx950)"; }
+const char *wh_last_error(void) { return wh::last_error(); }
+
+int wh_init(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    set_error("no HIP device visible");
+    return WH_ENODEV;
+  }
+  if (device < 0 || device >= n) {
+    set_error("device %d out of range (0..%d)", device, n - 1);
+    return WH_EINVAL;
+  }
+  HIPCHK(hipSetDevice(device));
+  g_device = device;
+  return WH_OK;
+}
+
+int wh_device_info(char *name, int name_len, int *cu_count, int64_t *hbm_bytes) {
+  if (g_device < 0) { int rc = wh_init(0); if (rc) return rc; }
+  hipDeviceProp_t p;
+  HIPCHK(hipGetDeviceProperties(&p, g_device));
+  if (name && name_len > 0) { strncpy(name, p.gcnArchName, (size_t)name_len - 1); name[name_len - 1] = 0; }
+  if (cu_count) *cu_count = p.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = (int64_t)p.totalGlobalMem;
+  return WH_OK;
+}
+
+int wh_digitize(int alphabet, const char *text, int64_t n, uint8_t *out) {
+  int K, Kp;
+  if (alphabet_sizes(alphabet, &K, &Kp) != 0 || !text || !out) { set_error("wh_digitize: bad argument"); return WH_EINVAL; }
+  return digitize(alphabet, text, n, out);
+}
+
+void wh_ehmm_free(wh_ehmm *e) {
+  if (!e) return;
+  for (DevBuf *b : {&e->d_hmms, &e->d_tables, &e->d_nseq, &e->d_index, &e->d_lists, &e->d_counter, &e->d_scratch,
+                    &e->s_res, &e->s_off, &e->s_deci, &e->s_flags, &e->s_fwd, &e->s_det, &e->s_idx, &e->s_w,
+                    &e->s_nk, &e->s_nu, &e->s_pq, &e->s_ph, &e->s_co, &e->s_cols, &e->s_pos, &e->d_order, &e->d_items})
+    b->release();
+  for (auto &t : e->timers) {
+    if (t.e0) (void)hipEventDestroy(t.e0);
+    if (t.e1) (void)hipEventDestroy(t.e1);
+  }
+  delete e;
+}
+
+wh_ehmm *wh_ehmm_load(const char *const *hmm_paths, const int32_t *hmm_index, const int32_t *nseq, int n) {
+  if (!hmm_paths || n <= 0) { set_error("wh_ehmm_load: no models"); return nullptr; }
+  if (g_device < 0 && wh_init(0) != WH_OK) return nullptr;
+  std::unique_ptr<wh_ehmm, void (*)(wh_ehmm *)> e(new wh_ehmm, wh_ehmm_free);
+  e->device = g_device;
+  e->hmms.resize((size_t)n);
+  std::vector<float> tables;
+  e->dev.resize((size_t)n);
+  for (int i = 0; i < n; i++) {
+    HostHMM &h = e->hmms[(size_t)i];
+    if (parse_hmm_file(hmm_paths[i], h) != WH_OK) return nullptr;
+    h.index = hmm_index ? hmm_index[i] : i;
+    if (nseq) h.nseq = nseq[i];
+    if (i == 0) { e->alphabet = h.alphabet; e->K = h.K; e->Kp = h.Kp; }
+    else if ((h.alphabet == WH_ALPH_AMINO) != (e->alphabet == WH_ALPH_AMINO)) {
+      set_error("%s: alphabet differs from the first model", hmm_paths[i]);
+      return nullptr;
+    }
+    const int Q = choose_Q(h.M);
+    if (Q < 0) {
+      set_error("%s: model length %d exceeds this build's limit of %d nodes", hmm_paths[i], h.M, kMaxQ * kWave);
+      return nullptr;
+    }
+    std::vector<float> fw, bw, em;
+    build_tables(h, Q, fw, bw, em);
+    DevHMM &d = e->dev[(size_t)i];
+    d.M = h.M; d.Q = Q; d.Mpad = Q * kWave; d.K = h.K; d.Kp = h.Kp; d.nseq = h.nseq; d.index = h.index; d.qclass = Q;
+    d.fw_off = (int64_t)tables.size(); tables.insert(tables.end(), fw.begin(), fw.end());
+    d.bw_off = (int64_t)tables.size(); tables.insert(tables.end(), bw.begin(), bw.end());
+    d.em_off = (int64_t)tables.size(); tables.insert(tables.end(), em.begin(), em.end());
+    e->by_q[Q].push_back(i);
+    e->max_M = std::max(e->max_M, h.M);
+  }
+  degen_masks(e->alphabet, e->degen);
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, e->device) == hipSuccess) e->cu_count = p.multiProcessorCount;
+  std::vector<int32_t> ns((size_t)n), ix((size_t)n);
+  for (int i = 0; i < n; i++) { ns[(size_t)i] = e->hmms[(size_t)i].nseq; ix[(size_t)i] = e->hmms[(size_t)i].index; }
+  if (e->d_hmms.ensure(sizeof(DevHMM) * (size_t)n) || e->d_tables.ensure(sizeof(float) * tables.size()) ||
+      e->d_nseq.ensure(sizeof(int32_t) * (size_t)n) || e->d_index.ensure(sizeof(int32_t) * (size_t)n) ||
+      e->d_lists.ensure(sizeof(int32_t) * (size_t)n) || e->d_counter.ensure(256))
+    return nullptr;
+  auto up = [&](void *dst, const void *src, size_t bytes) { return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess; };
+  std::vector<int32_t> lists;
+  for (auto &kv : e->by_q) lists.insert(lists.end(), kv.second.begin(), kv.second.end());
+  if (!up(e->d_hmms.p, e->dev.data(), sizeof(DevHMM) * (size_t)n) || !up(e->d_tables.p, tables.data(), sizeof(float) * tables.size()) ||
+      !up(e->d_nseq.p, ns.data(), sizeof(int32_t) * (size_t)n) || !up(e->d_index.p, ix.data(), sizeof(int32_t) * (size_t)n) ||
+      !up(e->d_lists.p, lists.data(), sizeof(int32_t) * (size_t)n)) {
+    set_error("upload of the eHMM tables failed");
+    return nullptr;
+  }
+  return e.release();
+}
+
+int wh_ehmm_count(const wh_ehmm *e) { return e ? (int)e->hmms.size() : WH_EINVAL; }
+int wh_ehmm_alphabet(const wh_ehmm *e) { return e ? e->alphabet : WH_EINVAL; }
+
+int wh_ehmm_info(const wh_ehmm *e, int32_t *M, int32_t *nseq, int32_t *hmm_index) {
+  if (!e) { set_error("null handle"); return WH_EINVAL; }
+  for (size_t i = 0; i < e->hmms.size(); i++) {
+    if (M) M[i] = e->hmms[i].M;
+    if (nseq) nseq[i] = e->hmms[i].nseq;
+    if (hmm_index) hmm_index[i] = e->hmms[i].index;
+  }
+  return WH_OK;
+}
+
+int wh_ehmm_map(const wh_ehmm *e, int h, int32_t *map_cols) {
+  if (!e || h < 0 || h >= (int)e->hmms.size() || !map_cols) { set_error("wh_ehmm_map: bad argument"); return WH_EINVAL; }
+  const HostHMM &m = e->hmms[(size_t)h];
+  for (int k = 1; k <= m.M; k++) map_cols[k - 1] = m.map[(size_t)k];
+  return WH_OK;
+}
+
+int wh_set_timing(wh_ehmm *e, int enabled) {
+  if (!e) return WH_EINVAL;
+  e->timing = enabled != 0;
+  return WH_OK;
+}
+
+static int timer_begin(wh_ehmm *e, int which, hipStream_t s) {
+  KernelTimer &t = e->timers[which];
+  t.pending = false; t.ms = 0.0; t.launches = 0;
+  if (!e->timing) return WH_OK;
+  if (!t.e0) { HIPCHK(hipEventCreate(&t.e0)); HIPCHK(hipEventCreate(&t.e1)); }
+  HIPCHK(hipEventRecord(t.e0, s));
+  return WH_OK;
+}
+static int timer_end(wh_ehmm *e, int which, hipStream_t s, int launches) {
+  KernelTimer &t = e->timers[which];
+  t.launches = launches;
+  if (!e->timing) return WH_OK;
+  HIPCHK(hipEventRecord(t.e1, s));
+  t.pending = true;
+  return WH_OK;
+}
+
+int wh_last_kernel_ms(wh_ehmm *e, int which, double *ms, int *launches) {
+  if (!e || which < 0 || which > 2) return WH_EINVAL;
+  KernelTimer &t = e->timers[which];
+  if (t.pending) {
+    HIPCHK(hipEventSynchronize(t.e1));
+    float f = 0.f;
+    HIPCHK(hipEventElapsedTime(&f, t.e0, t.e1));
+    t.ms = f;
+    t.pending = false;
+  }
+  if (ms) *ms = t.ms;
+  if (launches) *launches = t.launches;
+  return WH_OK;
+}
+
+// ------------------------------------------------------------------------------------ score
+static const size_t kLdsBudget = 160 * 1024 - 512;
+
+static int plan_block(int Q, int K, bool treg, int Lcap, int *waves, int *SP, int *wave_lds, size_t *lds) {
+  const int sp = (Lcap + 1 + 3) / 4 * 4;
+  const int wl = 6 * sp + 32 + 3 * WH_MAX_ENVELOPES + (Lcap + 3) / 4 + 4;
+  const size_t table = (size_t)(K + (treg ? 0 : 16)) * Q * kWave * sizeof(float);
+  int w = 8;
+  while (w >= 1 && table + (size_t)w * wl * sizeof(float) > kLdsBudget) w--;
+  if (w < 1) return WH_ERANGE;
+  *waves = w; *SP = sp; *wave_lds = wl; *lds = table + (size_t)w * wl * sizeof(float);
+  return WH_OK;
+}
+
+int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets, int64_t nq,
+                 int64_t total_residues, int32_t max_len, int32_t *d_decibits, uint8_t *d_flags,
+                 float *d_fwd_bits, wh_pair_detail *d_detail, void *stream) {
+  (void)total_residues;
+  if (!e || !d_residues || !d_offsets || !d_decibits || !d_flags || nq < 0 || max_len < 0) {
+    set_error("wh_score_dev: bad argument");
+    return WH_EINVAL;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHK(hipSetDevice(e->device));
+  if (timer_begin(e, 0, s)) return WH_EHIP;
+  int launches = 0;
+  if (nq > 0) {
+    const int H = (int)e->hmms.size();
+    int list_off = 0;
+    for (auto &kv : e->by_q) {
+      const int Q = kv.first;
+      const bool treg = false;
+      int waves, SP, wave_lds;
+      size_t lds;
+      if (plan_block(Q, e->K, treg, std::max(max_len, 1), &waves, &SP, &wave_lds, &lds) != WH_OK) {
+        set_error("query length %d with model class Q=%d does not fit in LDS", max_len, Q);
+        return WH_ERANGE;
+      }
+      ScoreArgs a;
+      memset(&a, 0, sizeof a);
+      a.hmms = (const DevHMM *)e->d_hmms.p;
+      a.tables = (const float *)e->d_tables.p;
+      a.hmm_list = (const int32_t *)e->d_lists.p + list_off;
+      a.n_list = (int)kv.second.size();
+      list_off += a.n_list;
+      a.residues = d_residues; a.offsets = d_offsets; a.nq = nq;
+      a.QB = waves * 4;
+      a.n_qblocks = (int)((nq + a.QB - 1) / a.QB);
+      a.n_items = a.n_list * a.n_qblocks;
+      a.counter = (int *)e->d_counter.p + launches;
+      a.Lcap = std::max(max_len, 1); a.SP = SP; a.wave_lds = wave_lds;
+      const int blocks = std::min(a.n_items, e->cu_count * std::max(1, 8 / waves));
+      a.scratch_stride = (size_t)(a.Lcap + 1) * 2 * Q * kWave;
+      if (e->d_scratch.ensure((size_t)blocks * waves * a.scratch_stride * sizeof(float))) return WH_ENOMEM;
+      a.scratch = (float *)e->d_scratch.p;
+      a.decibits = d_decibits; a.flags = d_flags; a.fwd_bits = d_fwd_bits; a.detail = d_detail;
+      a.H = H; a.K = e->K; a.Kp = e->Kp;
+      memcpy(a.degen, e->degen, sizeof a.degen);
+      HIPCHK(hipMemsetAsync(a.counter, 0, sizeof(int), s));
+      hipError_t err = launch_score(Q, a, blocks, waves * kWave, lds, s);
+      if (err != hipSuccess) { set_error("score kernel launch (Q=%d) failed: %s", Q, hipGetErrorString(err)); return WH_EHIP; }
+      launches++;
+      if (launches >= 60) break;
+    }
+  }
+  if (timer_end(e, 0, s, launches)) return WH_EHIP;
+  return WH_OK;
+}
+
+static int max_query_len(const int64_t *offsets, int64_t nq) {
+  int64_t m = 0;
+  for (int64_t i = 0; i < nq; i++) m = std::max(m, offsets[i + 1] - offsets[i]);
+  return (int)m;
+}
+
+int wh_score(wh_ehmm *e, const uint8_t *residues, const int64_t *offsets, int64_t nq, int32_t *decibits,
+             uint8_t *flags, float *fwd_bits, wh_pair_detail *detail) {
+  if (!e || !residues || !offsets || !decibits || !flags || nq < 0) { set_error("wh_score: bad argument"); return WH_EINVAL; }
+  if (nq == 0) return WH_OK;
+  HIPCHK(hipSetDevice(e->device));
+  const int H = (int)e->hmms.size();
+  const int64_t total = offsets[nq];
+  for (int64_t i = 0; i < total; i++)
+    if (residues[i] >= e->Kp) { set_error("residue code %d at position %lld is not in the alphabet", residues[i], (long long)i); return WH_EINVAL; }
+  const size_t np = (size_t)nq * H;
+  if (e->s_res.ensure((size_t)total + 16) || e->s_off.ensure(sizeof(int64_t) * (size_t)(nq + 1)) ||
+      e->s_deci.ensure(sizeof(int32_t) * np) || e->s_flags.ensure(np) ||
+      (fwd_bits && e->s_fwd.ensure(sizeof(float) * np)) || (detail && e->s_det.ensure(sizeof(wh_pair_detail) * np)))
+    return WH_ENOMEM;
+  HIPCHK(hipMemcpy(e->s_res.p, residues, (size_t)total, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(e->s_off.p, offsets, sizeof(int64_t) * (size_t)(nq + 1), hipMemcpyHostToDevice));
+  int rc = wh_score_dev(e, (const uint8_t *)e->s_res.p, (const int64_t *)e->s_off.p, nq, total, max_query_len(offsets, nq),
+                        (int32_t *)e->s_deci.p, (uint8_t *)e->s_flags.p, fwd_bits ? (float *)e->s_fwd.p : nullptr,
+                        detail ? (wh_pair_detail *)e->s_det.p : nullptr, nullptr);
+  if (rc) return rc;
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(decibits, e->s_deci.p, sizeof(int32_t) * np, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(flags, e->s_flags.p, np, hipMemcpyDeviceToHost));
+  if (fwd_bits) HIPCHK(hipMemcpy(fwd_bits, e->s_fwd.p, sizeof(float) * np, hipMemcpyDeviceToHost));
+  if (detail) HIPCHK(hipMemcpy(detail, e->s_det.p, sizeof(wh_pair_detail) * np, hipMemcpyDeviceToHost));
+  return WH_OK;
+}
+
+// ------------------------------------------------------------------------------------ top-k
+int wh_topk_dev(wh_ehmm *e, const int32_t *d_decibits, const uint8_t *d_flags, int64_t nq, int k, int32_t *d_idx,
+                double *d_w, int32_t *d_n_kept, int32_t *d_n_used, void *stream) {
+  if (!e || !d_decibits || !d_flags || !d_idx || !d_w || !d_n_kept || !d_n_used || k <= 0 || nq < 0) {
+    set_error("wh_topk_dev: bad argument");
+    return WH_EINVAL;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHK(hipSetDevice(e->device));
+  if (timer_begin(e, 1, s)) return WH_EHIP;
+  TopkArgs a;
+  a.decibits = d_decibits; a.flags = d_flags; a.nseq = (const int32_t *)e->d_nseq.p;
+  a.hmm_index = (const int32_t *)e->d_index.p; a.nq = nq; a.H = (int)e->hmms.size(); a.k = k;
+  a.idx = d_idx; a.w = d_w; a.n_kept = d_n_kept; a.n_used = d_n_used;
+  hipError_t err = launch_topk(a, s);
+  if (err != hipSuccess) { set_error("topk kernel launch failed: %s", hipGetErrorString(err)); return WH_EHIP; }
+  if (timer_end(e, 1, s, 1)) return WH_EHIP;
+  return WH_OK;
+}
+
+int wh_topk(wh_ehmm *e, const int32_t *decibits, const uint8_t *flags, int64_t nq, int k, int32_t *idx, double *w,
+            int32_t *n_kept, int32_t *n_used) {
+  if (!e || !decibits || !flags || !idx || !w || !n_kept || !n_used || k <= 0 || nq < 0) { set_error("wh_topk: bad argument"); return WH_EINVAL; }
+  if (nq == 0) return WH_OK;
+  HIPCHK(hipSetDevice(e->device));
+  const size_t np = (size_t)nq * e->hmms.size(), nk = (size_t)nq * (size_t)k;
+  if (e->s_deci.ensure(sizeof(int32_t) * np) || e->s_flags.ensure(np) || e->s_idx.ensure(sizeof(int32_t) * nk) ||
+      e->s_w.ensure(sizeof(double) * nk) || e->s_nk.ensure(sizeof(int32_t) * (size_t)nq) || e->s_nu.ensure(sizeof(int32_t) * (size_t)nq))
+    return WH_ENOMEM;
+  HIPCHK(hipMemcpy(e->s_deci.p, decibits, sizeof(int32_t) * np, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(e->s_flags.p, flags, np, hipMemcpyHostToDevice));
+  int rc = wh_topk_dev(e, (const int32_t *)e->s_deci.p, (const uint8_t *)e->s_flags.p, nq, k, (int32_t *)e->s_idx.p,
+                       (double *)e->s_w.p, (int32_t *)e->s_nk.p, (int32_t *)e->s_nu.p, nullptr);
+  if (rc) return rc;
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(idx, e->s_idx.p, sizeof(int32_t) * nk, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(w, e->s_w.p, sizeof(double) * nk, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(n_kept, e->s_nk.p, sizeof(int32_t) * (size_t)nq, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(n_used, e->s_nu.p, sizeof(int32_t) * (size_t)nq, hipMemcpyDeviceToHost));
+  return WH_OK;
+}
+
+// ------------------------------------------------------------------------------------ align
+static int plan_align_block(int Q, int K, int Lcap, int *waves, int *SP, int *wave_lds, size_t *lds) {
+  const int sp = (Lcap + 1 + 3) / 4 * 4;
+  const int wl = 11 * sp + (Lcap + 3) / 4 + 4;
+  const size_t table = (size_t)(K + 16) * Q * kWave * sizeof(float);
+  int w = 8;
+  while (w >= 1 && table + (size_t)w * wl * sizeof(float) > kLdsBudget) w--;
+  if (w < 1) return WH_ERANGE;
+  *waves = w; *SP = sp; *wave_lds = wl; *lds = table + (size_t)w * wl * sizeof(float);
+  return WH_OK;
+}
+
+int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets, int64_t nq, int64_t total_residues,
+                 int32_t max_len, const int64_t *d_pair_q, const int32_t *d_pair_h, int64_t npairs,
+                 const int64_t *d_col_offsets, int32_t *d_cols, void *stream) {
+  (void)nq; (void)total_residues;
+  if (!e || !d_residues || !d_offsets || !d_pair_q || !d_pair_h || !d_col_offsets || !d_cols || npairs < 0 || max_len < 0) {
+    set_error("wh_align_dev: bad argument");
+    return WH_EINVAL;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHK(hipSetDevice(e->device));
+  if (npairs == 0) { e->timers[2].launches = 0; e->timers[2].ms = 0; return WH_OK; }
+  if (npairs > 0x7FFFFFFF) { set_error("too many pairs"); return WH_ERANGE; }
+  // group the pairs by model on the host (the model's tables are shared through LDS by a workgroup)
+  std::vector<int32_t> ph((size_t)npairs);
+  HIPCHK(hipMemcpyAsync(ph.data(), d_pair_h, sizeof(int32_t) * (size_t)npairs, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  const int H = (int)e->hmms.size();
+  std::vector<int32_t> cnt((size_t)H + 1, 0);
+  for (int64_t p = 0; p < npairs; p++) {
+    if (ph[(size_t)p] < 0 || ph[(size_t)p] >= H) { set_error("pair %lld: model position %d out of range", (long long)p, ph[(size_t)p]); return WH_EINVAL; }
+    cnt[(size_t)ph[(size_t)p] + 1]++;
+  }
+  for (int h = 0; h < H; h++) cnt[(size_t)h + 1] += cnt[(size_t)h];
+  std::vector<int32_t> order((size_t)npairs), cursor(cnt.begin(), cnt.end() - 1);
+  for (int64_t p = 0; p < npairs; p++) order[(size_t)cursor[(size_t)ph[(size_t)p]]++] = (int32_t)p;
+  if (e->d_order.ensure(sizeof(int32_t) * (size_t)npairs)) return WH_ENOMEM;
+  HIPCHK(hipMemcpyAsync(e->d_order.p, order.data(), sizeof(int32_t) * (size_t)npairs, hipMemcpyHostToDevice, s));
+  if (timer_begin(e, 2, s)) return WH_EHIP;
+  int launches = 0;
+  std::vector<int32_t> items;   // all classes back to back: h, start, count
+  std::vector<std::array<int, 6>> plans;   // Q, first item, n items, waves, SP, wave_lds
+  std::vector<size_t> ldss;
+  for (auto &kv : e->by_q) {
+    const int Q = kv.first;
+    int waves, SP, wave_lds; size_t lds;
+    if (plan_align_block(Q, e->K, std::max(max_len, 1), &waves, &SP, &wave_lds, &lds) != WH_OK) {
+      set_error("query length %d with model class Q=%d does not fit in LDS", max_len, Q);
+      return WH_ERANGE;
+    }
+    const int first = (int)items.size() / 3;
+    for (int h : kv.second) {
+      int lo = cnt[(size_t)h], hi = cnt[(size_t)h + 1];
+      for (int st = lo; st < hi; st += waves) { items.push_back(h); items.push_back(st); items.push_back(std::min(waves, hi - st)); }
+    }
+    const int n = (int)items.size() / 3 - first;
+    if (n > 0) { plans.push_back({Q, first, n, waves, SP, wave_lds}); ldss.push_back(lds); }
+  }
+  const size_t nit = items.size() / 3;
+  std::vector<int32_t> soa(items.size());
+  for (size_t t = 0; t < nit; t++) { soa[t] = items[3 * t]; soa[nit + t] = items[3 * t + 1]; soa[2 * nit + t] = items[3 * t + 2]; }
+  if (e->d_items.ensure(sizeof(int32_t) * soa.size() + 16)) return WH_ENOMEM;
+  HIPCHK(hipMemcpyAsync(e->d_items.p, soa.data(), sizeof(int32_t) * soa.size(), hipMemcpyHostToDevice, s));
+  for (size_t pl = 0; pl < plans.size(); pl++) {
+    const int Q = plans[pl][0], first = plans[pl][1], n = plans[pl][2], waves = plans[pl][3];
+    AlignArgs a;
+    memset(&a, 0, sizeof a);
+    a.hmms = (const DevHMM *)e->d_hmms.p; a.tables = (const float *)e->d_tables.p;
+    a.residues = d_residues; a.offsets = d_offsets; a.pair_q = d_pair_q;
+    a.order = (const int32_t *)e->d_order.p;
+    a.item_h = (const int32_t *)e->d_items.p + first;
+    a.item_start = (const int32_t *)e->d_items.p + nit + first;
+    a.item_count = (const int32_t *)e->d_items.p + 2 * nit + first;
+    a.n_items = n;
+    a.col_offsets = d_col_offsets; a.cols = d_cols;
+    a.counter = (int *)e->d_counter.p + launches;
+    a.Lcap = std::max(max_len, 1); a.SP = plans[pl][4]; a.wave_lds = plans[pl][5];
+    a.K = e->K; a.Kp = e->Kp;
+    const int blocks = std::min(n, e->cu_count * std::max(1, 8 / waves));
+    a.scratch_stride = (size_t)(a.Lcap + 1) * 5 * Q * kWave;
+    if (e->d_scratch.ensure((size_t)blocks * waves * a.scratch_stride * sizeof(float))) return WH_ENOMEM;
+    a.scratch = (float *)e->d_scratch.p;
+    HIPCHK(hipMemsetAsync(a.counter, 0, sizeof(int), s));
+    hipError_t err = launch_align(Q, a, blocks, waves * kWave, ldss[pl], s);
+    if (err != hipSuccess) { set_error("align kernel launch (Q=%d) failed: %s", Q, hipGetErrorString(err)); return WH_EHIP; }
+    launches++;
+  }
+  if (timer_end(e, 2, s, launches)) return WH_EHIP;
+  // the host vectors above are consumed by async copies: drain before they go out of scope
+  HIPCHK(hipStreamSynchronize(s));
+  return WH_OK;
+}
+
+int wh_align(wh_ehmm *e, const uint8_t *residues, const int64_t *offsets, int64_t nq, const int64_t *pair_q,
+             const int32_t *pair_h, int64_t npairs, const int64_t *col_offsets, int32_t *cols) {
+  if (!e || !residues || !offsets || !pair_q || !pair_h || !col_offsets || !cols || nq < 0 || npairs < 0) {
+    set_error("wh_align: bad argument");
+    return WH_EINVAL;
+  }
+  if (npairs == 0) return WH_OK;
+  HIPCHK(hipSetDevice(e->device));
+  const int64_t total = offsets[nq];
+  for (int64_t i = 0; i < total; i++)
+    if (residues[i] >= e->Kp) { set_error("residue code %d at position %lld is not in the alphabet", residues[i], (long long)i); return WH_EINVAL; }
+  for (int64_t p = 0; p < npairs; p++)
+    if (pair_q[p] < 0 || pair_q[p] >= nq) { set_error("pair %lld: query %lld out of range", (long long)p, (long long)pair_q[p]); return WH_EINVAL; }
+  const int64_t ncols = col_offsets[npairs];
+  if (e->s_res.ensure((size_t)total + 16) || e->s_off.ensure(sizeof(int64_t) * (size_t)(nq + 1)) ||
+      e->s_pq.ensure(sizeof(int64_t) * (size_t)npairs) || e->s_ph.ensure(sizeof(int32_t) * (size_t)npairs) ||
+      e->s_co.ensure(sizeof(int64_t) * (size_t)(npairs + 1)) || e->s_cols.ensure(sizeof(int32_t) * (size_t)ncols + 16))
+    return WH_ENOMEM;
+  HIPCHK(hipMemcpy(e->s_res.p, residues, (size_t)total, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(e->s_off.p, offsets, sizeof(int64_t) * (size_t)(nq + 1), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(e->s_pq.p, pair_q, sizeof(int64_t) * (size_t)npairs, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(e->s_ph.p, pair_h, sizeof(int32_t) * (size_t)npairs, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(e->s_co.p, col_offsets, sizeof(int64_t) * (size_t)(npairs + 1), hipMemcpyHostToDevice));
+  int rc = wh_align_dev(e, (const uint8_t *)e->s_res.p, (const int64_t *)e->s_off.p, nq, total, max_query_len(offsets, nq),
+                        (const int64_t *)e->s_pq.p, (const int32_t *)e->s_ph.p, npairs, (const int64_t *)e->s_co.p,
+                        (int32_t *)e->s_cols.p, nullptr);
+  if (rc) return rc;
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(cols, e->s_cols.p, sizeof(int32_t) * (size_t)ncols, hipMemcpyDeviceToHost));
+  return WH_OK;
+}
+
+int wh_ehmm_max_query_len(const wh_ehmm *e) {
+  if (!e) return WH_EINVAL;
+  // longest query for which one wave's LDS block still fits beside the largest model's tables
+  int best = 0;
+  for (auto &kv : e->by_q) {
+    int lo = 1, hi = 1 << 20;
+    while (lo < hi) {
+      int mid = (lo + hi + 1) / 2, w, sp, wl; size_t lds;
+      if (plan_block(kv.first, e->K, false, mid, &w, &sp, &wl, &lds) == WH_OK) lo = mid; else hi = mid - 1;
+    }
+    best = best == 0 ? lo : std::min(best, lo);
+  }
+  return best;
+}
+
+}  // extern "C"

@@ -1,0 +1,56 @@
+// Internal declarations shared by the host side (parser, profile tables, C ABI) and
+// the HIP kernels of libwitch_hip.so.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/witch_hip.h"
+
+namespace wh {
+
+constexpr int kWave = 64;          // CDNA wavefront width
+constexpr int kMaxQ = 24;          // cells per lane supported by this build -> M <= 64*kMaxQ
+constexpr int kQRegMax = 16;       // up to this Q the transition tables live in VGPRs
+
+void set_error(const char *fmt, ...);
+
+// ---- one parsed HMMER3/f model + its configured local profile (host, float64) ----
+struct HostHMM {
+  int M = 0, K = 0, Kp = 0, alphabet = -1, nseq = 0, index = 0;
+  std::string name, path;
+  std::vector<double> t;      // [(M+1)*7]  MM MI MD IM II DM DD, as in the file (node 0..M)
+  std::vector<double> mat;    // [(M+1)*K]
+  std::vector<int32_t> map;   // [M+1]
+  // configured profile
+  std::vector<double> pt;     // [(M+1)*7], node 0 and node M zeroed
+  std::vector<double> entry;  // [M+2]
+  std::vector<double> odds;   // [Kp*(M+1)]
+};
+
+int  alphabet_sizes(int alphabet, int *K, int *Kp);
+void degen_masks(int alphabet, uint32_t *mask /*[32]*/);
+int  digitize(int alphabet, const char *text, int64_t n, uint8_t *out);
+int  parse_hmm_file(const std::string &path, HostHMM &h);   // 0 or WH_E*
+void configure_profile(HostHMM &h);
+
+// ---- device-side model descriptor -------------------------------------------------
+// Lane-blocked layout: lane r of a wavefront owns model nodes k = r*Q + q + 1, q in [0,Q).
+// Tables are float arrays [arr][Q/4][64 lanes][4] so that a lane fetches 4 consecutive
+// cells with one 16-byte access and a wavefront's access is one contiguous 1 KiB line.
+//   fw: 8 arrays (tMM,tIM,tDM into node k; entry_k; tMI_k, tII_k; tMD,tDD into D_k)
+//   bw: 8 arrays in REVERSED node order u = Mpad - k (tMM_k,tIM_k,tDM_k,tMI_k,tII_k,tMD_k,tDD_k,entry_k)
+//   em: Kp arrays, odds ratio e_k(a)/f(a) in forward node order
+struct DevHMM {
+  int32_t M, Q, Mpad, K, Kp, nseq, index, qclass;
+  int64_t fw_off, bw_off, em_off;    // offsets (in floats) into the table buffer
+};
+
+enum { FW_A = 0, FW_B, FW_C, FW_E, FW_MI, FW_II, FW_D1, FW_D2 };
+enum { BW_MM = 0, BW_IM, BW_DM, BW_MI, BW_II, BW_MD, BW_DD, BW_E };
+
+int  choose_Q(int M);     // cells per lane for a model of M nodes, or -1 if unsupported
+void build_tables(const HostHMM &h, int Q, std::vector<float> &fw, std::vector<float> &bw,
+                  std::vector<float> &em);
+
+}  // namespace wh

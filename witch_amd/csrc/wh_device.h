@@ -1,0 +1,353 @@
+// Device-side building blocks shared by the scoring and alignment kernels (gfx950 only).
+//
+// Execution model: ONE wavefront (64 lanes) owns one (query, HMM) pair.  Lane r holds the
+// DP cells of model nodes k = r*Q + q + 1 (q < Q) in VGPRs and sweeps the query row by row.
+//  * the in-row D->D dependency is an affine recurrence D_k = s_k + c_k * D_{k-1}: solved
+//    per lane serially, across lanes with a 6-step DPP prefix scan whose multiplicative
+//    part depends only on the model and is precomputed (ScanC);
+//  * row sums (the E state, B<-M_k) are DPP butterfly reductions;
+//  * the Backward sweep runs in REVERSED node order (lane r owns the block 63-r, cells
+//    descending) so that "k+1 -> k" is again "lane r-1 -> lane r" and reuses the same scan.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "wh_common.h"
+
+namespace wh {
+
+// ------------------------------------------------------------------ DPP primitives
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF, bool BOUND = false>
+__device__ __forceinline__ float dppf(float old, float src) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL,
+                                         ROW_MASK, BANK_MASK, BOUND));
+}
+
+// 16-byte streaming accesses that bypass the vector L1 (data written by one lane is re-read
+// by another lane of the same wave later; it has no reuse in L1)
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load4(const float4 *p) {
+  v4f_t v = __builtin_nontemporal_load(reinterpret_cast<const v4f_t *>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void nt_store4(float4 *p, float a, float b, float c, float d) {
+  v4f_t v = {a, b, c, d};
+  __builtin_nontemporal_store(v, reinterpret_cast<v4f_t *>(p));
+}
+
+// value of lane-1 (lane 0 receives 0): wave_shr:1
+__device__ __forceinline__ float wave_shr1(float x) { return dppf<0x138, 0xF, 0xF, true>(0.f, x); }
+
+__device__ __forceinline__ float readlane_f(float x, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane));
+}
+
+// sum over the 64 lanes, result uniform
+__device__ __forceinline__ float wave_sum(float x) {
+  x += dppf<0xB1>(0.f, x);    // quad_perm [1,0,3,2]
+  x += dppf<0x4E>(0.f, x);    // quad_perm [2,3,0,1]
+  x += dppf<0x141>(0.f, x);   // row_half_mirror
+  x += dppf<0x140>(0.f, x);   // row_mirror: every lane holds its 16-lane row sum
+  return (readlane_f(x, 0) + readlane_f(x, 16)) + (readlane_f(x, 32) + readlane_f(x, 48));
+}
+
+__device__ __forceinline__ float wave_max(float x) {
+  x = fmaxf(x, dppf<0xB1>(x, x));
+  x = fmaxf(x, dppf<0x4E>(x, x));
+  x = fmaxf(x, dppf<0x141>(x, x));
+  x = fmaxf(x, dppf<0x140>(x, x));
+  return fmaxf(fmaxf(readlane_f(x, 0), readlane_f(x, 16)), fmaxf(readlane_f(x, 32), readlane_f(x, 48)));
+}
+
+// ------------------------------------------------------------------ affine prefix scan
+// Inclusive scan over lanes of maps D -> A_r * D + B_r.  The A-part is model-only, so the
+// six per-step multipliers are computed once (scan_prepare) and each row costs 6 x (DPP + FMA).
+struct ScanC { float s[6]; };
+
+__device__ __forceinline__ ScanC scan_prepare(float A) {
+  ScanC c;
+  c.s[0] = A; A *= dppf<0x111>(1.f, A);                 // row_shr:1
+  c.s[1] = A; A *= dppf<0x112>(1.f, A);                 // row_shr:2
+  c.s[2] = A; A *= dppf<0x114>(1.f, A);                 // row_shr:4
+  c.s[3] = A; A *= dppf<0x118>(1.f, A);                 // row_shr:8
+  c.s[4] = A; A *= dppf<0x142, 0xA>(1.f, A);            // row_bcast:15 into rows 1,3
+  c.s[5] = A;
+  return c;
+}
+
+__device__ __forceinline__ float scan_apply(const ScanC &c, float B) {
+  B = fmaf(c.s[0], dppf<0x111>(0.f, B), B);
+  B = fmaf(c.s[1], dppf<0x112>(0.f, B), B);
+  B = fmaf(c.s[2], dppf<0x114>(0.f, B), B);
+  B = fmaf(c.s[3], dppf<0x118>(0.f, B), B);
+  B = fmaf(c.s[4], dppf<0x142, 0xA>(0.f, B), B);
+  B = fmaf(c.s[5], dppf<0x143, 0xC>(0.f, B), B);        // row_bcast:31 into rows 2,3
+  return B;
+}
+
+// ------------------------------------------------------------------ transition tables
+// TREG: the 8 arrays of one orientation live in VGPRs (reloaded per pass from L2);
+// otherwise they are read from LDS in 16-byte pieces on every use.
+template <int Q, bool TREG>
+struct TransTab;
+
+template <int Q>
+struct TransTab<Q, true> {
+  float4 v[8][Q / 4];
+  __device__ __forceinline__ void load(const float *g, const float * /*lds*/, int lane) {
+    const float4 *p = reinterpret_cast<const float4 *>(g);
+#pragma unroll
+    for (int a = 0; a < 8; a++)
+#pragma unroll
+      for (int q4 = 0; q4 < Q / 4; q4++) v[a][q4] = p[(a * (Q / 4) + q4) * kWave + lane];
+  }
+  __device__ __forceinline__ float4 ld(int a, int q4) const { return v[a][q4]; }
+};
+
+template <int Q>
+struct TransTab<Q, false> {
+  const float4 *p;
+  __device__ __forceinline__ void load(const float * /*g*/, const float *lds, int lane) {
+    p = reinterpret_cast<const float4 *>(lds) + lane;
+  }
+  __device__ __forceinline__ float4 ld(int a, int q4) const { return p[(a * (Q / 4) + q4) * kWave]; }
+};
+
+__device__ __forceinline__ float f4get(const float4 &v, int j) {
+  return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w;
+}
+
+// product over the lane's Q cells of array <arr> (the D->D coefficients)
+template <int Q, bool TREG>
+__device__ __forceinline__ float lane_product(const TransTab<Q, TREG> &T, int arr) {
+  float A = 1.f;
+#pragma unroll
+  for (int q4 = 0; q4 < Q / 4; q4++) {
+    float4 d = T.ld(arr, q4);
+    A *= d.x; A *= d.y; A *= d.z; A *= d.w;
+  }
+  return A;
+}
+
+// ------------------------------------------------------------------ emission rows
+// Canonical residues come from the LDS copy of the table, degenerate codes (rare) from L2.
+// The two sources are kept in separate branches so that the LDS path compiles to ds_read_b128
+// (a pointer select between LDS and global would degrade both to flat loads).
+template <int Q>
+__device__ __forceinline__ void load_em_fwd(float (&od)[Q], const float *emL, const float *emG, int x, int K,
+                                            int lane) {
+  if (x < K) {
+    const float4 *p = reinterpret_cast<const float4 *>(emL + (size_t)x * Q * kWave) + lane;
+#pragma unroll
+    for (int q4 = 0; q4 < Q / 4; q4++) {
+      float4 v = p[q4 * kWave];
+      od[4 * q4] = v.x; od[4 * q4 + 1] = v.y; od[4 * q4 + 2] = v.z; od[4 * q4 + 3] = v.w;
+    }
+  } else {
+    const float4 *p = reinterpret_cast<const float4 *>(emG + (size_t)x * Q * kWave) + lane;
+#pragma unroll
+    for (int q4 = 0; q4 < Q / 4; q4++) {
+      float4 v = p[q4 * kWave];
+      od[4 * q4] = v.x; od[4 * q4 + 1] = v.y; od[4 * q4 + 2] = v.z; od[4 * q4 + 3] = v.w;
+    }
+  }
+}
+
+// reversed node order: position (lane, p) is forward position (63-lane, Q-1-p)
+template <int Q>
+__device__ __forceinline__ void load_em_rev(float (&od)[Q], const float *emL, const float *emG, int x, int K,
+                                            int lane) {
+  if (x < K) {
+    const float4 *p = reinterpret_cast<const float4 *>(emL + (size_t)x * Q * kWave) + (kWave - 1 - lane);
+#pragma unroll
+    for (int p4 = 0; p4 < Q / 4; p4++) {
+      float4 v = p[(Q / 4 - 1 - p4) * kWave];
+      od[4 * p4] = v.w; od[4 * p4 + 1] = v.z; od[4 * p4 + 2] = v.y; od[4 * p4 + 3] = v.x;
+    }
+  } else {
+    const float4 *p = reinterpret_cast<const float4 *>(emG + (size_t)x * Q * kWave) + (kWave - 1 - lane);
+#pragma unroll
+    for (int p4 = 0; p4 < Q / 4; p4++) {
+      float4 v = p[(Q / 4 - 1 - p4) * kWave];
+      od[4 * p4] = v.w; od[4 * p4 + 1] = v.z; od[4 * p4 + 2] = v.y; od[4 * p4 + 3] = v.x;
+    }
+  }
+}
+
+// power-of-two rescale helpers: exact, so scaling adds no rounding error
+__device__ __forceinline__ int f32_exponent(float x) { return ((__builtin_bit_cast(int, x) >> 23) & 0xFF) - 127; }
+__device__ __forceinline__ float pow2f_int(int e) { return __builtin_bit_cast(float, (e + 127) << 23); }
+
+struct LenCfg { float loop, move, EJ, EC; };
+
+// A.1 length model; HMMER evaluates it in float32
+__device__ __forceinline__ LenCfg len_config(int Lcfg, bool multihit) {
+  LenCfg c;
+  float nj = multihit ? 1.0f : 0.0f;
+  c.move = (2.0f + nj) / ((float)Lcfg + 2.0f + nj);
+  c.loop = 1.0f - c.move;
+  c.EJ = multihit ? 0.5f : 0.0f;
+  c.EC = multihit ? 0.5f : 1.0f;
+  return c;
+}
+
+// Per-wave LDS block: six float arrays of SP entries (special states per row) + small tables.
+enum { SP_N = 0, SP_B, SP_E, SP_J, SP_C, SP_S };   // SP_S: cumulative scale exponent (int bits)
+
+constexpr float kRescaleHi = 1048576.0f;   // 2^20
+
+// ------------------------------------------------------------------ Forward sweep
+// Fills spec[SP_*][0..L]; with STORE also writes the M and I rows (1..L) to <Fs>
+// ([row][2][Q/4][64][4] floats, forward node order).  Returns C(L) and its scale exponent.
+template <int Q, bool TREG, bool STORE>
+__device__ __forceinline__ void forward_sweep(const TransTab<Q, TREG> &T, const ScanC &sc, const float *emL,
+                                              const float *emG, int K, const uint8_t *seq, int L, LenCfg cfg,
+                                              float *spec, int SP, float *Fs, int lane, float &xC_out,
+                                              int &ef_out) {
+  float Mp[Q], Ip[Q], Dp[Q];
+#pragma unroll
+  for (int q = 0; q < Q; q++) { Mp[q] = 0.f; Ip[q] = 0.f; Dp[q] = 0.f; }
+  float xN = 1.0f, xB = cfg.move, xJ = 0.f, xC = 0.f, xE = 0.f;
+  int ef = 0;
+  if (lane == 0) {
+    spec[SP_N * SP] = xN; spec[SP_B * SP] = xB; spec[SP_E * SP] = 0.f; spec[SP_J * SP] = 0.f;
+    spec[SP_C * SP] = 0.f; reinterpret_cast<int *>(spec)[SP_S * SP] = 0;
+  }
+#pragma unroll 1
+  for (int i = 1; i <= L; i++) {
+    asm volatile("" ::: "memory");   // keep LDS table reads inside the row (no hoisting into VGPRs)
+    const int x = seq[i - 1];
+    float od[Q];
+    load_em_fwd<Q>(od, emL, emG, x, K, lane);
+    const float mm1 = wave_shr1(Mp[Q - 1]), im1 = wave_shr1(Ip[Q - 1]), dm1 = wave_shr1(Dp[Q - 1]);
+#pragma unroll
+    for (int q4 = Q / 4 - 1; q4 >= 0; q4--) {
+      const float4 A = T.ld(FW_A, q4), B = T.ld(FW_B, q4), C = T.ld(FW_C, q4), E = T.ld(FW_E, q4);
+      const float4 MI = T.ld(FW_MI, q4), II = T.ld(FW_II, q4);
+#pragma unroll
+      for (int j = 3; j >= 0; j--) {
+        const int q = 4 * q4 + j;
+        const float pm = q > 0 ? Mp[q > 0 ? q - 1 : 0] : mm1;
+        const float pi = q > 0 ? Ip[q > 0 ? q - 1 : 0] : im1;
+        const float pd = q > 0 ? Dp[q > 0 ? q - 1 : 0] : dm1;
+        const float ni = fmaf(f4get(MI, j), Mp[q], f4get(II, j) * Ip[q]);
+        float acc = xB * f4get(E, j);
+        acc = fmaf(f4get(A, j), pm, acc);
+        acc = fmaf(f4get(B, j), pi, acc);
+        acc = fmaf(f4get(C, j), pd, acc);
+        Mp[q] = od[q] * acc;
+        Ip[q] = ni;
+      }
+    }
+    // D row: local chains, cross-lane scan, fix-up
+    const float mn1 = wave_shr1(Mp[Q - 1]);
+    float dprev = 0.f;
+#pragma unroll
+    for (int q4 = 0; q4 < Q / 4; q4++) {
+      const float4 D1 = T.ld(FW_D1, q4), D2 = T.ld(FW_D2, q4);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int q = 4 * q4 + j;
+        const float src = q > 0 ? Mp[q > 0 ? q - 1 : 0] : mn1;
+        dprev = fmaf(f4get(D2, j), dprev, f4get(D1, j) * src);
+        Dp[q] = dprev;
+      }
+    }
+    float carry = wave_shr1(scan_apply(sc, dprev));
+    float es = 0.f;
+#pragma unroll
+    for (int q4 = 0; q4 < Q / 4; q4++) {
+      const float4 D2 = T.ld(FW_D2, q4);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int q = 4 * q4 + j;
+        carry *= f4get(D2, j);
+        Dp[q] += carry;
+        es += Mp[q] + Dp[q];
+      }
+    }
+    xE = wave_sum(es);
+    xN = xN * cfg.loop;
+    xC = fmaf(xC, cfg.loop, xE * cfg.EC);
+    xJ = fmaf(xJ, cfg.loop, xE * cfg.EJ);
+    if (xE > kRescaleHi) {
+      const int e = f32_exponent(xE);
+      const float r = pow2f_int(-e);
+#pragma unroll
+      for (int q = 0; q < Q; q++) { Mp[q] *= r; Ip[q] *= r; Dp[q] *= r; }
+      xN *= r; xC *= r; xJ *= r; xE *= r;
+      ef += e;
+    }
+    xB = (xJ + xN) * cfg.move;
+    if (lane == 0) {
+      spec[SP_N * SP + i] = xN; spec[SP_B * SP + i] = xB; spec[SP_E * SP + i] = xE;
+      spec[SP_J * SP + i] = xJ; spec[SP_C * SP + i] = xC;
+      reinterpret_cast<int *>(spec)[SP_S * SP + i] = ef;
+    }
+    if (STORE) {
+      float4 *row = reinterpret_cast<float4 *>(Fs) + (size_t)i * (2 * (Q / 4) * kWave) + lane;
+#pragma unroll
+      for (int q4 = 0; q4 < Q / 4; q4++) {
+        // streamed once and re-read once by other lanes of this wave: keep it out of L1
+        nt_store4(row + q4 * kWave, Mp[4 * q4], Mp[4 * q4 + 1], Mp[4 * q4 + 2], Mp[4 * q4 + 3]);
+        nt_store4(row + (Q / 4 + q4) * kWave, Ip[4 * q4], Ip[4 * q4 + 1], Ip[4 * q4 + 2], Ip[4 * q4 + 3]);
+      }
+    }
+  }
+  xC_out = xC;
+  ef_out = ef;
+}
+
+// ------------------------------------------------------------------ Backward sweep core
+// One Backward row in reversed node order.  On entry Mb/Ib hold row i+1 (or zeros for
+// i = L) and <G> has been formed in place in Mb (G_k = o_k(x_{i+1}) * B_M_k(i+1)).
+// Produces row i in Mb/Ib.  xE = E(i).
+template <int Q, bool TREG>
+__device__ __forceinline__ void backward_cells(const TransTab<Q, TREG> &T, const ScanC &sc, float (&Mb)[Q],
+                                               float (&Ib)[Q], float xE) {
+  float Dn[Q];
+  const float gm1 = wave_shr1(Mb[Q - 1]);   // G of node k+1 across the lane boundary
+  float dprev = 0.f;
+#pragma unroll
+  for (int p4 = 0; p4 < Q / 4; p4++) {
+    const float4 DM = T.ld(BW_DM, p4), DD = T.ld(BW_DD, p4);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int p = 4 * p4 + j;
+      const float g = p > 0 ? Mb[p > 0 ? p - 1 : 0] : gm1;
+      dprev = fmaf(f4get(DD, j), dprev, fmaf(f4get(DM, j), g, xE));
+      Dn[p] = dprev;
+    }
+  }
+  float carry = wave_shr1(scan_apply(sc, dprev));
+#pragma unroll
+  for (int p4 = 0; p4 < Q / 4; p4++) {
+    const float4 DD = T.ld(BW_DD, p4);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int p = 4 * p4 + j;
+      carry *= f4get(DD, j);
+      Dn[p] += carry;
+    }
+  }
+  const float dm1 = wave_shr1(Dn[Q - 1]);
+#pragma unroll
+  for (int p4 = Q / 4 - 1; p4 >= 0; p4--) {
+    const float4 MM = T.ld(BW_MM, p4), IM = T.ld(BW_IM, p4), MI = T.ld(BW_MI, p4), II = T.ld(BW_II, p4);
+    const float4 MD = T.ld(BW_MD, p4);
+#pragma unroll
+    for (int j = 3; j >= 0; j--) {
+      const int p = 4 * p4 + j;
+      const float g = p > 0 ? Mb[p > 0 ? p - 1 : 0] : gm1;
+      const float dn = p > 0 ? Dn[p > 0 ? p - 1 : 0] : dm1;
+      float nm = fmaf(f4get(MM, j), g, xE);
+      nm = fmaf(f4get(MI, j), Ib[p], nm);
+      nm = fmaf(f4get(MD, j), dn, nm);
+      const float ni = fmaf(f4get(IM, j), g, f4get(II, j) * Ib[p]);
+      Mb[p] = nm;
+      Ib[p] = ni;
+    }
+  }
+}
+
+}  // namespace wh

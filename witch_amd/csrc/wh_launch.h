@@ -1,0 +1,72 @@
+// Kernel argument blocks and launcher prototypes (host <-> device glue).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "wh_common.h"
+
+namespace wh {
+
+struct ScoreArgs {
+  const DevHMM *hmms;          // all models of the eHMM
+  const float *tables;         // table buffer (fw / bw / em arrays of every model)
+  const int32_t *hmm_list;     // model positions of this size class
+  int n_list;
+  const uint8_t *residues;
+  const int64_t *offsets;
+  int64_t nq;
+  int QB;                      // queries per work item
+  int n_qblocks;
+  int n_items;                 // n_list * n_qblocks
+  int *counter;                // work-queue head (zeroed by a memset node before the launch)
+  int Lcap;                    // longest query of the batch
+  int SP;                      // stride of the per-row special-state arrays (>= Lcap+1)
+  int wave_lds;                // floats of LDS per wave
+  float *scratch;              // per-wave Forward slabs
+  size_t scratch_stride;       // floats per wave
+  int32_t *decibits;
+  uint8_t *flags;
+  float *fwd_bits;
+  wh_pair_detail *detail;
+  int H;
+  int K, Kp;
+  uint32_t degen[32];
+};
+
+hipError_t launch_score(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
+
+struct TopkArgs {
+  const int32_t *decibits;
+  const uint8_t *flags;
+  const int32_t *nseq;         // [H]
+  const int32_t *hmm_index;    // [H]
+  int64_t nq;
+  int H, k;
+  int32_t *idx;
+  double *w;
+  int32_t *n_kept;
+  int32_t *n_used;
+};
+hipError_t launch_topk(const TopkArgs &a, hipStream_t s);
+
+struct AlignArgs {
+  const DevHMM *hmms;
+  const float *tables;
+  const uint8_t *residues;
+  const int64_t *offsets;
+  const int64_t *pair_q;
+  const int32_t *order;        // pair indices grouped by model
+  const int32_t *item_h;       // work items: model position, first entry of <order>, entry count
+  const int32_t *item_start;
+  const int32_t *item_count;
+  int n_items;
+  const int64_t *col_offsets;
+  int32_t *cols;
+  int *counter;
+  int Lcap, SP, wave_lds;
+  float *scratch;              // per-wave slabs: Forward/posterior rows, then OA rows
+  size_t scratch_stride;       // floats per wave
+  int K, Kp;
+};
+hipError_t launch_align(int Q, const AlignArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
+
+}  // namespace wh

@@ -1,0 +1,391 @@
+// Scoring kernel: what "hmmsearch --cpu 1 --noali -E 99999999 --max" computes for one
+// (query, HMM) pair (witch_msa/gcmm/algorithm.py:526-532; algorithm: SURVEY.md A.2-A.6),
+// fused into one launch per model-size class:
+//   P1 multihit-local Forward (special states per row kept in LDS)
+//   P2 multihit-local Backward fused with domain decoding (btot/etot/mocc) and region scan
+//   per envelope: P3 unihit Forward (M/I rows spilled to a per-wave HBM slab),
+//                 P4 unihit Backward fused with posterior accumulation -> null2 -> bias
+//   score assembly, "%6.1f" rounding to deci-bits.
+// One wavefront per pair; a workgroup shares one model's emission table in LDS and pulls
+// (model, query-block) items from a global counter until the list is drained.
+#include <hip/hip_runtime.h>
+
+#include "wh_device.h"
+#include "wh_launch.h"
+
+namespace wh {
+
+// float32 table value of p7_FLogsum (A.6): table[i] = log(1 + exp(-i/1000)), 16000 entries
+__device__ __forceinline__ float flogsum0(float b) {
+  // FLogsum(0, b)
+  const float mx = b > 0.f ? b : 0.f, mn = b > 0.f ? 0.f : b;
+  if (mn == -INFINITY || (mx - mn) >= 15.7f) return mx;
+  const int idx = (int)((mx - mn) * 1000.0f);
+  return mx + (float)log(1.0 + exp((double)-idx / 1000.0));
+}
+
+template <int Q, bool TREG>
+__global__ __launch_bounds__(512) void score_kernel(ScoreArgs a) {
+  extern __shared__ float smem[];
+  __shared__ int s_item;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  constexpr int TBL = Q * kWave;   // floats per table array
+  float *emL = smem;
+  float *trL = smem + (size_t)a.K * TBL;                                   // !TREG: fw[8] then bw[8]
+  float *wbase = trL + (TREG ? 0 : 16 * TBL) + (size_t)wave * a.wave_lds;  // per-wave block
+  float *spec = wbase;                                                     // 6 * SP floats
+  float *n2tab = wbase + 6 * a.SP;                                         // 32 floats
+  int *regs = reinterpret_cast<int *>(n2tab + 32);                         // 3 * WH_MAX_ENVELOPES ints
+  uint8_t *seq = reinterpret_cast<uint8_t *>(regs + 3 * WH_MAX_ENVELOPES);
+  float *Fs = a.scratch + ((size_t)blockIdx.x * nwaves + wave) * a.scratch_stride;
+  const int SP = a.SP;
+  int cur_h = -1;
+  const DevHMM *hm = nullptr;
+
+  for (;;) {
+    if (threadIdx.x == 0) s_item = atomicAdd(a.counter, 1);
+    __syncthreads();
+    const int item = s_item;
+    __syncthreads();
+    if (item >= a.n_items) break;
+    const int h = a.hmm_list[item / a.n_qblocks];
+    const int64_t q_lo = (int64_t)(item % a.n_qblocks) * a.QB;
+    const int64_t q_hi = q_lo + a.QB < a.nq ? q_lo + a.QB : a.nq;
+    if (h != cur_h) {
+      hm = a.hmms + h;
+      const float4 *src = reinterpret_cast<const float4 *>(a.tables + hm->em_off);
+      float4 *dst = reinterpret_cast<float4 *>(emL);
+      for (int t = threadIdx.x; t < a.K * TBL / 4; t += blockDim.x) dst[t] = src[t];
+      if (!TREG) {
+        const float4 *s1 = reinterpret_cast<const float4 *>(a.tables + hm->fw_off);
+        const float4 *s2 = reinterpret_cast<const float4 *>(a.tables + hm->bw_off);
+        float4 *d1 = reinterpret_cast<float4 *>(trL);
+        for (int t = threadIdx.x; t < 8 * TBL / 4; t += blockDim.x) { d1[t] = s1[t]; d1[8 * TBL / 4 + t] = s2[t]; }
+      }
+      cur_h = h;
+      __syncthreads();
+    }
+    const float *emG = a.tables + hm->em_off;
+    const float *fwG = a.tables + hm->fw_off, *bwG = a.tables + hm->bw_off;
+
+    for (int64_t qi = q_lo + wave; qi < q_hi; qi += nwaves) {
+      const int64_t off = a.offsets[qi];
+      const int L = (int)(a.offsets[qi + 1] - off);
+      const size_t out = (size_t)qi * a.H + h;
+      int flags = 0, decibits = 0;
+      float fwd_bits_out = -INFINITY;
+      wh_pair_detail *dp = (a.detail && lane == 0) ? a.detail + out : nullptr;
+      if (dp) {
+        dp->fwd_bits = -INFINITY; dp->seq_score = 0.f; dp->pre_score = 0.f; dp->seqbias_nats = 0.f;
+        dp->nregions = 0; dp->nenv = 0;
+      }
+      if (L > 0 && L <= a.Lcap) {
+        for (int t = lane; t < L; t += kWave) {
+          int c = a.residues[off + t];
+          seq[t] = (uint8_t)(c < a.Kp ? c : a.Kp - 1);
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---------------- P1: multihit Forward
+        const LenCfg cm = len_config(L, true);
+        float xC_L; int ef_L;
+        {
+          TransTab<Q, TREG> T;
+          T.load(fwG, trL, lane);
+          const ScanC sc = scan_prepare(lane_product<Q, TREG>(T, FW_D2));
+          forward_sweep<Q, TREG, false>(T, sc, emL, emG, a.K, seq, L, cm, spec, SP, nullptr, lane, xC_L, ef_L);
+        }
+        const double fwd_nats = (double)ef_L * 0.69314718055994529 + log((double)(xC_L * cm.move));
+        const float fwdsc = (float)fwd_nats;
+        // A.3 null1 in float32 as p7_bg_SetLength / p7_bg_NullOne do
+        const float p1 = (float)L / (float)(L + 1);
+        const float nullsc = (float)((double)(float)L * log((double)p1) + log(1.0 - (double)p1));
+        fwd_bits_out = (float)((fwd_nats - (double)nullsc) / 0.69314718055994529);
+        if (dp) dp->fwd_bits = fwd_bits_out;
+
+        if (xC_L > 0.f && isfinite(fwdsc)) {
+          // ---------------- P2: multihit Backward + domain decoding
+          const float invZ = 1.0f / (xC_L * cm.move);
+          {
+            TransTab<Q, TREG> T;
+            T.load(bwG, trL + 8 * TBL, lane);
+            const ScanC sc = scan_prepare(lane_product<Q, TREG>(T, BW_DD));
+            float Mb[Q], Ib[Q];
+#pragma unroll
+            for (int p = 0; p < Q; p++) { Mb[p] = 0.f; Ib[p] = 0.f; }
+            float xC = cm.move, xJ = 0.f, xN = 0.f, xB = 0.f;
+            int eb = 0;
+#pragma unroll 1
+            for (int i = L; i >= 0; i--) {
+              asm volatile("" ::: "memory");
+              if (i < L) {
+                float od[Q];
+                load_em_rev<Q>(od, emL, emG, seq[i], a.K, lane);
+                float part = 0.f;
+#pragma unroll
+                for (int p4 = 0; p4 < Q / 4; p4++) {
+                  const float4 E = T.ld(BW_E, p4);
+#pragma unroll
+                  for (int j = 0; j < 4; j++) {
+                    const int p = 4 * p4 + j;
+                    Mb[p] *= od[p];
+                    part = fmaf(f4get(E, j), Mb[p], part);
+                  }
+                }
+                xB = wave_sum(part);
+                xJ = fmaf(xJ, cm.loop, xB * cm.move);
+                xC = xC * cm.loop;
+                xN = fmaf(xN, cm.loop, xB * cm.move);
+              }
+              float xE = fmaf(xC, cm.EC, xJ * cm.EJ);
+              if (i >= 1) backward_cells<Q, TREG>(T, sc, Mb, Ib, xE);
+              const float big = fmaxf(xB, xN);
+              if (big > kRescaleHi) {
+                const int e = f32_exponent(big);
+                const float r = pow2f_int(-e);
+#pragma unroll
+                for (int p = 0; p < Q; p++) { Mb[p] *= r; Ib[p] *= r; }
+                xB *= r; xJ *= r; xC *= r; xN *= r; xE *= r;
+                eb += e;
+              }
+              // domain decoding for row i (A.4); results overwrite row i's forward slots
+              const int *specI = reinterpret_cast<const int *>(spec);
+              const float s_i = ldexpf(invZ, specI[SP_S * SP + i] + eb - ef_L);
+              const float pe = spec[SP_E * SP + i] * xE * s_i;
+              const float pb = spec[SP_B * SP + i] * xB * s_i;
+              float njc = 0.f;
+              if (i >= 1) {
+                const float s_p = ldexpf(invZ, specI[SP_S * SP + i - 1] + eb - ef_L);
+                njc = spec[SP_N * SP + i - 1] * xN;
+                njc = fmaf(spec[SP_J * SP + i - 1], xJ, njc);
+                njc = fmaf(spec[SP_C * SP + i - 1], xC, njc);
+                njc = njc * cm.loop * s_p;
+              }
+              __builtin_amdgcn_wave_barrier();
+              if (lane == 0) { spec[SP_E * SP + i] = pe; spec[SP_B * SP + i] = pb; spec[SP_N * SP + i] = njc; }
+              __builtin_amdgcn_wave_barrier();
+            }
+          }
+
+          // ---------------- region scan (A.4), uniform over the wave
+          const float rt1 = 0.25f, rt2 = 0.10f, rt3 = 0.20f;
+          int nreg = 0, nenv = 0;
+          {
+            float btot = 0.f, etot = 0.f;
+            int i0 = -1;
+            bool trig = false;
+            if (lane == 0) { spec[SP_J * SP] = 0.f; spec[SP_C * SP] = 0.f; }
+            for (int j = 1; j <= L; j++) {
+              const float mocc = 1.0f - spec[SP_N * SP + j];
+              const float bold = btot, eold = etot;
+              btot += spec[SP_B * SP + j - 1];
+              etot += spec[SP_E * SP + j];
+              if (lane == 0) { spec[SP_J * SP + j] = btot; spec[SP_C * SP + j] = etot; }
+              if (!trig) {
+                if (mocc - (btot - bold) < rt2) i0 = j;
+                else if (i0 == -1) i0 = j;
+                if (mocc >= rt1) trig = true;
+              } else if (mocc - (etot - eold) < rt2) {
+                if (nenv < WH_MAX_ENVELOPES) {
+                  if (lane == 0) { regs[2 * nenv] = i0; regs[2 * nenv + 1] = j; }
+                  nenv++;
+                } else flags |= WH_FLAG_TRUNC;
+                nreg++;
+                i0 = -1;
+                trig = false;
+              }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // multidomain test: max_z min(etot[z]-etot[i-1], btot[j]-btot[z-1]) >= rt3
+            for (int e = 0; e < nenv; e++) {
+              const int ri = regs[2 * e], rj = regs[2 * e + 1];
+              float mx = -1.0f;
+              const float e0 = spec[SP_C * SP + ri - 1], bj = spec[SP_J * SP + rj];
+              for (int z = ri + lane; z <= rj; z += kWave) {
+                const float u = spec[SP_C * SP + z] - e0, v = bj - spec[SP_J * SP + z - 1];
+                mx = fmaxf(mx, fminf(u, v));
+              }
+              mx = wave_max(mx);
+              if (mx >= rt3) flags |= WH_FLAG_MULTI;
+            }
+          }
+          if (dp) { dp->nregions = nreg; dp->nenv = nenv; }
+
+          if (nenv > 0) {
+            // ---------------- envelopes: unihit Forward/Backward, null2 by expectation (A.5)
+            const LenCfg cu = len_config(L, false);
+            float seqbias_sum = 0.f, sum_score = 0.f, sb2 = 0.f;
+            int Ld_tot = 0;
+            for (int e = 0; e < nenv; e++) {
+              const int ri = regs[2 * e], rj = regs[2 * e + 1];
+              const int Ld = rj - ri + 1;
+              const uint8_t *eseq = seq + (ri - 1);
+              float xC_e; int ef_e;
+              {
+                TransTab<Q, TREG> T;
+                T.load(fwG, trL, lane);
+                const ScanC sc = scan_prepare(lane_product<Q, TREG>(T, FW_D2));
+                forward_sweep<Q, TREG, true>(T, sc, emL, emG, a.K, eseq, Ld, cu, spec, SP, Fs, lane, xC_e, ef_e);
+              }
+              // the rows were written by other lanes of this wave: order the stores before the loads
+              __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+              const float envsc = (float)((double)ef_e * 0.69314718055994529 + log((double)(xC_e * cu.move)));
+              float domcorr = 0.f;
+              if (xC_e > 0.f) {
+                const float invZe = 1.0f / (xC_e * cu.move);
+                TransTab<Q, TREG> T;
+                T.load(bwG, trL + 8 * TBL, lane);
+                const ScanC sc = scan_prepare(lane_product<Q, TREG>(T, BW_DD));
+                float Mb[Q], Ib[Q], fM[Q], fI[Q];
+#pragma unroll
+                for (int p = 0; p < Q; p++) { Mb[p] = 0.f; Ib[p] = 0.f; fM[p] = 0.f; fI[p] = 0.f; }
+                float xC = cu.move, xJ = 0.f, xN = 0.f, xB = 0.f, xfac = 0.f;
+                int eb = 0;
+                const int *specI = reinterpret_cast<const int *>(spec);
+#pragma unroll 1
+                for (int i = Ld; i >= 1; i--) {
+                  asm volatile("" ::: "memory");
+                  // issue the loads of Forward row i early; they are consumed after the cell update
+                  const float4 *row = reinterpret_cast<const float4 *>(Fs) + (size_t)i * (2 * (Q / 4) * kWave) +
+                                      (kWave - 1 - lane);
+                  float4 fm4[Q / 4], fi4[Q / 4];
+#pragma unroll
+                  for (int p4 = 0; p4 < Q / 4; p4++) {
+                    fm4[p4] = nt_load4(row + (Q / 4 - 1 - p4) * kWave);
+                    fi4[p4] = nt_load4(row + (Q / 4 + Q / 4 - 1 - p4) * kWave);
+                  }
+                  if (i < Ld) {
+                    float od[Q];
+                    load_em_rev<Q>(od, emL, emG, eseq[i], a.K, lane);
+                    float part = 0.f;
+#pragma unroll
+                    for (int p4 = 0; p4 < Q / 4; p4++) {
+                      const float4 E = T.ld(BW_E, p4);
+#pragma unroll
+                      for (int j = 0; j < 4; j++) {
+                        const int p = 4 * p4 + j;
+                        Mb[p] *= od[p];
+                        part = fmaf(f4get(E, j), Mb[p], part);
+                      }
+                    }
+                    xB = wave_sum(part);
+                    xJ = fmaf(xJ, cu.loop, xB * cu.move);
+                    xC = xC * cu.loop;
+                    xN = fmaf(xN, cu.loop, xB * cu.move);
+                  }
+                  float xE = fmaf(xC, cu.EC, xJ * cu.EJ);
+                  backward_cells<Q, TREG>(T, sc, Mb, Ib, xE);
+                  const float big = fmaxf(xB, xN);
+                  if (big > kRescaleHi) {
+                    const int ee = f32_exponent(big);
+                    const float r = pow2f_int(-ee);
+#pragma unroll
+                    for (int p = 0; p < Q; p++) { Mb[p] *= r; Ib[p] *= r; }
+                    xB *= r; xJ *= r; xC *= r; xN *= r; xE *= r;
+                    eb += ee;
+                  }
+                  const float s_i = ldexpf(invZe, specI[SP_S * SP + i] + eb - ef_e);
+                  const float s_p = ldexpf(invZe, specI[SP_S * SP + i - 1] + eb - ef_e);
+#pragma unroll
+                  for (int p4 = 0; p4 < Q / 4; p4++) {
+                    // reversed order: component 3-j of the forward-ordered vector is position 4*p4+j
+                    fM[4 * p4 + 0] = fmaf(fm4[p4].w * Mb[4 * p4 + 0], s_i, fM[4 * p4 + 0]);
+                    fM[4 * p4 + 1] = fmaf(fm4[p4].z * Mb[4 * p4 + 1], s_i, fM[4 * p4 + 1]);
+                    fM[4 * p4 + 2] = fmaf(fm4[p4].y * Mb[4 * p4 + 2], s_i, fM[4 * p4 + 2]);
+                    fM[4 * p4 + 3] = fmaf(fm4[p4].x * Mb[4 * p4 + 3], s_i, fM[4 * p4 + 3]);
+                    fI[4 * p4 + 0] = fmaf(fi4[p4].w * Ib[4 * p4 + 0], s_i, fI[4 * p4 + 0]);
+                    fI[4 * p4 + 1] = fmaf(fi4[p4].z * Ib[4 * p4 + 1], s_i, fI[4 * p4 + 1]);
+                    fI[4 * p4 + 2] = fmaf(fi4[p4].y * Ib[4 * p4 + 2], s_i, fI[4 * p4 + 2]);
+                    fI[4 * p4 + 3] = fmaf(fi4[p4].x * Ib[4 * p4 + 3], s_i, fI[4 * p4 + 3]);
+                  }
+                  float nj = spec[SP_N * SP + i - 1] * xN;
+                  nj = fmaf(spec[SP_J * SP + i - 1], xJ, nj);
+                  nj = fmaf(spec[SP_C * SP + i - 1], xC, nj);
+                  xfac = fmaf(nj * cu.loop, s_p, xfac);
+                }
+                // null2[a] = sum_k fM_k o_k(a) + sum_k fI_k + f_NJC, all / Ld
+                const float norm = 1.0f / (float)Ld;
+                float si = 0.f;
+#pragma unroll
+                for (int p = 0; p < Q; p++) si += fI[p];
+                si = wave_sum(si);
+                float mine = 1.0f;
+                for (int x = 0; x < a.K; x++) {
+                  float od[Q];
+                  load_em_rev<Q>(od, emL, emG, x, a.K, lane);
+                  float s = 0.f;
+#pragma unroll
+                  for (int p = 0; p < Q; p++) s = fmaf(fM[p], od[p], s);
+                  s = wave_sum(s);
+                  if (lane == x) mine = (s + si) * norm + xfac * norm;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (lane < a.K) n2tab[lane] = mine;
+                __builtin_amdgcn_wave_barrier();
+                if (lane >= a.K && lane < a.Kp) {
+                  // degenerate codes: unweighted mean of the canonical ratios; gap/*/~ -> 1
+                  const uint32_t m = a.degen[lane];
+                  float s = 0.f; int n = 0;
+                  for (int x = 0; x < a.K; x++) if (m & (1u << x)) { s += n2tab[x]; n++; }
+                  mine = n > 0 ? s / (float)n : 1.0f;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (lane < a.Kp) n2tab[lane] = logf(mine);
+                __builtin_amdgcn_wave_barrier();
+                float dc = 0.f;
+                for (int t = lane; t < Ld; t += kWave) dc += n2tab[eseq[t]];
+                domcorr = wave_sum(dc);
+              }
+              seqbias_sum += domcorr;
+              if (envsc - domcorr > 0.0f) { sum_score += envsc; Ld_tot += Ld; sb2 += domcorr; }
+              if (dp) { dp->env_i[e] = ri; dp->env_j[e] = rj; dp->envsc[e] = envsc; dp->domcorr[e] = domcorr; }
+            }
+            // ---------------- A.6 score assembly (float32 where HMMER is float32)
+            const double LOG2 = 0.69314718055994529;
+            const float lomega = (float)log(1.0 / 256.0);
+            const float seqbias = flogsum0(lomega + seqbias_sum);
+            float pre_score = (float)(((double)fwdsc - (double)nullsc) / LOG2);
+            float seq_score = (float)(((double)fwdsc - (double)(nullsc + seqbias)) / LOG2);
+            sb2 = flogsum0(lomega + sb2);
+            sum_score += (float)((double)(L - Ld_tot) * log((double)((float)L / (float)(L + 3))));
+            const float pre2 = (float)(((double)sum_score - (double)nullsc) / LOG2);
+            sum_score = (float)(((double)sum_score - (double)(nullsc + sb2)) / LOG2);
+            if (Ld_tot > 0 && sum_score > seq_score) { seq_score = sum_score; pre_score = pre2; flags |= WH_FLAG_OVERRIDE; }
+            decibits = (int)rint((double)seq_score * 10.0);
+            flags |= WH_FLAG_REPORTED;
+            if (dp) { dp->seq_score = seq_score; dp->pre_score = pre_score; dp->seqbias_nats = seqbias; }
+          }
+        }
+      }
+      if (lane == 0) {
+        a.decibits[out] = decibits;
+        a.flags[out] = (uint8_t)flags;
+        if (a.fwd_bits) a.fwd_bits[out] = fwd_bits_out;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+template <int Q, bool TREG>
+static hipError_t launch_one(const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&score_kernel<Q, TREG>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (err != hipSuccess) return err;
+  hipLaunchKernelGGL((score_kernel<Q, TREG>), dim3(blocks), dim3(threads), lds, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_score(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
+  switch (Q) {
+    case 4:  return launch_one<4, false>(a, blocks, threads, lds, s);
+    case 8:  return launch_one<8, false>(a, blocks, threads, lds, s);
+    case 12: return launch_one<12, false>(a, blocks, threads, lds, s);
+    case 16: return launch_one<16, false>(a, blocks, threads, lds, s);
+    case 20: return launch_one<20, false>(a, blocks, threads, lds, s);
+    case 24: return launch_one<24, false>(a, blocks, threads, lds, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace wh

@@ -1,0 +1,170 @@
+"""EHMM: an ensemble of profile HMMs resident on one MI355X, and the three operators of
+the hot path (score -> top-k weights -> align) over the C ABI of libwitch_hip.so.
+
+Host entry points take/return numpy arrays (the library stages them over PCIe);
+the ``*_t`` entry points take torch CUDA tensors already resident in HBM and enqueue
+on torch's current stream - PyTorch is only the allocator/stream plumbing here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import PairDetail, WitchHipError, check, lib
+
+
+def pack_queries(seqs):
+    """list of uint8 arrays -> (residues uint8 [total], offsets int64 [n+1])"""
+    offs = np.zeros(len(seqs) + 1, dtype=np.int64)
+    if len(seqs):
+        offs[1:] = np.cumsum([len(s) for s in seqs])
+        res = np.concatenate([np.asarray(s, dtype=np.uint8) for s in seqs])
+    else:
+        res = np.zeros(0, dtype=np.uint8)
+    return np.ascontiguousarray(res), offs
+
+
+class EHMM:
+    def __init__(self, hmm_paths, hmm_index=None, nseq=None, device: int = 0):
+        L = lib()
+        check(L.wh_init(int(device)), "wh_init")
+        n = len(hmm_paths)
+        arr = (C.c_char_p * n)(*[str(p).encode() for p in hmm_paths])
+        idx = np.ascontiguousarray(hmm_index if hmm_index is not None else np.arange(n), dtype=np.int32)
+        ns = None if nseq is None else np.ascontiguousarray(nseq, dtype=np.int32)
+        self._h = L.wh_ehmm_load(arr, idx.ctypes.data, None if ns is None else ns.ctypes.data, n)
+        if not self._h:
+            raise WitchHipError("wh_ehmm_load failed: %s" % L.wh_last_error().decode())
+        self.device = int(device)
+        self.paths = list(hmm_paths)
+        self.H = L.wh_ehmm_count(self._h)
+        self.alphabet = L.wh_ehmm_alphabet(self._h)
+        self.M = np.zeros(self.H, dtype=np.int32)
+        self.nseq = np.zeros(self.H, dtype=np.int32)
+        self.index = np.zeros(self.H, dtype=np.int32)
+        check(L.wh_ehmm_info(self._h, self.M.ctypes.data, self.nseq.ctypes.data, self.index.ctypes.data),
+              "wh_ehmm_info")
+        self.pos_of_index = {int(v): i for i, v in enumerate(self.index)}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().wh_ehmm_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ helpers
+    def digitize(self, text: str) -> np.ndarray:
+        out = np.empty(len(text), dtype=np.uint8)
+        bad = lib().wh_digitize(self.alphabet, text.encode(), len(text), out.ctypes.data)
+        if bad != 0:
+            raise ValueError("query contains %d characters outside the %s alphabet" %
+                             (bad, "amino" if self.alphabet == 2 else "nucleic"))
+        return out
+
+    def map_columns(self, h: int) -> np.ndarray:
+        out = np.zeros(int(self.M[h]), dtype=np.int32)
+        check(lib().wh_ehmm_map(self._h, int(h), out.ctypes.data), "wh_ehmm_map")
+        return out
+
+    def set_timing(self, on: bool):
+        check(lib().wh_set_timing(self._h, 1 if on else 0), "wh_set_timing")
+
+    def last_kernel_ms(self, which: int):
+        ms, n = C.c_double(0), C.c_int(0)
+        check(lib().wh_last_kernel_ms(self._h, which, C.byref(ms), C.byref(n)), "wh_last_kernel_ms")
+        return ms.value, n.value
+
+    # ------------------------------------------------------------------ host (numpy) operators
+    def score(self, residues, offsets, want_fwd=False, want_detail=False):
+        residues = np.ascontiguousarray(residues, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        nq = len(offsets) - 1
+        deci = np.zeros((nq, self.H), dtype=np.int32)
+        flags = np.zeros((nq, self.H), dtype=np.uint8)
+        fwd = np.zeros((nq, self.H), dtype=np.float32) if want_fwd else None
+        det = (PairDetail * (nq * self.H))() if want_detail else None
+        check(lib().wh_score(self._h, residues.ctypes.data, offsets.ctypes.data, nq, deci.ctypes.data,
+                             flags.ctypes.data, None if fwd is None else fwd.ctypes.data,
+                             None if det is None else C.addressof(det)), "wh_score")
+        out = [deci, flags]
+        if want_fwd:
+            out.append(fwd)
+        if want_detail:
+            out.append(det)
+        return tuple(out)
+
+    def topk(self, decibits, flags, k: int):
+        decibits = np.ascontiguousarray(decibits, dtype=np.int32)
+        flags = np.ascontiguousarray(flags, dtype=np.uint8)
+        nq = decibits.shape[0]
+        idx = np.full((nq, k), -1, dtype=np.int32)
+        w = np.zeros((nq, k), dtype=np.float64)
+        nk = np.zeros(nq, dtype=np.int32)
+        nu = np.zeros(nq, dtype=np.int32)
+        check(lib().wh_topk(self._h, decibits.ctypes.data, flags.ctypes.data, nq, int(k), idx.ctypes.data,
+                            w.ctypes.data, nk.ctypes.data, nu.ctypes.data), "wh_topk")
+        return idx, w, nk, nu
+
+    def align(self, residues, offsets, pair_q, pair_h):
+        """cols (CSR over the residues of each pair) and col_offsets."""
+        residues = np.ascontiguousarray(residues, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        pair_q = np.ascontiguousarray(pair_q, dtype=np.int64)
+        pair_h = np.ascontiguousarray(pair_h, dtype=np.int32)
+        lens = offsets[pair_q + 1] - offsets[pair_q] if len(pair_q) else np.zeros(0, np.int64)
+        co = np.zeros(len(pair_q) + 1, dtype=np.int64)
+        co[1:] = np.cumsum(lens)
+        cols = np.full(int(co[-1]), -1, dtype=np.int32)
+        if len(pair_q):
+            check(lib().wh_align(self._h, residues.ctypes.data, offsets.ctypes.data, len(offsets) - 1,
+                                 pair_q.ctypes.data, pair_h.ctypes.data, len(pair_q), co.ctypes.data,
+                                 cols.ctypes.data), "wh_align")
+        return cols, co
+
+    # ------------------------------------------------------------------ device (torch) operators
+    @staticmethod
+    def _stream():
+        import torch
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def score_t(self, residues_t, offsets_t, max_len: int, want_fwd=False):
+        import torch
+        nq = offsets_t.numel() - 1
+        dev = residues_t.device
+        deci = torch.empty((nq, self.H), dtype=torch.int32, device=dev)
+        flags = torch.empty((nq, self.H), dtype=torch.uint8, device=dev)
+        fwd = torch.empty((nq, self.H), dtype=torch.float32, device=dev) if want_fwd else None
+        check(lib().wh_score_dev(self._h, residues_t.data_ptr(), offsets_t.data_ptr(), nq, residues_t.numel(),
+                                 int(max_len), deci.data_ptr(), flags.data_ptr(),
+                                 None if fwd is None else fwd.data_ptr(), None, self._stream()), "wh_score_dev")
+        return (deci, flags, fwd) if want_fwd else (deci, flags)
+
+    def topk_t(self, deci_t, flags_t, k: int):
+        import torch
+        nq = deci_t.shape[0]
+        dev = deci_t.device
+        idx = torch.empty((nq, k), dtype=torch.int32, device=dev)
+        w = torch.empty((nq, k), dtype=torch.float64, device=dev)
+        nk = torch.empty(nq, dtype=torch.int32, device=dev)
+        nu = torch.empty(nq, dtype=torch.int32, device=dev)
+        check(lib().wh_topk_dev(self._h, deci_t.data_ptr(), flags_t.data_ptr(), nq, int(k), idx.data_ptr(),
+                                w.data_ptr(), nk.data_ptr(), nu.data_ptr(), self._stream()), "wh_topk_dev")
+        return idx, w, nk, nu
+
+    def align_t(self, residues_t, offsets_t, max_len: int, pair_q_t, pair_h_t, col_offsets_t, total_cols: int):
+        import torch
+        cols = torch.full((int(total_cols),), -1, dtype=torch.int32, device=residues_t.device)
+        npairs = pair_q_t.numel()
+        if npairs:
+            check(lib().wh_align_dev(self._h, residues_t.data_ptr(), offsets_t.data_ptr(), offsets_t.numel() - 1,
+                                     residues_t.numel(), int(max_len), pair_q_t.data_ptr(), pair_h_t.data_ptr(),
+                                     npairs, col_offsets_t.data_ptr(), cols.data_ptr(), self._stream()),
+                  "wh_align_dev")
+        return cols

@@ -77,6 +77,13 @@ def lib():
             raise WitchHipError(
                 "libwitch_hip.so is missing (%s). Build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` or `make -C witch_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+        # PyTorch-ROCm bundles its own HIP runtime; two HIP runtimes in one process cannot
+        # both own the GPU.  Importing torch first makes the loader bind this library to the
+        # runtime torch already loaded (same SONAME) whenever torch is used in the process.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             f = getattr(L, name)      # AttributeError if the library does not export it

@@ -134,6 +134,17 @@ class EHMM:
         import torch
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
+    def label_to_pos_t(self, labels_t):
+        """hmm_index labels (as returned by topk_t) -> model positions 0..H-1, on the device."""
+        import torch
+        lut = getattr(self, "_lut_t", None)
+        if lut is None or lut.device != labels_t.device:
+            lut = torch.full((int(self.index.max()) + 1,), -1, dtype=torch.int32, device=labels_t.device)
+            lut[torch.from_numpy(self.index.astype(np.int64)).to(labels_t.device)] = torch.arange(
+                self.H, dtype=torch.int32, device=labels_t.device)
+            self._lut_t = lut
+        return lut[labels_t.long()].contiguous()
+
     def score_t(self, residues_t, offsets_t, max_len: int, want_fwd=False):
         import torch
         nq = offsets_t.numel() - 1

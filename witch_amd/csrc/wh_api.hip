@@ -231,6 +231,7 @@ int wh_last_kernel_ms(wh_ehmm *e, int which, double *ms, int *launches) {
 
 // ------------------------------------------------------------------------------------ score
 static const size_t kLdsBudget = 160 * 1024 - 512;
+static const size_t kLdsHeader = 16;   // work-item slot in front of the tables (keeps them 16-byte aligned)
 
 static int plan_block(int Q, int K, bool treg, int Lcap, int *waves, int *SP, int *wave_lds, size_t *lds) {
   const int sp = (Lcap + 1 + 3) / 4 * 4;
@@ -239,7 +240,7 @@ static int plan_block(int Q, int K, bool treg, int Lcap, int *waves, int *SP, in
   int w = 8;
   while (w >= 1 && table + (size_t)w * wl * sizeof(float) > kLdsBudget) w--;
   if (w < 1) return WH_ERANGE;
-  *waves = w; *SP = sp; *wave_lds = wl; *lds = table + (size_t)w * wl * sizeof(float);
+  *waves = w; *SP = sp; *wave_lds = wl; *lds = kLdsHeader + table + (size_t)w * wl * sizeof(float);
   return WH_OK;
 }
 
@@ -382,7 +383,7 @@ static int plan_align_block(int Q, int K, int Lcap, int *waves, int *SP, int *wa
   int w = 8;
   while (w >= 1 && table + (size_t)w * wl * sizeof(float) > kLdsBudget) w--;
   if (w < 1) return WH_ERANGE;
-  *waves = w; *SP = sp; *wave_lds = wl; *lds = table + (size_t)w * wl * sizeof(float);
+  *waves = w; *SP = sp; *wave_lds = wl; *lds = kLdsHeader + table + (size_t)w * wl * sizeof(float);
   return WH_OK;
 }
 

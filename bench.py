@@ -122,8 +122,8 @@ def main():
         e = EHMM(synth_ehmm.paths, hmm_index=synth_ehmm.index, nseq=synth_ehmm.nseq, device=local_rank)
         nq_total = len(seqs)
         # contiguous query shards (weak scaling is NOT used: total work is fixed by the config)
-        lo = nq_total * rank // world
-        hi = nq_total * (rank + 1) // world
+        from witch_amd.distributed import shard_range
+        lo, hi = shard_range(nq_total, rank, world)
         res, offs = pack_queries([s.astype(np.uint8) for s in seqs[lo:hi]])
         maxlen = int(np.max(np.diff(offs))) if hi > lo else 1
         res_t = torch.from_numpy(res).cuda()
@@ -131,24 +131,9 @@ def main():
 
         gather = None
         if world > 1:
-            def gather(idx, w, nk, nu):
-                # the path's one exchange step: per-query top-k records to every rank over RCCL
-                shard = torch.tensor([idx.shape[0]], device=idx.device)
-                sizes = [torch.zeros_like(shard) for _ in range(world)]
-                dist.all_gather(sizes, shard)
-                nmax = int(max(int(s.item()) for s in sizes))
-                def pad(t):
-                    if t.shape[0] == nmax:
-                        return t.contiguous()
-                    p = torch.zeros((nmax,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-                    p[:t.shape[0]] = t
-                    return p
-                outs = []
-                for t in (idx, w, nk, nu):
-                    buf = [torch.empty_like(pad(t)) for _ in range(world)]
-                    dist.all_gather(buf, pad(t))
-                    outs.append(torch.cat([b[:int(s.item())] for b, s in zip(buf, sizes)], 0))
-                return tuple(outs)
+            from witch_amd.distributed import gather_topk
+            # the path's one exchange step: per-query top-k records to every rank over RCCL
+            gather = gather_topk
 
         def barrier():
             if world > 1:

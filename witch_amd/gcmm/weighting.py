@@ -1,0 +1,61 @@
+"""writeWeights and friends with the reference's signatures (witch_msa/gcmm/weighting.py)."""
+import numpy as np
+
+from .engine import current_engine
+
+
+def calculateWeights(packed_data, num_hmms=None):
+    """Reference formula (weighting.py:58-74) for ONE query given as
+    (taxon, indexes, bitscores, sizes); used for queries the engine has not seen.
+    w_i = 1 / sum_j 2^((s_j - s_i) + log2(n_j / n_i)); keep the top num_hmms, ties by
+    (-weight, -score, +index)."""
+    taxon, indexes, bitscores, sizes = packed_data
+    assert len(indexes) == len(bitscores) == len(sizes)
+    bits = np.array(bitscores, dtype=np.float64)
+    sz = np.array(sizes, dtype=np.float64)
+    weights = {}
+    for i in range(len(bitscores)):
+        exponents = bits - bits[i] + np.log2(sz / sz[i])
+        weights[indexes[i]] = 1. / np.sum(np.power(2, exponents))
+    k = current_engine().num_hmms if num_hmms is None else num_hmms
+    score_of = dict(zip(indexes, bitscores))
+    kept = sorted(weights.items(), key=lambda t: (-t[1], -score_of[t[0]], t[0]))[:min(k, len(weights))]
+    return {taxon: tuple(kept)}
+
+
+def writeWeights(index_to_hmm, ranked_bitscores, pool=None):
+    """{taxon: ((idx, np.float64 weight), ...)} for every taxon of ranked_bitscores
+    (weighting.py:121-169).  Weights come from the device top-k kernel."""
+    eng = current_engine()
+    out = {}
+    for taxon in ranked_bitscores.keys():
+        row = eng.taxon_row.get(taxon)
+        if row is None:
+            # renamed or foreign taxon: fall back to the formula on the scores handed in
+            scores = ranked_bitscores[taxon]
+            idxs = [x[0] for x in scores]
+            out.update(calculateWeights((taxon, idxs, [x[1] for x in scores],
+                                         [index_to_hmm[i].num_taxa for i in idxs])))
+        else:
+            out[taxon] = eng.weights(row)
+    return out
+
+
+def writeWeightsToLocal(taxon_to_weights, path):
+    """weights.txt: one line per query 'taxon:((idx, w), ...)' (weighting.py:174-179)."""
+    with open(path, 'w') as f:
+        for taxon, weights in taxon_to_weights.items():
+            f.write('{}:{}\n'.format(taxon, tuple((int(i), float(w)) for i, w in weights)))
+
+
+def readWeightsFromLocal(path):
+    """Inverse of writeWeightsToLocal (weighting.py:185-194), without eval()."""
+    import ast
+    out = {}
+    with open(path, 'r') as f:
+        for line in f:
+            if not line.strip():
+                continue
+            taxon, raw = line.split(':', 1)
+            out[taxon] = tuple((int(i), np.float64(w)) for i, w in ast.literal_eval(raw.strip()))
+    return out

@@ -67,6 +67,9 @@ def hot_path_step(e, res_t, off_t, maxlen, k, gather_topk=None):
     if gather_topk is not None:
         idx, w, nk, nu = gather_topk(idx, w, nk, nu)
     out = (idx.cpu(), w.cpu(), nk.cpu(), nu.cpu(), cols.cpu(), co.cpu())
+    hot_path_step.dense_redo = int(((flags & 16) != 0).sum().item())
+    hot_path_step.multidomain = int(((flags & 2) != 0).sum().item())
+    hot_path_step.reported = int(((flags & 1) != 0).sum().item())
     return out, int(pq.numel()), total_cols
 
 
@@ -201,7 +204,9 @@ def main():
                 "data": "synthetic",
                 "config": {"workload": args.workload, "n_queries": nq_total, "n_hmms": H,
                            "query_len": int(round(L)), "model_len_min": int(M.min()), "model_len_max": int(M.max()),
-                           "k": k, "aligned_pairs_per_step": npairs, "sharding": "queries/%d" % world},
+                           "k": k, "aligned_pairs_per_step": npairs, "sharding": "queries/%d" % world,
+                           "pairs_reported_rank0": hot_path_step.reported, "pairs_multidomain_rank0": hot_path_step.multidomain,
+                           "pairs_dense_redo_rank0": hot_path_step.dense_redo},
                 "stage_ms_per_step": {"score": round(kern_ms[0] / args.steps, 3), "topk": round(kern_ms[1] / args.steps, 3),
                                       "align": round(kern_ms[2] / args.steps, 3)},
                 "roofline": roofline,

@@ -56,6 +56,7 @@ extern "C" {
 #define WH_FLAG_MULTI     2   /* a region was multidomain (HMMER's stochastic class)     */
 #define WH_FLAG_OVERRIDE  4   /* reconstruction score overrode the Forward score         */
 #define WH_FLAG_TRUNC     8   /* more envelopes than WH_MAX_ENVELOPES; extra ones dropped */
+#define WH_FLAG_EXACT    16   /* an envelope failed the sparse-spill certificate and was redone dense */
 
 #define WH_MAX_ENVELOPES 8
 

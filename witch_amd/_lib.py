@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libwitch_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 WH_MAX_ENVELOPES = 8
-FLAG_REPORTED, FLAG_MULTI, FLAG_OVERRIDE, FLAG_TRUNC = 1, 2, 4, 8
+FLAG_REPORTED, FLAG_MULTI, FLAG_OVERRIDE, FLAG_TRUNC, FLAG_EXACT = 1, 2, 4, 8, 16
 ALPH_DNA, ALPH_RNA, ALPH_AMINO = 0, 1, 2
 
 

@@ -14,7 +14,7 @@
 
 namespace wh {
 
-enum { AL_PN = 0, AL_B, AL_E, AL_PJ, AL_PC, AL_S, AL_ON, AL_OB, AL_OE, AL_OJ, AL_OC, AL_NARR };
+enum { AL_PN = 0, AL_B, AL_E, AL_PJ, AL_PC, AL_S, AL_ML, AL_MH, AL_ON, AL_OB, AL_OE, AL_OJ, AL_OC, AL_NARR };
 
 __device__ __forceinline__ float gate(float t, float v) { return t > 0.f ? v : 0.f; }
 
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(512) void align_kernel(AlignArgs a) {
         T.load(fwG, trL, lane);
         const ScanC sc = scan_prepare(lane_product<Q, TREG>(T, FW_D2));
         // forward_sweep uses spec slots 0..5 = N,B,E,J,C,S with stride SP (AL_PN..AL_S coincide)
-        forward_sweep<Q, TREG, true>(T, sc, emL, emG, a.K, seq, L, cu, spec, SP, slabA, lane, xC_L, ef_L);
+        forward_sweep<Q, TREG, true>(T, sc, emL, emG, a.K, seq, L, cu, spec, SP, slabA, -1.0f, lane, xC_L, ef_L);   // dense
       }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       if (!(xC_L > 0.f)) continue;   // no alignment has non-zero probability: all residues stay -1

@@ -235,7 +235,7 @@ static const size_t kLdsHeader = 16;   // work-item slot in front of the tables 
 
 static int plan_block(int Q, int K, bool treg, int Lcap, int *waves, int *SP, int *wave_lds, size_t *lds) {
   const int sp = (Lcap + 1 + 3) / 4 * 4;
-  const int wl = 6 * sp + 32 + 3 * WH_MAX_ENVELOPES + (Lcap + 3) / 4 + 4;
+  const int wl = 8 * sp + 32 + 3 * WH_MAX_ENVELOPES + (Lcap + 3) / 4 + 4;
   const size_t table = (size_t)(K + (treg ? 0 : 16)) * Q * kWave * sizeof(float);
   int w = 8;
   while (w >= 1 && table + (size_t)w * wl * sizeof(float) > kLdsBudget) w--;
@@ -378,7 +378,7 @@ int wh_topk(wh_ehmm *e, const int32_t *decibits, const uint8_t *flags, int64_t n
 // ------------------------------------------------------------------------------------ align
 static int plan_align_block(int Q, int K, int Lcap, int *waves, int *SP, int *wave_lds, size_t *lds) {
   const int sp = (Lcap + 1 + 3) / 4 * 4;
-  const int wl = 11 * sp + (Lcap + 3) / 4 + 4;
+  const int wl = 13 * sp + (Lcap + 3) / 4 + 4;
   const size_t table = (size_t)(K + 16) * Q * kWave * sizeof(float);
   int w = 8;
   while (w >= 1 && table + (size_t)w * wl * sizeof(float) > kLdsBudget) w--;

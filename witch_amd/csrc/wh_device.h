@@ -192,18 +192,23 @@ __device__ __forceinline__ LenCfg len_config(int Lcfg, bool multihit) {
 }
 
 // Per-wave LDS block: six float arrays of SP entries (special states per row) + small tables.
-enum { SP_N = 0, SP_B, SP_E, SP_J, SP_C, SP_S };   // SP_S: cumulative scale exponent (int bits)
+enum { SP_N = 0, SP_B, SP_E, SP_J, SP_C, SP_S, SP_ML, SP_MH, SP_NARR };   // SP_S: cumulative scale exponent (int bits);
+                                                                  // SP_ML/MH: 64-bit mask of lanes whose row block was stored
 
 constexpr float kRescaleHi = 1048576.0f;   // 2^20
 
 // ------------------------------------------------------------------ Forward sweep
-// Fills spec[SP_*][0..L]; with STORE also writes the M and I rows (1..L) to <Fs>
-// ([row][2][Q/4][64][4] floats, forward node order).  Returns C(L) and its scale exponent.
+// Fills spec[SP_*][0..L]; with STORE also writes the M and I rows (1..L) to <Fs>:
+// [row][2][Q/4][64 lanes][4] floats (forward node order; a wavefront's store instruction covers
+// one contiguous 1 KiB line).  A lane's cells are written only when one of them exceeds
+// keep_scale * E(row) (exec-masked stores: adjacent kept lanes still form contiguous segments);
+// the 64-bit mask of kept lanes goes to spec[SP_ML/SP_MH].  keep_scale < 0 stores everything.  Returns C(L) and its
+// scale exponent.
 template <int Q, bool TREG, bool STORE>
 __device__ __forceinline__ void forward_sweep(const TransTab<Q, TREG> &T, const ScanC &sc, const float *emL,
                                               const float *emG, int K, const uint8_t *seq, int L, LenCfg cfg,
-                                              float *spec, int SP, float *Fs, int lane, float &xC_out,
-                                              int &ef_out) {
+                                              float *spec, int SP, float *Fs, float keep_scale, int lane,
+                                              float &xC_out, int &ef_out) {
   float Mp[Q], Ip[Q], Dp[Q];
 #pragma unroll
   for (int q = 0; q < Q; q++) { Mp[q] = 0.f; Ip[q] = 0.f; Dp[q] = 0.f; }
@@ -285,12 +290,23 @@ __device__ __forceinline__ void forward_sweep(const TransTab<Q, TREG> &T, const 
       reinterpret_cast<int *>(spec)[SP_S * SP + i] = ef;
     }
     if (STORE) {
-      float4 *row = reinterpret_cast<float4 *>(Fs) + (size_t)i * (2 * (Q / 4) * kWave) + lane;
+      float lmax = 0.f;
 #pragma unroll
-      for (int q4 = 0; q4 < Q / 4; q4++) {
-        // streamed once and re-read once by other lanes of this wave: keep it out of L1
-        nt_store4(row + q4 * kWave, Mp[4 * q4], Mp[4 * q4 + 1], Mp[4 * q4 + 2], Mp[4 * q4 + 3]);
-        nt_store4(row + (Q / 4 + q4) * kWave, Ip[4 * q4], Ip[4 * q4 + 1], Ip[4 * q4 + 2], Ip[4 * q4 + 3]);
+      for (int q = 0; q < Q; q += 2) lmax = fmaxf(lmax, fmaxf(fmaxf(Mp[q], Mp[q + 1]), fmaxf(Ip[q], Ip[q + 1])));
+      const bool keep = lmax > keep_scale * xE;
+      const unsigned long long mask = __ballot(keep);
+      if (lane == 0) {
+        reinterpret_cast<unsigned *>(spec)[SP_ML * SP + i] = (unsigned)(mask & 0xFFFFFFFFull);
+        reinterpret_cast<unsigned *>(spec)[SP_MH * SP + i] = (unsigned)(mask >> 32);
+      }
+      if (keep) {
+        float4 *row = reinterpret_cast<float4 *>(Fs) + (size_t)i * (2 * (Q / 4) * kWave) + lane;
+#pragma unroll
+        for (int q4 = 0; q4 < Q / 4; q4++) {
+          // streamed once and re-read once by another lane of this wave: keep it out of L1
+          nt_store4(row + q4 * kWave, Mp[4 * q4], Mp[4 * q4 + 1], Mp[4 * q4 + 2], Mp[4 * q4 + 3]);
+          nt_store4(row + (Q / 4 + q4) * kWave, Ip[4 * q4], Ip[4 * q4 + 1], Ip[4 * q4 + 2], Ip[4 * q4 + 3]);
+        }
       }
     }
   }

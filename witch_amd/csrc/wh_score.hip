@@ -24,6 +24,11 @@ __device__ __forceinline__ float flogsum0(float b) {
   return mx + (float)log(1.0 + exp((double)-idx / 1000.0));
 }
 
+// lanes whose Forward cells are all below kKeepScale * E(row) are not spilled (attempt 0)
+constexpr float kKeepScale = 9.094947e-13f;   // 2^-40
+// tolerated |Ld - posterior mass| / Ld of the certificate (float32 accumulation noise is ~1e-6)
+constexpr float kMassTol = 2e-5f;
+
 template <int Q, bool TREG>
 __global__ __launch_bounds__(512) void score_kernel(ScoreArgs a) {
   // all LDS in ONE 16-byte aligned dynamic array: a static __shared__ object in front of it
@@ -36,8 +41,8 @@ __global__ __launch_bounds__(512) void score_kernel(ScoreArgs a) {
   float *emL = smem;
   float *trL = smem + (size_t)a.K * TBL;                                   // !TREG: fw[8] then bw[8]
   float *wbase = trL + (TREG ? 0 : 16 * TBL) + (size_t)wave * a.wave_lds;  // per-wave block
-  float *spec = wbase;                                                     // 6 * SP floats
-  float *n2tab = wbase + 6 * a.SP;                                         // 32 floats
+  float *spec = wbase;                                                     // SP_NARR * SP floats
+  float *n2tab = wbase + SP_NARR * a.SP;                                         // 32 floats
   int *regs = reinterpret_cast<int *>(n2tab + 32);                         // 3 * WH_MAX_ENVELOPES ints
   uint8_t *seq = reinterpret_cast<uint8_t *>(regs + 3 * WH_MAX_ENVELOPES);
   float *Fs = a.scratch + ((size_t)blockIdx.x * nwaves + wave) * a.scratch_stride;
@@ -96,7 +101,7 @@ __global__ __launch_bounds__(512) void score_kernel(ScoreArgs a) {
           TransTab<Q, TREG> T;
           T.load(fwG, trL, lane);
           const ScanC sc = scan_prepare(lane_product<Q, TREG>(T, FW_D2));
-          forward_sweep<Q, TREG, false>(T, sc, emL, emG, a.K, seq, L, cm, spec, SP, nullptr, lane, xC_L, ef_L);
+          forward_sweep<Q, TREG, false>(T, sc, emL, emG, a.K, seq, L, cm, spec, SP, nullptr, 0.f, lane, xC_L, ef_L);
         }
         const double fwd_nats = (double)ef_L * 0.69314718055994529 + log((double)(xC_L * cm.move));
         const float fwdsc = (float)fwd_nats;
@@ -223,18 +228,26 @@ __global__ __launch_bounds__(512) void score_kernel(ScoreArgs a) {
               const int ri = regs[2 * e], rj = regs[2 * e + 1];
               const int Ld = rj - ri + 1;
               const uint8_t *eseq = seq + (ri - 1);
-              float xC_e; int ef_e;
-              {
-                TransTab<Q, TREG> T;
-                T.load(fwG, trL, lane);
-                const ScanC sc = scan_prepare(lane_product<Q, TREG>(T, FW_D2));
-                forward_sweep<Q, TREG, true>(T, sc, emL, emG, a.K, eseq, Ld, cu, spec, SP, Fs, lane, xC_e, ef_e);
-              }
-              // the rows were written by other lanes of this wave: order the stores before the loads
-              __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-              const float envsc = (float)((double)ef_e * 0.69314718055994529 + log((double)(xC_e * cu.move)));
-              float domcorr = 0.f;
-              if (xC_e > 0.f) {
+              float envsc = -INFINITY, domcorr = 0.f;
+              // Attempt 0 spills only the lanes whose Forward cells exceed 2^-40 of the row total;
+              // the posterior mass that reached the accumulators must then add up to Ld residues
+              // (every residue is emitted by exactly one state).  If the certificate fails the
+              // envelope is redone with every line stored.
+#pragma unroll 1
+              for (int attempt = 0; attempt < 2; attempt++) {
+                const float keep_scale = attempt == 0 ? kKeepScale : -1.0f;
+                float xC_e; int ef_e;
+                {
+                  TransTab<Q, TREG> T;
+                  T.load(fwG, trL, lane);
+                  const ScanC sc = scan_prepare(lane_product<Q, TREG>(T, FW_D2));
+                  forward_sweep<Q, TREG, true>(T, sc, emL, emG, a.K, eseq, Ld, cu, spec, SP, Fs, keep_scale, lane, xC_e, ef_e);
+                }
+                // the rows were written by other lanes of this wave: order the stores before the loads
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                envsc = (float)((double)ef_e * 0.69314718055994529 + log((double)(xC_e * cu.move)));
+                domcorr = 0.f;
+                if (!(xC_e > 0.f)) break;
                 const float invZe = 1.0f / (xC_e * cu.move);
                 TransTab<Q, TREG> T;
                 T.load(bwG, trL + 8 * TBL, lane);
@@ -245,17 +258,25 @@ __global__ __launch_bounds__(512) void score_kernel(ScoreArgs a) {
                 float xC = cu.move, xJ = 0.f, xN = 0.f, xB = 0.f, xfac = 0.f;
                 int eb = 0;
                 const int *specI = reinterpret_cast<const int *>(spec);
+                const unsigned *specU = reinterpret_cast<const unsigned *>(spec);
+                const int src = kWave - 1 - lane;   // the forward-order lane that owns my (reversed) cells
 #pragma unroll 1
                 for (int i = Ld; i >= 1; i--) {
                   asm volatile("" ::: "memory");
                   // issue the loads of Forward row i early; they are consumed after the cell update
-                  const float4 *row = reinterpret_cast<const float4 *>(Fs) + (size_t)i * (2 * (Q / 4) * kWave) +
-                                      (kWave - 1 - lane);
+                  const unsigned mword = src < 32 ? specU[SP_ML * SP + i] : specU[SP_MH * SP + i];
+                  const bool have = (mword >> (src & 31)) & 1u;
+                  const float4 *row = reinterpret_cast<const float4 *>(Fs) + (size_t)i * (2 * (Q / 4) * kWave) + src;
                   float4 fm4[Q / 4], fi4[Q / 4];
+                  if (have) {
 #pragma unroll
-                  for (int p4 = 0; p4 < Q / 4; p4++) {
-                    fm4[p4] = nt_load4(row + (Q / 4 - 1 - p4) * kWave);
-                    fi4[p4] = nt_load4(row + (Q / 4 + Q / 4 - 1 - p4) * kWave);
+                    for (int p4 = 0; p4 < Q / 4; p4++) {
+                      fm4[p4] = nt_load4(row + (Q / 4 - 1 - p4) * kWave);
+                      fi4[p4] = nt_load4(row + (Q / 4 + Q / 4 - 1 - p4) * kWave);
+                    }
+                  } else {
+#pragma unroll
+                    for (int p4 = 0; p4 < Q / 4; p4++) { fm4[p4] = make_float4(0.f, 0.f, 0.f, 0.f); fi4[p4] = fm4[p4]; }
                   }
                   if (i < Ld) {
                     float od[Q];
@@ -308,10 +329,15 @@ __global__ __launch_bounds__(512) void score_kernel(ScoreArgs a) {
                 }
                 // null2[a] = sum_k fM_k o_k(a) + sum_k fI_k + f_NJC, all / Ld
                 const float norm = 1.0f / (float)Ld;
-                float si = 0.f;
+                float si = 0.f, sm = 0.f;
 #pragma unroll
-                for (int p = 0; p < Q; p++) si += fI[p];
+                for (int p = 0; p < Q; p++) { si += fI[p]; sm += fM[p]; }
                 si = wave_sum(si);
+                sm = wave_sum(sm);
+                // certificate: posterior mass over all emitting states = number of residues
+                const float deficit = fabsf((float)Ld - (sm + si + xfac));
+                if (attempt == 0 && !(deficit <= kMassTol * (float)Ld)) continue;
+                if (attempt == 1) flags |= WH_FLAG_EXACT;
                 float mine = 1.0f;
                 for (int x = 0; x < a.K; x++) {
                   float od[Q];
@@ -338,6 +364,7 @@ __global__ __launch_bounds__(512) void score_kernel(ScoreArgs a) {
                 float dc = 0.f;
                 for (int t = lane; t < Ld; t += kWave) dc += n2tab[eseq[t]];
                 domcorr = wave_sum(dc);
+                break;
               }
               seqbias_sum += domcorr;
               if (envsc - domcorr > 0.0f) { sum_score += envsc; Ld_tot += Ld; sb2 += domcorr; }

@@ -233,12 +233,16 @@ int wh_last_kernel_ms(wh_ehmm *e, int which, double *ms, int *launches) {
 static const size_t kLdsBudget = 160 * 1024 - 512;
 static const size_t kLdsHeader = 16;   // work-item slot in front of the tables (keeps them 16-byte aligned)
 
+// LDS plan of score_kernel2: tables (K emission rows + 16 transition arrays) + per wave two
+// problem blocks (special-state arrays, null2 table, region list, residues).
 static int plan_block(int Q, int K, bool treg, int Lcap, int *waves, int *SP, int *wave_lds, size_t *lds) {
+  (void)treg;
   const int sp = (Lcap + 1 + 3) / 4 * 4;
-  const int wl = 8 * sp + 32 + 3 * WH_MAX_ENVELOPES + (Lcap + 3) / 4 + 4;
-  const size_t table = (size_t)(K + (treg ? 0 : 16)) * Q * kWave * sizeof(float);
+  const int prob = 8 * sp + 32 + 3 * WH_MAX_ENVELOPES + (Lcap + 3) / 4 + 4;
+  const int wl = 2 * prob;
+  const size_t table = (size_t)(K + 16) * Q * kWave * sizeof(float);
   int w = 8;
-  while (w >= 1 && table + (size_t)w * wl * sizeof(float) > kLdsBudget) w--;
+  while (w >= 1 && kLdsHeader + table + (size_t)w * wl * sizeof(float) > kLdsBudget) w--;
   if (w < 1) return WH_ERANGE;
   *waves = w; *SP = sp; *wave_lds = wl; *lds = kLdsHeader + table + (size_t)w * wl * sizeof(float);
   return WH_OK;
@@ -282,14 +286,14 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       a.counter = (int *)e->d_counter.p + launches;
       a.Lcap = std::max(max_len, 1); a.SP = SP; a.wave_lds = wave_lds;
       const int blocks = std::min(a.n_items, e->cu_count * std::max(1, 8 / waves));
-      a.scratch_stride = (size_t)(a.Lcap + 1) * 2 * Q * kWave;
+      a.scratch_stride = 2 * (size_t)(a.Lcap + 1) * 2 * Q * kWave;   // two Forward slabs per wave
       if (e->d_scratch.ensure((size_t)blocks * waves * a.scratch_stride * sizeof(float))) return WH_ENOMEM;
       a.scratch = (float *)e->d_scratch.p;
       a.decibits = d_decibits; a.flags = d_flags; a.fwd_bits = d_fwd_bits; a.detail = d_detail;
       a.H = H; a.K = e->K; a.Kp = e->Kp;
       memcpy(a.degen, e->degen, sizeof a.degen);
       HIPCHK(hipMemsetAsync(a.counter, 0, sizeof(int), s));
-      hipError_t err = launch_score(Q, a, blocks, waves * kWave, lds, s);
+      hipError_t err = launch_score2(Q, a, blocks, waves * kWave, lds, s);
       if (err != hipSuccess) { set_error("score kernel launch (Q=%d) failed: %s", Q, hipGetErrorString(err)); return WH_EHIP; }
       launches++;
       if (launches >= 60) break;

@@ -33,6 +33,7 @@ struct ScoreArgs {
 };
 
 hipError_t launch_score(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
+hipError_t launch_score2(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
 
 struct TopkArgs {
   const int32_t *decibits;

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <array>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -59,7 +60,7 @@ struct wh_ehmm {
   DevBuf d_hmms, d_tables, d_nseq, d_index, d_lists, d_counter, d_scratch;
   // staging for the host-pointer entry points
   DevBuf s_res, s_off, s_deci, s_flags, s_fwd, s_det, s_idx, s_w, s_nk, s_nu, s_pq, s_ph, s_co, s_cols, s_pos;
-  DevBuf d_order, d_items;
+  DevBuf d_order, d_items, d_recs;
   uint32_t degen[32];
   bool timing = false;
   KernelTimer timers[3];
@@ -108,7 +109,7 @@ void wh_ehmm_free(wh_ehmm *e) {
   if (!e) return;
   for (DevBuf *b : {&e->d_hmms, &e->d_tables, &e->d_nseq, &e->d_index, &e->d_lists, &e->d_counter, &e->d_scratch,
                     &e->s_res, &e->s_off, &e->s_deci, &e->s_flags, &e->s_fwd, &e->s_det, &e->s_idx, &e->s_w,
-                    &e->s_nk, &e->s_nu, &e->s_pq, &e->s_ph, &e->s_co, &e->s_cols, &e->s_pos, &e->d_order, &e->d_items})
+                    &e->s_nk, &e->s_nu, &e->s_pq, &e->s_ph, &e->s_co, &e->s_cols, &e->s_pos, &e->d_order, &e->d_items, &e->d_recs})
     b->release();
   for (auto &t : e->timers) {
     if (t.e0) (void)hipEventDestroy(t.e0);
@@ -242,6 +243,19 @@ static int plan_block(int Q, int K, bool treg, int Lcap, int *waves, int *SP, in
   const int wl = 2 * prob;
   const size_t table = (size_t)(K + 16) * Q * kWave * sizeof(float);
   int w = 8;
+  if (const char *ev = getenv("WH_MAX_WAVES")) w = std::max(1, std::min(16, atoi(ev)));   // tuning knob
+  while (w >= 1 && kLdsHeader + table + (size_t)w * wl * sizeof(float) > kLdsBudget) w--;
+  if (w < 1) return WH_ERANGE;
+  *waves = w; *SP = sp; *wave_lds = wl; *lds = kLdsHeader + table + (size_t)w * wl * sizeof(float);
+  return WH_OK;
+}
+
+static int plan_block1(int Q, int K, int Lcap, int wmax, int *waves, int *SP, int *wave_lds, size_t *lds) {
+  const int sp = (Lcap + 1 + 3) / 4 * 4;
+  const int wl = 8 * sp + 32 + 3 * WH_MAX_ENVELOPES + (Lcap + 3) / 4 + 4;
+  const size_t table = (size_t)(K + 16) * Q * kWave * sizeof(float);
+  int w = wmax;
+  if (const char *ev = getenv("WH_MAX_WAVES")) w = std::max(1, std::min(wmax, atoi(ev)));
   while (w >= 1 && kLdsHeader + table + (size_t)w * wl * sizeof(float) > kLdsBudget) w--;
   if (w < 1) return WH_ERANGE;
   *waves = w; *SP = sp; *wave_lds = wl; *lds = kLdsHeader + table + (size_t)w * wl * sizeof(float);
@@ -268,7 +282,49 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       const bool treg = false;
       int waves, SP, wave_lds;
       size_t lds;
-      if (plan_block(Q, e->K, treg, std::max(max_len, 1), &waves, &SP, &wave_lds, &lds) != WH_OK) {
+      const char *kenv = getenv("WH_SCORE_KERNEL");
+      const int kver = kenv ? atoi(kenv) : 1;    // 1 fused single (default, fastest measured), 2 fused packed pair, 3 split
+      if (kver == 3) {
+        // split: phase A (Forward/Backward parsers + regions) then phase B (envelopes + assembly)
+        const size_t np = (size_t)nq * H;
+        if (e->d_recs.ensure(np * sizeof(PairRec))) return WH_ENOMEM;
+        for (int phase = 1; phase <= 2; phase++) {
+          if (plan_block1(Q, e->K, std::max(max_len, 1), phase == 1 ? 16 : 12, &waves, &SP, &wave_lds, &lds) != WH_OK) {
+            set_error("query length %d with model class Q=%d does not fit in LDS", max_len, Q);
+            return WH_ERANGE;
+          }
+          ScoreArgs a;
+          memset(&a, 0, sizeof a);
+          a.hmms = (const DevHMM *)e->d_hmms.p;
+          a.tables = (const float *)e->d_tables.p;
+          a.hmm_list = (const int32_t *)e->d_lists.p + list_off;
+          a.n_list = (int)kv.second.size();
+          a.residues = d_residues; a.offsets = d_offsets; a.nq = nq;
+          a.QB = waves * 4;
+          a.n_qblocks = (int)((nq + a.QB - 1) / a.QB);
+          a.n_items = a.n_list * a.n_qblocks;
+          a.counter = (int *)e->d_counter.p + launches;
+          a.Lcap = std::max(max_len, 1); a.SP = SP; a.wave_lds = wave_lds;
+          const int blocks = std::min(a.n_items, e->cu_count);
+          a.scratch_stride = (size_t)(a.Lcap + 1) * 2 * Q * kWave;
+          if (phase == 2 && e->d_scratch.ensure((size_t)blocks * waves * a.scratch_stride * sizeof(float))) return WH_ENOMEM;
+          a.scratch = (float *)e->d_scratch.p;
+          a.decibits = d_decibits; a.flags = d_flags; a.fwd_bits = d_fwd_bits; a.detail = d_detail;
+          a.recs = (PairRec *)e->d_recs.p;
+          a.H = H; a.K = e->K; a.Kp = e->Kp;
+          memcpy(a.degen, e->degen, sizeof a.degen);
+          HIPCHK(hipMemsetAsync(a.counter, 0, sizeof(int), s));
+          hipError_t err = launch_score(Q, phase, a, blocks, waves * kWave, lds, s);
+          if (err != hipSuccess) { set_error("score kernel launch (Q=%d, phase %d) failed: %s", Q, phase, hipGetErrorString(err)); return WH_EHIP; }
+          launches++;
+        }
+        list_off += (int)kv.second.size();
+        if (launches >= 60) break;
+        continue;
+      }
+      const bool use1 = kver == 1;
+      if ((use1 ? plan_block1(Q, e->K, std::max(max_len, 1), 8, &waves, &SP, &wave_lds, &lds)
+                : plan_block(Q, e->K, treg, std::max(max_len, 1), &waves, &SP, &wave_lds, &lds)) != WH_OK) {
         set_error("query length %d with model class Q=%d does not fit in LDS", max_len, Q);
         return WH_ERANGE;
       }
@@ -293,7 +349,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       a.H = H; a.K = e->K; a.Kp = e->Kp;
       memcpy(a.degen, e->degen, sizeof a.degen);
       HIPCHK(hipMemsetAsync(a.counter, 0, sizeof(int), s));
-      hipError_t err = launch_score2(Q, a, blocks, waves * kWave, lds, s);
+      hipError_t err = use1 ? launch_score(Q, 0, a, blocks, waves * kWave, lds, s) : launch_score2(Q, a, blocks, waves * kWave, lds, s);
       if (err != hipSuccess) { set_error("score kernel launch (Q=%d) failed: %s", Q, hipGetErrorString(err)); return WH_EHIP; }
       launches++;
       if (launches >= 60) break;

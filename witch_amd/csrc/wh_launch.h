@@ -6,6 +6,14 @@
 
 namespace wh {
 
+// Hand-off between the two halves of the split scoring kernel (one record per pair).
+struct PairRec {
+  float fwdsc, nullsc, fwd_bits;
+  int32_t nenv, flags;
+  int16_t regs[2 * WH_MAX_ENVELOPES];
+  int32_t pad[3];
+};
+
 struct ScoreArgs {
   const DevHMM *hmms;          // all models of the eHMM
   const float *tables;         // table buffer (fw / bw / em arrays of every model)
@@ -27,12 +35,13 @@ struct ScoreArgs {
   uint8_t *flags;
   float *fwd_bits;
   wh_pair_detail *detail;
+  PairRec *recs;               // split mode only
   int H;
   int K, Kp;
   uint32_t degen[32];
 };
 
-hipError_t launch_score(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
+hipError_t launch_score(int Q, int phase, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
 hipError_t launch_score2(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
 
 struct TopkArgs {

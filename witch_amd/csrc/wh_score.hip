@@ -16,7 +16,7 @@
 namespace wh {
 
 // float32 table value of p7_FLogsum (A.6): table[i] = log(1 + exp(-i/1000)), 16000 entries
-__device__ __forceinline__ float flogsum0(float b) {
+__device__ __forceinline__ float flogsum0_v1(float b) {
   // FLogsum(0, b)
   const float mx = b > 0.f ? b : 0.f, mn = b > 0.f ? 0.f : b;
   if (mn == -INFINITY || (mx - mn) >= 15.7f) return mx;
@@ -25,12 +25,24 @@ __device__ __forceinline__ float flogsum0(float b) {
 }
 
 // lanes whose Forward cells are all below kKeepScale * E(row) are not spilled (attempt 0)
-constexpr float kKeepScale = 9.094947e-13f;   // 2^-40
+constexpr float kKeepScale1 = 9.094947e-13f;   // 2^-40
 // tolerated |Ld - posterior mass| / Ld of the certificate (float32 accumulation noise is ~1e-6)
-constexpr float kMassTol = 2e-5f;
+constexpr float kMassTol1 = 2e-5f;
 
-template <int Q, bool TREG>
-__global__ __launch_bounds__(512) void score_kernel(ScoreArgs a) {
+#ifndef WH_SCORE1_THREADS
+#define WH_SCORE1_THREADS 512
+#endif
+#ifndef WH_SCOREA_THREADS
+#define WH_SCOREA_THREADS 1024
+#endif
+#ifndef WH_SCOREB_THREADS
+#define WH_SCOREB_THREADS 768
+#endif
+// PHASE 0: everything in one launch.  PHASE 1: P1 + P2 + region scan, result to a PairRec.
+// PHASE 2: envelopes (P3/P4) + score assembly from the PairRec.  Splitting gives each half its
+// own register allocation (the fused kernel spills) and its own occupancy.
+template <int Q, bool TREG, int PHASE>
+__global__ __launch_bounds__(PHASE == 1 ? WH_SCOREA_THREADS : (PHASE == 2 ? WH_SCOREB_THREADS : WH_SCORE1_THREADS)) void score_kernel(ScoreArgs a) {
   // all LDS in ONE 16-byte aligned dynamic array: a static __shared__ object in front of it
   // would shift the base by 4 bytes and split every ds_read_b128 (measured: 13x LDS time)
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
@@ -83,7 +95,7 @@ __global__ __launch_bounds__(512) void score_kernel(ScoreArgs a) {
       int flags = 0, decibits = 0;
       float fwd_bits_out = -INFINITY;
       wh_pair_detail *dp = (a.detail && lane == 0) ? a.detail + out : nullptr;
-      if (dp) {
+      if (dp && PHASE != 2) {
         dp->fwd_bits = -INFINITY; dp->seq_score = 0.f; dp->pre_score = 0.f; dp->seqbias_nats = 0.f;
         dp->nregions = 0; dp->nenv = 0;
       }
@@ -94,9 +106,14 @@ __global__ __launch_bounds__(512) void score_kernel(ScoreArgs a) {
         }
         __builtin_amdgcn_wave_barrier();
 
+        float fwdsc = 0.f, nullsc = 0.f, invZ = 0.f;
+        int ef_L = 0, nreg = 0, nenv = 0;
+        bool ok = false;
+        PairRec *rec = a.recs ? a.recs + out : nullptr;
+        if constexpr (PHASE != 2) {
         // ---------------- P1: multihit Forward
         const LenCfg cm = len_config(L, true);
-        float xC_L; int ef_L;
+        float xC_L;
         {
           TransTab<Q, TREG> T;
           T.load(fwG, trL, lane);
@@ -104,16 +121,16 @@ __global__ __launch_bounds__(512) void score_kernel(ScoreArgs a) {
           forward_sweep<Q, TREG, false>(T, sc, emL, emG, a.K, seq, L, cm, spec, SP, nullptr, 0.f, lane, xC_L, ef_L);
         }
         const double fwd_nats = (double)ef_L * 0.69314718055994529 + log((double)(xC_L * cm.move));
-        const float fwdsc = (float)fwd_nats;
+        fwdsc = (float)fwd_nats;
         // A.3 null1 in float32 as p7_bg_SetLength / p7_bg_NullOne do
         const float p1 = (float)L / (float)(L + 1);
-        const float nullsc = (float)((double)(float)L * log((double)p1) + log(1.0 - (double)p1));
+        nullsc = (float)((double)(float)L * log((double)p1) + log(1.0 - (double)p1));
         fwd_bits_out = (float)((fwd_nats - (double)nullsc) / 0.69314718055994529);
         if (dp) dp->fwd_bits = fwd_bits_out;
-
-        if (xC_L > 0.f && isfinite(fwdsc)) {
+        ok = xC_L > 0.f && isfinite(fwdsc);
+        invZ = ok ? 1.0f / (xC_L * cm.move) : 0.f;
+        if (ok) {
           // ---------------- P2: multihit Backward + domain decoding
-          const float invZ = 1.0f / (xC_L * cm.move);
           {
             TransTab<Q, TREG> T;
             T.load(bwG, trL + 8 * TBL, lane);
@@ -177,7 +194,6 @@ __global__ __launch_bounds__(512) void score_kernel(ScoreArgs a) {
 
           // ---------------- region scan (A.4), uniform over the wave
           const float rt1 = 0.25f, rt2 = 0.10f, rt3 = 0.20f;
-          int nreg = 0, nenv = 0;
           {
             float btot = 0.f, etot = 0.f;
             int i0 = -1;
@@ -218,8 +234,23 @@ __global__ __launch_bounds__(512) void score_kernel(ScoreArgs a) {
             }
           }
           if (dp) { dp->nregions = nreg; dp->nenv = nenv; }
-
-          if (nenv > 0) {
+        }   // ok (P2 + region scan)
+        }   // PHASE != 2
+        if constexpr (PHASE == 1) {
+          if (lane == 0) {
+            rec->fwdsc = fwdsc; rec->nullsc = nullsc; rec->fwd_bits = fwd_bits_out;
+            rec->nenv = ok ? nenv : 0; rec->flags = flags;
+            for (int t = 0; t < 2 * nenv && t < 2 * WH_MAX_ENVELOPES; t++) rec->regs[t] = (int16_t)regs[t];
+          }
+        }
+        if constexpr (PHASE == 2) {
+          fwdsc = rec->fwdsc; nullsc = rec->nullsc; fwd_bits_out = rec->fwd_bits;
+          nenv = rec->nenv; flags = rec->flags; ok = nenv > 0;
+          if (lane < 2 * nenv) regs[lane] = rec->regs[lane];
+          __builtin_amdgcn_wave_barrier();
+        }
+        if constexpr (PHASE != 1) {
+          if (ok && nenv > 0) {
             // ---------------- envelopes: unihit Forward/Backward, null2 by expectation (A.5)
             const LenCfg cu = len_config(L, false);
             float seqbias_sum = 0.f, sum_score = 0.f, sb2 = 0.f;
@@ -235,7 +266,7 @@ __global__ __launch_bounds__(512) void score_kernel(ScoreArgs a) {
               // envelope is redone with every line stored.
 #pragma unroll 1
               for (int attempt = 0; attempt < 2; attempt++) {
-                const float keep_scale = attempt == 0 ? kKeepScale : -1.0f;
+                const float keep_scale = attempt == 0 ? kKeepScale1 : -1.0f;
                 float xC_e; int ef_e;
                 {
                   TransTab<Q, TREG> T;
@@ -336,7 +367,7 @@ __global__ __launch_bounds__(512) void score_kernel(ScoreArgs a) {
                 sm = wave_sum(sm);
                 // certificate: posterior mass over all emitting states = number of residues
                 const float deficit = fabsf((float)Ld - (sm + si + xfac));
-                if (attempt == 0 && !(deficit <= kMassTol * (float)Ld)) continue;
+                if (attempt == 0 && !(deficit <= kMassTol1 * (float)Ld)) continue;
                 if (attempt == 1) flags |= WH_FLAG_EXACT;
                 float mine = 1.0f;
                 for (int x = 0; x < a.K; x++) {
@@ -373,10 +404,10 @@ __global__ __launch_bounds__(512) void score_kernel(ScoreArgs a) {
             // ---------------- A.6 score assembly (float32 where HMMER is float32)
             const double LOG2 = 0.69314718055994529;
             const float lomega = (float)log(1.0 / 256.0);
-            const float seqbias = flogsum0(lomega + seqbias_sum);
+            const float seqbias = flogsum0_v1(lomega + seqbias_sum);
             float pre_score = (float)(((double)fwdsc - (double)nullsc) / LOG2);
             float seq_score = (float)(((double)fwdsc - (double)(nullsc + seqbias)) / LOG2);
-            sb2 = flogsum0(lomega + sb2);
+            sb2 = flogsum0_v1(lomega + sb2);
             sum_score += (float)((double)(L - Ld_tot) * log((double)((float)L / (float)(L + 3))));
             const float pre2 = (float)(((double)sum_score - (double)nullsc) / LOG2);
             sum_score = (float)(((double)sum_score - (double)(nullsc + sb2)) / LOG2);
@@ -385,9 +416,9 @@ __global__ __launch_bounds__(512) void score_kernel(ScoreArgs a) {
             flags |= WH_FLAG_REPORTED;
             if (dp) { dp->seq_score = seq_score; dp->pre_score = pre_score; dp->seqbias_nats = seqbias; }
           }
-        }
+        }   // PHASE != 1
       }
-      if (lane == 0) {
+      if (PHASE != 1 && lane == 0) {
         a.decibits[out] = decibits;
         a.flags[out] = (uint8_t)flags;
         if (a.fwd_bits) a.fwd_bits[out] = fwd_bits_out;
@@ -397,25 +428,32 @@ __global__ __launch_bounds__(512) void score_kernel(ScoreArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
-template <int Q, bool TREG>
+template <int Q, bool TREG, int PHASE>
 static hipError_t launch_one(const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
-  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&score_kernel<Q, TREG>),
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&score_kernel<Q, TREG, PHASE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (err != hipSuccess) return err;
-  hipLaunchKernelGGL((score_kernel<Q, TREG>), dim3(blocks), dim3(threads), lds, s, a);
+  hipLaunchKernelGGL((score_kernel<Q, TREG, PHASE>), dim3(blocks), dim3(threads), lds, s, a);
   return hipGetLastError();
 }
 
-hipError_t launch_score(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
+template <int PHASE>
+static hipError_t launch_phase(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
   switch (Q) {
-    case 4:  return launch_one<4, false>(a, blocks, threads, lds, s);
-    case 8:  return launch_one<8, false>(a, blocks, threads, lds, s);
-    case 12: return launch_one<12, false>(a, blocks, threads, lds, s);
-    case 16: return launch_one<16, false>(a, blocks, threads, lds, s);
-    case 20: return launch_one<20, false>(a, blocks, threads, lds, s);
-    case 24: return launch_one<24, false>(a, blocks, threads, lds, s);
+    case 4:  return launch_one<4, false, PHASE>(a, blocks, threads, lds, s);
+    case 8:  return launch_one<8, false, PHASE>(a, blocks, threads, lds, s);
+    case 12: return launch_one<12, false, PHASE>(a, blocks, threads, lds, s);
+    case 16: return launch_one<16, false, PHASE>(a, blocks, threads, lds, s);
+    case 20: return launch_one<20, false, PHASE>(a, blocks, threads, lds, s);
+    case 24: return launch_one<24, false, PHASE>(a, blocks, threads, lds, s);
     default: return hipErrorInvalidValue;
   }
+}
+
+hipError_t launch_score(int Q, int phase, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
+  if (phase == 1) return launch_phase<1>(Q, a, blocks, threads, lds, s);
+  if (phase == 2) return launch_phase<2>(Q, a, blocks, threads, lds, s);
+  return launch_phase<0>(Q, a, blocks, threads, lds, s);
 }
 
 }  // namespace wh

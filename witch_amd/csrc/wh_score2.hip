@@ -31,8 +31,11 @@ constexpr float kMassTol = 2e-5f;
 
 #define COMP(v, c) ((c) ? (v).y : (v).x)
 
+#ifndef WH_SCORE2_THREADS
+#define WH_SCORE2_THREADS 512
+#endif
 template <int Q>
-__global__ __launch_bounds__(512) void score_kernel2(ScoreArgs a) {
+__global__ __launch_bounds__(WH_SCORE2_THREADS) void score_kernel2(ScoreArgs a) {
   // all LDS in ONE 16-byte aligned dynamic array (a static __shared__ object in front of it
   // would shift the base by 4 bytes and split every ds_read_b128)
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];

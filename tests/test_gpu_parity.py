@@ -204,3 +204,45 @@ def test_edge_cases_empty_and_ragged():
     with pytest.raises(Exception):
         e.score(np.array([200], np.uint8), np.array([0, 1], np.int64))
     e.close()
+
+
+@pytest.mark.parametrize("case_name,lengths", [("amino_hmmbuild", (900, 2000)), ("dna_synth", (1200, 3000))])
+def test_long_queries_keep_special_states_in_hbm(case_name, lengths, orc):
+    """Queries too long for the per-wave LDS block (BASELINE config 5: up to 2000 aa) switch the
+    kernels to the HBM-resident special-state rows; results must still match the oracle."""
+    _need_gpu()
+    from tests.conftest import load_case
+    from witch_amd import synth
+    from witch_amd.ehmm import EHMM, pack_queries
+    case = load_case(case_name)
+    e = EHMM(case.hmm_paths, hmm_index=case.hmm_index, nseq=case.nseq)
+    rng = np.random.default_rng(3)
+    K = 20 if case.alphabet == "amino" else 4
+    bg = synth.background(case.alphabet)
+    # long queries: a real query embedded in random background flanks (+ one pure background)
+    seqs = []
+    for t in range(5):
+        L = int(rng.integers(lengths[0], lengths[1] + 1))
+        core = e.digitize(case.qseqs[t])
+        s = rng.choice(K, size=L, p=bg).astype(np.uint8)
+        if t < 4:
+            at = int(rng.integers(0, L - len(core)))
+            s[at:at + len(core)] = core
+        seqs.append(s)
+    res, offs = pack_queries(seqs)
+    deci, flags, fwd = e.score(res, offs, want_fwd=True)
+    ohm = [orc.OracleHMM(p) for p in case.hmm_paths]
+    od, of, ofwd, osc = orc.score_batch(ohm, res, offs)
+    assert np.max(np.abs(fwd - ofwd)) <= 2e-4, np.max(np.abs(fwd - ofwd))   # float32 ulp at ~2000 rows
+    assert np.array_equal(flags & 3, of & 3)
+    rep = (of & 1) == 1
+    for qi, hj in np.argwhere((deci != od) & rep):
+        assert abs(int(deci[qi, hj]) - int(od[qi, hj])) == 1 and _near_boundary(osc[qi, hj]), (qi, hj, deci[qi, hj], od[qi, hj], osc[qi, hj])
+    pq = [q for q in range(len(seqs)) for _ in range(2)]
+    ph = [h % e.H for q in range(len(seqs)) for h in (0, 1)]
+    cols, co = e.align(res, offs, pq, ph)
+    for p in range(len(pq)):
+        want = ohm[ph[p]].align(seqs[pq[p]])
+        got = cols[co[p]:co[p + 1]]
+        assert np.array_equal(got, want), (case_name, pq[p], ph[p], int((got != want).sum()))
+    e.close()

@@ -46,7 +46,10 @@ __device__ __forceinline__ float tab_load(const float *tab, int arr, int k) {
   return tab[((size_t)(arr * (Q / 4) + q / 4) * kWave + ln) * 4 + (q % 4)];
 }
 
-template <int Q, bool TREG>
+#define SPR(idx)  (SPECG ? __builtin_nontemporal_load(spec + (idx)) : spec[idx])
+#define SPRI(idx) (SPECG ? __builtin_nontemporal_load(reinterpret_cast<const int *>(spec) + (idx)) : reinterpret_cast<const int *>(spec)[idx])
+
+template <int Q, bool TREG, bool SPECG>
 __global__ __launch_bounds__(512) void align_kernel(AlignArgs a) {
   // all LDS in ONE 16-byte aligned dynamic array: a static __shared__ object in front of it
   // would shift the base by 4 bytes and split every ds_read_b128 (measured: 13x LDS time)
@@ -59,8 +62,8 @@ __global__ __launch_bounds__(512) void align_kernel(AlignArgs a) {
   float *emL = smem;
   float *trL = smem + (size_t)a.K * TBL;
   float *wbase = trL + (TREG ? 0 : 16 * TBL) + (size_t)wave * a.wave_lds;
-  float *spec = wbase;                                              // AL_NARR * SP floats
-  uint8_t *seq = reinterpret_cast<uint8_t *>(wbase + AL_NARR * a.SP);
+  float *spec = SPECG ? a.spec_scratch + ((size_t)blockIdx.x * nwaves + wave) * a.spec_stride : wbase;   // AL_NARR * SP floats
+  uint8_t *seq = reinterpret_cast<uint8_t *>(wbase + (SPECG ? 0 : AL_NARR * a.SP));
   const int SP = a.SP;
   float *slabA = a.scratch + ((size_t)blockIdx.x * nwaves + wave) * a.scratch_stride;   // F -> posteriors
   float *slabB = slabA + (size_t)(a.Lcap + 1) * 2 * TBL;                                // OA rows
@@ -131,7 +134,6 @@ __global__ __launch_bounds__(512) void align_kernel(AlignArgs a) {
         for (int p = 0; p < Q; p++) { Mb[p] = 0.f; Ib[p] = 0.f; }
         float xC = cu.move, xJ = 0.f, xN = 0.f, xB = 0.f;
         int eb = 0;
-        const int *specI = reinterpret_cast<const int *>(spec);
 #pragma unroll 1
         for (int i = L; i >= 1; i--) {
           asm volatile("" ::: "memory");
@@ -172,8 +174,8 @@ __global__ __launch_bounds__(512) void align_kernel(AlignArgs a) {
             xB *= r; xJ *= r; xC *= r; xN *= r; xE *= r;
             eb += ee;
           }
-          const float s_i = ldexpf(invZ, specI[AL_S * SP + i] + eb - ef_L);
-          const float s_p = ldexpf(invZ, specI[AL_S * SP + i - 1] + eb - ef_L);
+          const float s_i = ldexpf(invZ, SPRI(AL_S * SP + i) + eb - ef_L);
+          const float s_p = ldexpf(invZ, SPRI(AL_S * SP + i - 1) + eb - ef_L);
 #pragma unroll
           for (int p4 = 0; p4 < Q4; p4++) {
             // position 4*p4+j (reversed order) is component 3-j of the forward-ordered vector
@@ -182,9 +184,9 @@ __global__ __launch_bounds__(512) void align_kernel(AlignArgs a) {
             nt_store4(row + (Q4 + Q4 - 1 - p4) * kWave, (fi4[p4].x * Ib[4 * p4 + 3]) * s_i, (fi4[p4].y * Ib[4 * p4 + 2]) * s_i,
                       (fi4[p4].z * Ib[4 * p4 + 1]) * s_i, (fi4[p4].w * Ib[4 * p4 + 0]) * s_i);
           }
-          const float pn = spec[AL_PN * SP + i - 1] * xN * cu.loop * s_p;
-          const float pj = spec[AL_PJ * SP + i - 1] * xJ * cu.loop * s_p;
-          const float pc = spec[AL_PC * SP + i - 1] * xC * cu.loop * s_p;
+          const float pn = SPR(AL_PN * SP + i - 1) * xN * cu.loop * s_p;
+          const float pj = SPR(AL_PJ * SP + i - 1) * xJ * cu.loop * s_p;
+          const float pc = SPR(AL_PC * SP + i - 1) * xC * cu.loop * s_p;
           __builtin_amdgcn_wave_barrier();
           if (lane == 0) { spec[AL_PN * SP + i] = pn; spec[AL_PJ * SP + i] = pj; spec[AL_PC * SP + i] = pc; }
           __builtin_amdgcn_wave_barrier();
@@ -268,11 +270,11 @@ __global__ __launch_bounds__(512) void align_kernel(AlignArgs a) {
           }
           const float xE = wave_max(rowmax);
           {
-            const float a1 = tNl * (oJ + spec[AL_PJ * SP + i]), b1 = tEJ * xE;
+            const float a1 = tNl * (oJ + SPR(AL_PJ * SP + i)), b1 = tEJ * xE;
             oJ = a1 > b1 ? a1 : b1;
-            const float a2 = tNl * (oC + spec[AL_PC * SP + i]), b2 = tEC * xE;
+            const float a2 = tNl * (oC + SPR(AL_PC * SP + i)), b2 = tEC * xE;
             oC = a2 > b2 ? a2 : b2;
-            oN = tNl * (oN + spec[AL_PN * SP + i]);
+            oN = tNl * (oN + SPR(AL_PN * SP + i));
             const float a3 = tNm * oN, b3 = tNm * oJ;
             oB = a3 > b3 ? a3 : b3;
           }
@@ -301,12 +303,12 @@ __global__ __launch_bounds__(512) void align_kernel(AlignArgs a) {
         while (s0 != stS && guard-- > 0) {
           switch (s0) {
             case stC: {
-              const float av = tNl * (spec[AL_OC * SP + i - 1] + spec[AL_PC * SP + i]), bv = tEC * spec[AL_OE * SP + i];
+              const float av = tNl * (SPR(AL_OC * SP + i - 1) + SPR(AL_PC * SP + i)), bv = tEC * SPR(AL_OE * SP + i);
               s1 = bv > av ? stE : stC;
               break;
             }
             case stJ: {
-              const float av = tNl * (spec[AL_OJ * SP + i - 1] + spec[AL_PJ * SP + i]), bv = tEJ * spec[AL_OE * SP + i];
+              const float av = tNl * (SPR(AL_OJ * SP + i - 1) + SPR(AL_PJ * SP + i)), bv = tEJ * SPR(AL_OE * SP + i);
               s1 = bv > av ? stE : stJ;
               break;
             }
@@ -348,7 +350,7 @@ __global__ __launch_bounds__(512) void align_kernel(AlignArgs a) {
             }
             case stM: {
               float path[4];
-              path[0] = gate(tab_load<Q>(fwG, FW_E, k), spec[AL_OB * SP + i - 1]);
+              path[0] = gate(tab_load<Q>(fwG, FW_E, k), SPR(AL_OB * SP + i - 1));
               if (i > 1 && k > 1) {
                 path[1] = gate(tab_load<Q>(fwG, FW_A, k), cell_load<Q>(slabB, i - 1, 3, 0, k - 1));
                 path[2] = gate(tab_load<Q>(fwG, FW_B, k), cell_load<Q>(slabB, i - 1, 3, 1, k - 1));
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(512) void align_kernel(AlignArgs a) {
               break;
             }
             case stB: {
-              const float av = tNm * spec[AL_ON * SP + i], bv = tNm * spec[AL_OJ * SP + i];
+              const float av = tNm * SPR(AL_ON * SP + i), bv = tNm * SPR(AL_OJ * SP + i);
               s1 = bv > av ? stJ : stN;
               break;
             }
@@ -399,25 +401,30 @@ __global__ __launch_bounds__(512) void align_kernel(AlignArgs a) {
   }
 }
 
-template <int Q, bool TREG>
+template <int Q, bool TREG, bool SPECG>
 static hipError_t launch_one(const AlignArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
-  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&align_kernel<Q, TREG>),
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&align_kernel<Q, TREG, SPECG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (err != hipSuccess) return err;
-  hipLaunchKernelGGL((align_kernel<Q, TREG>), dim3(blocks), dim3(threads), lds, s, a);
+  hipLaunchKernelGGL((align_kernel<Q, TREG, SPECG>), dim3(blocks), dim3(threads), lds, s, a);
   return hipGetLastError();
 }
 
-hipError_t launch_align(int Q, const AlignArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
+template <bool SPECG>
+static hipError_t launch_align_q(int Q, const AlignArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
   switch (Q) {
-    case 4:  return launch_one<4, false>(a, blocks, threads, lds, s);
-    case 8:  return launch_one<8, false>(a, blocks, threads, lds, s);
-    case 12: return launch_one<12, false>(a, blocks, threads, lds, s);
-    case 16: return launch_one<16, false>(a, blocks, threads, lds, s);
-    case 20: return launch_one<20, false>(a, blocks, threads, lds, s);
-    case 24: return launch_one<24, false>(a, blocks, threads, lds, s);
+    case 4:  return launch_one<4, false, SPECG>(a, blocks, threads, lds, s);
+    case 8:  return launch_one<8, false, SPECG>(a, blocks, threads, lds, s);
+    case 12: return launch_one<12, false, SPECG>(a, blocks, threads, lds, s);
+    case 16: return launch_one<16, false, SPECG>(a, blocks, threads, lds, s);
+    case 20: return launch_one<20, false, SPECG>(a, blocks, threads, lds, s);
+    case 24: return launch_one<24, false, SPECG>(a, blocks, threads, lds, s);
     default: return hipErrorInvalidValue;
   }
+}
+
+hipError_t launch_align(int Q, const AlignArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
+  return a.spec_scratch ? launch_align_q<true>(Q, a, blocks, threads, lds, s) : launch_align_q<false>(Q, a, blocks, threads, lds, s);
 }
 
 }  // namespace wh

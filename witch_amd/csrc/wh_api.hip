@@ -60,7 +60,7 @@ struct wh_ehmm {
   DevBuf d_hmms, d_tables, d_nseq, d_index, d_lists, d_counter, d_scratch;
   // staging for the host-pointer entry points
   DevBuf s_res, s_off, s_deci, s_flags, s_fwd, s_det, s_idx, s_w, s_nk, s_nu, s_pq, s_ph, s_co, s_cols, s_pos;
-  DevBuf d_order, d_items, d_recs;
+  DevBuf d_order, d_items, d_recs, d_spec;
   uint32_t degen[32];
   bool timing = false;
   KernelTimer timers[3];
@@ -109,7 +109,7 @@ void wh_ehmm_free(wh_ehmm *e) {
   if (!e) return;
   for (DevBuf *b : {&e->d_hmms, &e->d_tables, &e->d_nseq, &e->d_index, &e->d_lists, &e->d_counter, &e->d_scratch,
                     &e->s_res, &e->s_off, &e->s_deci, &e->s_flags, &e->s_fwd, &e->s_det, &e->s_idx, &e->s_w,
-                    &e->s_nk, &e->s_nu, &e->s_pq, &e->s_ph, &e->s_co, &e->s_cols, &e->s_pos, &e->d_order, &e->d_items, &e->d_recs})
+                    &e->s_nk, &e->s_nu, &e->s_pq, &e->s_ph, &e->s_co, &e->s_cols, &e->s_pos, &e->d_order, &e->d_items, &e->d_recs, &e->d_spec})
     b->release();
   for (auto &t : e->timers) {
     if (t.e0) (void)hipEventDestroy(t.e0);
@@ -323,8 +323,21 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
         continue;
       }
       const bool use1 = kver == 1;
-      if ((use1 ? plan_block1(Q, e->K, std::max(max_len, 1), 8, &waves, &SP, &wave_lds, &lds)
-                : plan_block(Q, e->K, treg, std::max(max_len, 1), &waves, &SP, &wave_lds, &lds)) != WH_OK) {
+      bool specg = false;
+      int rc_plan = use1 ? plan_block1(Q, e->K, std::max(max_len, 1), 8, &waves, &SP, &wave_lds, &lds)
+                         : plan_block(Q, e->K, treg, std::max(max_len, 1), &waves, &SP, &wave_lds, &lds);
+      if (use1 && (rc_plan != WH_OK || waves < 4)) {
+        // long queries: the per-row special-state arrays move to a per-wave HBM region
+        specg = true;
+        SP = (std::max(max_len, 1) + 1 + 3) / 4 * 4;
+        wave_lds = 32 + 3 * WH_MAX_ENVELOPES + (std::max(max_len, 1) + 3) / 4 + 4;
+        const size_t table = (size_t)(e->K + 16) * Q * kWave * sizeof(float);
+        waves = 8;
+        while (waves >= 1 && kLdsHeader + table + (size_t)waves * wave_lds * sizeof(float) > kLdsBudget) waves--;
+        rc_plan = waves >= 1 ? WH_OK : WH_ERANGE;
+        lds = kLdsHeader + table + (size_t)waves * wave_lds * sizeof(float);
+      }
+      if (rc_plan != WH_OK) {
         set_error("query length %d with model class Q=%d does not fit in LDS", max_len, Q);
         return WH_ERANGE;
       }
@@ -342,11 +355,16 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       a.counter = (int *)e->d_counter.p + launches;
       a.Lcap = std::max(max_len, 1); a.SP = SP; a.wave_lds = wave_lds;
       const int blocks = std::min(a.n_items, e->cu_count * std::max(1, 8 / waves));
-      a.scratch_stride = 2 * (size_t)(a.Lcap + 1) * 2 * Q * kWave;   // two Forward slabs per wave
+      a.scratch_stride = (use1 ? 1 : 2) * (size_t)(a.Lcap + 1) * 2 * Q * kWave;   // Forward slab(s) per wave
       if (e->d_scratch.ensure((size_t)blocks * waves * a.scratch_stride * sizeof(float))) return WH_ENOMEM;
       a.scratch = (float *)e->d_scratch.p;
       a.decibits = d_decibits; a.flags = d_flags; a.fwd_bits = d_fwd_bits; a.detail = d_detail;
       a.H = H; a.K = e->K; a.Kp = e->Kp;
+      if (specg) {
+        a.spec_stride = (size_t)8 * SP;
+        if (e->d_spec.ensure((size_t)blocks * waves * a.spec_stride * sizeof(float))) return WH_ENOMEM;
+        a.spec_scratch = (float *)e->d_spec.p;
+      }
       memcpy(a.degen, e->degen, sizeof a.degen);
       HIPCHK(hipMemsetAsync(a.counter, 0, sizeof(int), s));
       hipError_t err = use1 ? launch_score(Q, 0, a, blocks, waves * kWave, lds, s) : launch_score2(Q, a, blocks, waves * kWave, lds, s);
@@ -486,6 +504,15 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       set_error("query length %d with model class Q=%d does not fit in LDS", max_len, Q);
       return WH_ERANGE;
     }
+    if (waves < 4) {   // long queries: special-state rows in HBM
+      SP = (std::max(max_len, 1) + 1 + 3) / 4 * 4;
+      wave_lds = -((std::max(max_len, 1) + 3) / 4 + 4);   // negative marks the HBM mode for the launch loop below
+      const size_t table = (size_t)(e->K + 16) * Q * kWave * sizeof(float);
+      waves = 8;
+      while (waves >= 1 && kLdsHeader + table + (size_t)waves * (size_t)(-wave_lds) * sizeof(float) > kLdsBudget) waves--;
+      if (waves < 1) { set_error("model class Q=%d does not fit in LDS", Q); return WH_ERANGE; }
+      lds = kLdsHeader + table + (size_t)waves * (size_t)(-wave_lds) * sizeof(float);
+    }
     const int first = (int)items.size() / 3;
     for (int h : kv.second) {
       int lo = cnt[(size_t)h], hi = cnt[(size_t)h + 1];
@@ -512,9 +539,14 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
     a.n_items = n;
     a.col_offsets = d_col_offsets; a.cols = d_cols;
     a.counter = (int *)e->d_counter.p + launches;
-    a.Lcap = std::max(max_len, 1); a.SP = plans[pl][4]; a.wave_lds = plans[pl][5];
+    a.Lcap = std::max(max_len, 1); a.SP = plans[pl][4]; a.wave_lds = std::abs(plans[pl][5]);
     a.K = e->K; a.Kp = e->Kp;
     const int blocks = std::min(n, e->cu_count * std::max(1, 8 / waves));
+    if (plans[pl][5] < 0) {
+      a.spec_stride = (size_t)13 * a.SP;
+      if (e->d_spec.ensure((size_t)blocks * waves * a.spec_stride * sizeof(float))) return WH_ENOMEM;
+      a.spec_scratch = (float *)e->d_spec.p;
+    }
     a.scratch_stride = (size_t)(a.Lcap + 1) * 5 * Q * kWave;
     if (e->d_scratch.ensure((size_t)blocks * waves * a.scratch_stride * sizeof(float))) return WH_ENOMEM;
     a.scratch = (float *)e->d_scratch.p;
@@ -563,15 +595,14 @@ int wh_align(wh_ehmm *e, const uint8_t *residues, const int64_t *offsets, int64_
 
 int wh_ehmm_max_query_len(const wh_ehmm *e) {
   if (!e) return WH_EINVAL;
-  // longest query for which one wave's LDS block still fits beside the largest model's tables
-  int best = 0;
+  // Long queries keep their special-state rows in HBM; what remains in LDS per wave is the
+  // residue buffer, so the bound is one wave's residues beside the largest model's tables
+  // (the HBM workspace grows with L x M and may still fail with WH_ENOMEM).
+  int best = 1 << 20;
   for (auto &kv : e->by_q) {
-    int lo = 1, hi = 1 << 20;
-    while (lo < hi) {
-      int mid = (lo + hi + 1) / 2, w, sp, wl; size_t lds;
-      if (plan_block(kv.first, e->K, false, mid, &w, &sp, &wl, &lds) == WH_OK) lo = mid; else hi = mid - 1;
-    }
-    best = best == 0 ? lo : std::min(best, lo);
+    const size_t table = (size_t)(e->K + 16) * kv.first * kWave * sizeof(float);
+    const size_t left = kLdsBudget - kLdsHeader - table - (32 + 3 * WH_MAX_ENVELOPES + 8) * sizeof(float);
+    best = std::min(best, (int)std::min<size_t>(left, 1u << 20));
   }
   return best;
 }

@@ -36,6 +36,8 @@ struct ScoreArgs {
   float *fwd_bits;
   wh_pair_detail *detail;
   PairRec *recs;               // split mode only
+  float *spec_scratch;         // long-query mode: per-wave special-state rows in HBM (else NULL -> LDS)
+  size_t spec_stride;          // floats per wave
   int H;
   int K, Kp;
   uint32_t degen[32];
@@ -75,6 +77,8 @@ struct AlignArgs {
   int Lcap, SP, wave_lds;
   float *scratch;              // per-wave slabs: Forward/posterior rows, then OA rows
   size_t scratch_stride;       // floats per wave
+  float *spec_scratch;         // long-query mode: per-wave special-state rows in HBM (else NULL -> LDS)
+  size_t spec_stride;
   int K, Kp;
 };
 hipError_t launch_align(int Q, const AlignArgs &a, int blocks, int threads, size_t lds, hipStream_t s);

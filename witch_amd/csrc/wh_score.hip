@@ -41,7 +41,13 @@ constexpr float kMassTol1 = 2e-5f;
 // PHASE 0: everything in one launch.  PHASE 1: P1 + P2 + region scan, result to a PairRec.
 // PHASE 2: envelopes (P3/P4) + score assembly from the PairRec.  Splitting gives each half its
 // own register allocation (the fused kernel spills) and its own occupancy.
-template <int Q, bool TREG, int PHASE>
+// Special-state rows live in the per-wave LDS block, or (SPECG, long queries) in a per-wave
+// global scratch region read with L1-bypassing loads (the slots are rewritten for every pair).
+#define SPR(idx)  (SPECG ? __builtin_nontemporal_load(spec + (idx)) : spec[idx])
+#define SPRI(idx) (SPECG ? __builtin_nontemporal_load(reinterpret_cast<const int *>(spec) + (idx)) : reinterpret_cast<const int *>(spec)[idx])
+#define SPRU(idx) (SPECG ? __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(spec) + (idx)) : reinterpret_cast<const unsigned *>(spec)[idx])
+
+template <int Q, bool TREG, int PHASE, bool SPECG>
 __global__ __launch_bounds__(PHASE == 1 ? WH_SCOREA_THREADS : (PHASE == 2 ? WH_SCOREB_THREADS : WH_SCORE1_THREADS)) void score_kernel(ScoreArgs a) {
   // all LDS in ONE 16-byte aligned dynamic array: a static __shared__ object in front of it
   // would shift the base by 4 bytes and split every ds_read_b128 (measured: 13x LDS time)
@@ -53,8 +59,8 @@ __global__ __launch_bounds__(PHASE == 1 ? WH_SCOREA_THREADS : (PHASE == 2 ? WH_S
   float *emL = smem;
   float *trL = smem + (size_t)a.K * TBL;                                   // !TREG: fw[8] then bw[8]
   float *wbase = trL + (TREG ? 0 : 16 * TBL) + (size_t)wave * a.wave_lds;  // per-wave block
-  float *spec = wbase;                                                     // SP_NARR * SP floats
-  float *n2tab = wbase + SP_NARR * a.SP;                                         // 32 floats
+  float *spec = SPECG ? a.spec_scratch + ((size_t)blockIdx.x * nwaves + wave) * a.spec_stride : wbase;   // SP_NARR * SP floats
+  float *n2tab = wbase + (SPECG ? 0 : SP_NARR * a.SP);                                         // 32 floats
   int *regs = reinterpret_cast<int *>(n2tab + 32);                         // 3 * WH_MAX_ENVELOPES ints
   uint8_t *seq = reinterpret_cast<uint8_t *>(regs + 3 * WH_MAX_ENVELOPES);
   float *Fs = a.scratch + ((size_t)blockIdx.x * nwaves + wave) * a.scratch_stride;
@@ -120,6 +126,7 @@ __global__ __launch_bounds__(PHASE == 1 ? WH_SCOREA_THREADS : (PHASE == 2 ? WH_S
           const ScanC sc = scan_prepare(lane_product<Q, TREG>(T, FW_D2));
           forward_sweep<Q, TREG, false>(T, sc, emL, emG, a.K, seq, L, cm, spec, SP, nullptr, 0.f, lane, xC_L, ef_L);
         }
+        if (SPECG) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         const double fwd_nats = (double)ef_L * 0.69314718055994529 + log((double)(xC_L * cm.move));
         fwdsc = (float)fwd_nats;
         // A.3 null1 in float32 as p7_bg_SetLength / p7_bg_NullOne do
@@ -174,16 +181,15 @@ __global__ __launch_bounds__(PHASE == 1 ? WH_SCOREA_THREADS : (PHASE == 2 ? WH_S
                 eb += e;
               }
               // domain decoding for row i (A.4); results overwrite row i's forward slots
-              const int *specI = reinterpret_cast<const int *>(spec);
-              const float s_i = ldexpf(invZ, specI[SP_S * SP + i] + eb - ef_L);
-              const float pe = spec[SP_E * SP + i] * xE * s_i;
-              const float pb = spec[SP_B * SP + i] * xB * s_i;
+              const float s_i = ldexpf(invZ, SPRI(SP_S * SP + i) + eb - ef_L);
+              const float pe = SPR(SP_E * SP + i) * xE * s_i;
+              const float pb = SPR(SP_B * SP + i) * xB * s_i;
               float njc = 0.f;
               if (i >= 1) {
-                const float s_p = ldexpf(invZ, specI[SP_S * SP + i - 1] + eb - ef_L);
-                njc = spec[SP_N * SP + i - 1] * xN;
-                njc = fmaf(spec[SP_J * SP + i - 1], xJ, njc);
-                njc = fmaf(spec[SP_C * SP + i - 1], xC, njc);
+                const float s_p = ldexpf(invZ, SPRI(SP_S * SP + i - 1) + eb - ef_L);
+                njc = SPR(SP_N * SP + i - 1) * xN;
+                njc = fmaf(SPR(SP_J * SP + i - 1), xJ, njc);
+                njc = fmaf(SPR(SP_C * SP + i - 1), xC, njc);
                 njc = njc * cm.loop * s_p;
               }
               __builtin_amdgcn_wave_barrier();
@@ -192,6 +198,7 @@ __global__ __launch_bounds__(PHASE == 1 ? WH_SCOREA_THREADS : (PHASE == 2 ? WH_S
             }
           }
 
+          if (SPECG) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
           // ---------------- region scan (A.4), uniform over the wave
           const float rt1 = 0.25f, rt2 = 0.10f, rt3 = 0.20f;
           {
@@ -200,10 +207,10 @@ __global__ __launch_bounds__(PHASE == 1 ? WH_SCOREA_THREADS : (PHASE == 2 ? WH_S
             bool trig = false;
             if (lane == 0) { spec[SP_J * SP] = 0.f; spec[SP_C * SP] = 0.f; }
             for (int j = 1; j <= L; j++) {
-              const float mocc = 1.0f - spec[SP_N * SP + j];
+              const float mocc = 1.0f - SPR(SP_N * SP + j);
               const float bold = btot, eold = etot;
-              btot += spec[SP_B * SP + j - 1];
-              etot += spec[SP_E * SP + j];
+              btot += SPR(SP_B * SP + j - 1);
+              etot += SPR(SP_E * SP + j);
               if (lane == 0) { spec[SP_J * SP + j] = btot; spec[SP_C * SP + j] = etot; }
               if (!trig) {
                 if (mocc - (btot - bold) < rt2) i0 = j;
@@ -220,13 +227,14 @@ __global__ __launch_bounds__(PHASE == 1 ? WH_SCOREA_THREADS : (PHASE == 2 ? WH_S
               }
             }
             __builtin_amdgcn_wave_barrier();
+            if (SPECG) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             // multidomain test: max_z min(etot[z]-etot[i-1], btot[j]-btot[z-1]) >= rt3
             for (int e = 0; e < nenv; e++) {
               const int ri = regs[2 * e], rj = regs[2 * e + 1];
               float mx = -1.0f;
-              const float e0 = spec[SP_C * SP + ri - 1], bj = spec[SP_J * SP + rj];
+              const float e0 = SPR(SP_C * SP + ri - 1), bj = SPR(SP_J * SP + rj);
               for (int z = ri + lane; z <= rj; z += kWave) {
-                const float u = spec[SP_C * SP + z] - e0, v = bj - spec[SP_J * SP + z - 1];
+                const float u = SPR(SP_C * SP + z) - e0, v = bj - SPR(SP_J * SP + z - 1);
                 mx = fmaxf(mx, fminf(u, v));
               }
               mx = wave_max(mx);
@@ -288,14 +296,12 @@ __global__ __launch_bounds__(PHASE == 1 ? WH_SCOREA_THREADS : (PHASE == 2 ? WH_S
                 for (int p = 0; p < Q; p++) { Mb[p] = 0.f; Ib[p] = 0.f; fM[p] = 0.f; fI[p] = 0.f; }
                 float xC = cu.move, xJ = 0.f, xN = 0.f, xB = 0.f, xfac = 0.f;
                 int eb = 0;
-                const int *specI = reinterpret_cast<const int *>(spec);
-                const unsigned *specU = reinterpret_cast<const unsigned *>(spec);
-                const int src = kWave - 1 - lane;   // the forward-order lane that owns my (reversed) cells
+                  const int src = kWave - 1 - lane;   // the forward-order lane that owns my (reversed) cells
 #pragma unroll 1
                 for (int i = Ld; i >= 1; i--) {
                   asm volatile("" ::: "memory");
                   // issue the loads of Forward row i early; they are consumed after the cell update
-                  const unsigned mword = src < 32 ? specU[SP_ML * SP + i] : specU[SP_MH * SP + i];
+                  const unsigned mword = src < 32 ? SPRU(SP_ML * SP + i) : SPRU(SP_MH * SP + i);
                   const bool have = (mword >> (src & 31)) & 1u;
                   const float4 *row = reinterpret_cast<const float4 *>(Fs) + (size_t)i * (2 * (Q / 4) * kWave) + src;
                   float4 fm4[Q / 4], fi4[Q / 4];
@@ -339,8 +345,8 @@ __global__ __launch_bounds__(PHASE == 1 ? WH_SCOREA_THREADS : (PHASE == 2 ? WH_S
                     xB *= r; xJ *= r; xC *= r; xN *= r; xE *= r;
                     eb += ee;
                   }
-                  const float s_i = ldexpf(invZe, specI[SP_S * SP + i] + eb - ef_e);
-                  const float s_p = ldexpf(invZe, specI[SP_S * SP + i - 1] + eb - ef_e);
+                  const float s_i = ldexpf(invZe, SPRI(SP_S * SP + i) + eb - ef_e);
+                  const float s_p = ldexpf(invZe, SPRI(SP_S * SP + i - 1) + eb - ef_e);
 #pragma unroll
                   for (int p4 = 0; p4 < Q / 4; p4++) {
                     // reversed order: component 3-j of the forward-ordered vector is position 4*p4+j
@@ -353,9 +359,9 @@ __global__ __launch_bounds__(PHASE == 1 ? WH_SCOREA_THREADS : (PHASE == 2 ? WH_S
                     fI[4 * p4 + 2] = fmaf(fi4[p4].y * Ib[4 * p4 + 2], s_i, fI[4 * p4 + 2]);
                     fI[4 * p4 + 3] = fmaf(fi4[p4].x * Ib[4 * p4 + 3], s_i, fI[4 * p4 + 3]);
                   }
-                  float nj = spec[SP_N * SP + i - 1] * xN;
-                  nj = fmaf(spec[SP_J * SP + i - 1], xJ, nj);
-                  nj = fmaf(spec[SP_C * SP + i - 1], xC, nj);
+                  float nj = SPR(SP_N * SP + i - 1) * xN;
+                  nj = fmaf(SPR(SP_J * SP + i - 1), xJ, nj);
+                  nj = fmaf(SPR(SP_C * SP + i - 1), xC, nj);
                   xfac = fmaf(nj * cu.loop, s_p, xfac);
                 }
                 // null2[a] = sum_k fM_k o_k(a) + sum_k fI_k + f_NJC, all / Ld
@@ -428,32 +434,33 @@ __global__ __launch_bounds__(PHASE == 1 ? WH_SCOREA_THREADS : (PHASE == 2 ? WH_S
 }
 
 // ---------------------------------------------------------------------------------------
-template <int Q, bool TREG, int PHASE>
+template <int Q, bool TREG, int PHASE, bool SPECG>
 static hipError_t launch_one(const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
-  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&score_kernel<Q, TREG, PHASE>),
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&score_kernel<Q, TREG, PHASE, SPECG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (err != hipSuccess) return err;
-  hipLaunchKernelGGL((score_kernel<Q, TREG, PHASE>), dim3(blocks), dim3(threads), lds, s, a);
+  hipLaunchKernelGGL((score_kernel<Q, TREG, PHASE, SPECG>), dim3(blocks), dim3(threads), lds, s, a);
   return hipGetLastError();
 }
 
-template <int PHASE>
+template <int PHASE, bool SPECG>
 static hipError_t launch_phase(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
   switch (Q) {
-    case 4:  return launch_one<4, false, PHASE>(a, blocks, threads, lds, s);
-    case 8:  return launch_one<8, false, PHASE>(a, blocks, threads, lds, s);
-    case 12: return launch_one<12, false, PHASE>(a, blocks, threads, lds, s);
-    case 16: return launch_one<16, false, PHASE>(a, blocks, threads, lds, s);
-    case 20: return launch_one<20, false, PHASE>(a, blocks, threads, lds, s);
-    case 24: return launch_one<24, false, PHASE>(a, blocks, threads, lds, s);
+    case 4:  return launch_one<4, false, PHASE, SPECG>(a, blocks, threads, lds, s);
+    case 8:  return launch_one<8, false, PHASE, SPECG>(a, blocks, threads, lds, s);
+    case 12: return launch_one<12, false, PHASE, SPECG>(a, blocks, threads, lds, s);
+    case 16: return launch_one<16, false, PHASE, SPECG>(a, blocks, threads, lds, s);
+    case 20: return launch_one<20, false, PHASE, SPECG>(a, blocks, threads, lds, s);
+    case 24: return launch_one<24, false, PHASE, SPECG>(a, blocks, threads, lds, s);
     default: return hipErrorInvalidValue;
   }
 }
 
 hipError_t launch_score(int Q, int phase, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
-  if (phase == 1) return launch_phase<1>(Q, a, blocks, threads, lds, s);
-  if (phase == 2) return launch_phase<2>(Q, a, blocks, threads, lds, s);
-  return launch_phase<0>(Q, a, blocks, threads, lds, s);
+  if (a.spec_scratch) return launch_phase<0, true>(Q, a, blocks, threads, lds, s);   // long queries: fused only
+  if (phase == 1) return launch_phase<1, false>(Q, a, blocks, threads, lds, s);
+  if (phase == 2) return launch_phase<2, false>(Q, a, blocks, threads, lds, s);
+  return launch_phase<0, false>(Q, a, blocks, threads, lds, s);
 }
 
 }  // namespace wh

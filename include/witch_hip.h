@@ -124,8 +124,28 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
                  const int64_t *d_pair_q, const int32_t *d_pair_h, int64_t npairs,
                  const int64_t *d_col_offsets, int32_t *d_cols, void *stream);
 
+/* Weighted consensus of each query's per-HMM alignments (witch-ng merge DP; replaces the Python
+ * loops of alignSubQueriesNew, witch_msa/gcmm/aligner.py:376-473).  Pairs are grouped by
+ * query in top-k order: query q owns pairs qpair_off[q] .. qpair_off[q+1]; pair p aligned
+ * the query to model pair_h[p] (position 0..H-1) with weight pair_w[p] and per-residue match
+ * columns cols[col_offsets[p] ..] as produced by wh_align.  retained / nongaps are the
+ * reference's subset_to_retained_columns / subset_to_nongaps_per_column
+ * (witch_msa/gcmm/algorithm.py:423-429), CSR over models by ret_off[H+1].
+ * out (CSR by <offsets>, one int per residue): backbone column >= 0 for a match, -1 - nc for
+ * an insertion placed before backbone column nc.  minmax[2q], minmax[2q+1]: first/last
+ * backbone column touched (max < 0: nothing aligned). */
+int wh_consensus(wh_ehmm *e, const int64_t *offsets, int64_t nq, const int64_t *qpair_off,
+                 const int32_t *pair_h, const double *pair_w, const int64_t *col_offsets, const int32_t *cols,
+                 const int64_t *ret_off, const int32_t *retained, const int32_t *nongaps,
+                 int32_t backbone_length, int32_t *out, int32_t *minmax);
+int wh_consensus_dev(wh_ehmm *e, const int64_t *d_offsets, int64_t nq, int32_t max_len, const int64_t *d_qpair_off,
+                     const int32_t *d_pair_h, const double *d_pair_w, const int64_t *d_col_offsets,
+                     const int32_t *d_cols, const int64_t *d_ret_off, const int32_t *d_retained,
+                     const int32_t *d_nongaps, int32_t backbone_length, int32_t max_pairs_per_query,
+                     int32_t *d_out, int32_t *d_minmax, void *stream);
+
 /* Duration (ms) and launch count of the kernels of the last *_dev/plain call, measured
- * with HIP events on the stream the kernels ran on: which = 0 score, 1 topk, 2 align. */
+ * with HIP events on the stream the kernels ran on: which = 0 score, 1 topk, 2 align, 3 consensus. */
 int wh_last_kernel_ms(wh_ehmm *e, int which, double *ms, int *launches);
 /* When enabled, every kernel launch is bracketed by HIP events (bench/roofline use). */
 int wh_set_timing(wh_ehmm *e, int enabled);

@@ -51,8 +51,9 @@ def import_reference():
     from witch_msa.configs import Configs
     from witch_msa.gcmm.algorithm import evalHMMSearchOutput
     from witch_msa.gcmm.weighting import calculateWeights
-    from witch_msa.gcmm.aligner import getBackbones
-    return scratch, Configs, evalHMMSearchOutput, calculateWeights, getBackbones
+    from witch_msa.gcmm.aligner import getBackbones, alignSubQueriesNew
+    from witch_msa.helpers.alignment_tools import Alignment
+    return scratch, Configs, evalHMMSearchOutput, calculateWeights, getBackbones, alignSubQueriesNew, Alignment
 
 
 def run(cmd):
@@ -87,6 +88,8 @@ class Case:
         os.makedirs(os.path.join(self.dir, "hmms"))
         self.hmm_files, self.hmm_index, self.nseq = [], [], []
         self.qnames, self.qseqs = [], []
+        self.backbone = None          # list of (name, aligned text) = the backbone alignment
+        self.subset_rows = []         # per HMM: (lo, hi) rows of the backbone it was built from
 
     def add_hmm(self, path, index, nseq):
         self.hmm_files.append(os.path.relpath(path, self.dir))
@@ -94,7 +97,7 @@ class Case:
         self.nseq.append(nseq)
 
     def finish(self, ref):
-        scratch, Configs, evalHMMSearchOutput, calculateWeights, getBackbones = ref
+        scratch, Configs, evalHMMSearchOutput, calculateWeights, getBackbones, alignSubQueriesNew, Alignment = ref
         qpath = os.path.join(self.dir, "queries.fasta")
         synth.write_fasta(qpath, self.qnames, self.qseqs, self.alphabet)
         tmp = tempfile.mkdtemp(prefix="golden_")
@@ -127,7 +130,33 @@ class Case:
         Configs.num_hmms = self.k
         Configs.use_weight = True
         Configs.hmmalignpath = HMMER + "/hmmalign"
-        weights, align = {}, {}
+        weights, align, merged = {}, {}, {}
+        retained, nongaps = {}, {}
+        if self.backbone is not None:
+            # algorithm.py:400-429: retained columns / non-gap counts of each subset alignment
+            for idx, (lo, hi) in zip(self.hmm_index, self.subset_rows):
+                sub = Alignment()
+                for name, text in self.backbone[lo:hi]:
+                    sub[name] = text
+                retained[idx] = tuple(int(x) for x in sub.delete_all_gaps())
+                cnt = [0] * sub.sequence_length()
+                for text in sub.values():
+                    for c, ch in enumerate(text):
+                        cnt[c] += int(ch != '-')
+                nongaps[idx] = tuple(cnt)
+            alignSubQueriesNew.subset_to_retained_columns = retained
+            alignSubQueriesNew.subset_to_nongaps_per_column = nongaps
+            Configs.outdir = tmp
+            Configs.keeptemp = False
+            Configs.log_path = None
+            Configs.runtime_path = os.path.join(tmp, 'runtime.txt')
+
+            class _Lock:
+                def acquire(self):
+                    pass
+
+                def release(self):
+                    pass
 
         class _Sub:
             pass
@@ -159,12 +188,21 @@ class Case:
                                os.path.join(tmp, "bb"), use_gcm=False)
             ret_str, weights_map, cols = ret
             align[qn] = {"ret_str": ret_str.replace(self.dir, "."),
-                         "cols": {str(i): [int(c) for c in v] for i, v in cols.items()}}
+                         "cols": {str(i): [int(c) for c in v] for i, v in cols.items()},
+                         "order": [int(i) for i in cols.keys()]}
+            if self.backbone is not None:
+                # aligner.py:350-538: weighted consensus DP + compressInsertions (next row #1)
+                q, _, _ = alignSubQueriesNew('unused', len(self.backbone[0][1]), index_to_hmm, _Lock(), 120,
+                                             qn, text, w, qi)
+                merged[qn] = q[qn] if len(q) else None
         shutil.rmtree(tmp, ignore_errors=True)
         gold = {"case": self.name, "alphabet": self.alphabet, "k": self.k,
                 "hmm_files": self.hmm_files, "hmm_index": self.hmm_index, "nseq": self.nseq,
                 "queries": self.qnames, "search": search, "search_nonull2": nonull2,
-                "weights": weights, "align": align}
+                "weights": weights, "align": align, "merged": merged,
+                "retained": {str(k): list(v) for k, v in retained.items()},
+                "nongaps": {str(k): list(v) for k, v in nongaps.items()},
+                "backbone_length": (len(self.backbone[0][1]) if self.backbone else 0)}
         with gzip.open(os.path.join(self.dir, "golden.json.gz"), "wt") as f:
             json.dump(gold, f, separators=(",", ":"), sort_keys=True)
         n_rep = sum(len(v) for v in search.values())
@@ -186,6 +224,9 @@ def family_case(ref, name, alphabet, seed, root_len, n_leaves, n_sub, sub_rate, 
     fam = synth.make_family(seed, root_len, n_leaves, alphabet, sub_rate, indel_rate)
     c = Case(name, alphabet, k)
     subs = synth.bfs_subsets(n_leaves, n_sub)
+    sym = synth.symbols(alphabet) + '-'
+    c.backbone = [(fam.names[i], ''.join(sym[int(x)] for x in fam.msa[i])) for i in range(n_leaves)]
+    c.subset_rows = list(subs)
     for idx, (lo, hi) in enumerate(subs):
         hp = os.path.join(c.dir, "hmms", "A_0_%d.hmm" % idx)
         if use_hmmbuild:

@@ -246,3 +246,52 @@ def test_long_queries_keep_special_states_in_hbm(case_name, lengths, orc):
         got = cols[co[p]:co[p + 1]]
         assert np.array_equal(got, want), (case_name, pq[p], ph[p], int((got != want).sum()))
     e.close()
+
+
+def test_consensus_merge_against_oracle_and_reference(golden_case):
+    """Next row #1: the witch-ng weighted consensus DP (aligner.py:376-495) on the GPU,
+    end to end through the reference-shaped functions; bit-exact float64 arithmetic, so the
+    aligned strings must equal the reference's own alignSubQueriesNew output."""
+    _need_gpu()
+    from oracle import consensus as ocons
+    from witch_amd import gcmm
+    case = golden_case
+    g = case.g
+    if not g.get("merged"):
+        pytest.skip("case has no backbone alignment")
+
+    class _Sub:
+        def __init__(self, path, n):
+            self.hmm_model_path, self.num_taxa = path, n
+    index_to_hmm = {i: _Sub(p, n) for i, p, n in zip(case.hmm_index, case.hmm_paths, case.nseq)}
+    retained = {int(k): v for k, v in g["retained"].items()}
+    nongaps = {int(k): v for k, v in g["nongaps"].items()}
+    eng = gcmm.install(gcmm.QueryAlignmentEngine.run(
+        index_to_hmm, list(zip(case.qnames, case.qseqs)), case.k,
+        subset_to_retained_columns=retained, subset_to_nongaps_per_column=nongaps,
+        backbone_length=g["backbone_length"]))
+    ranked = gcmm.rankBitscores(index_to_hmm, {})
+    weights = gcmm.writeWeights(index_to_hmm, ranked)
+    n_ref = n_orc = 0
+    for q, (qn, qs) in enumerate(zip(case.qnames, case.qseqs)):
+        if qn not in weights:
+            continue
+        query, _, _ = gcmm.alignSubQueriesNew("bb", g["backbone_length"], index_to_hmm, None, 120, qn, qs, weights[qn], q)
+        got = query[qn]
+        # oracle on the GPU path's own inputs (same top-k order and weights)
+        _, wmap, cols = gcmm.getBackbones(index_to_hmm, qn, q, qs, "p", weights[qn], ".", ".", use_gcm=False)
+        codes, _ = ocons.consensus_trace(len(qs), list(cols.items()), wmap, retained, nongaps, g["backbone_length"])
+        assert got == ocons.trace_to_string(qs, codes, g["backbone_length"]), (case.name, qn)
+        n_orc += 1
+        # and the reference's own output, whenever the reference's tie order among equal weights
+        # did not pick a different (equally weighted) set of HMMs
+        want = g["merged"].get(qn)
+        gold_w = g["weights"].get(qn)      # absent: HMMER reported no HMM (multidomain class)
+        tied = gold_w is None or len(set(x[1] for x in gold_w)) < len(gold_w)
+        same_hmms = gold_w is not None and [i for i, _ in gold_w] == [i for i, _ in weights[qn]]
+        if want is not None and not tied and same_hmms:
+            assert got == want, (case.name, qn)
+            n_ref += 1
+        labels = query._col_labels
+        assert sum(1 for x in labels if x >= 0) == g["backbone_length"] and len(labels) == len(got)
+    assert n_orc > 0 and n_ref > 0

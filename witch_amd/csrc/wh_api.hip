@@ -60,10 +60,10 @@ struct wh_ehmm {
   DevBuf d_hmms, d_tables, d_nseq, d_index, d_lists, d_counter, d_scratch;
   // staging for the host-pointer entry points
   DevBuf s_res, s_off, s_deci, s_flags, s_fwd, s_det, s_idx, s_w, s_nk, s_nu, s_pq, s_ph, s_co, s_cols, s_pos;
-  DevBuf d_order, d_items, d_recs, d_spec;
+  DevBuf d_order, d_items, d_recs, d_spec, d_back, d_cwj, d_cwv, d_cwn, c_buf[10];
   uint32_t degen[32];
   bool timing = false;
-  KernelTimer timers[3];
+  KernelTimer timers[4];
   int max_M = 0;
 };
 
@@ -109,7 +109,9 @@ void wh_ehmm_free(wh_ehmm *e) {
   if (!e) return;
   for (DevBuf *b : {&e->d_hmms, &e->d_tables, &e->d_nseq, &e->d_index, &e->d_lists, &e->d_counter, &e->d_scratch,
                     &e->s_res, &e->s_off, &e->s_deci, &e->s_flags, &e->s_fwd, &e->s_det, &e->s_idx, &e->s_w,
-                    &e->s_nk, &e->s_nu, &e->s_pq, &e->s_ph, &e->s_co, &e->s_cols, &e->s_pos, &e->d_order, &e->d_items, &e->d_recs, &e->d_spec})
+                    &e->s_nk, &e->s_nu, &e->s_pq, &e->s_ph, &e->s_co, &e->s_cols, &e->s_pos, &e->d_order, &e->d_items, &e->d_recs, &e->d_spec, &e->d_back, &e->d_cwj, &e->d_cwv, &e->d_cwn,
+                    &e->c_buf[0], &e->c_buf[1], &e->c_buf[2], &e->c_buf[3], &e->c_buf[4], &e->c_buf[5], &e->c_buf[6],
+                    &e->c_buf[7], &e->c_buf[8], &e->c_buf[9]})
     b->release();
   for (auto &t : e->timers) {
     if (t.e0) (void)hipEventDestroy(t.e0);
@@ -216,7 +218,7 @@ static int timer_end(wh_ehmm *e, int which, hipStream_t s, int launches) {
 }
 
 int wh_last_kernel_ms(wh_ehmm *e, int which, double *ms, int *launches) {
-  if (!e || which < 0 || which > 2) return WH_EINVAL;
+  if (!e || which < 0 || which > 3) return WH_EINVAL;
   KernelTimer &t = e->timers[which];
   if (t.pending) {
     HIPCHK(hipEventSynchronize(t.e1));
@@ -313,6 +315,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
           a.recs = (PairRec *)e->d_recs.p;
           a.H = H; a.K = e->K; a.Kp = e->Kp;
           memcpy(a.degen, e->degen, sizeof a.degen);
+          if (const char *dv = getenv("WH_DBG")) a.dbg = atoi(dv);
           HIPCHK(hipMemsetAsync(a.counter, 0, sizeof(int), s));
           hipError_t err = launch_score(Q, phase, a, blocks, waves * kWave, lds, s);
           if (err != hipSuccess) { set_error("score kernel launch (Q=%d, phase %d) failed: %s", Q, phase, hipGetErrorString(err)); return WH_EHIP; }
@@ -366,6 +369,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
         a.spec_scratch = (float *)e->d_spec.p;
       }
       memcpy(a.degen, e->degen, sizeof a.degen);
+      if (const char *dv = getenv("WH_DBG")) a.dbg = atoi(dv);
       HIPCHK(hipMemsetAsync(a.counter, 0, sizeof(int), s));
       hipError_t err = use1 ? launch_score(Q, 0, a, blocks, waves * kWave, lds, s) : launch_score2(Q, a, blocks, waves * kWave, lds, s);
       if (err != hipSuccess) { set_error("score kernel launch (Q=%d) failed: %s", Q, hipGetErrorString(err)); return WH_EHIP; }
@@ -590,6 +594,93 @@ int wh_align(wh_ehmm *e, const uint8_t *residues, const int64_t *offsets, int64_
   if (rc) return rc;
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(cols, e->s_cols.p, sizeof(int32_t) * (size_t)ncols, hipMemcpyDeviceToHost));
+  return WH_OK;
+}
+
+// ------------------------------------------------------------------------------------ consensus
+static const int kConsKmax = 16;
+
+int wh_consensus_dev(wh_ehmm *e, const int64_t *d_offsets, int64_t nq, int32_t max_len, const int64_t *d_qpair_off,
+                     const int32_t *d_pair_h, const double *d_pair_w, const int64_t *d_col_offsets,
+                     const int32_t *d_cols, const int64_t *d_ret_off, const int32_t *d_retained,
+                     const int32_t *d_nongaps, int32_t backbone_length, int32_t max_pairs_per_query,
+                     int32_t *d_out, int32_t *d_minmax, void *stream) {
+  if (!e || !d_offsets || !d_qpair_off || !d_pair_h || !d_pair_w || !d_col_offsets || !d_cols || !d_ret_off ||
+      !d_retained || !d_nongaps || !d_out || !d_minmax || nq < 0 || backbone_length <= 0 || max_len < 0) {
+    set_error("wh_consensus_dev: bad argument");
+    return WH_EINVAL;
+  }
+  if (max_pairs_per_query > kConsKmax) { set_error("more than %d HMMs per query are not supported by the consensus kernel", kConsKmax); return WH_ERANGE; }
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHK(hipSetDevice(e->device));
+  if (timer_begin(e, 3, s)) return WH_EHIP;
+  if (nq > 0) {
+    ConsArgs a;
+    memset(&a, 0, sizeof a);
+    a.offsets = d_offsets; a.nq = nq; a.qpair_off = d_qpair_off; a.pair_h = d_pair_h; a.pair_w = d_pair_w;
+    a.col_offsets = d_col_offsets; a.cols = d_cols; a.ret_off = d_ret_off; a.retained = d_retained; a.nongaps = d_nongaps;
+    a.backbone_length = backbone_length; a.out = d_out; a.minmax = d_minmax;
+    a.Lcap = std::max(max_len, 1); a.Wcap = backbone_length + 1; a.KMAX = kConsKmax;
+    int waves = 4;
+    while (waves >= 1 && (size_t)waves * (a.Wcap + 2) * sizeof(double) > kLdsBudget) waves--;
+    if (waves < 1) { set_error("backbone of %d columns does not fit the consensus kernel's LDS row", backbone_length); return WH_ERANGE; }
+    const size_t lds = (size_t)waves * (a.Wcap + 2) * sizeof(double);
+    const int blocks = (int)std::min<int64_t>((nq + waves - 1) / waves, (int64_t)e->cu_count * 2);
+    const size_t nw = (size_t)blocks * waves;
+    if (e->d_back.ensure(nw * (size_t)(a.Lcap + 1) * (a.Wcap + 2)) || e->d_cwj.ensure(nw * (size_t)a.Lcap * a.KMAX * sizeof(int32_t)) ||
+        e->d_cwv.ensure(nw * (size_t)a.Lcap * a.KMAX * sizeof(double)) || e->d_cwn.ensure(nw * (size_t)a.Lcap * sizeof(int32_t)))
+      return WH_ENOMEM;
+    a.back = (uint8_t *)e->d_back.p; a.cwj = (int32_t *)e->d_cwj.p; a.cwv = (double *)e->d_cwv.p; a.cwn = (int32_t *)e->d_cwn.p;
+    a.counter = (int *)e->d_counter.p + 63;
+    HIPCHK(hipMemsetAsync(a.counter, 0, sizeof(int), s));
+    hipError_t err = launch_consensus(a, blocks, waves * kWave, lds, s);
+    if (err != hipSuccess) { set_error("consensus kernel launch failed: %s", hipGetErrorString(err)); return WH_EHIP; }
+  }
+  if (timer_end(e, 3, s, nq > 0 ? 1 : 0)) return WH_EHIP;
+  return WH_OK;
+}
+
+int wh_consensus(wh_ehmm *e, const int64_t *offsets, int64_t nq, const int64_t *qpair_off, const int32_t *pair_h,
+                 const double *pair_w, const int64_t *col_offsets, const int32_t *cols, const int64_t *ret_off,
+                 const int32_t *retained, const int32_t *nongaps, int32_t backbone_length, int32_t *out, int32_t *minmax) {
+  if (!e || !offsets || !qpair_off || !pair_h || !pair_w || !col_offsets || !cols || !ret_off || !retained || !nongaps ||
+      !out || !minmax || nq < 0) {
+    set_error("wh_consensus: bad argument");
+    return WH_EINVAL;
+  }
+  if (nq == 0) return WH_OK;
+  HIPCHK(hipSetDevice(e->device));
+  const int H = (int)e->hmms.size();
+  const int64_t npairs = qpair_off[nq], ncols = col_offsets[npairs], nret = ret_off[H], total = offsets[nq];
+  int maxpp = 0;
+  for (int64_t q = 0; q < nq; q++) maxpp = std::max<int>(maxpp, (int)(qpair_off[q + 1] - qpair_off[q]));
+  for (int64_t p = 0; p < npairs; p++)
+    if (pair_h[p] < 0 || pair_h[p] >= H) { set_error("pair %lld: model position out of range", (long long)p); return WH_EINVAL; }
+  for (int h = 0; h < H; h++)
+    if (ret_off[h + 1] - ret_off[h] != e->hmms[(size_t)h].M) {
+      set_error("model %d: %lld retained columns but %d match states", h, (long long)(ret_off[h + 1] - ret_off[h]), e->hmms[(size_t)h].M);
+      return WH_EINVAL;
+    }
+  for (int64_t t = 0; t < nret; t++)
+    if (retained[t] < 0 || retained[t] >= backbone_length) { set_error("retained column %d outside the backbone", retained[t]); return WH_EINVAL; }
+  const void *src[10] = {offsets, qpair_off, pair_h, pair_w, col_offsets, cols, ret_off, retained, nongaps, nullptr};
+  const size_t bytes[10] = {sizeof(int64_t) * (size_t)(nq + 1), sizeof(int64_t) * (size_t)(nq + 1), sizeof(int32_t) * (size_t)npairs,
+                            sizeof(double) * (size_t)npairs, sizeof(int64_t) * (size_t)(npairs + 1), sizeof(int32_t) * (size_t)ncols,
+                            sizeof(int64_t) * (size_t)(H + 1), sizeof(int32_t) * (size_t)nret, sizeof(int32_t) * (size_t)nret,
+                            sizeof(int32_t) * (size_t)(total + 2 * nq)};
+  for (int t = 0; t < 10; t++) {
+    if (e->c_buf[t].ensure(bytes[t] + 16)) return WH_ENOMEM;
+    if (src[t] && bytes[t]) HIPCHK(hipMemcpy(e->c_buf[t].p, src[t], bytes[t], hipMemcpyHostToDevice));
+  }
+  int32_t *d_out = (int32_t *)e->c_buf[9].p, *d_mm = d_out + total;
+  int rc = wh_consensus_dev(e, (const int64_t *)e->c_buf[0].p, nq, max_query_len(offsets, nq), (const int64_t *)e->c_buf[1].p,
+                            (const int32_t *)e->c_buf[2].p, (const double *)e->c_buf[3].p, (const int64_t *)e->c_buf[4].p,
+                            (const int32_t *)e->c_buf[5].p, (const int64_t *)e->c_buf[6].p, (const int32_t *)e->c_buf[7].p,
+                            (const int32_t *)e->c_buf[8].p, backbone_length, maxpp, d_out, d_mm, nullptr);
+  if (rc) return rc;
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(out, d_out, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(minmax, d_mm, sizeof(int32_t) * (size_t)(2 * nq), hipMemcpyDeviceToHost));
   return WH_OK;
 }
 

@@ -41,6 +41,7 @@ struct ScoreArgs {
   int H;
   int K, Kp;
   uint32_t degen[32];
+  int dbg;                     // timing experiments only: 1 = skip Forward-row stores, 2 = skip Forward-row loads
 };
 
 hipError_t launch_score(int Q, int phase, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
@@ -82,5 +83,28 @@ struct AlignArgs {
   int K, Kp;
 };
 hipError_t launch_align(int Q, const AlignArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
+
+struct ConsArgs {
+  const int64_t *offsets;
+  int64_t nq;
+  const int64_t *qpair_off;
+  const int32_t *pair_h;
+  const double *pair_w;
+  const int64_t *col_offsets;
+  const int32_t *cols;
+  const int64_t *ret_off;
+  const int32_t *retained;
+  const int32_t *nongaps;
+  int backbone_length;
+  int32_t *out;
+  int32_t *minmax;
+  int *counter;
+  int Lcap, Wcap, KMAX;
+  uint8_t *back;               // per wave (Lcap+1) x (Wcap+2) back-pointers
+  int32_t *cwj;                // per wave Lcap x KMAX edge columns
+  double *cwv;                 // per wave Lcap x KMAX edge weights
+  int32_t *cwn;                // per wave Lcap edge counts
+};
+hipError_t launch_consensus(const ConsArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
 
 }  // namespace wh

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(PHASE == 1 ? WH_SCOREA_THREADS : (PHASE == 2 ? WH_S
               // envelope is redone with every line stored.
 #pragma unroll 1
               for (int attempt = 0; attempt < 2; attempt++) {
-                const float keep_scale = attempt == 0 ? kKeepScale1 : -1.0f;
+                const float keep_scale = (a.dbg & 1) ? INFINITY : (attempt == 0 ? kKeepScale1 : -1.0f);
                 float xC_e; int ef_e;
                 {
                   TransTab<Q, TREG> T;
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(PHASE == 1 ? WH_SCOREA_THREADS : (PHASE == 2 ? WH_S
                   asm volatile("" ::: "memory");
                   // issue the loads of Forward row i early; they are consumed after the cell update
                   const unsigned mword = src < 32 ? SPRU(SP_ML * SP + i) : SPRU(SP_MH * SP + i);
-                  const bool have = (mword >> (src & 31)) & 1u;
+                  const bool have = ((mword >> (src & 31)) & 1u) && !(a.dbg & 2);
                   const float4 *row = reinterpret_cast<const float4 *>(Fs) + (size_t)i * (2 * (Q / 4) * kWave) + src;
                   float4 fm4[Q / 4], fi4[Q / 4];
                   if (have) {
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(PHASE == 1 ? WH_SCOREA_THREADS : (PHASE == 2 ? WH_S
                 sm = wave_sum(sm);
                 // certificate: posterior mass over all emitting states = number of residues
                 const float deficit = fabsf((float)Ld - (sm + si + xfac));
-                if (attempt == 0 && !(deficit <= kMassTol1 * (float)Ld)) continue;
+                if (attempt == 0 && !a.dbg && !(deficit <= kMassTol1 * (float)Ld)) continue;
                 if (attempt == 1) flags |= WH_FLAG_EXACT;
                 float mine = 1.0f;
                 for (int x = 0; x < a.K; x++) {

@@ -128,6 +128,27 @@ class EHMM:
                                  cols.ctypes.data), "wh_align")
         return cols, co
 
+    def consensus(self, offsets, qpair_off, pair_h, pair_w, col_offsets, cols, retained, nongaps, backbone_length):
+        """Weighted consensus DP (wh_consensus).  retained / nongaps: one int array per model."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        qpair_off = np.ascontiguousarray(qpair_off, dtype=np.int64)
+        pair_h = np.ascontiguousarray(pair_h, dtype=np.int32)
+        pair_w = np.ascontiguousarray(pair_w, dtype=np.float64)
+        col_offsets = np.ascontiguousarray(col_offsets, dtype=np.int64)
+        cols = np.ascontiguousarray(cols, dtype=np.int32)
+        ro = np.zeros(self.H + 1, dtype=np.int64)
+        ro[1:] = np.cumsum([len(r) for r in retained])
+        ret = np.ascontiguousarray(np.concatenate(retained), dtype=np.int32)
+        ng = np.ascontiguousarray(np.concatenate(nongaps), dtype=np.int32)
+        nq = len(offsets) - 1
+        out = np.zeros(int(offsets[-1]), dtype=np.int32)
+        mm = np.zeros(2 * nq, dtype=np.int32)
+        check(lib().wh_consensus(self._h, offsets.ctypes.data, nq, qpair_off.ctypes.data, pair_h.ctypes.data,
+                                 pair_w.ctypes.data, col_offsets.ctypes.data, cols.ctypes.data, ro.ctypes.data,
+                                 ret.ctypes.data, ng.ctypes.data, int(backbone_length), out.ctypes.data,
+                                 mm.ctypes.data), "wh_consensus")
+        return out, mm.reshape(nq, 2)
+
     # ------------------------------------------------------------------ device (torch) operators
     @staticmethod
     def _stream():

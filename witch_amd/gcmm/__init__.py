@@ -10,6 +10,7 @@ behaviour and serve their answers from that precomputed table:
     writeWeights    witch_msa/gcmm/weighting.py:121-169
     getBackbones    witch_msa/gcmm/aligner.py:33-148
     search          witch_msa/gcmm/algorithm.py:273-336 (result files: :524-537)
+    alignSubQueriesNew  witch_msa/gcmm/aligner.py:350-538 (weighted consensus DP on the GPU)
 
 INTEGRATION.md shows the three-line change in witch_msa/gcmm/gcmm.py that installs them.
 """
@@ -18,3 +19,4 @@ from .loader import rankBitscores, readAndRankBitscoreMP  # noqa: F401
 from .weighting import writeWeights, calculateWeights, writeWeightsToLocal, readWeightsFromLocal  # noqa: F401
 from .aligner import getBackbones  # noqa: F401
 from .algorithm import search, evalHMMSearchOutput  # noqa: F401
+from .merge import alignSubQueriesNew, compressInsertions, trace_to_string  # noqa: F401

@@ -43,10 +43,14 @@ class QueryAlignmentEngine:
         self.pair_of = {}             # (row, hmm label) -> pair number
         self.num_hmms = 0
         self.timings = {}
+        self.merged = None            # int32 CSR by query: consensus codes (gcmm/merge.py)
+        self.query_offsets = None     # int64 [nq+1]
+        self.merged_minmax = None
 
     # ------------------------------------------------------------------ construction
     @classmethod
-    def run(cls, index_to_hmm, unaligned, num_hmms: int, device: int = 0, multidomain_policy: str = "envelope"):
+    def run(cls, index_to_hmm, unaligned, num_hmms: int, device: int = 0, multidomain_policy: str = "envelope",
+            subset_to_retained_columns=None, subset_to_nongaps_per_column=None, backbone_length=None):
         """Score, weight and align every query of ``unaligned`` ({taxon: sequence text} or
         a list of (taxon, text)) against every HMM of ``index_to_hmm`` on one MI355X."""
         import time
@@ -85,6 +89,17 @@ class QueryAlignmentEngine:
         t3 = time.time()
         # same three stage names the reference logs (algorithm.py:333-335, weighting.py:165-168, aligner.py:520-525)
         self.timings = {"search": t1 - t0, "weights": t2 - t1, "align": t3 - t2}
+        self.query_offsets = offs
+        if subset_to_retained_columns is not None:
+            # the weighted consensus DP of alignSubQueriesNew (aligner.py:376-473), all queries at once
+            qpo = np.zeros(len(self.taxa) + 1, dtype=np.int64)
+            qpo[1:] = np.cumsum(self.n_used)
+            pw = np.array([self.topk_w[r, j] for r in range(len(self.taxa)) for j in range(int(self.n_used[r]))], dtype=np.float64)
+            ret = [np.asarray(subset_to_retained_columns[i], dtype=np.int32) for i in labels]
+            ng = [np.asarray(subset_to_nongaps_per_column[i], dtype=np.int32) for i in labels]
+            self.merged, self.merged_minmax = e.consensus(offs, qpo, ph, pw, self.col_offsets, self.cols, ret, ng,
+                                                          int(backbone_length))
+            self.timings["merge"] = time.time() - t3
         e.close()
         return self
 

@@ -295,3 +295,36 @@ def test_consensus_merge_against_oracle_and_reference(golden_case):
         labels = query._col_labels
         assert sum(1 for x in labels if x >= 0) == g["backbone_length"] and len(labels) == len(got)
     assert n_orc > 0 and n_ref > 0
+
+
+@pytest.mark.parametrize("root_len", [1700, 2950])
+def test_long_models_use_the_pass_synchronous_kernels(root_len, orc, tmp_path):
+    """Models beyond 1536 nodes (the reference's example backbone has up to 2574 match
+    columns) run with one transition orientation resident in LDS; parity with the oracle."""
+    _need_gpu()
+    from witch_amd import synth
+    from witch_amd.ehmm import EHMM, pack_queries
+    fam = synth.make_family(77 + root_len, root_len, 8, "dna", 0.03, 0.001)
+    eh = synth.make_ehmm(fam, 3, str(tmp_path), witch_layout=False)
+    assert max(h.M for h in eh.hmms) > 1536
+    names, seqs = synth.make_queries(fam, 5, 6, (80, 160))
+    rng = np.random.default_rng(1)
+    seqs.append(rng.integers(0, 4, size=120).astype(np.int8))     # unrelated
+    seqs = [s.astype(np.uint8) for s in seqs]
+    e = EHMM(eh.paths, hmm_index=eh.index, nseq=eh.nseq)
+    res, offs = pack_queries(seqs)
+    deci, flags, fwd = e.score(res, offs, want_fwd=True)
+    ohm = [orc.OracleHMM(p) for p in eh.paths]
+    od, of, ofwd, osc = orc.score_batch(ohm, res, offs)
+    assert np.max(np.abs(fwd - ofwd)) <= 1e-4, np.max(np.abs(fwd - ofwd))
+    assert np.array_equal(flags & 3, of & 3)
+    rep = (of & 1) == 1
+    for qi, hj in np.argwhere((deci != od) & rep):
+        assert abs(int(deci[qi, hj]) - int(od[qi, hj])) == 1 and _near_boundary(osc[qi, hj])
+    pq = [q for q in range(len(seqs)) for _ in range(e.H)]
+    ph = [h for q in range(len(seqs)) for h in range(e.H)]
+    cols, co = e.align(res, offs, pq, ph)
+    for p in range(len(pq)):
+        want = ohm[ph[p]].align(seqs[pq[p]])
+        assert np.array_equal(cols[co[p]:co[p + 1]], want), (root_len, pq[p], ph[p])
+    e.close()

@@ -49,8 +49,10 @@ __device__ __forceinline__ float tab_load(const float *tab, int arr, int k) {
 #define SPR(idx)  (SPECG ? __builtin_nontemporal_load(spec + (idx)) : spec[idx])
 #define SPRI(idx) (SPECG ? __builtin_nontemporal_load(reinterpret_cast<const int *>(spec) + (idx)) : reinterpret_cast<const int *>(spec)[idx])
 
-template <int Q, bool TREG, bool SPECG>
-__global__ __launch_bounds__(512) void align_kernel(AlignArgs a) {
+// SWAP (long models, Q > 24): only ONE transition orientation is resident in LDS; the waves of a
+// workgroup run the three sweeps in lockstep and swap the tables between them (see wh_score_big.hip).
+template <int Q, bool TREG, bool SPECG, bool SWAP>
+__global__ __launch_bounds__(SWAP ? 256 : 512) void align_kernel(AlignArgs a) {
   // all LDS in ONE 16-byte aligned dynamic array: a static __shared__ object in front of it
   // would shift the base by 4 bytes and split every ds_read_b128 (measured: 13x LDS time)
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
@@ -60,15 +62,29 @@ __global__ __launch_bounds__(512) void align_kernel(AlignArgs a) {
   constexpr int TBL = Q * kWave;
   constexpr int Q4 = Q / 4;
   float *emL = smem;
-  float *trL = smem + (size_t)a.K * TBL;
-  float *wbase = trL + (TREG ? 0 : 16 * TBL) + (size_t)wave * a.wave_lds;
+  const int Klds = a.Klds;   // emission rows staged in LDS (K, or 0 when they are read from L2)
+  float *trL = smem + (size_t)Klds * TBL;
+  float *wbase = trL + (TREG ? 0 : (SWAP ? 8 : 16) * TBL) + (size_t)wave * a.wave_lds;
   float *spec = SPECG ? a.spec_scratch + ((size_t)blockIdx.x * nwaves + wave) * a.spec_stride : wbase;   // AL_NARR * SP floats
   uint8_t *seq = reinterpret_cast<uint8_t *>(wbase + (SPECG ? 0 : AL_NARR * a.SP));
   const int SP = a.SP;
   float *slabA = a.scratch + ((size_t)blockIdx.x * nwaves + wave) * a.scratch_stride;   // F -> posteriors
   float *slabB = slabA + (size_t)(a.Lcap + 1) * 2 * TBL;                                // OA rows
-  int cur_h = -1;
+  int cur_h = -1, cur_orient = -1;
   const DevHMM *hm = nullptr;
+  const float *fwG = nullptr, *bwG = nullptr, *emG = nullptr;
+  // SWAP: every thread of the workgroup calls this at the same points
+  auto orient = [&](int o) {
+    if (SWAP && cur_orient != o) {
+      __syncthreads();
+      const float4 *src = reinterpret_cast<const float4 *>(o ? bwG : fwG);
+      float4 *dst = reinterpret_cast<float4 *>(trL);
+      for (int t = threadIdx.x; t < 8 * TBL / 4; t += blockDim.x) dst[t] = src[t];
+      __syncthreads();
+      cur_orient = o;
+    }
+  };
+  float *const trF = trL, *const trB = SWAP ? trL : trL + 8 * TBL;
 
   for (;;) {
     if (threadIdx.x == 0) *s_item_p = atomicAdd(a.counter, 1);
@@ -80,10 +96,12 @@ __global__ __launch_bounds__(512) void align_kernel(AlignArgs a) {
     const int p_lo = a.item_start[item], p_hi = p_lo + a.item_count[item];
     if (h != cur_h) {
       hm = a.hmms + h;
+      fwG = a.tables + hm->fw_off; bwG = a.tables + hm->bw_off; emG = a.tables + hm->em_off;
       const float4 *src = reinterpret_cast<const float4 *>(a.tables + hm->em_off);
       float4 *dst = reinterpret_cast<float4 *>(emL);
-      for (int t = threadIdx.x; t < a.K * TBL / 4; t += blockDim.x) dst[t] = src[t];
-      if (!TREG) {
+      for (int t = threadIdx.x; t < Klds * TBL / 4; t += blockDim.x) dst[t] = src[t];
+      cur_orient = -1;
+      if (!TREG && !SWAP) {
         const float4 *s1 = reinterpret_cast<const float4 *>(a.tables + hm->fw_off);
         const float4 *s2 = reinterpret_cast<const float4 *>(a.tables + hm->bw_off);
         float4 *d1 = reinterpret_cast<float4 *>(trL);
@@ -92,42 +110,44 @@ __global__ __launch_bounds__(512) void align_kernel(AlignArgs a) {
       cur_h = h;
       __syncthreads();
     }
-    const float *emG = a.tables + hm->em_off;
-    const float *fwG = a.tables + hm->fw_off, *bwG = a.tables + hm->bw_off;
     const int M = hm->M;
 
-    for (int pi = p_lo + wave; pi < p_hi; pi += nwaves) {
-      const int pair = a.order[pi];
-      const int64_t qi = a.pair_q[pair];
+    for (int pbase = p_lo; pbase < p_hi; pbase += nwaves) {
+      const int pi = pbase + wave;
+      bool active = pi < p_hi;
+      const int pair = active ? a.order[pi] : 0;
+      const int64_t qi = active ? a.pair_q[pair] : 0;
       const int64_t off = a.offsets[qi];
-      const int L = (int)(a.offsets[qi + 1] - off);
-      int32_t *cols = a.cols + a.col_offsets[pair];
+      const int L = active ? (int)(a.offsets[qi + 1] - off) : 0;
+      int32_t *cols = a.cols + (active ? a.col_offsets[pair] : 0);
       for (int t = lane; t < L; t += kWave) cols[t] = -1;
-      if (L <= 0 || L > a.Lcap) continue;
-      for (int t = lane; t < L; t += kWave) {
+      if (L <= 0 || L > a.Lcap) active = false;
+      for (int t = lane; active && t < L; t += kWave) {
         int c = a.residues[off + t];
         seq[t] = (uint8_t)(c < a.Kp ? c : a.Kp - 1);
       }
       __builtin_amdgcn_wave_barrier();
-      const LenCfg cu = len_config(L, false);
+      const LenCfg cu = len_config(L > 0 ? L : 1, false);
 
       // ---------------- unihit Forward, rows spilled to slab A
-      float xC_L; int ef_L;
-      {
+      float xC_L = 0.f; int ef_L = 0;
+      orient(0);
+      if (active) {
         TransTab<Q, TREG> T;
-        T.load(fwG, trL, lane);
+        T.load(fwG, trF, lane);
         const ScanC sc = scan_prepare(lane_product<Q, TREG>(T, FW_D2));
         // forward_sweep uses spec slots 0..5 = N,B,E,J,C,S with stride SP (AL_PN..AL_S coincide)
-        forward_sweep<Q, TREG, true>(T, sc, emL, emG, a.K, seq, L, cu, spec, SP, slabA, -1.0f, lane, xC_L, ef_L);   // dense
+        forward_sweep<Q, TREG, true>(T, sc, emL, emG, Klds, seq, L, cu, spec, SP, slabA, -1.0f, lane, xC_L, ef_L);   // dense
       }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-      if (!(xC_L > 0.f)) continue;   // no alignment has non-zero probability: all residues stay -1
+      if (!(xC_L > 0.f)) active = false;   // no alignment has non-zero probability: all residues stay -1
 
       // ---------------- Backward + posterior decoding, in place over slab A
-      {
+      orient(1);
+      if (active) {
         const float invZ = 1.0f / (xC_L * cu.move);
         TransTab<Q, TREG> T;
-        T.load(bwG, trL + 8 * TBL, lane);
+        T.load(bwG, trB, lane);
         const ScanC sc = scan_prepare(lane_product<Q, TREG>(T, BW_DD));
         float Mb[Q], Ib[Q];
 #pragma unroll
@@ -146,7 +166,7 @@ __global__ __launch_bounds__(512) void align_kernel(AlignArgs a) {
           }
           if (i < L) {
             float od[Q];
-            load_em_rev<Q>(od, emL, emG, seq[i], a.K, lane);
+            load_em_rev<Q>(od, emL, emG, seq[i], Klds, lane);
             float part = 0.f;
 #pragma unroll
             for (int p4 = 0; p4 < Q4; p4++) {
@@ -197,9 +217,10 @@ __global__ __launch_bounds__(512) void align_kernel(AlignArgs a) {
       // ---------------- optimal-accuracy fill (A.7), rows to slab B
       const float tNl = cu.loop > 0.f ? 1.f : 0.f, tNm = cu.move > 0.f ? 1.f : 0.f;
       const float tEJ = cu.EJ > 0.f ? 1.f : 0.f, tEC = cu.EC > 0.f ? 1.f : 0.f;
-      {
+      orient(0);
+      if (active) {
         TransTab<Q, TREG> T;
-        T.load(fwG, trL, lane);
+        T.load(fwG, trF, lane);
         float allpass = 1.f;
 #pragma unroll
         for (int q4 = 0; q4 < Q4; q4++) {
@@ -294,7 +315,7 @@ __global__ __launch_bounds__(512) void align_kernel(AlignArgs a) {
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 
       // ---------------- traceback: first maximum wins, candidate orders as in SURVEY.md A.7
-      {
+      if (active) {
         enum { stS, stN, stB, stM, stI, stD, stE, stJ, stC };
         int s0 = stC, s1 = stS, i = L, k = 0;
         int guard = 4 * (L + M) + 16;
@@ -401,24 +422,31 @@ __global__ __launch_bounds__(512) void align_kernel(AlignArgs a) {
   }
 }
 
-template <int Q, bool TREG, bool SPECG>
+template <int Q, bool TREG, bool SPECG, bool SWAP>
 static hipError_t launch_one(const AlignArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
-  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&align_kernel<Q, TREG, SPECG>),
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&align_kernel<Q, TREG, SPECG, SWAP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (err != hipSuccess) return err;
-  hipLaunchKernelGGL((align_kernel<Q, TREG, SPECG>), dim3(blocks), dim3(threads), lds, s, a);
+  hipLaunchKernelGGL((align_kernel<Q, TREG, SPECG, SWAP>), dim3(blocks), dim3(threads), lds, s, a);
   return hipGetLastError();
 }
 
 template <bool SPECG>
 static hipError_t launch_align_q(int Q, const AlignArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
   switch (Q) {
-    case 4:  return launch_one<4, false, SPECG>(a, blocks, threads, lds, s);
-    case 8:  return launch_one<8, false, SPECG>(a, blocks, threads, lds, s);
-    case 12: return launch_one<12, false, SPECG>(a, blocks, threads, lds, s);
-    case 16: return launch_one<16, false, SPECG>(a, blocks, threads, lds, s);
-    case 20: return launch_one<20, false, SPECG>(a, blocks, threads, lds, s);
-    case 24: return launch_one<24, false, SPECG>(a, blocks, threads, lds, s);
+    case 4:  return launch_one<4, false, SPECG, false>(a, blocks, threads, lds, s);
+    case 8:  return launch_one<8, false, SPECG, false>(a, blocks, threads, lds, s);
+    case 12: return launch_one<12, false, SPECG, false>(a, blocks, threads, lds, s);
+    case 16: return launch_one<16, false, SPECG, false>(a, blocks, threads, lds, s);
+    case 20: return launch_one<20, false, SPECG, false>(a, blocks, threads, lds, s);
+    case 24: return launch_one<24, false, SPECG, false>(a, blocks, threads, lds, s);
+    // long models: pass-synchronous table swapping, special states always in HBM
+    case 28: return launch_one<28, false, true, true>(a, blocks, threads, lds, s);
+    case 32: return launch_one<32, false, true, true>(a, blocks, threads, lds, s);
+    case 36: return launch_one<36, false, true, true>(a, blocks, threads, lds, s);
+    case 40: return launch_one<40, false, true, true>(a, blocks, threads, lds, s);
+    case 44: return launch_one<44, false, true, true>(a, blocks, threads, lds, s);
+    case 48: return launch_one<48, false, true, true>(a, blocks, threads, lds, s);
     default: return hipErrorInvalidValue;
   }
 }

@@ -284,6 +284,47 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       const bool treg = false;
       int waves, SP, wave_lds;
       size_t lds;
+      if (Q > kMaxQFast) {
+        // long models: pass-synchronous kernel, one transition orientation resident, 4 waves per workgroup
+        const int Lc = std::max(max_len, 1);
+        const int wl = 32 + 3 * WH_MAX_ENVELOPES + (Lc + 3) / 4 + 4;
+        waves = 4;
+        int Klds = e->K;
+        size_t table = (size_t)(Klds + 8) * Q * kWave * sizeof(float);
+        if (kLdsHeader + table + (size_t)waves * wl * sizeof(float) > kLdsBudget) { Klds = 0; table = (size_t)8 * Q * kWave * sizeof(float); }
+        lds = kLdsHeader + table + (size_t)waves * wl * sizeof(float);
+        if (lds > kLdsBudget) { set_error("query length %d with model class Q=%d does not fit in LDS", max_len, Q); return WH_ERANGE; }
+        ScoreArgs a;
+        memset(&a, 0, sizeof a);
+        a.hmms = (const DevHMM *)e->d_hmms.p;
+        a.tables = (const float *)e->d_tables.p;
+        a.hmm_list = (const int32_t *)e->d_lists.p + list_off;
+        a.n_list = (int)kv.second.size();
+        list_off += a.n_list;
+        a.residues = d_residues; a.offsets = d_offsets; a.nq = nq;
+        a.QB = waves * 4;
+        a.n_qblocks = (int)((nq + a.QB - 1) / a.QB);
+        a.n_items = a.n_list * a.n_qblocks;
+        a.counter = (int *)e->d_counter.p + launches;
+        a.Lcap = Lc; a.SP = (Lc + 1 + 3) / 4 * 4; a.wave_lds = wl; a.Klds = Klds;
+        const int blocks = std::min(a.n_items, e->cu_count);
+        a.scratch_stride = (size_t)(a.Lcap + 1) * 2 * Q * kWave;
+        a.spec_stride = (size_t)8 * a.SP;
+        if (e->d_scratch.ensure((size_t)blocks * waves * a.scratch_stride * sizeof(float)) ||
+            e->d_spec.ensure((size_t)blocks * waves * a.spec_stride * sizeof(float)))
+          return WH_ENOMEM;
+        a.scratch = (float *)e->d_scratch.p;
+        a.spec_scratch = (float *)e->d_spec.p;
+        a.decibits = d_decibits; a.flags = d_flags; a.fwd_bits = d_fwd_bits; a.detail = d_detail;
+        a.H = H; a.K = e->K; a.Kp = e->Kp;
+        memcpy(a.degen, e->degen, sizeof a.degen);
+        HIPCHK(hipMemsetAsync(a.counter, 0, sizeof(int), s));
+        hipError_t err = launch_score_big(Q, a, blocks, waves * kWave, lds, s);
+        if (err != hipSuccess) { set_error("score kernel launch (Q=%d, long model) failed: %s", Q, hipGetErrorString(err)); return WH_EHIP; }
+        launches++;
+        if (launches >= 60) break;
+        continue;
+      }
       const char *kenv = getenv("WH_SCORE_KERNEL");
       const int kver = kenv ? atoi(kenv) : 1;    // 1 fused single (default, fastest measured), 2 fused packed pair, 3 split
       if (kver == 3) {
@@ -499,16 +540,22 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
   if (timer_begin(e, 2, s)) return WH_EHIP;
   int launches = 0;
   std::vector<int32_t> items;   // all classes back to back: h, start, count
-  std::vector<std::array<int, 6>> plans;   // Q, first item, n items, waves, SP, wave_lds
+  std::vector<std::array<int, 7>> plans;   // Q, first item, n items, waves, SP, wave_lds, Klds
   std::vector<size_t> ldss;
   for (auto &kv : e->by_q) {
     const int Q = kv.first;
-    int waves, SP, wave_lds; size_t lds;
-    if (plan_align_block(Q, e->K, std::max(max_len, 1), &waves, &SP, &wave_lds, &lds) != WH_OK) {
-      set_error("query length %d with model class Q=%d does not fit in LDS", max_len, Q);
-      return WH_ERANGE;
-    }
-    if (waves < 4) {   // long queries: special-state rows in HBM
+    int waves = 0, SP = 0, wave_lds = 0; size_t lds = 0;
+    if (Q <= kMaxQFast && plan_align_block(Q, e->K, std::max(max_len, 1), &waves, &SP, &wave_lds, &lds) != WH_OK) waves = 0;
+    int Klds = e->K;
+    if (Q > kMaxQFast) {   // long models: one orientation resident, 4 waves, special states in HBM
+      SP = (std::max(max_len, 1) + 1 + 3) / 4 * 4;
+      wave_lds = -((std::max(max_len, 1) + 3) / 4 + 4);
+      waves = 4;
+      size_t table = (size_t)(Klds + 8) * Q * kWave * sizeof(float);
+      if (kLdsHeader + table + (size_t)waves * (size_t)(-wave_lds) * sizeof(float) > kLdsBudget) { Klds = 0; table = (size_t)8 * Q * kWave * sizeof(float); }
+      lds = kLdsHeader + table + (size_t)waves * (size_t)(-wave_lds) * sizeof(float);
+      if (lds > kLdsBudget) { set_error("query length %d with model class Q=%d does not fit in LDS", max_len, Q); return WH_ERANGE; }
+    } else if (waves < 4) {   // long queries: special-state rows in HBM
       SP = (std::max(max_len, 1) + 1 + 3) / 4 * 4;
       wave_lds = -((std::max(max_len, 1) + 3) / 4 + 4);   // negative marks the HBM mode for the launch loop below
       const size_t table = (size_t)(e->K + 16) * Q * kWave * sizeof(float);
@@ -523,7 +570,7 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       for (int st = lo; st < hi; st += waves) { items.push_back(h); items.push_back(st); items.push_back(std::min(waves, hi - st)); }
     }
     const int n = (int)items.size() / 3 - first;
-    if (n > 0) { plans.push_back({Q, first, n, waves, SP, wave_lds}); ldss.push_back(lds); }
+    if (n > 0) { plans.push_back({Q, first, n, waves, SP, wave_lds, Klds}); ldss.push_back(lds); }
   }
   const size_t nit = items.size() / 3;
   std::vector<int32_t> soa(items.size());
@@ -544,7 +591,7 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
     a.col_offsets = d_col_offsets; a.cols = d_cols;
     a.counter = (int *)e->d_counter.p + launches;
     a.Lcap = std::max(max_len, 1); a.SP = plans[pl][4]; a.wave_lds = std::abs(plans[pl][5]);
-    a.K = e->K; a.Kp = e->Kp;
+    a.K = e->K; a.Kp = e->Kp; a.Klds = plans[pl][6];
     const int blocks = std::min(n, e->cu_count * std::max(1, 8 / waves));
     if (plans[pl][5] < 0) {
       a.spec_stride = (size_t)13 * a.SP;

@@ -10,7 +10,8 @@
 namespace wh {
 
 constexpr int kWave = 64;          // CDNA wavefront width
-constexpr int kMaxQ = 24;          // cells per lane supported by this build -> M <= 64*kMaxQ
+constexpr int kMaxQ = 48;          // cells per lane supported by this build -> M <= 64*kMaxQ = 3072
+constexpr int kMaxQFast = 24;      // up to here both transition orientations stay resident in LDS
 constexpr int kQRegMax = 16;       // up to this Q the transition tables live in VGPRs
 
 void set_error(const char *fmt, ...);

@@ -188,7 +188,7 @@ int choose_Q(int M) {
   int q = (M + kWave - 1) / kWave;
   q = (q + 3) / 4 * 4;
   if (q < 4) q = 4;
-  // instantiated classes: 4, 8, 12, 16 (transitions in VGPRs), 20, 24 (transitions in LDS)
+  // instantiated classes: 4..24 (both orientations resident in LDS), 28..48 (pass-synchronous swap)
   if (q > kMaxQ) return -1;
   return q;
 }

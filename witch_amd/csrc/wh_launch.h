@@ -41,10 +41,12 @@ struct ScoreArgs {
   int H;
   int K, Kp;
   uint32_t degen[32];
+  int Klds;                    // emission rows staged in LDS (= K, or 0: read from L2)
   int dbg;                     // timing experiments only: 1 = skip Forward-row stores, 2 = skip Forward-row loads
 };
 
 hipError_t launch_score(int Q, int phase, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
+hipError_t launch_score_big(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
 hipError_t launch_score2(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
 
 struct TopkArgs {
@@ -80,6 +82,7 @@ struct AlignArgs {
   size_t scratch_stride;       // floats per wave
   float *spec_scratch;         // long-query mode: per-wave special-state rows in HBM (else NULL -> LDS)
   size_t spec_stride;
+  int Klds;                    // emission rows staged in LDS (= K, or 0: read from L2)
   int K, Kp;
 };
 hipError_t launch_align(int Q, const AlignArgs &a, int blocks, int threads, size_t lds, hipStream_t s);

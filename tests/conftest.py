@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-CASES = ["dna_hmmbuild", "dna_synth", "amino_hmmbuild", "example_sub30"]
+CASES = ["dna_hmmbuild", "dna_synth", "amino_hmmbuild", "example_sub30", "example_ehmm"]
 
 
 def pytest_configure(config):
@@ -35,12 +35,28 @@ class GoldenCase:
         with gzip.open(os.path.join(self.dir, "golden.json.gz"), "rt") as f:
             self.g = json.load(f)
         self.qnames, self.qseqs = read_fasta(os.path.join(self.dir, "queries.fasta"))
-        self.hmm_paths = [os.path.join(self.dir, hf) for hf in self.g["hmm_files"]]
+        self.hmm_paths = [self._materialize(hf) for hf in self.g["hmm_files"]]
         self.hmm_files = self.g["hmm_files"]
         self.hmm_index = self.g["hmm_index"]
         self.nseq = self.g["nseq"]
         self.k = self.g["k"]
         self.alphabet = self.g["alphabet"]
+
+
+    def _materialize(self, hf):
+        """Big model files are committed gzipped; unpack them once into the temp dir."""
+        path = os.path.join(self.dir, hf)
+        if os.path.exists(path) or not os.path.exists(path + ".gz"):
+            return path
+        import tempfile
+        d = os.path.join(tempfile.gettempdir(), "witch_golden_%d_%s" % (os.getuid(), self.name))
+        os.makedirs(d, exist_ok=True)
+        out = os.path.join(d, os.path.basename(hf))
+        if not os.path.exists(out):
+            with gzip.open(path + ".gz", "rb") as fi, open(out + ".tmp", "wb") as fo:
+                fo.write(fi.read())
+            os.replace(out + ".tmp", out)
+        return out
 
 
 _cache = {}

@@ -306,12 +306,55 @@ def example_case(ref):
     c.finish(ref)
 
 
+def example_ehmm_case(ref):
+    """Mini-eHMM over the reference's own example backbone (500 sequences, 2574 columns): nested
+    subsets of 500 / 125 / 62 sequences -> hmmbuild models of 2574 / ~1500 / ~1300 nodes; the first
+    40 example fragments as queries; includes the weighted-consensus strings of alignSubQueriesNew.
+    The HMM text files are stored gzipped (they are 0.4-0.6 MB each)."""
+    c = Case("example_ehmm", "dna", 3)
+    rows = []
+    with gzip.open(os.path.join(REF, "examples/data/backbone.aln.fasta.gz"), "rt") as f:
+        for line in f:
+            line = line.strip()
+            if line.startswith(">"):
+                rows.append([line[1:].split()[0], ""])
+            elif line:
+                rows[-1][1] += line.upper()
+    c.backbone = [(n, t) for n, t in rows]
+    c.subset_rows = [(0, len(rows)), (0, 125), (0, 62)]
+    for idx, (lo, hi) in enumerate(c.subset_rows):
+        fa = os.path.join(c.dir, "sub.fasta")
+        with open(fa, "w") as o:
+            for n, t in rows[lo:hi]:
+                o.write(">%s\n%s\n" % (n, t))
+        hp = os.path.join(c.dir, "hmms", "A_0_%d.hmm" % idx)
+        hmmbuild("dna", hp, fa)
+        os.remove(fa)
+        c.add_hmm(hp, idx, hi - lo)
+    names, seqs = [], []
+    for line in open(os.path.join(REF, "examples/data/unaligned_frag.fasta")):
+        line = line.strip()
+        if line.startswith(">"):
+            names.append(line[1:].split()[0])
+            seqs.append("")
+        elif line:
+            seqs[-1] += line.upper()
+    c.qnames, c.qseqs = names[:40], seqs[:40]
+    c.finish(ref)
+    for hf in c.hmm_files:      # gzip the big model files
+        hp = os.path.join(c.dir, hf)
+        with open(hp, "rb") as fi, gzip.open(hp + ".gz", "wb", compresslevel=9) as fo:
+            fo.write(fi.read())
+        os.remove(hp)
+
+
 def main():
     ref = import_reference()
     family_case(ref, "dna_hmmbuild", "dna", 11, 120, 32, 8, 0.04, 0.004, 4, 30, (60, 110), True)
     family_case(ref, "dna_synth", "dna", 12, 150, 16, 4, 0.03, 0.003, 4, 20, 100, False)
     family_case(ref, "amino_hmmbuild", "amino", 13, 90, 16, 4, 0.08, 0.004, 4, 20, (40, 120), True)
     example_case(ref)
+    example_ehmm_case(ref)
     shutil.rmtree(ref[0], ignore_errors=True)
 
 

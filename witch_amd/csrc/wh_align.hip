@@ -64,7 +64,7 @@ __global__ __launch_bounds__(SWAP ? 256 : 512) void align_kernel(AlignArgs a) {
   float *emL = smem;
   const int Klds = a.Klds;   // emission rows staged in LDS (K, or 0 when they are read from L2)
   float *trL = smem + (size_t)Klds * TBL;
-  float *wbase = trL + (TREG ? 0 : (SWAP ? 8 : 16) * TBL) + (size_t)wave * a.wave_lds;
+  float *wbase = trL + (TREG ? 0 : (SWAP ? 8 : 2 * FW_NARR) * TBL) + (size_t)wave * a.wave_lds;
   float *spec = SPECG ? a.spec_scratch + ((size_t)blockIdx.x * nwaves + wave) * a.spec_stride : wbase;   // AL_NARR * SP floats
   uint8_t *seq = reinterpret_cast<uint8_t *>(wbase + (SPECG ? 0 : AL_NARR * a.SP));
   const int SP = a.SP;
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(SWAP ? 256 : 512) void align_kernel(AlignArgs a) {
       cur_orient = o;
     }
   };
-  float *const trF = trL, *const trB = SWAP ? trL : trL + 8 * TBL;
+  float *const trF = trL, *const trB = SWAP ? trL : trL + FW_NARR * TBL;
 
   for (;;) {
     if (threadIdx.x == 0) *s_item_p = atomicAdd(a.counter, 1);
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(SWAP ? 256 : 512) void align_kernel(AlignArgs a) {
         const float4 *s1 = reinterpret_cast<const float4 *>(a.tables + hm->fw_off);
         const float4 *s2 = reinterpret_cast<const float4 *>(a.tables + hm->bw_off);
         float4 *d1 = reinterpret_cast<float4 *>(trL);
-        for (int t = threadIdx.x; t < 8 * TBL / 4; t += blockDim.x) { d1[t] = s1[t]; d1[8 * TBL / 4 + t] = s2[t]; }
+        for (int t = threadIdx.x; t < FW_NARR * TBL / 4; t += blockDim.x) { d1[t] = s1[t]; d1[FW_NARR * TBL / 4 + t] = s2[t]; }
       }
       cur_h = h;
       __syncthreads();

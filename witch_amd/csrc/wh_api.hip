@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <array>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -243,7 +244,7 @@ static int plan_block(int Q, int K, bool treg, int Lcap, int *waves, int *SP, in
   const int sp = (Lcap + 1 + 3) / 4 * 4;
   const int prob = 8 * sp + 32 + 3 * WH_MAX_ENVELOPES + (Lcap + 3) / 4 + 4;
   const int wl = 2 * prob;
-  const size_t table = (size_t)(K + 16) * Q * kWave * sizeof(float);
+  const size_t table = (size_t)(K + 2 * FW_NARR) * Q * kWave * sizeof(float);
   int w = 8;
   if (const char *ev = getenv("WH_MAX_WAVES")) w = std::max(1, std::min(16, atoi(ev)));   // tuning knob
   while (w >= 1 && kLdsHeader + table + (size_t)w * wl * sizeof(float) > kLdsBudget) w--;
@@ -255,7 +256,7 @@ static int plan_block(int Q, int K, bool treg, int Lcap, int *waves, int *SP, in
 static int plan_block1(int Q, int K, int Lcap, int wmax, int *waves, int *SP, int *wave_lds, size_t *lds) {
   const int sp = (Lcap + 1 + 3) / 4 * 4;
   const int wl = 8 * sp + 32 + 3 * WH_MAX_ENVELOPES + (Lcap + 3) / 4 + 4;
-  const size_t table = (size_t)(K + 16) * Q * kWave * sizeof(float);
+  const size_t table = (size_t)(K + 2 * FW_NARR) * Q * kWave * sizeof(float);
   int w = wmax;
   if (const char *ev = getenv("WH_MAX_WAVES")) w = std::max(1, std::min(wmax, atoi(ev)));
   while (w >= 1 && kLdsHeader + table + (size_t)w * wl * sizeof(float) > kLdsBudget) w--;
@@ -284,8 +285,9 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       const bool treg = false;
       int waves, SP, wave_lds;
       size_t lds;
-      if (Q > kMaxQFast) {
-        // long models: pass-synchronous kernel, one transition orientation resident, 4 waves per workgroup
+      // pass-synchronous kernel (wh_score_big.hip): long models, and long queries on models of
+      // 20+ cells per lane (there the fused kernel's HBM special-state variant misbehaves on gfx950)
+      auto run_big = [&]() -> int {
         const int Lc = std::max(max_len, 1);
         const int wl = 32 + 3 * WH_MAX_ENVELOPES + (Lc + 3) / 4 + 4;
         waves = 4;
@@ -322,6 +324,11 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
         hipError_t err = launch_score_big(Q, a, blocks, waves * kWave, lds, s);
         if (err != hipSuccess) { set_error("score kernel launch (Q=%d, long model) failed: %s", Q, hipGetErrorString(err)); return WH_EHIP; }
         launches++;
+        return WH_OK;
+      };
+      if (Q > kMaxQFast) {
+        int rcb = run_big();
+        if (rcb) return rcb;
         if (launches >= 60) break;
         continue;
       }
@@ -370,16 +377,23 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       bool specg = false;
       int rc_plan = use1 ? plan_block1(Q, e->K, std::max(max_len, 1), 8, &waves, &SP, &wave_lds, &lds)
                          : plan_block(Q, e->K, treg, std::max(max_len, 1), &waves, &SP, &wave_lds, &lds);
-      if (use1 && (rc_plan != WH_OK || waves < 4)) {
+      if (use1 && (rc_plan != WH_OK || waves < 4 || getenv("WH_FORCE_SPECG"))) {
         // long queries: the per-row special-state arrays move to a per-wave HBM region
         specg = true;
         SP = (std::max(max_len, 1) + 1 + 3) / 4 * 4;
         wave_lds = 32 + 3 * WH_MAX_ENVELOPES + (std::max(max_len, 1) + 3) / 4 + 4;
-        const size_t table = (size_t)(e->K + 16) * Q * kWave * sizeof(float);
+        const size_t table = (size_t)(e->K + 2 * FW_NARR) * Q * kWave * sizeof(float);
         waves = 8;
+        if (const char *ev = getenv("WH_MAX_WAVES")) waves = std::max(1, std::min(8, atoi(ev)));
         while (waves >= 1 && kLdsHeader + table + (size_t)waves * wave_lds * sizeof(float) > kLdsBudget) waves--;
         rc_plan = waves >= 1 ? WH_OK : WH_ERANGE;
         lds = kLdsHeader + table + (size_t)waves * wave_lds * sizeof(float);
+      }
+      if (specg && Q >= 20) {
+        int rcb = run_big();
+        if (rcb) return rcb;
+        if (launches >= 60) break;
+        continue;
       }
       if (rc_plan != WH_OK) {
         set_error("query length %d with model class Q=%d does not fit in LDS", max_len, Q);
@@ -411,6 +425,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       }
       memcpy(a.degen, e->degen, sizeof a.degen);
       if (const char *dv = getenv("WH_DBG")) a.dbg = atoi(dv);
+      if (getenv("WH_TRACE")) fprintf(stderr, "[wh] score Q=%d kver=%d specg=%d waves=%d blocks=%d lds=%zu SP=%d wave_lds=%d items=%d Lcap=%d\n", Q, kver, (int)specg, waves, blocks, lds, SP, wave_lds, a.n_items, a.Lcap);
       HIPCHK(hipMemsetAsync(a.counter, 0, sizeof(int), s));
       hipError_t err = use1 ? launch_score(Q, 0, a, blocks, waves * kWave, lds, s) : launch_score2(Q, a, blocks, waves * kWave, lds, s);
       if (err != hipSuccess) { set_error("score kernel launch (Q=%d) failed: %s", Q, hipGetErrorString(err)); return WH_EHIP; }
@@ -502,7 +517,7 @@ int wh_topk(wh_ehmm *e, const int32_t *decibits, const uint8_t *flags, int64_t n
 static int plan_align_block(int Q, int K, int Lcap, int *waves, int *SP, int *wave_lds, size_t *lds) {
   const int sp = (Lcap + 1 + 3) / 4 * 4;
   const int wl = 13 * sp + (Lcap + 3) / 4 + 4;
-  const size_t table = (size_t)(K + 16) * Q * kWave * sizeof(float);
+  const size_t table = (size_t)(K + 2 * FW_NARR) * Q * kWave * sizeof(float);
   int w = 8;
   while (w >= 1 && table + (size_t)w * wl * sizeof(float) > kLdsBudget) w--;
   if (w < 1) return WH_ERANGE;
@@ -555,10 +570,10 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       if (kLdsHeader + table + (size_t)waves * (size_t)(-wave_lds) * sizeof(float) > kLdsBudget) { Klds = 0; table = (size_t)8 * Q * kWave * sizeof(float); }
       lds = kLdsHeader + table + (size_t)waves * (size_t)(-wave_lds) * sizeof(float);
       if (lds > kLdsBudget) { set_error("query length %d with model class Q=%d does not fit in LDS", max_len, Q); return WH_ERANGE; }
-    } else if (waves < 4) {   // long queries: special-state rows in HBM
+    } else if (waves < 4 || getenv("WH_FORCE_SPECG")) {   // long queries: special-state rows in HBM
       SP = (std::max(max_len, 1) + 1 + 3) / 4 * 4;
       wave_lds = -((std::max(max_len, 1) + 3) / 4 + 4);   // negative marks the HBM mode for the launch loop below
-      const size_t table = (size_t)(e->K + 16) * Q * kWave * sizeof(float);
+      const size_t table = (size_t)(e->K + 2 * FW_NARR) * Q * kWave * sizeof(float);
       waves = 8;
       while (waves >= 1 && kLdsHeader + table + (size_t)waves * (size_t)(-wave_lds) * sizeof(float) > kLdsBudget) waves--;
       if (waves < 1) { set_error("model class Q=%d does not fit in LDS", Q); return WH_ERANGE; }
@@ -738,7 +753,7 @@ int wh_ehmm_max_query_len(const wh_ehmm *e) {
   // (the HBM workspace grows with L x M and may still fail with WH_ENOMEM).
   int best = 1 << 20;
   for (auto &kv : e->by_q) {
-    const size_t table = (size_t)(e->K + 16) * kv.first * kWave * sizeof(float);
+    const size_t table = (size_t)(e->K + 2 * FW_NARR) * kv.first * kWave * sizeof(float);
     const size_t left = kLdsBudget - kLdsHeader - table - (32 + 3 * WH_MAX_ENVELOPES + 8) * sizeof(float);
     best = std::min(best, (int)std::min<size_t>(left, 1u << 20));
   }

@@ -93,11 +93,11 @@ struct TransTab;
 
 template <int Q>
 struct TransTab<Q, true> {
-  float4 v[8][Q / 4];
+  float4 v[FW_NARR][Q / 4];
   __device__ __forceinline__ void load(const float *g, const float * /*lds*/, int lane) {
     const float4 *p = reinterpret_cast<const float4 *>(g);
 #pragma unroll
-    for (int a = 0; a < 8; a++)
+    for (int a = 0; a < FW_NARR; a++)
 #pragma unroll
       for (int q4 = 0; q4 < Q / 4; q4++) v[a][q4] = p[(a * (Q / 4) + q4) * kWave + lane];
   }
@@ -204,7 +204,7 @@ constexpr float kRescaleHi = 1048576.0f;   // 2^20
 // keep_scale * E(row) (exec-masked stores: adjacent kept lanes still form contiguous segments);
 // the 64-bit mask of kept lanes goes to spec[SP_ML/SP_MH].  keep_scale < 0 stores everything.  Returns C(L) and its
 // scale exponent.
-template <int Q, bool TREG, bool STORE>
+template <int Q, bool TREG, bool STORE, bool USEP = false>
 __device__ __forceinline__ void forward_sweep(const TransTab<Q, TREG> &T, const ScanC &sc, const float *emL,
                                               const float *emG, int K, const uint8_t *seq, int L, LenCfg cfg,
                                               float *spec, int SP, float *Fs, float keep_scale, int lane,
@@ -262,12 +262,16 @@ __device__ __forceinline__ void forward_sweep(const TransTab<Q, TREG> &T, const 
     float es = 0.f;
 #pragma unroll
     for (int q4 = 0; q4 < Q / 4; q4++) {
-      const float4 D2 = T.ld(FW_D2, q4);
+      const float4 D2 = T.ld(USEP ? FW_P : FW_D2, q4);
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const int q = 4 * q4 + j;
-        carry *= f4get(D2, j);
-        Dp[q] += carry;
+        if (USEP) {
+          Dp[q] = fmaf(f4get(D2, j), carry, Dp[q]);   // D2 holds the in-lane running product here
+        } else {
+          carry *= f4get(D2, j);
+          Dp[q] += carry;
+        }
         es += Mp[q] + Dp[q];
       }
     }
@@ -318,7 +322,7 @@ __device__ __forceinline__ void forward_sweep(const TransTab<Q, TREG> &T, const 
 // One Backward row in reversed node order.  On entry Mb/Ib hold row i+1 (or zeros for
 // i = L) and <G> has been formed in place in Mb (G_k = o_k(x_{i+1}) * B_M_k(i+1)).
 // Produces row i in Mb/Ib.  xE = E(i).
-template <int Q, bool TREG>
+template <int Q, bool TREG, bool USEP = false>
 __device__ __forceinline__ void backward_cells(const TransTab<Q, TREG> &T, const ScanC &sc, float (&Mb)[Q],
                                                float (&Ib)[Q], float xE) {
   float Dn[Q];
@@ -338,12 +342,16 @@ __device__ __forceinline__ void backward_cells(const TransTab<Q, TREG> &T, const
   float carry = wave_shr1(scan_apply(sc, dprev));
 #pragma unroll
   for (int p4 = 0; p4 < Q / 4; p4++) {
-    const float4 DD = T.ld(BW_DD, p4);
+    const float4 DD = T.ld(USEP ? BW_P : BW_DD, p4);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       const int p = 4 * p4 + j;
-      carry *= f4get(DD, j);
-      Dn[p] += carry;
+      if (USEP) {
+        Dn[p] = fmaf(f4get(DD, j), carry, Dn[p]);
+      } else {
+        carry *= f4get(DD, j);
+        Dn[p] += carry;
+      }
     }
   }
   const float dm1 = wave_shr1(Dn[Q - 1]);

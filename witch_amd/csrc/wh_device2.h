@@ -110,9 +110,12 @@ __device__ __forceinline__ void forward_sweep2(const TransTab<Q, false> &T, cons
 #pragma unroll 1
   for (int i = 1; i <= Lmax; i++) {
     asm volatile("" ::: "memory");   // keep LDS table reads inside the row (no hoisting into VGPRs)
-    v2f od[Q];
-    // rows beyond a problem's own length compute garbage in its component only; give them a valid residue
-    load_em2_fwd<Q>(od, emL, emG, i <= p0.L ? p0.seq[i - 1] : 0, i <= p1.L ? p1.seq[i - 1] : 0, K, lane);
+    // emission rows of the two problems stay in separate registers: pairing them would cost a
+    // v_mov per cell, two scalar multiplies into the halves of the packed cell cost nothing extra.
+    // Rows beyond a problem's own length compute garbage in its component only (valid residue 0).
+    float od0[Q], od1[Q];
+    load_em_fwd<Q>(od0, emL, emG, i <= p0.L ? p0.seq[i - 1] : 0, K, lane);
+    load_em_fwd<Q>(od1, emL, emG, i <= p1.L ? p1.seq[i - 1] : 0, K, lane);
     const v2f mm1 = wave_shr1(Mp[Q - 1]), im1 = wave_shr1(Ip[Q - 1]), dm1 = wave_shr1(Dp[Q - 1]);
 #pragma unroll
     for (int q4 = Q / 4 - 1; q4 >= 0; q4--) {
@@ -129,7 +132,8 @@ __device__ __forceinline__ void forward_sweep2(const TransTab<Q, false> &T, cons
         acc = fma2(f4get(A, j), pm, acc);
         acc = fma2(f4get(B, j), pi, acc);
         acc = fma2(f4get(C, j), pd, acc);
-        Mp[q] = od[q] * acc;
+        Mp[q].x = od0[q] * acc.x;
+        Mp[q].y = od1[q] * acc.y;
         Ip[q] = ni;
       }
     }
@@ -283,8 +287,9 @@ __device__ __forceinline__ v2f backward_row2(const TransTab<Q, false> &T, const 
                                              int i, int lane, v2f (&Mb)[Q], v2f (&Ib)[Q], Bck2 &st, bool cells) {
   const int Lmax = p0.L > p1.L ? p0.L : p1.L;
   if (i < Lmax) {
-    v2f od[Q];
-    load_em2_rev<Q>(od, emL, emG, i < p0.L ? p0.seq[i] : 0, i < p1.L ? p1.seq[i] : 0, K, lane);
+    float od0[Q], od1[Q];
+    load_em_rev<Q>(od0, emL, emG, i < p0.L ? p0.seq[i] : 0, K, lane);
+    load_em_rev<Q>(od1, emL, emG, i < p1.L ? p1.seq[i] : 0, K, lane);
     v2f part = splat(0.f);
 #pragma unroll
     for (int p4 = 0; p4 < Q / 4; p4++) {
@@ -292,7 +297,8 @@ __device__ __forceinline__ v2f backward_row2(const TransTab<Q, false> &T, const 
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const int p = 4 * p4 + j;
-        Mb[p] *= od[p];
+        Mb[p].x *= od0[p];
+        Mb[p].y *= od1[p];
         part = fma2(f4get(E, j), Mb[p], part);
       }
     }

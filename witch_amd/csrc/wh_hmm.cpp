@@ -201,8 +201,8 @@ void build_tables(const HostHMM &h, int Q, std::vector<float> &fw, std::vector<f
     int lane = pos / Q, q = pos % Q;
     return (((size_t)arr * Q4 + q / 4) * kWave + lane) * 4 + (q % 4);
   };
-  fw.assign((size_t)8 * Mpad, 0.f);
-  bw.assign((size_t)8 * Mpad, 0.f);
+  fw.assign((size_t)FW_NARR * Mpad, 0.f);
+  bw.assign((size_t)BW_NARR * Mpad, 0.f);
   em.assign((size_t)h.Kp * Mpad, 0.f);
   for (int k = 1; k <= M; k++) {
     const double *tp = &h.pt[(size_t)(k - 1) * 7];

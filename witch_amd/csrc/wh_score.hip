@@ -58,7 +58,7 @@ __global__ __launch_bounds__(PHASE == 1 ? WH_SCOREA_THREADS : (PHASE == 2 ? WH_S
   constexpr int TBL = Q * kWave;   // floats per table array
   float *emL = smem;
   float *trL = smem + (size_t)a.K * TBL;                                   // !TREG: fw[8] then bw[8]
-  float *wbase = trL + (TREG ? 0 : 16 * TBL) + (size_t)wave * a.wave_lds;  // per-wave block
+  float *wbase = trL + (TREG ? 0 : 2 * FW_NARR * TBL) + (size_t)wave * a.wave_lds;  // per-wave block
   float *spec = SPECG ? a.spec_scratch + ((size_t)blockIdx.x * nwaves + wave) * a.spec_stride : wbase;   // SP_NARR * SP floats
   float *n2tab = wbase + (SPECG ? 0 : SP_NARR * a.SP);                                         // 32 floats
   int *regs = reinterpret_cast<int *>(n2tab + 32);                         // 3 * WH_MAX_ENVELOPES ints
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(PHASE == 1 ? WH_SCOREA_THREADS : (PHASE == 2 ? WH_S
         const float4 *s1 = reinterpret_cast<const float4 *>(a.tables + hm->fw_off);
         const float4 *s2 = reinterpret_cast<const float4 *>(a.tables + hm->bw_off);
         float4 *d1 = reinterpret_cast<float4 *>(trL);
-        for (int t = threadIdx.x; t < 8 * TBL / 4; t += blockDim.x) { d1[t] = s1[t]; d1[8 * TBL / 4 + t] = s2[t]; }
+        for (int t = threadIdx.x; t < FW_NARR * TBL / 4; t += blockDim.x) { d1[t] = s1[t]; d1[FW_NARR * TBL / 4 + t] = s2[t]; }
       }
       cur_h = h;
       __syncthreads();
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(PHASE == 1 ? WH_SCOREA_THREADS : (PHASE == 2 ? WH_S
           // ---------------- P2: multihit Backward + domain decoding
           {
             TransTab<Q, TREG> T;
-            T.load(bwG, trL + 8 * TBL, lane);
+            T.load(bwG, trL + FW_NARR * TBL, lane);
             const ScanC sc = scan_prepare(lane_product<Q, TREG>(T, BW_DD));
             float Mb[Q], Ib[Q];
 #pragma unroll
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(PHASE == 1 ? WH_SCOREA_THREADS : (PHASE == 2 ? WH_S
                 if (!(xC_e > 0.f)) break;
                 const float invZe = 1.0f / (xC_e * cu.move);
                 TransTab<Q, TREG> T;
-                T.load(bwG, trL + 8 * TBL, lane);
+                T.load(bwG, trL + FW_NARR * TBL, lane);
                 const ScanC sc = scan_prepare(lane_product<Q, TREG>(T, BW_DD));
                 float Mb[Q], Ib[Q], fM[Q], fI[Q];
 #pragma unroll

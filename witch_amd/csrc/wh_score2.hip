@@ -45,7 +45,7 @@ __global__ __launch_bounds__(WH_SCORE2_THREADS) void score_kernel2(ScoreArgs a) 
   constexpr int TBL = Q * kWave;
   float *emL = smem;
   float *trL = smem + (size_t)a.K * TBL;                    // fw[8] then bw[8]
-  float *wbase = trL + 16 * TBL + (size_t)wave * a.wave_lds;
+  float *wbase = trL + 2 * FW_NARR * TBL + (size_t)wave * a.wave_lds;
   const int SP = a.SP;
   // per-wave block: for each of the two problems: spec[SP_NARR*SP], n2tab[32], regs[3*MAXENV], seq[Lcap pad 4]
   const int prob_lds = a.wave_lds / 2;
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(WH_SCORE2_THREADS) void score_kernel2(ScoreArgs a) 
       const float4 *s1 = reinterpret_cast<const float4 *>(a.tables + hm->fw_off);
       const float4 *s2 = reinterpret_cast<const float4 *>(a.tables + hm->bw_off);
       float4 *d1 = reinterpret_cast<float4 *>(trL);
-      for (int t = threadIdx.x; t < 8 * TBL / 4; t += blockDim.x) { d1[t] = s1[t]; d1[8 * TBL / 4 + t] = s2[t]; }
+      for (int t = threadIdx.x; t < FW_NARR * TBL / 4; t += blockDim.x) { d1[t] = s1[t]; d1[FW_NARR * TBL / 4 + t] = s2[t]; }
       cur_h = h;
       __syncthreads();
     }
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(WH_SCORE2_THREADS) void score_kernel2(ScoreArgs a) 
       if (L_[0] > 0 || L_[1] > 0) {
         TransTab<Q, false> Tf, Tb;
         Tf.load(nullptr, trL, lane);
-        Tb.load(nullptr, trL + 8 * TBL, lane);
+        Tb.load(nullptr, trL + FW_NARR * TBL, lane);
         const ScanC scf = scan_prepare(lane_product<Q, false>(Tf, FW_D2));
         const ScanC scb = scan_prepare(lane_product<Q, false>(Tb, BW_DD));
         Prob p0 = {seq_[0], L_[0], spec_[0], Fs_[0]}, p1 = {seq_[1], L_[1], spec_[1], Fs_[1]};

@@ -406,6 +406,8 @@ static hipError_t launch_big(const ScoreArgs &a, int blocks, int threads, size_t
 
 hipError_t launch_score_big(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
   switch (Q) {
+    case 20: return launch_big<20>(a, blocks, threads, lds, s);
+    case 24: return launch_big<24>(a, blocks, threads, lds, s);
     case 28: return launch_big<28>(a, blocks, threads, lds, s);
     case 32: return launch_big<32>(a, blocks, threads, lds, s);
     case 36: return launch_big<36>(a, blocks, threads, lds, s);

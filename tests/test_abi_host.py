@@ -42,3 +42,28 @@ def test_product_does_not_use_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 for needle in ("import oracle", "from oracle", "p7_oracle", "libp7oracle"):
                     assert needle not in text, (f, needle)
+
+
+def test_no_gpu_fails_loudly_instead_of_falling_back():
+    """On a box without a GPU the product must raise, never compute on the CPU."""
+    import pytest
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from tests.conftest import load_case
+    from witch_amd.ehmm import EHMM
+    from witch_amd._lib import WitchHipError
+    case = load_case("dna_synth")
+    with pytest.raises(WitchHipError) as ei:
+        EHMM(case.hmm_paths)
+    assert "no HIP device" in str(ei.value) or "wh_init" in str(ei.value)
+
+
+def test_error_codes_and_messages_without_a_device():
+    from witch_amd import _lib
+    L = _lib.lib()
+    assert L.wh_digitize(7, b"ACGT", 4, np.zeros(4, np.uint8).ctypes.data) < 0     # unknown alphabet
+    assert b"bad argument" in L.wh_last_error()
+    assert L.wh_ehmm_count(None) < 0
+    assert L.wh_score(None, None, None, 0, None, None, None, None) < 0
+    assert b"wh_score" in L.wh_last_error()

@@ -32,6 +32,9 @@ WORKLOADS = {
     "dna_100k_x200": ("dna", 20251205, 900, 1024, 0.03, 1e-4, 200, 100000, 150, 10),
     # configs[1]: 1k queries x 10 HMMs, k=4 (parity-test sized)
     "dna_1k_x10": ("dna", 20251205, 1000, 256, 0.03, 2e-3, 10, 1000, 150, 4),
+    # development only: longer models (24 and 12 DP cells per lane)
+    "dna_m1450": ("dna", 20251205, 1450, 256, 0.03, 1e-4, 20, 2048, 150, 4),
+    "dna_m700": ("dna", 20251205, 700, 256, 0.03, 1e-4, 20, 2048, 150, 4),
 }
 
 

@@ -333,7 +333,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
         continue;
       }
       const char *kenv = getenv("WH_SCORE_KERNEL");
-      const int kver = kenv ? atoi(kenv) : 1;    // 1 fused single (default, fastest measured), 2 fused packed pair, 3 split
+      const int kver = kenv ? atoi(kenv) : 7;    // 7 phase-call kernel, 3 waves/SIMD (default, fastest measured); 1 fused single; 2 fused packed pair; 3 split; 5/6 register-table experiments
       if (kver == 3) {
         // split: phase A (Forward/Backward parsers + regions) then phase B (envelopes + assembly)
         const size_t np = (size_t)nq * H;
@@ -373,11 +373,23 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
         if (launches >= 60) break;
         continue;
       }
-      const bool use1 = kver == 1;
+      const bool use4 = false;
+      bool use5 = false;
+      if (kver == 5 && Q <= 16) {
+        // v1 with the transition tables in VGPRs: LDS holds only the emission rows
+        const int sp = (std::max(max_len, 1) + 1 + 3) / 4 * 4;
+        const int wl = 8 * sp + 32 + 3 * WH_MAX_ENVELOPES + (std::max(max_len, 1) + 3) / 4 + 4;
+        const size_t table = (size_t)e->K * Q * kWave * sizeof(float);
+        int w = 8;
+        if (const char *ev = getenv("WH_MAX_WAVES")) w = std::max(1, std::min(16, atoi(ev)));
+        while (w >= 1 && kLdsHeader + table + (size_t)w * wl * sizeof(float) > kLdsBudget) w--;
+        if (w >= 4) { use5 = true; waves = w; SP = sp; wave_lds = wl; lds = kLdsHeader + table + (size_t)w * wl * sizeof(float); }
+      }
+      const bool use1 = kver == 1 || kver == 6 || kver == 7 || (kver == 4 && !use4) || (kver == 5 && !use5);
       bool specg = false;
-      int rc_plan = use1 ? plan_block1(Q, e->K, std::max(max_len, 1), 8, &waves, &SP, &wave_lds, &lds)
+      int rc_plan = (use4 || use5) ? WH_OK : use1 ? plan_block1(Q, e->K, std::max(max_len, 1), kver == 7 ? (getenv("WH_WMAX") ? atoi(getenv("WH_WMAX")) : (Q <= 16 ? 12 : 8)) : 8, &waves, &SP, &wave_lds, &lds)
                          : plan_block(Q, e->K, treg, std::max(max_len, 1), &waves, &SP, &wave_lds, &lds);
-      if (use1 && (rc_plan != WH_OK || waves < 4 || getenv("WH_FORCE_SPECG"))) {
+      if (use1 && !use5 && (rc_plan != WH_OK || waves < 4 || getenv("WH_FORCE_SPECG"))) {
         // long queries: the per-row special-state arrays move to a per-wave HBM region
         specg = true;
         SP = (std::max(max_len, 1) + 1 + 3) / 4 * 4;
@@ -413,7 +425,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       a.counter = (int *)e->d_counter.p + launches;
       a.Lcap = std::max(max_len, 1); a.SP = SP; a.wave_lds = wave_lds;
       const int blocks = std::min(a.n_items, e->cu_count * std::max(1, 8 / waves));
-      a.scratch_stride = (use1 ? 1 : 2) * (size_t)(a.Lcap + 1) * 2 * Q * kWave;   // Forward slab(s) per wave
+      a.scratch_stride = (use1 || use4 || use5 ? 1 : 2) * (size_t)(a.Lcap + 1) * 2 * Q * kWave;   // Forward slab(s) per wave
       if (e->d_scratch.ensure((size_t)blocks * waves * a.scratch_stride * sizeof(float))) return WH_ENOMEM;
       a.scratch = (float *)e->d_scratch.p;
       a.decibits = d_decibits; a.flags = d_flags; a.fwd_bits = d_fwd_bits; a.detail = d_detail;
@@ -425,11 +437,30 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       }
       memcpy(a.degen, e->degen, sizeof a.degen);
       if (const char *dv = getenv("WH_DBG")) a.dbg = atoi(dv);
+      if (const char *kv2 = getenv("WH_KEEP_LOG2")) a.keep_scale = ldexpf(1.0f, atoi(kv2));
+      if (getenv("WH_STATS")) {
+        if (e->d_recs.ensure(128)) return WH_ENOMEM;
+        HIPCHK(hipMemsetAsync(e->d_recs.p, 0, 128, s));
+        a.stats = (unsigned long long *)e->d_recs.p;
+      }
       if (getenv("WH_TRACE")) fprintf(stderr, "[wh] score Q=%d kver=%d specg=%d waves=%d blocks=%d lds=%zu SP=%d wave_lds=%d items=%d Lcap=%d\n", Q, kver, (int)specg, waves, blocks, lds, SP, wave_lds, a.n_items, a.Lcap);
       HIPCHK(hipMemsetAsync(a.counter, 0, sizeof(int), s));
-      hipError_t err = use1 ? launch_score(Q, 0, a, blocks, waves * kWave, lds, s) : launch_score2(Q, a, blocks, waves * kWave, lds, s);
+      hipError_t err = use5 ? launch_score_treg(Q, a, blocks, waves * kWave, lds, s)
+                       : (kver == 7 && !specg) ? launch_score7(Q, a, blocks, waves * kWave, lds, s)
+                       : (kver == 6 && Q == 16 && !specg) ? launch_score_tr12(Q, getenv("WH_TRM") ? atoi(getenv("WH_TRM")) : 1, a, blocks, waves * kWave, lds, s)
+                       : use1 ? launch_score(Q, 0, a, blocks, waves * kWave, lds, s) : launch_score2(Q, a, blocks, waves * kWave, lds, s);
       if (err != hipSuccess) { set_error("score kernel launch (Q=%d) failed: %s", Q, hipGetErrorString(err)); return WH_EHIP; }
       launches++;
+      if (a.stats) {
+        unsigned long long st[16];
+        HIPCHK(hipMemcpyAsync(st, a.stats, sizeof st, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        fprintf(stderr, "[wh] stats Q=%d: envelope rows %llu, lane blocks kept %llu (%.1f of 64 per row), envelopes %llu, dense redos %llu\n", Q, st[0], st[1],
+                st[0] ? (double)st[1] / (double)st[0] : 0.0, st[2], st[3]);
+        const double tot = (double)(st[4] + st[5] + st[6] + st[7] + st[8] + st[9]);
+        fprintf(stderr, "[wh] wave cycles: P1 %.1f%%  P2 %.1f%%  regions %.1f%%  P3 %.1f%%  P4 %.1f%%  null2 %.1f%%  (total %.3g ticks; P1 per row %.0f ticks)\n", 100.0 * st[4] / tot,
+                100.0 * st[5] / tot, 100.0 * st[6] / tot, 100.0 * st[7] / tot, 100.0 * st[8] / tot, 100.0 * st[9] / tot, tot, (double)st[4] / ((double)nq * a.n_list * 150.0));
+      }
       if (launches >= 60) break;
     }
   }

@@ -43,10 +43,15 @@ struct ScoreArgs {
   uint32_t degen[32];
   int Klds;                    // emission rows staged in LDS (= K, or 0: read from L2)
   int dbg;                     // timing experiments only: 1 = skip Forward-row stores, 2 = skip Forward-row loads
+  float keep_scale;            // Forward-row spill threshold relative to E(row); 0 = default 2^-40
+  unsigned long long *stats;   // experiments: [0] envelope rows, [1] lane blocks kept, [2] envelopes, [3] dense redos (or NULL)
 };
 
 hipError_t launch_score(int Q, int phase, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
 hipError_t launch_score_big(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
+hipError_t launch_score7(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
+hipError_t launch_score_tr12(int Q, int mask, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
+hipError_t launch_score_treg(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
 hipError_t launch_score2(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
 
 struct TopkArgs {

@@ -24,8 +24,10 @@ __device__ __forceinline__ float flogsum0_v1(float b) {
   return mx + (float)log(1.0 + exp((double)-idx / 1000.0));
 }
 
-// lanes whose Forward cells are all below kKeepScale * E(row) are not spilled (attempt 0)
-constexpr float kKeepScale1 = 9.094947e-13f;   // 2^-40
+// lanes whose Forward cells are all below kKeepScale * E(row) are not spilled (attempt 0).
+// 2^-24 keeps ~19 of 64 lane blocks per row on the headline workload (2^-40: ~29) with no
+// certificate failure and bit-identical deci-bit scores on 1.6M pairs (tools/ab_score.py).
+constexpr float kKeepScale1 = 5.9604645e-08f;   // 2^-24
 // tolerated |Ld - posterior mass| / Ld of the certificate (float32 accumulation noise is ~1e-6)
 constexpr float kMassTol1 = 2e-5f;
 
@@ -47,7 +49,9 @@ constexpr float kMassTol1 = 2e-5f;
 #define SPRI(idx) (SPECG ? __builtin_nontemporal_load(reinterpret_cast<const int *>(spec) + (idx)) : reinterpret_cast<const int *>(spec)[idx])
 #define SPRU(idx) (SPECG ? __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(spec) + (idx)) : reinterpret_cast<const unsigned *>(spec)[idx])
 
-template <int Q, bool TREG, int PHASE, bool SPECG>
+#define WH_TICK(slot) do { if (a.stats) { const long long t_now = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(a.stats + (slot), (unsigned long long)(t_now - t_last)); t_last = t_now; } } while (0)
+
+template <int Q, bool TREG, int PHASE, bool SPECG, int TRM = 0>
 __global__ __launch_bounds__(PHASE == 1 ? WH_SCOREA_THREADS : (PHASE == 2 ? WH_SCOREB_THREADS : WH_SCORE1_THREADS)) void score_kernel(ScoreArgs a) {
   // all LDS in ONE 16-byte aligned dynamic array: a static __shared__ object in front of it
   // would shift the base by 4 bytes and split every ds_read_b128 (measured: 13x LDS time)
@@ -113,6 +117,7 @@ __global__ __launch_bounds__(PHASE == 1 ? WH_SCOREA_THREADS : (PHASE == 2 ? WH_S
         __builtin_amdgcn_wave_barrier();
 
         float fwdsc = 0.f, nullsc = 0.f, invZ = 0.f;
+        long long t_last = a.stats ? __builtin_readcyclecounter() : 0;
         int ef_L = 0, nreg = 0, nenv = 0;
         bool ok = false;
         PairRec *rec = a.recs ? a.recs + out : nullptr;
@@ -121,10 +126,11 @@ __global__ __launch_bounds__(PHASE == 1 ? WH_SCOREA_THREADS : (PHASE == 2 ? WH_S
         const LenCfg cm = len_config(L, true);
         float xC_L;
         {
-          TransTab<Q, TREG> T;
+          constexpr bool TR1 = TREG || (TRM & 1);
+          TransTab<Q, TR1> T;
           T.load(fwG, trL, lane);
-          const ScanC sc = scan_prepare(lane_product<Q, TREG>(T, FW_D2));
-          forward_sweep<Q, TREG, false>(T, sc, emL, emG, a.K, seq, L, cm, spec, SP, nullptr, 0.f, lane, xC_L, ef_L);
+          const ScanC sc = scan_prepare(lane_product<Q, TR1>(T, FW_D2));
+          forward_sweep<Q, TR1, false>(T, sc, emL, emG, a.K, seq, L, cm, spec, SP, nullptr, 0.f, lane, xC_L, ef_L);
         }
         if (SPECG) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         const double fwd_nats = (double)ef_L * 0.69314718055994529 + log((double)(xC_L * cm.move));
@@ -137,11 +143,13 @@ __global__ __launch_bounds__(PHASE == 1 ? WH_SCOREA_THREADS : (PHASE == 2 ? WH_S
         ok = xC_L > 0.f && isfinite(fwdsc);
         invZ = ok ? 1.0f / (xC_L * cm.move) : 0.f;
         if (ok) {
+          WH_TICK(4);
           // ---------------- P2: multihit Backward + domain decoding
           {
-            TransTab<Q, TREG> T;
+            constexpr bool TR2 = TREG || (TRM & 2);
+            TransTab<Q, TR2> T;
             T.load(bwG, trL + FW_NARR * TBL, lane);
-            const ScanC sc = scan_prepare(lane_product<Q, TREG>(T, BW_DD));
+            const ScanC sc = scan_prepare(lane_product<Q, TR2>(T, BW_DD));
             float Mb[Q], Ib[Q];
 #pragma unroll
             for (int p = 0; p < Q; p++) { Mb[p] = 0.f; Ib[p] = 0.f; }
@@ -170,7 +178,7 @@ __global__ __launch_bounds__(PHASE == 1 ? WH_SCOREA_THREADS : (PHASE == 2 ? WH_S
                 xN = fmaf(xN, cm.loop, xB * cm.move);
               }
               float xE = fmaf(xC, cm.EC, xJ * cm.EJ);
-              if (i >= 1) backward_cells<Q, TREG>(T, sc, Mb, Ib, xE);
+              if (i >= 1) backward_cells<Q, TR2>(T, sc, Mb, Ib, xE);
               const float big = fmaxf(xB, xN);
               if (big > kRescaleHi) {
                 const int e = f32_exponent(big);
@@ -199,6 +207,7 @@ __global__ __launch_bounds__(PHASE == 1 ? WH_SCOREA_THREADS : (PHASE == 2 ? WH_S
           }
 
           if (SPECG) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+          WH_TICK(5);
           // ---------------- region scan (A.4), uniform over the wave
           const float rt1 = 0.25f, rt2 = 0.10f, rt3 = 0.20f;
           {
@@ -259,6 +268,7 @@ __global__ __launch_bounds__(PHASE == 1 ? WH_SCOREA_THREADS : (PHASE == 2 ? WH_S
         }
         if constexpr (PHASE != 1) {
           if (ok && nenv > 0) {
+            WH_TICK(6);
             // ---------------- envelopes: unihit Forward/Backward, null2 by expectation (A.5)
             const LenCfg cu = len_config(L, false);
             float seqbias_sum = 0.f, sum_score = 0.f, sb2 = 0.f;
@@ -268,25 +278,36 @@ __global__ __launch_bounds__(PHASE == 1 ? WH_SCOREA_THREADS : (PHASE == 2 ? WH_S
               const int Ld = rj - ri + 1;
               const uint8_t *eseq = seq + (ri - 1);
               float envsc = -INFINITY, domcorr = 0.f;
-              // Attempt 0 spills only the lanes whose Forward cells exceed 2^-40 of the row total;
+              // Attempt 0 spills only the lanes whose Forward cells exceed 2^-24 of the row total;
               // the posterior mass that reached the accumulators must then add up to Ld residues
               // (every residue is emitted by exactly one state).  If the certificate fails the
               // envelope is redone with every line stored.
 #pragma unroll 1
               for (int attempt = 0; attempt < 2; attempt++) {
-                const float keep_scale = (a.dbg & 1) ? INFINITY : (attempt == 0 ? kKeepScale1 : -1.0f);
+                const float keep_scale = (a.dbg & 1) ? INFINITY : (attempt == 0 ? (a.keep_scale > 0.f ? a.keep_scale : kKeepScale1) : -1.0f);
                 float xC_e; int ef_e;
                 {
-                  TransTab<Q, TREG> T;
+                  constexpr bool TR3 = TREG || (TRM & 4);
+                  TransTab<Q, TR3> T;
                   T.load(fwG, trL, lane);
-                  const ScanC sc = scan_prepare(lane_product<Q, TREG>(T, FW_D2));
-                  forward_sweep<Q, TREG, true>(T, sc, emL, emG, a.K, eseq, Ld, cu, spec, SP, Fs, keep_scale, lane, xC_e, ef_e);
+                  const ScanC sc = scan_prepare(lane_product<Q, TR3>(T, FW_D2));
+                  forward_sweep<Q, TR3, true>(T, sc, emL, emG, a.K, eseq, Ld, cu, spec, SP, Fs, keep_scale, lane, xC_e, ef_e);
                 }
                 // the rows were written by other lanes of this wave: order the stores before the loads
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                if (a.stats) {
+                  unsigned kept = 0;
+                  for (int t = 1 + lane; t <= Ld; t += kWave) kept += __popc(SPRU(SP_ML * SP + t)) + __popc(SPRU(SP_MH * SP + t));
+                  kept = (unsigned)wave_sum((float)kept);
+                  if (lane == 0) {
+                    atomicAdd(a.stats + 0, (unsigned long long)Ld); atomicAdd(a.stats + 1, (unsigned long long)kept);
+                    atomicAdd(a.stats + (attempt == 0 ? 2 : 3), 1ull);
+                  }
+                }
                 envsc = (float)((double)ef_e * 0.69314718055994529 + log((double)(xC_e * cu.move)));
                 domcorr = 0.f;
                 if (!(xC_e > 0.f)) break;
+                WH_TICK(7);
                 const float invZe = 1.0f / (xC_e * cu.move);
                 TransTab<Q, TREG> T;
                 T.load(bwG, trL + FW_NARR * TBL, lane);
@@ -364,6 +385,7 @@ __global__ __launch_bounds__(PHASE == 1 ? WH_SCOREA_THREADS : (PHASE == 2 ? WH_S
                   nj = fmaf(SPR(SP_C * SP + i - 1), xC, nj);
                   xfac = fmaf(nj * cu.loop, s_p, xfac);
                 }
+                WH_TICK(8);
                 // null2[a] = sum_k fM_k o_k(a) + sum_k fI_k + f_NJC, all / Ld
                 const float norm = 1.0f / (float)Ld;
                 float si = 0.f, sm = 0.f;
@@ -407,6 +429,7 @@ __global__ __launch_bounds__(PHASE == 1 ? WH_SCOREA_THREADS : (PHASE == 2 ? WH_S
               if (envsc - domcorr > 0.0f) { sum_score += envsc; Ld_tot += Ld; sb2 += domcorr; }
               if (dp) { dp->env_i[e] = ri; dp->env_j[e] = rj; dp->envsc[e] = envsc; dp->domcorr[e] = domcorr; }
             }
+            WH_TICK(9);
             // ---------------- A.6 score assembly (float32 where HMMER is float32)
             const double LOG2 = 0.69314718055994529;
             const float lomega = (float)log(1.0 / 256.0);
@@ -434,12 +457,12 @@ __global__ __launch_bounds__(PHASE == 1 ? WH_SCOREA_THREADS : (PHASE == 2 ? WH_S
 }
 
 // ---------------------------------------------------------------------------------------
-template <int Q, bool TREG, int PHASE, bool SPECG>
+template <int Q, bool TREG, int PHASE, bool SPECG, int TRM = 0>
 static hipError_t launch_one(const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
-  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&score_kernel<Q, TREG, PHASE, SPECG>),
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&score_kernel<Q, TREG, PHASE, SPECG, TRM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (err != hipSuccess) return err;
-  hipLaunchKernelGGL((score_kernel<Q, TREG, PHASE, SPECG>), dim3(blocks), dim3(threads), lds, s, a);
+  hipLaunchKernelGGL((score_kernel<Q, TREG, PHASE, SPECG, TRM>), dim3(blocks), dim3(threads), lds, s, a);
   return hipGetLastError();
 }
 
@@ -454,6 +477,26 @@ static hipError_t launch_phase(int Q, const ScoreArgs &a, int blocks, int thread
     case 24: return launch_one<24, false, PHASE, SPECG>(a, blocks, threads, lds, s);
     default: return hipErrorInvalidValue;
   }
+}
+
+// transition tables in VGPRs (one orientation at a time, reloaded from L2 per sweep)
+hipError_t launch_score_treg(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
+  switch (Q) {
+    case 4:  return launch_one<4, true, 0, false>(a, blocks, threads, lds, s);
+    case 8:  return launch_one<8, true, 0, false>(a, blocks, threads, lds, s);
+    case 12: return launch_one<12, true, 0, false>(a, blocks, threads, lds, s);
+    case 16: return launch_one<16, true, 0, false>(a, blocks, threads, lds, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// selected sweeps with register-resident transition tables (mask: 1 = P1, 2 = P2, 4 = P3)
+hipError_t launch_score_tr12(int Q, int mask, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
+  if (Q == 16 && mask == 1) return launch_one<16, false, 0, false, 1>(a, blocks, threads, lds, s);
+  if (Q == 16 && mask == 5) return launch_one<16, false, 0, false, 5>(a, blocks, threads, lds, s);
+  if (Q == 16 && mask == 3) return launch_one<16, false, 0, false, 3>(a, blocks, threads, lds, s);
+  if (Q == 16 && mask == 7) return launch_one<16, false, 0, false, 7>(a, blocks, threads, lds, s);
+  return launch_one<16, false, 0, false, 0>(a, blocks, threads, lds, s);
 }
 
 hipError_t launch_score(int Q, int phase, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {

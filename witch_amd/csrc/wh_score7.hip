@@ -1,0 +1,485 @@
+// Scoring kernel, phase-call variant: the same five sweeps as wh_score.hip (P1 multihit Forward,
+// P2 multihit Backward + domain decoding, region scan, per envelope P3 unihit Forward with the
+// sparse row spill and P4 unihit Backward + posterior accumulation -> null2), but every sweep is
+// a separate non-inlined device function.  Each sweep then gets a register allocation of its own
+// (the fused body keeps values of all phases alive and spills), which lets the kernel run at
+// THREE waves per SIMD (168 VGPRs) instead of two: measured on MI355X, the DP rows are bound by
+// how many waves can issue, not by a pipe, so the third wave is worth more than wider registers.
+// (hmmsearch --max per pair: witch_msa/gcmm/algorithm.py:526-532; algorithm SURVEY.md A.2-A.6.)
+#include <hip/hip_runtime.h>
+
+#include "wh_device.h"
+#include "wh_launch.h"
+
+namespace wh {
+
+
+constexpr float kKeepScale7 = 5.9604645e-08f;   // 2^-24, see wh_score.hip
+constexpr float kMassTol7 = 2e-5f;
+
+__device__ __forceinline__ float flogsum0_v7(float b) {
+  const float mx = b > 0.f ? b : 0.f, mn = b > 0.f ? 0.f : b;
+  if (mn == -INFINITY || (mx - mn) >= 15.7f) return mx;
+  const int idx = (int)((mx - mn) * 1000.0f);
+  return mx + (float)log(1.0 + exp((double)-idx / 1000.0));
+}
+
+// what every sweep needs to find its tables and its per-wave LDS block
+// LDS pointers cross the call boundary with their address space in the type: inside a
+// non-inlined function a plain float* would be a flat pointer and every table read a flat_load.
+typedef __attribute__((address_space(3))) float lds_f;
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+typedef __attribute__((address_space(3))) int lds_i;
+typedef __attribute__((address_space(1))) float glb_f;   // same for HBM pointers: flat accesses would tie vmcnt to lgkmcnt
+
+struct WaveCtx {
+  lds_f *emL;                 // emission rows of the canonical residues (LDS)
+  const glb_f *emG;           // all emission rows (L2; degenerate codes)
+  lds_f *fwL, *bwL;           // transition arrays, forward / reversed orientation (LDS)
+  lds_f *spec;                // SP_NARR per-row arrays, stride SP (LDS)
+  lds_f *n2tab;               // 32 floats (LDS)
+  glb_f *Fs;                  // Forward-row slab of this wave (HBM)
+  int SP, K, Kp, lane;
+  uint32_t degen;             // this lane's degenerate-code mask (lane = residue code)
+};
+struct P4Out { float mass, domcorr; };
+struct RegOut { int nenv, nreg, flags; };
+
+struct FwdOut { float xC; int ef; };
+
+// ---------------------------------------------------------------- P1 / P3
+template <int Q, bool STORE, int TH>
+__device__ __noinline__ FwdOut sweep_forward(const WaveCtx c, lds_u8 *seq3, int L, LenCfg cfg, float keep_scale) {
+  const uint8_t *seq = (const uint8_t *)seq3;
+  TransTab<Q, false> T;
+  T.load(nullptr, (const float *)c.fwL, c.lane);
+  const ScanC sc = scan_prepare(lane_product<Q, false>(T, FW_D2));
+  FwdOut o;
+  forward_sweep<Q, false, STORE>(T, sc, (const float *)c.emL, (const float *)c.emG, c.K, seq, L, cfg, (float *)c.spec, c.SP, (float *)c.Fs, keep_scale, c.lane, o.xC, o.ef);
+  return o;
+}
+
+// ---------------------------------------------------------------- P2: multihit Backward + decoding (A.4)
+// Overwrites spec[SP_E], spec[SP_B], spec[SP_N] rows with the per-row posteriors pe, pb, njc.
+template <int Q, int TH>
+__device__ __noinline__ void sweep_backward_decode(const WaveCtx c, lds_u8 *seq3, int L, LenCfg cm, float invZ, int ef_L) {
+  const uint8_t *seq = (const uint8_t *)seq3;
+  const float *emL = (const float *)c.emL;
+  TransTab<Q, false> T;
+  T.load(nullptr, (const float *)c.bwL, c.lane);
+  const ScanC sc = scan_prepare(lane_product<Q, false>(T, BW_DD));
+  const int lane = c.lane, SP = c.SP;
+  float *spec = (float *)c.spec;
+  const int *specI = reinterpret_cast<const int *>(spec);
+  float Mb[Q], Ib[Q];
+#pragma unroll
+  for (int p = 0; p < Q; p++) { Mb[p] = 0.f; Ib[p] = 0.f; }
+  float xC = cm.move, xJ = 0.f, xN = 0.f, xB = 0.f;
+  int eb = 0;
+#pragma unroll 1
+  for (int i = L; i >= 0; i--) {
+    asm volatile("" ::: "memory");
+    if (i < L) {
+      float od[Q];
+      load_em_rev<Q>(od, emL, (const float *)c.emG, seq[i], c.K, lane);
+      float part = 0.f;
+#pragma unroll
+      for (int p4 = 0; p4 < Q / 4; p4++) {
+        const float4 E = T.ld(BW_E, p4);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int p = 4 * p4 + j;
+          Mb[p] *= od[p];
+          part = fmaf(f4get(E, j), Mb[p], part);
+        }
+      }
+      xB = wave_sum(part);
+      xJ = fmaf(xJ, cm.loop, xB * cm.move);
+      xC = xC * cm.loop;
+      xN = fmaf(xN, cm.loop, xB * cm.move);
+    }
+    float xE = fmaf(xC, cm.EC, xJ * cm.EJ);
+    if (i >= 1) backward_cells<Q, false>(T, sc, Mb, Ib, xE);
+    const float big = fmaxf(xB, xN);
+    if (big > kRescaleHi) {
+      const int e = f32_exponent(big);
+      const float r = pow2f_int(-e);
+#pragma unroll
+      for (int p = 0; p < Q; p++) { Mb[p] *= r; Ib[p] *= r; }
+      xB *= r; xJ *= r; xC *= r; xN *= r; xE *= r;
+      eb += e;
+    }
+    const float s_i = ldexpf(invZ, specI[SP_S * SP + i] + eb - ef_L);
+    const float pe = spec[SP_E * SP + i] * xE * s_i;
+    const float pb = spec[SP_B * SP + i] * xB * s_i;
+    float njc = 0.f;
+    if (i >= 1) {
+      const float s_p = ldexpf(invZ, specI[SP_S * SP + i - 1] + eb - ef_L);
+      njc = spec[SP_N * SP + i - 1] * xN;
+      njc = fmaf(spec[SP_J * SP + i - 1], xJ, njc);
+      njc = fmaf(spec[SP_C * SP + i - 1], xC, njc);
+      njc = njc * cm.loop * s_p;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) { spec[SP_E * SP + i] = pe; spec[SP_B * SP + i] = pb; spec[SP_N * SP + i] = njc; }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---------------------------------------------------------------- P4: unihit Backward + posterior -> null2
+// Returns the null2 correction of the envelope (A.5) in *domcorr and the posterior mass that
+// reached the accumulators (the certificate for the sparse spill, see wh_score.hip).
+template <int Q, int TH>
+__device__ __noinline__ P4Out sweep_backward_null2(const WaveCtx c, lds_u8 *eseq3, int Ld, LenCfg cu, float invZe, int ef_e, float mass_tol) {
+  const uint8_t *eseq = (const uint8_t *)eseq3;
+  const float *emL = (const float *)c.emL;
+  TransTab<Q, false> T;
+  T.load(nullptr, (const float *)c.bwL, c.lane);
+  const ScanC sc = scan_prepare(lane_product<Q, false>(T, BW_DD));
+  const int lane = c.lane, SP = c.SP;
+  const float *spec = (const float *)c.spec;
+  const int *specI = reinterpret_cast<const int *>(spec);
+  const unsigned *specU = reinterpret_cast<const unsigned *>(spec);
+  float Mb[Q], Ib[Q], fM[Q];
+#pragma unroll
+  for (int p = 0; p < Q; p++) { Mb[p] = 0.f; Ib[p] = 0.f; fM[p] = 0.f; }
+  float xC = cu.move, xJ = 0.f, xN = 0.f, xB = 0.f, xfac = 0.f, fIs = 0.f;
+  int eb = 0;
+  const int src = kWave - 1 - lane;   // the forward-order lane that owns my (reversed) cells
+#pragma unroll 1
+  for (int i = Ld; i >= 1; i--) {
+    asm volatile("" ::: "memory");
+    // Forward row i: with three or more waves per SIMD the other waves cover the HBM latency,
+    // so the row is requested only after the cell update (TH >= 768; saves 2*Q registers
+    // across backward_cells); with two waves it is requested first.
+    float4 fm4[Q / 4], fi4[Q / 4];
+    auto request_row = [&]() {
+      const unsigned mword = src < 32 ? specU[SP_ML * SP + i] : specU[SP_MH * SP + i];
+      const bool have = (mword >> (src & 31)) & 1u;
+      const float4 *row = reinterpret_cast<const float4 *>((const float *)c.Fs) + (size_t)i * (2 * (Q / 4) * kWave) + src;
+      if (have) {
+#pragma unroll
+        for (int p4 = 0; p4 < Q / 4; p4++) {
+          fm4[p4] = nt_load4(row + (Q / 4 - 1 - p4) * kWave);
+          fi4[p4] = nt_load4(row + (Q / 4 + Q / 4 - 1 - p4) * kWave);
+        }
+      } else {
+#pragma unroll
+        for (int p4 = 0; p4 < Q / 4; p4++) { fm4[p4] = make_float4(0.f, 0.f, 0.f, 0.f); fi4[p4] = fm4[p4]; }
+      }
+    };
+    if (TH < 768) request_row();
+    if (i < Ld) {
+      float od[Q];
+      load_em_rev<Q>(od, emL, (const float *)c.emG, eseq[i], c.K, lane);
+      float part = 0.f;
+#pragma unroll
+      for (int p4 = 0; p4 < Q / 4; p4++) {
+        const float4 E = T.ld(BW_E, p4);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int p = 4 * p4 + j;
+          Mb[p] *= od[p];
+          part = fmaf(f4get(E, j), Mb[p], part);
+        }
+      }
+      xB = wave_sum(part);
+      xJ = fmaf(xJ, cu.loop, xB * cu.move);
+      xC = xC * cu.loop;
+      xN = fmaf(xN, cu.loop, xB * cu.move);
+    }
+    float xE = fmaf(xC, cu.EC, xJ * cu.EJ);
+    backward_cells<Q, false>(T, sc, Mb, Ib, xE);
+    const float big = fmaxf(xB, xN);
+    if (big > kRescaleHi) {
+      const int ee = f32_exponent(big);
+      const float r = pow2f_int(-ee);
+#pragma unroll
+      for (int p = 0; p < Q; p++) { Mb[p] *= r; Ib[p] *= r; }
+      xB *= r; xJ *= r; xC *= r; xN *= r; xE *= r;
+      eb += ee;
+    }
+    if (TH >= 768) { asm volatile("" ::: "memory"); request_row(); }
+    const float s_i = ldexpf(invZe, specI[SP_S * SP + i] + eb - ef_e);
+    const float s_p = ldexpf(invZe, specI[SP_S * SP + i - 1] + eb - ef_e);
+    float idot = 0.f;
+#pragma unroll
+    for (int p4 = 0; p4 < Q / 4; p4++) {
+      // reversed order: component 3-j of the forward-ordered vector is position 4*p4+j
+      fM[4 * p4 + 0] = fmaf(fm4[p4].w * Mb[4 * p4 + 0], s_i, fM[4 * p4 + 0]);
+      fM[4 * p4 + 1] = fmaf(fm4[p4].z * Mb[4 * p4 + 1], s_i, fM[4 * p4 + 1]);
+      fM[4 * p4 + 2] = fmaf(fm4[p4].y * Mb[4 * p4 + 2], s_i, fM[4 * p4 + 2]);
+      fM[4 * p4 + 3] = fmaf(fm4[p4].x * Mb[4 * p4 + 3], s_i, fM[4 * p4 + 3]);
+      idot = fmaf(fi4[p4].w, Ib[4 * p4 + 0], idot); idot = fmaf(fi4[p4].z, Ib[4 * p4 + 1], idot);
+      idot = fmaf(fi4[p4].y, Ib[4 * p4 + 2], idot); idot = fmaf(fi4[p4].x, Ib[4 * p4 + 3], idot);
+    }
+    fIs = fmaf(idot, s_i, fIs);
+    float nj = spec[SP_N * SP + i - 1] * xN;
+    nj = fmaf(spec[SP_J * SP + i - 1], xJ, nj);
+    nj = fmaf(spec[SP_C * SP + i - 1], xC, nj);
+    xfac = fmaf(nj * cu.loop, s_p, xfac);
+  }
+  // null2[a] = sum_k fM_k o_k(a) + sum_k fI_k + f_NJC, all / Ld
+  float sm = 0.f;
+#pragma unroll
+  for (int p = 0; p < Q; p++) sm += fM[p];
+  sm = wave_sum(sm);
+  const float si = wave_sum(fIs);
+  const float mass = sm + si + xfac;
+  P4Out o;
+  o.mass = mass; o.domcorr = 0.f;
+  if (!(fabsf((float)Ld - mass) <= mass_tol * (float)Ld)) return o;   // certificate failed: the caller redoes the envelope densely
+  const float norm = 1.0f / (float)Ld;
+  float mine = 1.0f;
+  for (int x = 0; x < c.K; x++) {
+    float od[Q];
+    load_em_rev<Q>(od, emL, (const float *)c.emG, x, c.K, lane);
+    float s = 0.f;
+#pragma unroll
+    for (int p = 0; p < Q; p++) s = fmaf(fM[p], od[p], s);
+    s = wave_sum(s);
+    if (lane == x) mine = (s + si) * norm + xfac * norm;
+  }
+  float *n2tab = (float *)c.n2tab;
+  __builtin_amdgcn_wave_barrier();
+  if (lane < c.K) n2tab[lane] = mine;
+  __builtin_amdgcn_wave_barrier();
+  if (lane >= c.K && lane < c.Kp) {
+    // degenerate codes: unweighted mean of the canonical ratios; gap/*/~ -> 1
+    const uint32_t m = c.degen;
+    float s = 0.f; int n = 0;
+    for (int x = 0; x < c.K; x++) if (m & (1u << x)) { s += n2tab[x]; n++; }
+    mine = n > 0 ? s / (float)n : 1.0f;
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (lane < c.Kp) n2tab[lane] = logf(mine);
+  __builtin_amdgcn_wave_barrier();
+  float dc = 0.f;
+  for (int t = lane; t < Ld; t += kWave) dc += n2tab[eseq[t]];
+  o.domcorr = wave_sum(dc);
+  return o;
+}
+
+// ---------------------------------------------------------------- region scan (A.4)
+template <int TH>
+__device__ __noinline__ RegOut region_scan(lds_f *spec3, int SP, int L, lds_i *regs3, int lane) {
+  float *spec = (float *)spec3;
+  int *regs = (int *)regs3;
+  const float rt1 = 0.25f, rt2 = 0.10f, rt3 = 0.20f;
+  int nenv = 0, nreg = 0, flags = 0;
+  float btot = 0.f, etot = 0.f;
+  int i0 = -1;
+  bool trig = false;
+  if (lane == 0) { spec[SP_J * SP] = 0.f; spec[SP_C * SP] = 0.f; }
+  for (int j = 1; j <= L; j++) {
+    const float mocc = 1.0f - spec[SP_N * SP + j];
+    const float bold = btot, eold = etot;
+    btot += spec[SP_B * SP + j - 1];
+    etot += spec[SP_E * SP + j];
+    if (lane == 0) { spec[SP_J * SP + j] = btot; spec[SP_C * SP + j] = etot; }
+    if (!trig) {
+      if (mocc - (btot - bold) < rt2) i0 = j;
+      else if (i0 == -1) i0 = j;
+      if (mocc >= rt1) trig = true;
+    } else if (mocc - (etot - eold) < rt2) {
+      if (nenv < WH_MAX_ENVELOPES) {
+        if (lane == 0) { regs[2 * nenv] = i0; regs[2 * nenv + 1] = j; }
+        nenv++;
+      } else flags |= WH_FLAG_TRUNC;
+      nreg++;
+      i0 = -1;
+      trig = false;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  // multidomain test: max_z min(etot[z]-etot[i-1], btot[j]-btot[z-1]) >= rt3
+  for (int e = 0; e < nenv; e++) {
+    const int ri = regs[2 * e], rj = regs[2 * e + 1];
+    float mx = -1.0f;
+    const float e0 = spec[SP_C * SP + ri - 1], bj = spec[SP_J * SP + rj];
+    for (int z = ri + lane; z <= rj; z += kWave) {
+      const float u = spec[SP_C * SP + z] - e0, v = bj - spec[SP_J * SP + z - 1];
+      mx = fmaxf(mx, fminf(u, v));
+    }
+    mx = wave_max(mx);
+    if (mx >= rt3) flags |= WH_FLAG_MULTI;
+  }
+  RegOut o;
+  o.nenv = nenv; o.nreg = nreg; o.flags = flags;
+  return o;
+}
+
+#define WH_TICK7(slot) do { if (a.stats) { const long long t_now = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(a.stats + (slot), (unsigned long long)(t_now - t_last)); t_last = t_now; } } while (0)
+
+template <int Q, int TH>
+__global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem_raw[];
+  volatile int *s_item_p = reinterpret_cast<volatile int *>(smem_raw);
+  float *smem = smem_raw + 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  constexpr int TBL = Q * kWave;
+  float *emL = smem;
+  float *trL = smem + (size_t)a.K * TBL;
+  float *wbase = trL + 2 * FW_NARR * TBL + (size_t)wave * a.wave_lds;
+  const int SP = a.SP;
+  WaveCtx c;
+  c.emL = (lds_f *)emL; c.fwL = (lds_f *)trL; c.bwL = (lds_f *)(trL + FW_NARR * TBL);
+  c.spec = (lds_f *)wbase; c.n2tab = (lds_f *)(wbase + SP_NARR * SP);
+  c.degen = 0;
+  for (int t = 0; t < 32; t++) if (t == lane) c.degen = a.degen[t];
+  c.Fs = (glb_f *)(a.scratch + ((size_t)blockIdx.x * nwaves + wave) * a.scratch_stride);
+  c.SP = SP; c.K = a.K; c.Kp = a.Kp; c.lane = lane;
+  int *regs = reinterpret_cast<int *>(wbase + SP_NARR * SP + 32);
+  uint8_t *seq = reinterpret_cast<uint8_t *>(regs + 3 * WH_MAX_ENVELOPES);
+  const double LOG2 = 0.69314718055994529;
+  int cur_h = -1;
+  const DevHMM *hm = nullptr;
+
+  for (;;) {
+    if (threadIdx.x == 0) *s_item_p = atomicAdd(a.counter, 1);
+    __syncthreads();
+    const int item = *s_item_p;
+    __syncthreads();
+    if (item >= a.n_items) break;
+    const int h = a.hmm_list[item / a.n_qblocks];
+    const int64_t q_lo = (int64_t)(item % a.n_qblocks) * a.QB;
+    const int64_t q_hi = q_lo + a.QB < a.nq ? q_lo + a.QB : a.nq;
+    if (h != cur_h) {
+      hm = a.hmms + h;
+      const float4 *src = reinterpret_cast<const float4 *>(a.tables + hm->em_off);
+      float4 *dst = reinterpret_cast<float4 *>(emL);
+      for (int t = threadIdx.x; t < a.K * TBL / 4; t += blockDim.x) dst[t] = src[t];
+      const float4 *s1 = reinterpret_cast<const float4 *>(a.tables + hm->fw_off);
+      const float4 *s2 = reinterpret_cast<const float4 *>(a.tables + hm->bw_off);
+      float4 *d1 = reinterpret_cast<float4 *>(trL);
+      for (int t = threadIdx.x; t < FW_NARR * TBL / 4; t += blockDim.x) { d1[t] = s1[t]; d1[FW_NARR * TBL / 4 + t] = s2[t]; }
+      cur_h = h;
+      __syncthreads();
+    }
+    c.emG = (const glb_f *)(a.tables + hm->em_off);
+
+    for (int64_t qi = q_lo + wave; qi < q_hi; qi += nwaves) {
+      const int64_t off = a.offsets[qi];
+      const int L = (int)(a.offsets[qi + 1] - off);
+      const size_t out = (size_t)qi * a.H + h;
+      int flags = 0, decibits = 0;
+      float fwd_bits_out = -INFINITY;
+      wh_pair_detail *dp = (a.detail && lane == 0) ? a.detail + out : nullptr;
+      if (dp) {
+        dp->fwd_bits = -INFINITY; dp->seq_score = 0.f; dp->pre_score = 0.f; dp->seqbias_nats = 0.f;
+        dp->nregions = 0; dp->nenv = 0;
+      }
+      if (L > 0 && L <= a.Lcap) {
+        for (int t = lane; t < L; t += kWave) {
+          int r = a.residues[off + t];
+          seq[t] = (uint8_t)(r < a.Kp ? r : a.Kp - 1);
+        }
+        __builtin_amdgcn_wave_barrier();
+        long long t_last = a.stats ? __builtin_readcyclecounter() : 0;
+        // ---------------- P1
+        const LenCfg cm = len_config(L, true);
+        const FwdOut f1 = sweep_forward<Q, false, TH>(c, (lds_u8 *)seq, L, cm, 0.f);
+        const double fwd_nats = (double)f1.ef * LOG2 + log((double)(f1.xC * cm.move));
+        const float fwdsc = (float)fwd_nats;
+        const float p1 = (float)L / (float)(L + 1);
+        const float nullsc = (float)((double)(float)L * log((double)p1) + log(1.0 - (double)p1));
+        fwd_bits_out = (float)((fwd_nats - (double)nullsc) / LOG2);
+        if (dp) dp->fwd_bits = fwd_bits_out;
+        if (f1.xC > 0.f && isfinite(fwdsc)) {
+          WH_TICK7(4);
+          // ---------------- P2 + region scan
+          sweep_backward_decode<Q, TH>(c, (lds_u8 *)seq, L, cm, 1.0f / (f1.xC * cm.move), f1.ef);
+          WH_TICK7(5);
+          const RegOut ro = region_scan<TH>(c.spec, SP, L, (lds_i *)regs, lane);
+          const int nenv = ro.nenv, nreg = ro.nreg;
+          flags |= ro.flags;
+          if (dp) { dp->nregions = nreg; dp->nenv = nenv; }
+          if (nenv > 0) {
+            WH_TICK7(6);
+            // ---------------- envelopes
+            const LenCfg cu = len_config(L, false);
+            float seqbias_sum = 0.f, sum_score = 0.f, sb2 = 0.f;
+            int Ld_tot = 0;
+            for (int e = 0; e < nenv; e++) {
+              const int ri = regs[2 * e], rj = regs[2 * e + 1];
+              const int Ld = rj - ri + 1;
+              const uint8_t *eseq = seq + (ri - 1);
+              float envsc = -INFINITY, domcorr = 0.f;
+#pragma unroll 1
+              for (int attempt = 0; attempt < 2; attempt++) {
+                const float keep_scale = attempt == 0 ? (a.keep_scale > 0.f ? a.keep_scale : kKeepScale7) : -1.0f;
+                const FwdOut f3 = sweep_forward<Q, true, TH>(c, (lds_u8 *)eseq, Ld, cu, keep_scale);
+                // the rows were written by other lanes of this wave: order the stores before the loads
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                envsc = (float)((double)f3.ef * LOG2 + log((double)(f3.xC * cu.move)));
+                domcorr = 0.f;
+                if (!(f3.xC > 0.f)) break;
+                WH_TICK7(7);
+                const float tol = attempt == 0 ? kMassTol7 : INFINITY;
+                const P4Out p4 = sweep_backward_null2<Q, TH>(c, (lds_u8 *)eseq, Ld, cu, 1.0f / (f3.xC * cu.move), f3.ef, tol);
+                domcorr = p4.domcorr;
+                WH_TICK7(8);
+                if (attempt == 0 && !(fabsf((float)Ld - p4.mass) <= kMassTol7 * (float)Ld)) continue;
+                if (attempt == 1) flags |= WH_FLAG_EXACT;
+                break;
+              }
+              seqbias_sum += domcorr;
+              if (envsc - domcorr > 0.0f) { sum_score += envsc; Ld_tot += Ld; sb2 += domcorr; }
+              if (dp) { dp->env_i[e] = ri; dp->env_j[e] = rj; dp->envsc[e] = envsc; dp->domcorr[e] = domcorr; }
+            }
+            // ---------------- A.6 score assembly (float32 where HMMER is float32)
+            const float lomega = (float)log(1.0 / 256.0);
+            const float seqbias = flogsum0_v7(lomega + seqbias_sum);
+            float pre_score = (float)(((double)fwdsc - (double)nullsc) / LOG2);
+            float seq_score = (float)(((double)fwdsc - (double)(nullsc + seqbias)) / LOG2);
+            sb2 = flogsum0_v7(lomega + sb2);
+            sum_score += (float)((double)(L - Ld_tot) * log((double)((float)L / (float)(L + 3))));
+            const float pre2 = (float)(((double)sum_score - (double)nullsc) / LOG2);
+            sum_score = (float)(((double)sum_score - (double)(nullsc + sb2)) / LOG2);
+            if (Ld_tot > 0 && sum_score > seq_score) { seq_score = sum_score; pre_score = pre2; flags |= WH_FLAG_OVERRIDE; }
+            decibits = (int)rint((double)seq_score * 10.0);
+            flags |= WH_FLAG_REPORTED;
+            if (dp) { dp->seq_score = seq_score; dp->pre_score = pre_score; dp->seqbias_nats = seqbias; }
+          }
+        }
+      }
+      if (lane == 0) {
+        a.decibits[out] = decibits;
+        a.flags[out] = (uint8_t)flags;
+        if (a.fwd_bits) a.fwd_bits[out] = fwd_bits_out;
+      }
+    }
+  }
+}
+
+template <int Q, int TH>
+static hipError_t launch7(const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&score_kernel7<Q, TH>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (err != hipSuccess) return err;
+  hipLaunchKernelGGL((score_kernel7<Q, TH>), dim3(blocks), dim3(threads), lds, s, a);
+  return hipGetLastError();
+}
+
+// threads per workgroup sets the register budget of every sweep: 512 -> 256 VGPRs, 768 -> 168
+template <int TH>
+static hipError_t launch7_q(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
+  switch (Q) {
+    case 4:  return launch7<4, TH>(a, blocks, threads, lds, s);
+    case 8:  return launch7<8, TH>(a, blocks, threads, lds, s);
+    case 12: return launch7<12, TH>(a, blocks, threads, lds, s);
+    case 16: return launch7<16, TH>(a, blocks, threads, lds, s);
+    case 20: return launch7<20, TH>(a, blocks, threads, lds, s);
+    case 24: return launch7<24, TH>(a, blocks, threads, lds, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+hipError_t launch_score7(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
+  if (threads <= 512) return launch7_q<512>(Q, a, blocks, threads, lds, s);
+  if (threads <= 768) return launch7_q<768>(Q, a, blocks, threads, lds, s);
+  if (threads <= 1024) return launch7_q<1024>(Q, a, blocks, threads, lds, s);
+  return hipErrorInvalidValue;
+}
+
+}  // namespace wh

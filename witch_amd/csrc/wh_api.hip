@@ -385,9 +385,9 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
         while (w >= 1 && kLdsHeader + table + (size_t)w * wl * sizeof(float) > kLdsBudget) w--;
         if (w >= 4) { use5 = true; waves = w; SP = sp; wave_lds = wl; lds = kLdsHeader + table + (size_t)w * wl * sizeof(float); }
       }
-      const bool use1 = kver == 1 || kver == 6 || kver == 7 || (kver == 4 && !use4) || (kver == 5 && !use5);
+      const bool use1 = kver == 1 || kver == 6 || kver == 7 || kver == 8 || (kver == 4 && !use4) || (kver == 5 && !use5);
       bool specg = false;
-      int rc_plan = (use4 || use5) ? WH_OK : use1 ? plan_block1(Q, e->K, std::max(max_len, 1), kver == 7 ? (getenv("WH_WMAX") ? atoi(getenv("WH_WMAX")) : (Q <= 16 ? 12 : 8)) : 8, &waves, &SP, &wave_lds, &lds)
+      int rc_plan = (use4 || use5) ? WH_OK : use1 ? plan_block1(Q, e->K, std::max(max_len, 1), (kver == 7 || kver == 8) ? (getenv("WH_WMAX") ? atoi(getenv("WH_WMAX")) : (Q <= 16 ? 12 : 8)) : 8, &waves, &SP, &wave_lds, &lds)
                          : plan_block(Q, e->K, treg, std::max(max_len, 1), &waves, &SP, &wave_lds, &lds);
       if (use1 && !use5 && (rc_plan != WH_OK || waves < 4 || getenv("WH_FORCE_SPECG"))) {
         // long queries: the per-row special-state arrays move to a per-wave HBM region
@@ -447,6 +447,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       HIPCHK(hipMemsetAsync(a.counter, 0, sizeof(int), s));
       hipError_t err = use5 ? launch_score_treg(Q, a, blocks, waves * kWave, lds, s)
                        : (kver == 7 && !specg) ? launch_score7(Q, a, blocks, waves * kWave, lds, s)
+                       : (kver == 8 && !specg) ? launch_score7b(Q, a, blocks, waves * kWave, lds, s)
                        : (kver == 6 && Q == 16 && !specg) ? launch_score_tr12(Q, getenv("WH_TRM") ? atoi(getenv("WH_TRM")) : 1, a, blocks, waves * kWave, lds, s)
                        : use1 ? launch_score(Q, 0, a, blocks, waves * kWave, lds, s) : launch_score2(Q, a, blocks, waves * kWave, lds, s);
       if (err != hipSuccess) { set_error("score kernel launch (Q=%d) failed: %s", Q, hipGetErrorString(err)); return WH_EHIP; }

@@ -76,6 +76,19 @@ __device__ __forceinline__ ScanC scan_prepare(float A) {
 }
 
 __device__ __forceinline__ float scan_apply(const ScanC &c, float B) {
+#ifndef WH_PLAIN_DPP_SCAN
+  // B += c * B[lane - n] as ONE v_fmac_f32_dpp per step (lanes without a source are not
+  // written, which equals adding c * 0); the s_nop covers the VALU-write -> DPP-read hazard,
+  // which the assembler does not fill in for inline code
+  asm("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(B) : "v"(c.s[0]));
+  asm("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %1 row_shr:2 row_mask:0xf bank_mask:0xf" : "+v"(B) : "v"(c.s[1]));
+  asm("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %1 row_shr:4 row_mask:0xf bank_mask:0xf" : "+v"(B) : "v"(c.s[2]));
+  asm("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %1 row_shr:8 row_mask:0xf bank_mask:0xf" : "+v"(B) : "v"(c.s[3]));
+  asm("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %1 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(B) : "v"(c.s[4]));
+  asm("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %1 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(B) : "v"(c.s[5]));
+  asm("s_nop 1" : "+v"(B));
+  return B;
+#else
   B = fmaf(c.s[0], dppf<0x111>(0.f, B), B);
   B = fmaf(c.s[1], dppf<0x112>(0.f, B), B);
   B = fmaf(c.s[2], dppf<0x114>(0.f, B), B);
@@ -83,6 +96,7 @@ __device__ __forceinline__ float scan_apply(const ScanC &c, float B) {
   B = fmaf(c.s[4], dppf<0x142, 0xA>(0.f, B), B);
   B = fmaf(c.s[5], dppf<0x143, 0xC>(0.f, B), B);        // row_bcast:31 into rows 2,3
   return B;
+#endif
 }
 
 // ------------------------------------------------------------------ transition tables

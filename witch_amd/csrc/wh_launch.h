@@ -50,6 +50,7 @@ struct ScoreArgs {
 hipError_t launch_score(int Q, int phase, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
 hipError_t launch_score_big(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
 hipError_t launch_score7(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
+hipError_t launch_score7b(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);   // A/B slot
 hipError_t launch_score_tr12(int Q, int mask, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
 hipError_t launch_score_treg(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
 hipError_t launch_score2(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);

@@ -11,7 +11,16 @@
 #include "wh_device.h"
 #include "wh_launch.h"
 
+// The file can be compiled a second time into the same library under another namespace and
+// entry-point name (-DWH_K7NS=... -DWH_K7LAUNCH=...): the A/B slot for compiler-flag and source
+// experiments (tools/ab_score.py compares both in one process).
+#ifndef WH_K7NS
+#define WH_K7NS k7
+#define WH_K7LAUNCH launch_score7
+#endif
+
 namespace wh {
+namespace WH_K7NS {
 
 
 constexpr float kKeepScale7 = 5.9604645e-08f;   // 2^-24, see wh_score.hip
@@ -475,7 +484,10 @@ static hipError_t launch7_q(int Q, const ScoreArgs &a, int blocks, int threads, 
   }
 }
 
-hipError_t launch_score7(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
+}  // namespace WH_K7NS
+
+hipError_t WH_K7LAUNCH(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
+  using namespace WH_K7NS;
   if (threads <= 512) return launch7_q<512>(Q, a, blocks, threads, lds, s);
   if (threads <= 768) return launch7_q<768>(Q, a, blocks, threads, lds, s);
   if (threads <= 1024) return launch7_q<1024>(Q, a, blocks, threads, lds, s);

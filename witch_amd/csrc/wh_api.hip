@@ -253,10 +253,10 @@ static int plan_block(int Q, int K, bool treg, int Lcap, int *waves, int *SP, in
   return WH_OK;
 }
 
-static int plan_block1(int Q, int K, int Lcap, int wmax, int *waves, int *SP, int *wave_lds, size_t *lds) {
+static int plan_block1(int Q, int K, int Lcap, int wmax, int *waves, int *SP, int *wave_lds, size_t *lds, int narr = FW_NARR) {
   const int sp = (Lcap + 1 + 3) / 4 * 4;
   const int wl = 8 * sp + 32 + 3 * WH_MAX_ENVELOPES + (Lcap + 3) / 4 + 4;
-  const size_t table = (size_t)(K + 2 * FW_NARR) * Q * kWave * sizeof(float);
+  const size_t table = (size_t)(K + 2 * narr) * Q * kWave * sizeof(float);
   int w = wmax;
   if (const char *ev = getenv("WH_MAX_WAVES")) w = std::max(1, std::min(wmax, atoi(ev)));
   while (w >= 1 && kLdsHeader + table + (size_t)w * wl * sizeof(float) > kLdsBudget) w--;
@@ -387,7 +387,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       }
       const bool use1 = kver == 1 || kver == 6 || kver == 7 || kver == 8 || (kver == 4 && !use4) || (kver == 5 && !use5);
       bool specg = false;
-      int rc_plan = (use4 || use5) ? WH_OK : use1 ? plan_block1(Q, e->K, std::max(max_len, 1), (kver == 7 || kver == 8) ? (getenv("WH_WMAX") ? atoi(getenv("WH_WMAX")) : (Q <= 16 ? 12 : 8)) : 8, &waves, &SP, &wave_lds, &lds)
+      int rc_plan = (use4 || use5) ? WH_OK : use1 ? plan_block1(Q, e->K, std::max(max_len, 1), (kver == 7 || kver == 8) ? (getenv("WH_WMAX") ? atoi(getenv("WH_WMAX")) : (Q <= 16 ? 12 : 8)) : 8, &waves, &SP, &wave_lds, &lds, FW_NARR)
                          : plan_block(Q, e->K, treg, std::max(max_len, 1), &waves, &SP, &wave_lds, &lds);
       if (use1 && !use5 && (rc_plan != WH_OK || waves < 4 || getenv("WH_FORCE_SPECG"))) {
         // long queries: the per-row special-state arrays move to a per-wave HBM region

@@ -49,10 +49,10 @@ struct DevHMM {
 
 enum { FW_A = 0, FW_B, FW_C, FW_E, FW_MI, FW_II, FW_D1, FW_D2, FW_NARR, FW_P = FW_NARR };
 enum { BW_MM = 0, BW_IM, BW_DM, BW_MI, BW_II, BW_MD, BW_DD, BW_E, BW_NARR, BW_P = BW_NARR };
-// FW_P / BW_P (a 9th array with the in-lane running products of the D->D coefficients, turning
-// the carry fix-up into one FMA per cell) was measured on MI355X: +3 % kernel time (extra LDS
-// reads and spills outweigh the saved multiplies), so the tables are not built; the USEP code
-// path in wh_device.h is kept disabled for reference.
+// FW_P / BW_P: a 9th array per orientation in the table buffer with the in-lane running products
+// of the D->D coefficients; it turns the carry fix-up of the D chain into one FMA per cell.
+// Kernels copy it to LDS only if they ask for it (wh_score7.hip, WH_K7_MAXQP); measured on MI355X
+// it does not pay: +3 % kernel time at two waves per SIMD, +0.5 % at three.
 
 int  choose_Q(int M);     // cells per lane for a model of M nodes, or -1 if unsupported
 void build_tables(const HostHMM &h, int Q, std::vector<float> &fw, std::vector<float> &bw,

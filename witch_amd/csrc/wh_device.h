@@ -332,6 +332,34 @@ __device__ __forceinline__ void forward_sweep(const TransTab<Q, TREG> &T, const 
   ef_out = ef;
 }
 
+// G_k = o_k(x) * B_M_k in place (reversed node order) and the B-state sum  sum_k E_k G_k;
+// the emission piece of each 4-cell group is fetched where it is used.
+template <int Q, bool TREG>
+__device__ __forceinline__ float backward_emit(const TransTab<Q, TREG> &T, const float *emL, const float *emG, int x,
+                                               int K, int lane, float (&Mb)[Q]) {
+  float part = 0.f;
+  auto groups = [&](auto em_ld) {
+#pragma unroll
+    for (int p4 = 0; p4 < Q / 4; p4++) {
+      const float4 E = T.ld(BW_E, p4);
+      const float4 O = em_ld(Q / 4 - 1 - p4);      // forward-ordered piece; component 3-j is position 4*p4+j
+      Mb[4 * p4 + 0] *= O.w; part = fmaf(E.x, Mb[4 * p4 + 0], part);
+      Mb[4 * p4 + 1] *= O.z; part = fmaf(E.y, Mb[4 * p4 + 1], part);
+      Mb[4 * p4 + 2] *= O.y; part = fmaf(E.z, Mb[4 * p4 + 2], part);
+      Mb[4 * p4 + 3] *= O.x; part = fmaf(E.w, Mb[4 * p4 + 3], part);
+    }
+  };
+  x = __builtin_amdgcn_readfirstlane(x);
+  if (x < K) {
+    const float4 *ep = reinterpret_cast<const float4 *>(emL + (size_t)x * Q * kWave) + (kWave - 1 - lane);
+    groups([&](int q4) { return ep[q4 * kWave]; });
+  } else {
+    const float4 *ep = reinterpret_cast<const float4 *>(emG + (size_t)x * Q * kWave) + (kWave - 1 - lane);
+    groups([&](int q4) { return ep[q4 * kWave]; });
+  }
+  return part;
+}
+
 // ------------------------------------------------------------------ Backward sweep core
 // One Backward row in reversed node order.  On entry Mb/Ib hold row i+1 (or zeros for
 // i = L) and <G> has been formed in place in Mb (G_k = o_k(x_{i+1}) * B_M_k(i+1)).

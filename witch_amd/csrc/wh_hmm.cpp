@@ -201,8 +201,8 @@ void build_tables(const HostHMM &h, int Q, std::vector<float> &fw, std::vector<f
     int lane = pos / Q, q = pos % Q;
     return (((size_t)arr * Q4 + q / 4) * kWave + lane) * 4 + (q % 4);
   };
-  fw.assign((size_t)FW_NARR * Mpad, 0.f);
-  bw.assign((size_t)BW_NARR * Mpad, 0.f);
+  fw.assign((size_t)(FW_NARR + 1) * Mpad, 0.f);   // + FW_P
+  bw.assign((size_t)(BW_NARR + 1) * Mpad, 0.f);   // + BW_P
   em.assign((size_t)h.Kp * Mpad, 0.f);
   for (int k = 1; k <= M; k++) {
     const double *tp = &h.pt[(size_t)(k - 1) * 7];
@@ -226,6 +226,17 @@ void build_tables(const HostHMM &h, int Q, std::vector<float> &fw, std::vector<f
     bw[at(BW_DD, u)] = (float)tk[tDD];
     bw[at(BW_E, u)] = (float)h.entry[k];
     for (int x = 0; x < h.Kp; x++) em[at(x, pos)] = (float)h.odds[(size_t)x * (M + 1) + k];
+  }
+  // FW_P / BW_P: running products of the D->D coefficients inside each lane's block, in float32
+  // like the kernels' own products (the in-lane carry of the D chain becomes one FMA per cell)
+  for (int lane = 0; lane < kWave; lane++) {
+    float pf = 1.0f, pb = 1.0f;
+    for (int q = 0; q < Q; q++) {
+      pf *= fw[at(FW_D2, lane * Q + q)];
+      pb *= bw[at(BW_DD, lane * Q + q)];
+      fw[at(FW_P, lane * Q + q)] = pf;
+      bw[at(BW_P, lane * Q + q)] = pb;
+    }
   }
 }
 

@@ -25,6 +25,14 @@ namespace WH_K7NS {
 
 constexpr float kKeepScale7 = 5.9604645e-08f;   // 2^-24, see wh_score.hip
 constexpr float kMassTol7 = 2e-5f;
+// model classes that keep the FW_P / BW_P arrays in LDS (0 = none).  Measured at three waves per
+// SIMD on the headline workload: 557 ms with the arrays (Q <= 16) vs 554 ms without - the saved
+// multiplies do not show, so the arrays stay out of LDS.
+#ifndef WH_K7_MAXQP
+#define WH_K7_MAXQP 0
+#endif
+constexpr int kMaxQP = WH_K7_MAXQP;
+constexpr bool kMaskedAcc = true;   // P4: only lanes that own a stored Forward block accumulate
 
 __device__ __forceinline__ float flogsum0_v7(float b) {
   const float mx = b > 0.f ? b : 0.f, mn = b > 0.f ? 0.f : b;
@@ -64,7 +72,7 @@ __device__ __noinline__ FwdOut sweep_forward(const WaveCtx c, lds_u8 *seq3, int 
   T.load(nullptr, (const float *)c.fwL, c.lane);
   const ScanC sc = scan_prepare(lane_product<Q, false>(T, FW_D2));
   FwdOut o;
-  forward_sweep<Q, false, STORE>(T, sc, (const float *)c.emL, (const float *)c.emG, c.K, seq, L, cfg, (float *)c.spec, c.SP, (float *)c.Fs, keep_scale, c.lane, o.xC, o.ef);
+  forward_sweep<Q, false, STORE, (Q <= kMaxQP)>(T, sc, (const float *)c.emL, (const float *)c.emG, c.K, seq, L, cfg, (float *)c.spec, c.SP, (float *)c.Fs, keep_scale, c.lane, o.xC, o.ef);
   return o;
 }
 
@@ -89,26 +97,13 @@ __device__ __noinline__ void sweep_backward_decode(const WaveCtx c, lds_u8 *seq3
   for (int i = L; i >= 0; i--) {
     asm volatile("" ::: "memory");
     if (i < L) {
-      float od[Q];
-      load_em_rev<Q>(od, emL, (const float *)c.emG, seq[i], c.K, lane);
-      float part = 0.f;
-#pragma unroll
-      for (int p4 = 0; p4 < Q / 4; p4++) {
-        const float4 E = T.ld(BW_E, p4);
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const int p = 4 * p4 + j;
-          Mb[p] *= od[p];
-          part = fmaf(f4get(E, j), Mb[p], part);
-        }
-      }
-      xB = wave_sum(part);
+      xB = wave_sum(backward_emit<Q, false>(T, emL, (const float *)c.emG, seq[i], c.K, lane, Mb));
       xJ = fmaf(xJ, cm.loop, xB * cm.move);
       xC = xC * cm.loop;
       xN = fmaf(xN, cm.loop, xB * cm.move);
     }
     float xE = fmaf(xC, cm.EC, xJ * cm.EJ);
-    if (i >= 1) backward_cells<Q, false>(T, sc, Mb, Ib, xE);
+    if (i >= 1) backward_cells<Q, false, (Q <= kMaxQP)>(T, sc, Mb, Ib, xE);
     const float big = fmaxf(xB, xN);
     if (big > kRescaleHi) {
       const int e = f32_exponent(big);
@@ -179,26 +174,13 @@ __device__ __noinline__ P4Out sweep_backward_null2(const WaveCtx c, lds_u8 *eseq
     };
     if (TH < 768) request_row();
     if (i < Ld) {
-      float od[Q];
-      load_em_rev<Q>(od, emL, (const float *)c.emG, eseq[i], c.K, lane);
-      float part = 0.f;
-#pragma unroll
-      for (int p4 = 0; p4 < Q / 4; p4++) {
-        const float4 E = T.ld(BW_E, p4);
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const int p = 4 * p4 + j;
-          Mb[p] *= od[p];
-          part = fmaf(f4get(E, j), Mb[p], part);
-        }
-      }
-      xB = wave_sum(part);
+      xB = wave_sum(backward_emit<Q, false>(T, emL, (const float *)c.emG, eseq[i], c.K, lane, Mb));
       xJ = fmaf(xJ, cu.loop, xB * cu.move);
       xC = xC * cu.loop;
       xN = fmaf(xN, cu.loop, xB * cu.move);
     }
     float xE = fmaf(xC, cu.EC, xJ * cu.EJ);
-    backward_cells<Q, false>(T, sc, Mb, Ib, xE);
+    backward_cells<Q, false, (Q <= kMaxQP)>(T, sc, Mb, Ib, xE);
     const float big = fmaxf(xB, xN);
     if (big > kRescaleHi) {
       const int ee = f32_exponent(big);
@@ -208,21 +190,43 @@ __device__ __noinline__ P4Out sweep_backward_null2(const WaveCtx c, lds_u8 *eseq
       xB *= r; xJ *= r; xC *= r; xN *= r; xE *= r;
       eb += ee;
     }
-    if (TH >= 768) { asm volatile("" ::: "memory"); request_row(); }
     const float s_i = ldexpf(invZe, specI[SP_S * SP + i] + eb - ef_e);
     const float s_p = ldexpf(invZe, specI[SP_S * SP + i - 1] + eb - ef_e);
-    float idot = 0.f;
+    if (TH >= 768 && kMaskedAcc) {
+      // only the lanes that own a stored block run the accumulation (the others would add zeros)
+      asm volatile("" ::: "memory");
+      const unsigned mword = src < 32 ? specU[SP_ML * SP + i] : specU[SP_MH * SP + i];
+      if ((mword >> (src & 31)) & 1u) {
+        const float4 *row = reinterpret_cast<const float4 *>((const float *)c.Fs) + (size_t)i * (2 * (Q / 4) * kWave) + src;
+        float idot = 0.f;
 #pragma unroll
-    for (int p4 = 0; p4 < Q / 4; p4++) {
-      // reversed order: component 3-j of the forward-ordered vector is position 4*p4+j
-      fM[4 * p4 + 0] = fmaf(fm4[p4].w * Mb[4 * p4 + 0], s_i, fM[4 * p4 + 0]);
-      fM[4 * p4 + 1] = fmaf(fm4[p4].z * Mb[4 * p4 + 1], s_i, fM[4 * p4 + 1]);
-      fM[4 * p4 + 2] = fmaf(fm4[p4].y * Mb[4 * p4 + 2], s_i, fM[4 * p4 + 2]);
-      fM[4 * p4 + 3] = fmaf(fm4[p4].x * Mb[4 * p4 + 3], s_i, fM[4 * p4 + 3]);
-      idot = fmaf(fi4[p4].w, Ib[4 * p4 + 0], idot); idot = fmaf(fi4[p4].z, Ib[4 * p4 + 1], idot);
-      idot = fmaf(fi4[p4].y, Ib[4 * p4 + 2], idot); idot = fmaf(fi4[p4].x, Ib[4 * p4 + 3], idot);
+        for (int p4 = 0; p4 < Q / 4; p4++) {
+          // reversed order: component 3-j of the forward-ordered vector is position 4*p4+j
+          const float4 fm = nt_load4(row + (Q / 4 - 1 - p4) * kWave);
+          const float4 fi = nt_load4(row + (Q / 4 + Q / 4 - 1 - p4) * kWave);
+          fM[4 * p4 + 0] = fmaf(fm.w * Mb[4 * p4 + 0], s_i, fM[4 * p4 + 0]);
+          fM[4 * p4 + 1] = fmaf(fm.z * Mb[4 * p4 + 1], s_i, fM[4 * p4 + 1]);
+          fM[4 * p4 + 2] = fmaf(fm.y * Mb[4 * p4 + 2], s_i, fM[4 * p4 + 2]);
+          fM[4 * p4 + 3] = fmaf(fm.x * Mb[4 * p4 + 3], s_i, fM[4 * p4 + 3]);
+          idot = fmaf(fi.w, Ib[4 * p4 + 0], idot); idot = fmaf(fi.z, Ib[4 * p4 + 1], idot);
+          idot = fmaf(fi.y, Ib[4 * p4 + 2], idot); idot = fmaf(fi.x, Ib[4 * p4 + 3], idot);
+        }
+        fIs = fmaf(idot, s_i, fIs);
+      }
+    } else {
+      if (TH >= 768) { asm volatile("" ::: "memory"); request_row(); }
+      float idot = 0.f;
+#pragma unroll
+      for (int p4 = 0; p4 < Q / 4; p4++) {
+        fM[4 * p4 + 0] = fmaf(fm4[p4].w * Mb[4 * p4 + 0], s_i, fM[4 * p4 + 0]);
+        fM[4 * p4 + 1] = fmaf(fm4[p4].z * Mb[4 * p4 + 1], s_i, fM[4 * p4 + 1]);
+        fM[4 * p4 + 2] = fmaf(fm4[p4].y * Mb[4 * p4 + 2], s_i, fM[4 * p4 + 2]);
+        fM[4 * p4 + 3] = fmaf(fm4[p4].x * Mb[4 * p4 + 3], s_i, fM[4 * p4 + 3]);
+        idot = fmaf(fi4[p4].w, Ib[4 * p4 + 0], idot); idot = fmaf(fi4[p4].z, Ib[4 * p4 + 1], idot);
+        idot = fmaf(fi4[p4].y, Ib[4 * p4 + 2], idot); idot = fmaf(fi4[p4].x, Ib[4 * p4 + 3], idot);
+      }
+      fIs = fmaf(idot, s_i, fIs);
     }
-    fIs = fmaf(idot, s_i, fIs);
     float nj = spec[SP_N * SP + i - 1] * xN;
     nj = fmaf(spec[SP_J * SP + i - 1], xJ, nj);
     nj = fmaf(spec[SP_C * SP + i - 1], xC, nj);
@@ -329,10 +333,11 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
   constexpr int TBL = Q * kWave;
   float *emL = smem;
   float *trL = smem + (size_t)a.K * TBL;
-  float *wbase = trL + 2 * FW_NARR * TBL + (size_t)wave * a.wave_lds;
+  constexpr int NARR = FW_NARR + (Q <= kMaxQP ? 1 : 0);   // arrays per orientation in LDS
+  float *wbase = trL + 2 * NARR * TBL + (size_t)wave * a.wave_lds;
   const int SP = a.SP;
   WaveCtx c;
-  c.emL = (lds_f *)emL; c.fwL = (lds_f *)trL; c.bwL = (lds_f *)(trL + FW_NARR * TBL);
+  c.emL = (lds_f *)emL; c.fwL = (lds_f *)trL; c.bwL = (lds_f *)(trL + NARR * TBL);
   c.spec = (lds_f *)wbase; c.n2tab = (lds_f *)(wbase + SP_NARR * SP);
   c.degen = 0;
   for (int t = 0; t < 32; t++) if (t == lane) c.degen = a.degen[t];
@@ -361,7 +366,7 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
       const float4 *s1 = reinterpret_cast<const float4 *>(a.tables + hm->fw_off);
       const float4 *s2 = reinterpret_cast<const float4 *>(a.tables + hm->bw_off);
       float4 *d1 = reinterpret_cast<float4 *>(trL);
-      for (int t = threadIdx.x; t < FW_NARR * TBL / 4; t += blockDim.x) { d1[t] = s1[t]; d1[FW_NARR * TBL / 4 + t] = s2[t]; }
+      for (int t = threadIdx.x; t < NARR * TBL / 4; t += blockDim.x) { d1[t] = s1[t]; d1[NARR * TBL / 4 + t] = s2[t]; }
       cur_h = h;
       __syncthreads();
     }

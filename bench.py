@@ -35,6 +35,9 @@ WORKLOADS = {
     # development only: longer models (24 and 12 DP cells per lane)
     "dna_m1450": ("dna", 20251205, 1450, 256, 0.03, 1e-4, 20, 2048, 150, 4),
     "dna_m700": ("dna", 20251205, 700, 256, 0.03, 1e-4, 20, 2048, 150, 4),
+    # SURVEY.md section 8d config 5 (reported in DESIGN.md, not the headline): protein family,
+    # 500-HMM eHMM, 50k queries of 50..2000 residues built from family windows and random flanks
+    "aa_50k_x500": ("amino", 20251206, 600, 2048, 0.03, 1e-4, 500, 50000, (50, 2000), 10),
 }
 
 
@@ -47,7 +50,10 @@ def make_workload(name, workdir, nq_override=None, nh_override=None):
         n_hmms = nh_override
     fam = synth.make_family(seed, root_len, leaves, alph, sub, indel)
     ehmm = synth.make_ehmm(fam, n_hmms, workdir)
-    names, seqs = synth.make_queries(fam, seed + 1, nq, qlen)
+    if isinstance(qlen, tuple):
+        names, seqs = synth.make_queries(fam, seed + 1, nq, qlen, flank_frac=0.3)
+    else:
+        names, seqs = synth.make_queries(fam, seed + 1, nq, qlen)
     return fam, ehmm, names, seqs, k
 
 

@@ -328,3 +328,33 @@ def test_long_models_use_the_pass_synchronous_kernels(root_len, orc, tmp_path):
         want = ohm[ph[p]].align(seqs[pq[p]])
         assert np.array_equal(cols[co[p]:co[p + 1]], want), (root_len, pq[p], ph[p])
     e.close()
+
+
+def test_long_protein_queries_with_several_hits(orc, tmp_path):
+    """Queries of 500-2000 residues that hold several unequal hits to the family (one envelope
+    can span two of them): the envelope Backward sweep must keep the best path's cells in float32
+    range (mirrored Forward scaling, wh_device.h) - an earlier build lost their posterior mass and
+    produced NaN null2 corrections here."""
+    _need_gpu()
+    from witch_amd import synth
+    from witch_amd.ehmm import EHMM, pack_queries
+    fam = synth.make_family(20251206, 600, 64, "amino", 0.03, 1e-4)
+    eh = synth.make_ehmm(fam, 6, str(tmp_path), witch_layout=False)
+    names, seqs = synth.make_queries(fam, 20251207, 16, (500, 2000), flank_frac=0.3)
+    seqs = [s.astype(np.uint8) for s in seqs]
+    e = EHMM(eh.paths, hmm_index=eh.index, nseq=eh.nseq)
+    res, offs = pack_queries(seqs)
+    deci, flags, fwd, det = e.score(res, offs, want_fwd=True, want_detail=True)
+    ohm = [orc.OracleHMM(p) for p in eh.paths]
+    od, of, ofwd, osc = orc.score_batch(ohm, res, offs)
+    assert np.max(np.abs(fwd - ofwd)) <= 2e-4 * np.maximum(1.0, np.abs(ofwd) / 1000).max()
+    assert np.array_equal(flags & 3, of & 3)
+    assert ((of & 2) != 0).sum() > 0          # the case does contain multi-hit envelopes
+    assert not ((flags & 16) != 0).any()      # and none needed the dense redo
+    for d in det:
+        for t in range(d.nenv):
+            assert np.isfinite(d.domcorr[t]) and np.isfinite(d.envsc[t])
+    diff = np.abs(deci.astype(np.int64) - od)
+    assert diff.max() <= 1, diff.max()        # long envelopes: float32 vs float64 null2 sums, one deci-bit at most
+    assert (diff == 0).mean() >= 0.9
+    e.close()

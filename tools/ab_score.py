@@ -29,7 +29,7 @@ def main():
     from witch_amd.ehmm import EHMM, pack_queries
     wd = tempfile.mkdtemp(prefix="witch_ab_")
     try:
-        fam, se, names, seqs, k = bench.make_workload(wl, wd, nq, None)
+        fam, se, names, seqs, k = bench.make_workload(wl, wd, nq, int(os.environ.get("AB_NH", "0")) or None)
         e = EHMM(se.paths, hmm_index=se.index, nseq=se.nseq, device=0)
         res, offs = pack_queries([s.astype(np.uint8) for s in seqs])
         maxlen = int(np.max(np.diff(offs)))

@@ -441,6 +441,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       if (getenv("WH_STATS")) {
         if (e->d_recs.ensure(128)) return WH_ENOMEM;
         HIPCHK(hipMemsetAsync(e->d_recs.p, 0, 128, s));
+        { unsigned long long big = ~0ull; HIPCHK(hipMemcpyAsync((char *)e->d_recs.p + 13 * 8, &big, 8, hipMemcpyHostToDevice, s)); }
         a.stats = (unsigned long long *)e->d_recs.p;
       }
       if (getenv("WH_TRACE")) fprintf(stderr, "[wh] score Q=%d kver=%d specg=%d waves=%d blocks=%d lds=%zu SP=%d wave_lds=%d items=%d Lcap=%d\n", Q, kver, (int)specg, waves, blocks, lds, SP, wave_lds, a.n_items, a.Lcap);
@@ -458,6 +459,10 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
         HIPCHK(hipStreamSynchronize(s));
         fprintf(stderr, "[wh] stats Q=%d: envelope rows %llu, lane blocks kept %llu (%.1f of 64 per row), envelopes %llu, dense redos %llu\n", Q, st[0], st[1],
                 st[0] ? (double)st[1] / (double)st[0] : 0.0, st[2], st[3]);
+        { unsigned u0 = (unsigned)st[10], u1 = (unsigned)st[11]; float f0, f1; memcpy(&f0, &u0, 4); memcpy(&f1, &u1, 4);
+          fprintf(stderr, "[wh] max |Ld - mass|/Ld: sparse attempt %.3g, dense attempt %.3g\n", f0, f1); }
+        fprintf(stderr, "[wh] dbg: scale exponent k range [%lld, %lld]; last row with non-finite B cells %llu, F cells %llu, specials %llu\n",
+                (long long)st[13] - 100000, (long long)st[12] - 100000, st[14], st[15], st[9]);
         const double tot = (double)(st[4] + st[5] + st[6] + st[7] + st[8] + st[9]);
         fprintf(stderr, "[wh] wave cycles: P1 %.1f%%  P2 %.1f%%  regions %.1f%%  P3 %.1f%%  P4 %.1f%%  null2 %.1f%%  (total %.3g ticks; P1 per row %.0f ticks)\n", 100.0 * st[4] / tot,
                 100.0 * st[5] / tot, 100.0 * st[6] / tot, 100.0 * st[7] / tot, 100.0 * st[8] / tot, 100.0 * st[9] / tot, tot, (double)st[4] / ((double)nq * a.n_list * 150.0));

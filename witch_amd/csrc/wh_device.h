@@ -332,6 +332,38 @@ __device__ __forceinline__ void forward_sweep(const TransTab<Q, TREG> &T, const 
   ef_out = ef;
 }
 
+// ------------------------------------------------------------------ envelope Backward scaling
+// The unihit Backward sweep of an envelope carries the scale the Forward sweep left on the rows
+// still to come, 2^-(ef_e - S(i)): F_s(i,k) * B_s(i,k) / Z_s is then the posterior with no per-row
+// exponent, and every cell whose posterior matters stays in float32 range because its Forward
+// partner is O(1).  (A normaliser of Backward's own - max(B, N), as the multihit sweep uses - lets
+// a strong alternative hit that starts later push the cells of the best path below 2^-149 in
+// envelopes that hold two unequal hits: lost posterior mass, 0 * inf in the accumulators.)
+// mirror_scale applies the Forward rescale of row i+1 (dn = S(i+1) - S(i)) to the carried state;
+// clamp_backward saturates values whose Forward partner has underflowed (posterior nil) instead of
+// rescaling the row.  All factors are powers of two: results are bit-identical to any other exact
+// scaling as long as nothing leaves the float32 range.
+constexpr float kClampHi = 1.1529215e18f;   // 2^60
+
+template <int Q>
+__device__ __forceinline__ void mirror_scale(int dn, float (&Mb)[Q], float (&Ib)[Q], float &xJ, float &xC, float &xN) {
+  if (dn != 0) {
+    const float r = __builtin_bit_cast(float, (127 - dn) << 23);
+#pragma unroll
+    for (int p = 0; p < Q; p++) { Mb[p] *= r; Ib[p] *= r; }
+    xJ *= r; xC *= r; xN *= r;
+  }
+}
+
+template <int Q>
+__device__ __forceinline__ void clamp_backward(float (&Mb)[Q], float (&Ib)[Q], float &xB, float &xJ, float &xC, float &xN) {
+  if (fmaxf(xB, fmaxf(xN, xC)) > kClampHi) {
+#pragma unroll
+    for (int p = 0; p < Q; p++) { Mb[p] = fminf(Mb[p], kClampHi); Ib[p] = fminf(Ib[p], kClampHi); }
+    xB = fminf(xB, kClampHi); xN = fminf(xN, kClampHi); xC = fminf(xC, kClampHi); xJ = fminf(xJ, kClampHi);
+  }
+}
+
 // G_k = o_k(x) * B_M_k in place (reversed node order) and the B-state sum  sum_k E_k G_k;
 // the emission piece of each 4-cell group is fetched where it is used.
 template <int Q, bool TREG>

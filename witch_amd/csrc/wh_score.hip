@@ -316,7 +316,7 @@ __global__ __launch_bounds__(PHASE == 1 ? WH_SCOREA_THREADS : (PHASE == 2 ? WH_S
 #pragma unroll
                 for (int p = 0; p < Q; p++) { Mb[p] = 0.f; Ib[p] = 0.f; fM[p] = 0.f; fI[p] = 0.f; }
                 float xC = cu.move, xJ = 0.f, xN = 0.f, xB = 0.f, xfac = 0.f;
-                int eb = 0;
+
                   const int src = kWave - 1 - lane;   // the forward-order lane that owns my (reversed) cells
 #pragma unroll 1
                 for (int i = Ld; i >= 1; i--) {
@@ -337,6 +337,7 @@ __global__ __launch_bounds__(PHASE == 1 ? WH_SCOREA_THREADS : (PHASE == 2 ? WH_S
                     for (int p4 = 0; p4 < Q / 4; p4++) { fm4[p4] = make_float4(0.f, 0.f, 0.f, 0.f); fi4[p4] = fm4[p4]; }
                   }
                   if (i < Ld) {
+                    mirror_scale<Q>(SPRI(SP_S * SP + i + 1) - SPRI(SP_S * SP + i), Mb, Ib, xJ, xC, xN);
                     float od[Q];
                     load_em_rev<Q>(od, emL, emG, eseq[i], a.K, lane);
                     float part = 0.f;
@@ -357,17 +358,10 @@ __global__ __launch_bounds__(PHASE == 1 ? WH_SCOREA_THREADS : (PHASE == 2 ? WH_S
                   }
                   float xE = fmaf(xC, cu.EC, xJ * cu.EJ);
                   backward_cells<Q, TREG>(T, sc, Mb, Ib, xE);
-                  const float big = fmaxf(xB, xN);
-                  if (big > kRescaleHi) {
-                    const int ee = f32_exponent(big);
-                    const float r = pow2f_int(-ee);
-#pragma unroll
-                    for (int p = 0; p < Q; p++) { Mb[p] *= r; Ib[p] *= r; }
-                    xB *= r; xJ *= r; xC *= r; xN *= r; xE *= r;
-                    eb += ee;
-                  }
-                  const float s_i = ldexpf(invZe, SPRI(SP_S * SP + i) + eb - ef_e);
-                  const float s_p = ldexpf(invZe, SPRI(SP_S * SP + i - 1) + eb - ef_e);
+                  clamp_backward<Q>(Mb, Ib, xB, xJ, xC, xN);
+                  // mirrored scaling (wh_device.h, "envelope Backward scaling")
+                  const float s_i = invZe;
+                  const float s_p = ldexpf(invZe, SPRI(SP_S * SP + i - 1) - SPRI(SP_S * SP + i));
 #pragma unroll
                   for (int p4 = 0; p4 < Q / 4; p4++) {
                     // reversed order: component 3-j of the forward-ordered vector is position 4*p4+j
@@ -395,6 +389,7 @@ __global__ __launch_bounds__(PHASE == 1 ? WH_SCOREA_THREADS : (PHASE == 2 ? WH_S
                 sm = wave_sum(sm);
                 // certificate: posterior mass over all emitting states = number of residues
                 const float deficit = fabsf((float)Ld - (sm + si + xfac));
+                if (a.stats && lane == 0) atomicMax(a.stats + 10 + attempt, (unsigned long long)__float_as_uint(deficit / (float)Ld));
                 if (attempt == 0 && !a.dbg && !(deficit <= kMassTol1 * (float)Ld)) continue;
                 if (attempt == 1) flags |= WH_FLAG_EXACT;
                 float mine = 1.0f;

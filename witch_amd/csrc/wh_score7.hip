@@ -148,7 +148,6 @@ __device__ __noinline__ P4Out sweep_backward_null2(const WaveCtx c, lds_u8 *eseq
 #pragma unroll
   for (int p = 0; p < Q; p++) { Mb[p] = 0.f; Ib[p] = 0.f; fM[p] = 0.f; }
   float xC = cu.move, xJ = 0.f, xN = 0.f, xB = 0.f, xfac = 0.f, fIs = 0.f;
-  int eb = 0;
   const int src = kWave - 1 - lane;   // the forward-order lane that owns my (reversed) cells
 #pragma unroll 1
   for (int i = Ld; i >= 1; i--) {
@@ -173,7 +172,10 @@ __device__ __noinline__ P4Out sweep_backward_null2(const WaveCtx c, lds_u8 *eseq
       }
     };
     if (TH < 768) request_row();
+    // mirrored scaling (wh_device.h, "envelope Backward scaling")
+    const int dS = specI[SP_S * SP + i] - specI[SP_S * SP + i - 1];      // Forward rescale at row i (>= 0)
     if (i < Ld) {
+      mirror_scale<Q>(specI[SP_S * SP + i + 1] - specI[SP_S * SP + i], Mb, Ib, xJ, xC, xN);
       xB = wave_sum(backward_emit<Q, false>(T, emL, (const float *)c.emG, eseq[i], c.K, lane, Mb));
       xJ = fmaf(xJ, cu.loop, xB * cu.move);
       xC = xC * cu.loop;
@@ -181,17 +183,9 @@ __device__ __noinline__ P4Out sweep_backward_null2(const WaveCtx c, lds_u8 *eseq
     }
     float xE = fmaf(xC, cu.EC, xJ * cu.EJ);
     backward_cells<Q, false, (Q <= kMaxQP)>(T, sc, Mb, Ib, xE);
-    const float big = fmaxf(xB, xN);
-    if (big > kRescaleHi) {
-      const int ee = f32_exponent(big);
-      const float r = pow2f_int(-ee);
-#pragma unroll
-      for (int p = 0; p < Q; p++) { Mb[p] *= r; Ib[p] *= r; }
-      xB *= r; xJ *= r; xC *= r; xN *= r; xE *= r;
-      eb += ee;
-    }
-    const float s_i = ldexpf(invZe, specI[SP_S * SP + i] + eb - ef_e);
-    const float s_p = ldexpf(invZe, specI[SP_S * SP + i - 1] + eb - ef_e);
+    clamp_backward<Q>(Mb, Ib, xB, xJ, xC, xN);
+    const float s_i = invZe;
+    const float s_p = ldexpf(invZe, -dS);
     if (TH >= 768 && kMaskedAcc) {
       // only the lanes that own a stored block run the accumulation (the others would add zeros)
       asm volatile("" ::: "memory");

@@ -261,12 +261,13 @@ __global__ __launch_bounds__(256) void score_big_kernel(ScoreArgs a) {
 #pragma unroll
             for (int p = 0; p < Q; p++) { Mb[p] = 0.f; Ib[p] = 0.f; fM[p] = 0.f; }
             float xC = cu.move, xJ = 0.f, xN = 0.f, xB = 0.f, xfac = 0.f, fIs = 0.f;
-            int eb = 0;
+
             const int src = kWave - 1 - lane;
 #pragma unroll 1
             for (int i = Ld; i >= 1; i--) {
               asm volatile("" ::: "memory");
               if (i < Ld) {
+                mirror_scale<Q>(BSPRI(SP_S * SP + i + 1) - BSPRI(SP_S * SP + i), Mb, Ib, xJ, xC, xN);
                 float od[Q];
                 load_em_rev<Q>(od, emL, emG, eseq[i], Klds, lane);
                 float part = 0.f;
@@ -287,17 +288,10 @@ __global__ __launch_bounds__(256) void score_big_kernel(ScoreArgs a) {
               }
               float xE = fmaf(xC, cu.EC, xJ * cu.EJ);
               backward_cells<Q, false>(T, sc, Mb, Ib, xE);
-              const float big = fmaxf(xB, xN);
-              if (big > kRescaleHi) {
-                const int ee = f32_exponent(big);
-                const float r = pow2f_int(-ee);
-#pragma unroll
-                for (int p = 0; p < Q; p++) { Mb[p] *= r; Ib[p] *= r; }
-                xB *= r; xJ *= r; xC *= r; xN *= r; xE *= r;
-                eb += ee;
-              }
-              const float s_i = ldexpf(invZe, BSPRI(SP_S * SP + i) + eb - ef_e);
-              const float s_p = ldexpf(invZe, BSPRI(SP_S * SP + i - 1) + eb - ef_e);
+              clamp_backward<Q>(Mb, Ib, xB, xJ, xC, xN);
+              // mirrored scaling (wh_device.h, "envelope Backward scaling")
+              const float s_i = invZe;
+              const float s_p = ldexpf(invZe, BSPRI(SP_S * SP + i - 1) - BSPRI(SP_S * SP + i));
               const unsigned mword = src < 32 ? BSPRU(SP_ML * SP + i) : BSPRU(SP_MH * SP + i);
               if ((mword >> (src & 31)) & 1u) {
                 const float4 *row = reinterpret_cast<const float4 *>(Fs) + (size_t)i * (2 * (Q / 4) * kWave) + src;

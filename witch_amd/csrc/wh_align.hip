@@ -153,7 +153,6 @@ __global__ __launch_bounds__(SWAP ? 256 : 512) void align_kernel(AlignArgs a) {
 #pragma unroll
         for (int p = 0; p < Q; p++) { Mb[p] = 0.f; Ib[p] = 0.f; }
         float xC = cu.move, xJ = 0.f, xN = 0.f, xB = 0.f;
-        int eb = 0;
 #pragma unroll 1
         for (int i = L; i >= 1; i--) {
           asm volatile("" ::: "memory");
@@ -165,6 +164,8 @@ __global__ __launch_bounds__(SWAP ? 256 : 512) void align_kernel(AlignArgs a) {
             fi4[p4] = nt_load4(row + (Q4 + Q4 - 1 - p4) * kWave);
           }
           if (i < L) {
+            // mirrored scaling (wh_device.h, "envelope Backward scaling")
+            mirror_scale<Q>(SPRI(AL_S * SP + i + 1) - SPRI(AL_S * SP + i), Mb, Ib, xJ, xC, xN);
             float od[Q];
             load_em_rev<Q>(od, emL, emG, seq[i], Klds, lane);
             float part = 0.f;
@@ -185,17 +186,9 @@ __global__ __launch_bounds__(SWAP ? 256 : 512) void align_kernel(AlignArgs a) {
           }
           float xE = fmaf(xC, cu.EC, xJ * cu.EJ);
           backward_cells<Q, TREG>(T, sc, Mb, Ib, xE);
-          const float big = fmaxf(xB, xN);
-          if (big > kRescaleHi) {
-            const int ee = f32_exponent(big);
-            const float r = pow2f_int(-ee);
-#pragma unroll
-            for (int p = 0; p < Q; p++) { Mb[p] *= r; Ib[p] *= r; }
-            xB *= r; xJ *= r; xC *= r; xN *= r; xE *= r;
-            eb += ee;
-          }
-          const float s_i = ldexpf(invZ, SPRI(AL_S * SP + i) + eb - ef_L);
-          const float s_p = ldexpf(invZ, SPRI(AL_S * SP + i - 1) + eb - ef_L);
+          clamp_backward<Q>(Mb, Ib, xB, xJ, xC, xN);
+          const float s_i = invZ;
+          const float s_p = ldexpf(invZ, SPRI(AL_S * SP + i - 1) - SPRI(AL_S * SP + i));
 #pragma unroll
           for (int p4 = 0; p4 < Q4; p4++) {
             // position 4*p4+j (reversed order) is component 3-j of the forward-ordered vector

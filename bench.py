@@ -200,7 +200,7 @@ def main():
             # VALU view of the same kernel (it is arithmetic-bound by design):
             # 5 DP sweeps (2 multihit parsers, 2 envelope sweeps, decoding) ~ 77 flop per cell
             flops = n_local * float(np.sum(L * M)) * 77.0 * args.steps / score_launches
-            roofline = {"bound": "hbm", "kernel": "score_kernel", "achieved": round(achieved, 1), "peak": 8000.0,
+            roofline = {"bound": "hbm", "kernel": "wh::k7::score_kernel7", "achieved": round(achieved, 1), "peak": 8000.0,
                         "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                         "kernel_ms_avg": round(score_ms, 3), "launches": score_launches,
                         "valu_tflops": round(flops / (score_ms * 1e-3) / 1e12, 2) if score_ms > 0 else 0.0,

@@ -11,6 +11,7 @@ behaviour and serve their answers from that precomputed table:
     getBackbones    witch_msa/gcmm/aligner.py:33-148
     search          witch_msa/gcmm/algorithm.py:273-336 (result files: :524-537)
     alignSubQueriesNew  witch_msa/gcmm/aligner.py:350-538 (weighted consensus DP on the GPU)
+    mergeAlignmentsCollapsed  witch_msa/gcmm/merger.py:40-131 (final transitive merge, closed form)
 
 INTEGRATION.md shows the three-line change in witch_msa/gcmm/gcmm.py that installs them.
 """
@@ -20,3 +21,4 @@ from .weighting import writeWeights, calculateWeights, writeWeightsToLocal, read
 from .aligner import getBackbones  # noqa: F401
 from .algorithm import search, evalHMMSearchOutput  # noqa: F401
 from .merge import alignSubQueriesNew, compressInsertions, trace_to_string  # noqa: F401
+from .merger import mergeAlignmentsCollapsed  # noqa: F401

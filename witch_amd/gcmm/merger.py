@@ -1,0 +1,155 @@
+"""Final transitive merge with the reference's shape (witch_msa/gcmm/merger.py:40-131).
+
+The reference merges the query alignments into the backbone ONE AT A TIME with
+ExtendedAlignment.merge_in (helpers/alignment_tools.py:1183-1316): two cursors walk the column
+labels and every new run of insertion columns is spliced into EVERY sequence collected so far
+(`seq[me:me] = ins`), i.e. O(queries x rows x width) byte moves - the step SURVEY.md section 8f
+ranks as the second host bottleneck at 100k queries.
+
+What that loop computes has a closed form, used here:
+  * every query alignment carries all B backbone columns (labels 0..B-1) plus insertion
+    columns (lowercase, negative labels) in the B+1 gaps before / between / after them;
+  * when both sides hold insertion columns at the same gap the runs are walked together from
+    the left ("We both have a series of insertion columns"), the longer run's tail is appended;
+    so after all merges gap g is W[g] = max over queries of their run length there, and every
+    query's run is LEFT-justified in it; everybody else shows '-';
+  * rows: the backbone sequences in file order, then the queries in list order (a query whose
+    name already exists is not added, alignment_tools.py:1226-1230, but its insertion columns
+    still widen the gaps); 'skipped' entries and empty alignments contribute nothing;
+  * renamed taxa are popped and re-inserted under their original name, which moves them to
+    the end in the order of the rename map (merger.py:84-93);
+  * <name>.masked.fasta is the same matrix without the insertion columns (merger.py:100-103).
+The result is byte-identical to the reference's two output files (tests/test_merger_host.py
+against vectors produced by the reference's own function).
+"""
+import time
+
+import numpy as np
+
+_DASH = ord('-')
+
+
+def masked_path(outpath):
+    """merger.py:47-56: '<name>.masked.<suffix>' for .fa/.fasta, else '<outpath>.masked.fasta'."""
+    suffix = outpath.split('.')[-1]
+    if suffix in ('fa', 'fasta'):
+        return '.'.join(outpath.split('.')[:-1]) + '.masked.' + suffix
+    return outpath + '.masked.fasta'
+
+
+def read_fasta_upper(path):
+    """Alignment.read_file_object (alignment_tools.py:716-733): names verbatim, sequences
+    upper-cased; a repeated name replaces the earlier sequence but keeps its position."""
+    rows, name, chunks = {}, None, []
+    opener = open
+    if str(path).endswith('.gz'):
+        import gzip
+        opener = gzip.open
+    with opener(path, 'rt') as f:
+        for line in f:
+            line = line.strip()
+            if line.startswith('>'):
+                if name is not None:
+                    rows[name] = ''.join(chunks).upper()
+                name, chunks = line[1:], []
+            elif line and name is not None:
+                chunks.append(line)
+    if name is not None:
+        rows[name] = ''.join(chunks).upper()
+    return rows
+
+
+def _split_query(text, B):
+    """(column characters uint8[B], gap index of every lowercase residue, the residues)."""
+    a = np.frombuffer(text.encode('ascii'), dtype=np.uint8)
+    low = (a >= 97) & (a <= 122)                     # str.islower() of a single ASCII character
+    cols = a[~low]
+    if cols.size != B:
+        raise ValueError("query alignment has %d backbone columns, the backbone has %d" % (cols.size, B))
+    gap_of = np.cumsum(~low)[low]                    # columns seen before the residue = its gap 0..B
+    return cols, gap_of, a[low]
+
+
+def merge_collapsed(backbone_rows, queries, renamed_taxa=None):
+    """backbone_rows: {name: aligned string} (insertion-ordered); queries: iterable of
+    {taxon: aligned string} alignments (the objects alignSubQueriesNew returns), 'skipped'
+    markers or empty alignments.  Returns (names, full uint8 matrix, backbone column positions)."""
+    names = list(backbone_rows.keys())
+    if not names:
+        raise ValueError("empty backbone alignment")
+    B = len(backbone_rows[names[0]])
+    parsed = []                                       # (name, cols, gap_of, residues, add_row)
+    seen = set(names)
+    W = np.zeros(B + 1, dtype=np.int64)
+    for q in queries:
+        if isinstance(q, str) or q is None or len(q) == 0:
+            continue                                  # 'skipped' / failed query (merger.py:75-77, merge_in:1210)
+        for name, text in q.items():
+            cols, gap_of, res = _split_query(text, B)
+            if gap_of.size:
+                run = np.bincount(gap_of, minlength=B + 1)
+                np.maximum(W, run, out=W)
+            add = name not in seen
+            seen.add(name)
+            parsed.append((name, cols, gap_of, res, add))
+    # column layout: gap g (W[g] insertion columns) precedes backbone column g; gap B closes the row
+    gap_start = np.concatenate(([0], np.cumsum(W)[:-1])) + np.arange(B + 1)
+    col_pos = gap_start[:B] + W[:B]
+    width = int(B + W.sum())
+    rows_q = [p for p in parsed if p[4]]
+    out = np.full((len(names) + len(rows_q), width), _DASH, dtype=np.uint8)
+    for r, n in enumerate(names):
+        s = np.frombuffer(backbone_rows[n].encode('ascii'), dtype=np.uint8)
+        if s.size != B:
+            raise ValueError("backbone row %s has %d columns, expected %d" % (n, s.size, B))
+        out[r, col_pos] = s
+    for r, (name, cols, gap_of, res, _) in enumerate(rows_q, start=len(names)):
+        out[r, col_pos] = cols
+        if gap_of.size:
+            # left-justified inside the gap: k-th residue of a run sits at gap_start + k
+            first = np.concatenate(([True], gap_of[1:] != gap_of[:-1]))
+            run_begin = np.maximum.accumulate(np.where(first, np.arange(gap_of.size), 0))
+            out[r, gap_start[gap_of] + (np.arange(gap_of.size) - run_begin)] = res
+        names.append(name)
+    # merger.py:84-93: rename back; popped entries move to the end in rename-map order
+    order = list(range(len(names)))
+    if renamed_taxa:
+        name_map = {v: k for k, v in renamed_taxa.items()}
+        pos = {n: i for i, n in enumerate(names)}
+        for name, ori in name_map.items():
+            if name in pos:
+                i = pos.pop(name)
+                order.remove(i)
+                if ori in pos:                        # overwriting an existing key keeps that key's slot
+                    order[order.index(pos[ori])] = i
+                else:
+                    order.append(i)
+                pos[ori] = i
+                names[i] = ori
+    return [names[i] for i in order], out[order], col_pos
+
+
+def write_fasta_matrix(path, names, mat):
+    with open(path, 'wb') as f:
+        for n, row in zip(names, mat):
+            f.write(b'>' + n.encode() + b'\n' + row.tobytes() + b'\n')
+
+
+def mergeAlignmentsCollapsed(backbone_alignment_path, queries, renamed_taxa, pool, output_path=None,
+                             log=None):
+    """Same arguments as merger.py:40 (pool is unused there too) plus the output path the
+    reference takes from Configs.output_path.  Writes <output_path> and its masked twin; returns
+    (output_path, masked_output_path)."""
+    if output_path is None:
+        raise ValueError("output_path is required (the reference reads Configs.output_path)")
+    start = time.time()
+    if not len(queries) > 0:
+        raise SystemExit('No query alignment provided to merger!')   # merger.py:60-62 prints and exits
+    backbone = read_fasta_upper(backbone_alignment_path)
+    names, mat, col_pos = merge_collapsed(backbone, queries, renamed_taxa)
+    write_fasta_matrix(output_path, names, mat)
+    mpath = masked_path(output_path)
+    write_fasta_matrix(mpath, names, mat[:, col_pos])
+    if log is not None:
+        log('Time to merge all outputs (s): {}'.format(time.time() - start))
+    return output_path, mpath

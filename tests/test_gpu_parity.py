@@ -375,3 +375,59 @@ def test_long_protein_queries_with_several_hits(orc, tmp_path):
             assert len(m) > 0 and np.all(np.diff(m) > 0)
     assert bad <= 0.35 * len(pq), (bad, len(pq))
     e.close()
+
+
+def test_level0_shims_reproduce_hmmer_outputs(tmp_path):
+    """WITCH's own plug-in boundary (hmmsearchpath / hmmalignpath): the C clients + the resident
+    GPU server, driven with the reference's exact command lines, against HMMER's golden results
+    parsed the way the reference parses them."""
+    _need_gpu()
+    import os
+    import subprocess
+    import threading
+    from tests.conftest import load_case, ROOT
+    from witch_amd.gcmm.algorithm import evalHMMSearchOutput
+    from witch_amd.shim import formats
+    from witch_amd.shim.server import Server, GpuBackend
+    bindir = os.path.join(ROOT, "witch_amd", "shim", "bin")
+    subprocess.run(["make", "-C", os.path.join(ROOT, "witch_amd", "shim")], check=True, stdout=subprocess.DEVNULL)
+    sock = str(tmp_path / "gpu.sock")
+    srv = Server(GpuBackend(0), sock)
+    ready = threading.Event()
+    threading.Thread(target=srv.serve_forever, args=(ready,), daemon=True).start()
+    assert ready.wait(10)
+    env = dict(os.environ, WITCH_HIP_SOCKET=sock)
+    case = load_case("dna_hmmbuild")
+    fa = os.path.join(case.dir, "queries.fasta")
+    n_scores = n_aln = 0
+    for hf, hp in list(zip(case.hmm_files, case.hmm_paths))[:4]:
+        out = str(tmp_path / ("hmmsearch.results." + os.path.basename(hf)))
+        r = subprocess.run([os.path.join(bindir, "hmmsearch"), "--cpu", "1", "--noali", "-E", "99999999", "-o", out,
+                            "--max", hp, fa], env=env, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        got = evalHMMSearchOutput(out)
+        want = case.g["search"][hf]
+        multi = {q for q, v in want.items() if len(v.get("dom", [0])) != 1}     # stochastic multidomain class
+        # sequences whose only regions are multidomain (HMMER resolves those stochastically) may be
+        # reported on one side only: the same tolerance class as test_score_against_oracle_and_golden
+        assert len(set(got) ^ set(want)) <= max(1, len(want) // 20), (hf, set(got) ^ set(want))
+        for q, (ev, sc) in got.items():
+            if q in multi or q not in want:
+                continue
+            assert abs(sc - want[q]["score"]) <= 0.1001, (hf, q, sc, want[q]["score"])
+            n_scores += sc == want[q]["score"]
+    seqs = dict(zip(case.qnames, case.qseqs))
+    procs = []
+    for qn, a in list(case.g["align"].items())[:12]:
+        one = tmp_path / (qn + ".fa")
+        one.write_text(">%s\n%s\n" % (qn, seqs[qn]))
+        for idx, cols in a["cols"].items():
+            hp = case.hmm_paths[case.hmm_index.index(int(idx))]
+            out = str(tmp_path / ("hmmalign.%s.%s.out" % (qn, idx)))
+            procs.append((subprocess.Popen([os.path.join(bindir, "hmmalign"), "-o", out, hp, str(one)], env=env), out, qn, cols))
+    for p, out, qn, cols in procs:
+        assert p.wait() == 0
+        row = "".join(l.split()[1] for l in open(out) if l.strip() and not l.startswith("#") and l.strip() != "//")
+        assert formats.decode_stockholm_row(row) == list(cols), (qn, out)
+        n_aln += 1
+    assert n_scores > 50 and n_aln > 10

@@ -1,0 +1,134 @@
+"""Level-0 shim, host side (no GPU): the text it writes is what the reference's parsers read,
+the argv of WITCH's two command lines is understood, and the C clients talk to the server."""
+import os
+import subprocess
+import threading
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "witch_amd", "shim", "bin")
+
+
+class FakeBackend:
+    """Deterministic stand-in for the GPU (NOT the oracle): score = 10 * length, columns = identity."""
+    def search(self, hmm_path, records):
+        from witch_amd.shim import formats
+        hdr = formats.hmm_header(hmm_path)
+        rows = [(n, 10.0 * len(t) + 0.5, 1.25, 1) for n, t in records if len(t) > 0 and not n.startswith("unrep")]
+        return hdr, rows
+
+    def align(self, jobs):
+        out = []
+        for hp, name, text in jobs:
+            cols = np.arange(len(text), dtype=np.int32) + 2
+            cols[:1] = -1
+            out.append((len(text) + 5, cols))
+        return out
+
+
+def _hmm(tmp_path):
+    p = tmp_path / "m.hmm"
+    p.write_text("HMMER3/f [3.1b2 | February 2015]\nNAME  A_0_7\nLENG  12\nALPH  DNA\n"
+                 "STATS LOCAL MSV      -9.0 0.71\nSTATS LOCAL VITERBI -9.5 0.71\nSTATS LOCAL FORWARD  -4.2 0.71\nHMM  A C G T\n")
+    return str(p)
+
+
+@pytest.fixture()
+def server(tmp_path):
+    from witch_amd.shim.server import Server
+    sock = str(tmp_path / "s.sock")
+    srv = Server(FakeBackend(), sock)
+    ready = threading.Event()
+    threading.Thread(target=srv.serve_forever, args=(ready,), daemon=True).start()
+    assert ready.wait(10)
+    return sock
+
+
+def test_hmmsearch_table_is_readable_by_the_reference_parser(tmp_path):
+    from witch_amd.shim import formats
+    from witch_amd.gcmm.algorithm import evalHMMSearchOutput
+    hdr = formats.hmm_header(_hmm(tmp_path))
+    assert hdr == {"name": "A_0_7", "M": 12, "ftau": -4.2, "flambda": 0.71}
+    rows = [("q1", 123.4, 0.3, 1), ("a_long_query_name_with_many_chars", -5.2, 0.0, 2), ("q3", 7.0, 11.1, 1)]
+    out = tmp_path / "o.txt"
+    out.write_text(formats.format_hmmsearch("m.hmm", "q.fa", hdr, rows, 3))
+    got = evalHMMSearchOutput(str(out))
+    assert {k: v[1] for k, v in got.items()} == {"q1": 123.4, "a_long_query_name_with_many_chars": -5.2, "q3": 7.0}
+    assert got["q1"][0] == 0.0 or got["q1"][0] < 1e-30          # E-value column parses as a float
+    out.write_text(formats.format_hmmsearch("m.hmm", "q.fa", hdr, [], 3))
+    assert evalHMMSearchOutput(str(out)) == {}
+
+
+def test_stockholm_row_round_trip_against_hmmer_columns(golden_case):
+    """cols -> Stockholm row -> the reference's decoding (aligner.py:126-142) -> cols, for every
+    golden hmmalign result (inserts, flanks, deletions as HMMER placed them)."""
+    from witch_amd.shim import formats
+    n = 0
+    for qn, a in golden_case.g["align"].items():
+        seq = dict(zip(golden_case.qnames, golden_case.qseqs))[qn]
+        for idx, cols in a["cols"].items():
+            M = max([c for c in cols if c >= 0] + [0]) + 3
+            row = formats.stockholm_row(seq, cols, M)
+            assert len(row.replace("-", "")) == len(seq)
+            assert sum(1 for ch in row if not ch.islower()) == M
+            assert formats.decode_stockholm_row(row) == list(cols)
+            sto = formats.format_stockholm(qn, row, width=60)
+            body = "".join(l.split()[1] for l in sto.splitlines() if l and not l.startswith("#") and l != "//")
+            assert body == row
+            n += 1
+    assert n > 0
+
+
+def test_argv_of_witch_command_lines():
+    from witch_amd.shim.server import parse_hmmsearch_argv, parse_hmmalign_argv, ArgError
+    opts, hmm, fa = parse_hmmsearch_argv("--cpu 1 --noali -E 99999999 -o out.txt --max m.hmm q.fa".split())
+    assert (hmm, fa, opts["-o"], opts["--cpu"], opts["-E"]) == ("m.hmm", "q.fa", "out.txt", "1", "99999999")
+    assert opts["--max"] is True and opts["--noali"] is True
+    opts, hmm, fa = parse_hmmalign_argv("-o a.sto m.hmm q.fa".split())
+    assert (hmm, fa, opts["-o"]) == ("m.hmm", "q.fa", "a.sto")
+    with pytest.raises(ArgError):
+        parse_hmmsearch_argv(["m.hmm"])
+    with pytest.raises(ArgError):
+        parse_hmmalign_argv(["-o"])
+
+
+def test_clients_end_to_end_with_a_stub_backend(server, tmp_path):
+    if not os.path.exists(os.path.join(BIN, "hmmsearch")):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "witch_amd", "shim")], check=True, stdout=subprocess.DEVNULL)
+    from witch_amd.gcmm.algorithm import evalHMMSearchOutput
+    from witch_amd.shim import formats
+    hmm = _hmm(tmp_path)
+    fa = tmp_path / "q.fa"
+    fa.write_text(">q1 some description\nACGTAC\nGT\n>unrep2\nAC\n>q3\nACG\n")
+    env = dict(os.environ, WITCH_HIP_SOCKET=server)
+    # the exact command line of gcmm/algorithm.py:526-532, relative paths resolved against the client's cwd
+    r = subprocess.run([os.path.join(BIN, "hmmsearch"), "--cpu", "1", "--noali", "-E", "99999999", "-o", "res.txt",
+                        "--max", "m.hmm", "q.fa"], cwd=str(tmp_path), env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = evalHMMSearchOutput(str(tmp_path / "res.txt"))
+    assert {k: v[1] for k, v in got.items()} == {"q1": 80.5, "q3": 30.5}
+    # gcmm/aligner.py:98-100
+    one = tmp_path / "one.fa"
+    one.write_text(">q1\nACGTACGT\n")
+    r = subprocess.run([os.path.join(BIN, "hmmalign"), "-o", str(tmp_path / "a.sto"), hmm, str(one)], env=env,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rows = [l.split() for l in open(tmp_path / "a.sto") if l.strip() and not l.startswith("#") and l.strip() != "//"]
+    row = "".join(x[1] for x in rows if x[0] == "q1")
+    assert formats.decode_stockholm_row(row) == [-1] + list(range(3, 10))
+    # failures exit non-zero with a message, and leave no output file
+    r = subprocess.run([os.path.join(BIN, "hmmsearch"), "-o", str(tmp_path / "x.txt"), str(tmp_path / "missing.hmm"), str(fa)],
+                       env=env, capture_output=True, text=True)
+    assert r.returncode == 1 and "HMM file" in r.stderr and not os.path.exists(tmp_path / "x.txt")
+    r = subprocess.run([os.path.join(BIN, "hmmalign"), hmm, str(fa)], env=env, capture_output=True, text=True)
+    assert r.returncode == 1 and "one sequence per call" in r.stderr
+    # many concurrent hmmalign calls are batched and all answered
+    procs = [subprocess.Popen([os.path.join(BIN, "hmmalign"), "-o", str(tmp_path / ("b%d.sto" % i)), hmm, str(one)], env=env)
+             for i in range(24)]
+    assert all(p.wait() == 0 for p in procs)
+    assert all(os.path.getsize(tmp_path / ("b%d.sto" % i)) > 0 for i in range(24))
+    from witch_amd.shim.server import request
+    st, body = request(server, "ping", [])
+    assert st == 0 and body.split()[:1] == ["pong"] and int(body.split()[2]) >= 25

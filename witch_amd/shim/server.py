@@ -1,0 +1,310 @@
+"""Resident GPU server behind the level-0 hmmsearch / hmmalign executables (see __init__.py).
+
+    python -m witch_amd.shim.server --socket /tmp/witch_hip.sock [--device 0] [--daemonize]
+
+Protocol (one request per connection): the client sends  tool \\0 cwd \\0 arg \\0 arg ... and shuts
+its write side; the server answers "<exit status>\\n<message>".  Requests are served by one
+thread per connection; GPU work is serialised, and hmmalign requests that arrive together (WITCH
+issues them from up to num_cpus workers at once) are batched into ONE wh_align launch.
+"""
+import argparse
+import os
+import socket
+import sys
+import threading
+import time
+
+import numpy as np
+
+from . import formats
+
+
+def default_socket_path():
+    return os.environ.get("WITCH_HIP_SOCKET", "/tmp/witch_hip_%d.sock" % os.getuid())
+
+
+class ArgError(Exception):
+    pass
+
+
+def parse_hmmsearch_argv(argv):
+    """The options WITCH passes (algorithm.py:526-532) plus the ones that take a value in HMMER,
+    so that positional arguments are found; unknown flags are ignored like a no-op."""
+    takes_value = {"-o", "-A", "-E", "-T", "-Z", "--cpu", "--tblout", "--domtblout", "--pfamtblout", "--domE", "--domT",
+                   "--incE", "--incT", "--incdomE", "--incdomT", "--F1", "--F2", "--F3", "--domZ", "--seed", "--tformat",
+                   "--textw"}
+    opts, pos, i = {}, [], 0
+    while i < len(argv):
+        a = argv[i]
+        if a in takes_value:
+            if i + 1 >= len(argv):
+                raise ArgError("option %s needs a value" % a)
+            opts[a] = argv[i + 1]
+            i += 2
+        elif a.startswith("-") and a != "-":
+            opts[a] = True
+            i += 1
+        else:
+            pos.append(a)
+            i += 1
+    if len(pos) != 2:
+        raise ArgError("Incorrect number of command line arguments.\nUsage: hmmsearch [options] <hmmfile> <seqdb>")
+    return opts, pos[0], pos[1]
+
+
+def parse_hmmalign_argv(argv):
+    takes_value = {"-o", "--mapali", "--informat", "--outformat"}
+    opts, pos, i = {}, [], 0
+    while i < len(argv):
+        a = argv[i]
+        if a in takes_value:
+            if i + 1 >= len(argv):
+                raise ArgError("option %s needs a value" % a)
+            opts[a] = argv[i + 1]
+            i += 2
+        elif a.startswith("-") and a != "-":
+            opts[a] = True
+            i += 1
+        else:
+            pos.append(a)
+            i += 1
+    if len(pos) != 2:
+        raise ArgError("Incorrect number of command line arguments.\nUsage: hmmalign [-options] <hmmfile> <seqfile>")
+    return opts, pos[0], pos[1]
+
+
+class GpuBackend:
+    """The only place that touches libwitch_hip.so.  One single-model EHMM per HMM file
+    (hmmsearch works one model at a time; hmmalign batches are grouped by model)."""
+
+    def __init__(self, device=0):
+        self.device = device
+        self.cache = {}          # realpath -> (mtime, EHMM, header)
+        self.lock = threading.Lock()
+
+    def model(self, path):
+        from witch_amd.ehmm import EHMM
+        rp = os.path.realpath(path)
+        mt = os.stat(rp).st_mtime
+        hit = self.cache.get(rp)
+        if hit is None or hit[0] != mt:
+            if hit is not None:
+                hit[1].close()
+            hit = (mt, EHMM([rp], device=self.device), formats.hmm_header(rp))
+            self.cache[rp] = hit
+        return hit[1], hit[2]
+
+    def search(self, hmm_path, records):
+        """records: [(name, text)] -> [(name, bits, bias_bits, n_domains)] of reported sequences."""
+        from witch_amd.ehmm import pack_queries
+        with self.lock:
+            e, hdr = self.model(hmm_path)
+            seqs = [e.digitize(t.upper()) for _, t in records]     # alignment_tools.py:730-731 upper-cases
+            res, offs = pack_queries(seqs)
+            deci, flags, det = e.score(res, offs, want_detail=True)
+        rows = []
+        for i, (name, _) in enumerate(records):
+            if flags[i, 0] & 1:
+                d = det[i]
+                bias = max(0.0, float(d.pre_score) - float(d.seq_score))
+                rows.append((name, deci[i, 0] / 10.0, bias, int(d.nenv)))
+        return hdr, rows
+
+    def align(self, jobs):
+        """jobs: [(hmm_path, name, text)] -> [(M, cols)]; one launch per distinct model."""
+        from witch_amd.ehmm import pack_queries
+        out = [None] * len(jobs)
+        by_model = {}
+        for j, (hp, _, _) in enumerate(jobs):
+            by_model.setdefault(os.path.realpath(hp), []).append(j)
+        with self.lock:
+            for hp, idxs in by_model.items():
+                e, hdr = self.model(hp)
+                seqs = [e.digitize(jobs[j][2].upper()) for j in idxs]
+                res, offs = pack_queries(seqs)
+                cols, co = e.align(res, offs, np.arange(len(idxs)), np.zeros(len(idxs), dtype=np.int32))
+                for n, j in enumerate(idxs):
+                    out[j] = (int(e.M[0]), cols[co[n]:co[n + 1]].copy())
+        return out
+
+
+class AlignBatcher:
+    """Collects hmmalign jobs that arrive within a short window and runs them together."""
+
+    def __init__(self, backend, window_s=0.0005, max_batch=4096):
+        self.backend, self.window, self.max_batch = backend, window_s, max_batch
+        self.cv = threading.Condition()
+        self.queue = []
+        self.thread = threading.Thread(target=self._run, daemon=True)
+        self.thread.start()
+
+    def submit(self, job):
+        slot = {"job": job, "done": threading.Event(), "result": None, "error": None}
+        with self.cv:
+            self.queue.append(slot)
+            self.cv.notify()
+        slot["done"].wait()
+        if slot["error"] is not None:
+            raise slot["error"]
+        return slot["result"]
+
+    def _run(self):
+        while True:
+            with self.cv:
+                while not self.queue:
+                    self.cv.wait()
+            time.sleep(self.window)                       # let the other workers' requests arrive
+            with self.cv:
+                batch, self.queue = self.queue[:self.max_batch], self.queue[self.max_batch:]
+            try:
+                res = self.backend.align([s["job"] for s in batch])
+                for s, r in zip(batch, res):
+                    s["result"] = r
+            except Exception as ex:                       # one bad job fails alone on the retry
+                for s in batch:
+                    try:
+                        s["result"] = self.backend.align([s["job"]])[0]
+                    except Exception as ex1:
+                        s["error"] = ex1
+                del ex
+            for s in batch:
+                s["done"].set()
+
+
+class Server:
+    def __init__(self, backend, sock_path):
+        self.backend = backend
+        self.batcher = AlignBatcher(backend)
+        self.sock_path = sock_path
+        self.stats = {"hmmsearch": 0, "hmmalign": 0}
+
+    # ---------------------------------------------------------------- the two tools
+    def run_hmmsearch(self, argv, cwd):
+        opts, hmm, fa = parse_hmmsearch_argv(argv)
+        hmm, fa = os.path.join(cwd, hmm), os.path.join(cwd, fa)
+        if not os.path.exists(hmm):
+            raise ArgError("Error: File existence/permissions problem in trying to open HMM file %s." % hmm)
+        if not os.path.exists(fa):
+            raise ArgError("Error: Failed to open sequence file %s for reading" % fa)
+        records = formats.read_fasta(fa)
+        hdr, rows = self.backend.search(hmm, records)
+        text = formats.format_hmmsearch(hmm, fa, hdr, rows, len(records))
+        if "-o" in opts:
+            with open(os.path.join(cwd, opts["-o"]), "w") as f:
+                f.write(text)
+            return ""
+        return text
+
+    def run_hmmalign(self, argv, cwd):
+        opts, hmm, fa = parse_hmmalign_argv(argv)
+        hmm, fa = os.path.join(cwd, hmm), os.path.join(cwd, fa)
+        if not os.path.exists(hmm):
+            raise ArgError("Error: File existence/permissions problem in trying to open HMM file %s." % hmm)
+        if not os.path.exists(fa):
+            raise ArgError("Error: Failed to open sequence file %s for reading" % fa)
+        records = formats.read_fasta(fa)
+        if len(records) != 1:
+            # WITCH aligns one query per call (aligner.py:90-100); a multi-sequence alignment
+            # needs the shared insert columns hmmalign computes, which this shim does not emit
+            raise ArgError("witch-hip hmmalign shim: exactly one sequence per call (got %d)" % len(records))
+        name, text = records[0]
+        M, cols = self.batcher.submit((hmm, name, text))
+        sto = formats.format_stockholm(name, formats.stockholm_row(text, cols, M))
+        if "-o" in opts:
+            with open(os.path.join(cwd, opts["-o"]), "w") as f:
+                f.write(sto)
+            return ""
+        return sto
+
+    # ---------------------------------------------------------------- plumbing
+    def handle(self, conn):
+        try:
+            buf = b""
+            while True:
+                chunk = conn.recv(65536)
+                if not chunk:
+                    break
+                buf += chunk
+            parts = buf.split(b"\0")
+            if parts and parts[-1] == b"":
+                parts.pop()
+            if len(parts) < 2:
+                raise ArgError("malformed request")
+            tool, cwd, argv = parts[0].decode(), parts[1].decode(), [p.decode() for p in parts[2:]]
+            if tool == "hmmsearch":
+                out = self.run_hmmsearch(argv, cwd)
+            elif tool == "hmmalign":
+                out = self.run_hmmalign(argv, cwd)
+            elif tool == "shutdown":
+                conn.sendall(b"0\nbye\n")
+                conn.close()
+                os._exit(0)
+            elif tool == "ping":
+                out = "pong %d %d\n" % (self.stats["hmmsearch"], self.stats["hmmalign"])
+            else:
+                raise ArgError("unknown tool %r" % tool)
+            if tool in self.stats:
+                self.stats[tool] += 1
+            conn.sendall(b"0\n" + out.encode())
+        except ArgError as ex:
+            conn.sendall(b"1\n" + str(ex).encode() + b"\n")
+        except Exception as ex:                           # HMMER exits 1 with a message; so do we
+            conn.sendall(b"1\nError: " + ("%s: %s" % (type(ex).__name__, ex)).encode() + b"\n")
+        finally:
+            try:
+                conn.close()
+            except OSError:
+                pass
+
+    def serve_forever(self, ready=None):
+        if os.path.exists(self.sock_path):
+            os.unlink(self.sock_path)
+        srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        srv.bind(self.sock_path)
+        srv.listen(512)
+        if ready is not None:
+            ready.set()
+        while True:
+            conn, _ = srv.accept()
+            threading.Thread(target=self.handle, args=(conn,), daemon=True).start()
+
+
+def request(sock_path, tool, argv, cwd=None):
+    """Python twin of client.c (tests and tooling): returns (status, text)."""
+    s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+    s.connect(sock_path)
+    s.sendall(b"\0".join([tool.encode(), (cwd or os.getcwd()).encode()] + [a.encode() for a in argv]) + b"\0")
+    s.shutdown(socket.SHUT_WR)
+    buf = b""
+    while True:
+        chunk = s.recv(65536)
+        if not chunk:
+            break
+        buf += chunk
+    s.close()
+    head, _, body = buf.partition(b"\n")
+    return int(head or b"1"), body.decode()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--socket", default=default_socket_path())
+    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--daemonize", action="store_true", help="detach (the clients start the server this way)")
+    args = ap.parse_args()
+    if args.daemonize:
+        # fork BEFORE anything touches HIP
+        if os.fork() > 0:
+            return
+        os.setsid()
+        if os.fork() > 0:
+            os._exit(0)
+        log = open(args.socket + ".log", "a")
+        os.dup2(log.fileno(), 1)
+        os.dup2(log.fileno(), 2)
+        sys.stdin.close()
+    Server(GpuBackend(args.device), args.socket).serve_forever()
+
+
+if __name__ == "__main__":
+    main()

@@ -53,7 +53,8 @@ struct WaveCtx {
   lds_f *emL;                 // emission rows of the canonical residues (LDS)
   const glb_f *emG;           // all emission rows (L2; degenerate codes)
   lds_f *fwL, *bwL;           // transition arrays, forward / reversed orientation (LDS)
-  lds_f *spec;                // SP_NARR per-row arrays, stride SP (LDS)
+  lds_f *spec;                // SP_NARR per-row arrays, stride SP (LDS) ...
+  glb_f *specg;               // ... or, for long queries (SG sweeps), in a per-wave HBM region
   lds_f *n2tab;               // 32 floats (LDS)
   glb_f *Fs;                  // Forward-row slab of this wave (HBM)
   int SP, K, Kp, lane;
@@ -65,20 +66,21 @@ struct RegOut { int nenv, nreg, flags; };
 struct FwdOut { float xC; int ef; };
 
 // ---------------------------------------------------------------- P1 / P3
-template <int Q, bool STORE, int TH>
+template <int Q, bool STORE, int TH, bool SG>
 __device__ __noinline__ FwdOut sweep_forward(const WaveCtx c, lds_u8 *seq3, int L, LenCfg cfg, float keep_scale) {
   const uint8_t *seq = (const uint8_t *)seq3;
   TransTab<Q, false> T;
   T.load(nullptr, (const float *)c.fwL, c.lane);
   const ScanC sc = scan_prepare(lane_product<Q, false>(T, FW_D2));
   FwdOut o;
-  forward_sweep<Q, false, STORE, (Q <= kMaxQP)>(T, sc, (const float *)c.emL, (const float *)c.emG, c.K, seq, L, cfg, (float *)c.spec, c.SP, (float *)c.Fs, keep_scale, c.lane, o.xC, o.ef);
+  forward_sweep<Q, false, STORE, (Q <= kMaxQP)>(T, sc, (const float *)c.emL, (const float *)c.emG, c.K, seq, L, cfg, SG ? (float *)c.specg : (float *)c.spec, c.SP, (float *)c.Fs, keep_scale, c.lane, o.xC, o.ef);
+  if (SG) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // the rows were written by lane 0, every lane reads them next
   return o;
 }
 
 // ---------------------------------------------------------------- P2: multihit Backward + decoding (A.4)
 // Overwrites spec[SP_E], spec[SP_B], spec[SP_N] rows with the per-row posteriors pe, pb, njc.
-template <int Q, int TH>
+template <int Q, int TH, bool SG>
 __device__ __noinline__ void sweep_backward_decode(const WaveCtx c, lds_u8 *seq3, int L, LenCfg cm, float invZ, int ef_L) {
   const uint8_t *seq = (const uint8_t *)seq3;
   const float *emL = (const float *)c.emL;
@@ -86,8 +88,10 @@ __device__ __noinline__ void sweep_backward_decode(const WaveCtx c, lds_u8 *seq3
   T.load(nullptr, (const float *)c.bwL, c.lane);
   const ScanC sc = scan_prepare(lane_product<Q, false>(T, BW_DD));
   const int lane = c.lane, SP = c.SP;
-  float *spec = (float *)c.spec;
-  const int *specI = reinterpret_cast<const int *>(spec);
+  float *spec = SG ? (float *)c.specg : (float *)c.spec;
+  // long-query mode: L1-bypassing loads (the slots are rewritten for every pair)
+  auto ldf = [&](int idx) -> float { return SG ? __builtin_nontemporal_load(spec + idx) : spec[idx]; };
+  auto ldi = [&](int idx) -> int { return SG ? __builtin_nontemporal_load(reinterpret_cast<const int *>(spec) + idx) : reinterpret_cast<const int *>(spec)[idx]; };
   float Mb[Q], Ib[Q];
 #pragma unroll
   for (int p = 0; p < Q; p++) { Mb[p] = 0.f; Ib[p] = 0.f; }
@@ -113,27 +117,28 @@ __device__ __noinline__ void sweep_backward_decode(const WaveCtx c, lds_u8 *seq3
       xB *= r; xJ *= r; xC *= r; xN *= r; xE *= r;
       eb += e;
     }
-    const float s_i = ldexpf(invZ, specI[SP_S * SP + i] + eb - ef_L);
-    const float pe = spec[SP_E * SP + i] * xE * s_i;
-    const float pb = spec[SP_B * SP + i] * xB * s_i;
+    const float s_i = ldexpf(invZ, ldi(SP_S * SP + i) + eb - ef_L);
+    const float pe = ldf(SP_E * SP + i) * xE * s_i;
+    const float pb = ldf(SP_B * SP + i) * xB * s_i;
     float njc = 0.f;
     if (i >= 1) {
-      const float s_p = ldexpf(invZ, specI[SP_S * SP + i - 1] + eb - ef_L);
-      njc = spec[SP_N * SP + i - 1] * xN;
-      njc = fmaf(spec[SP_J * SP + i - 1], xJ, njc);
-      njc = fmaf(spec[SP_C * SP + i - 1], xC, njc);
+      const float s_p = ldexpf(invZ, ldi(SP_S * SP + i - 1) + eb - ef_L);
+      njc = ldf(SP_N * SP + i - 1) * xN;
+      njc = fmaf(ldf(SP_J * SP + i - 1), xJ, njc);
+      njc = fmaf(ldf(SP_C * SP + i - 1), xC, njc);
       njc = njc * cm.loop * s_p;
     }
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) { spec[SP_E * SP + i] = pe; spec[SP_B * SP + i] = pb; spec[SP_N * SP + i] = njc; }
     __builtin_amdgcn_wave_barrier();
   }
+  if (SG) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 }
 
 // ---------------------------------------------------------------- P4: unihit Backward + posterior -> null2
 // Returns the null2 correction of the envelope (A.5) in *domcorr and the posterior mass that
 // reached the accumulators (the certificate for the sparse spill, see wh_score.hip).
-template <int Q, int TH>
+template <int Q, int TH, bool SG>
 __device__ __noinline__ P4Out sweep_backward_null2(const WaveCtx c, lds_u8 *eseq3, int Ld, LenCfg cu, float invZe, int ef_e, float mass_tol) {
   const uint8_t *eseq = (const uint8_t *)eseq3;
   const float *emL = (const float *)c.emL;
@@ -141,14 +146,16 @@ __device__ __noinline__ P4Out sweep_backward_null2(const WaveCtx c, lds_u8 *eseq
   T.load(nullptr, (const float *)c.bwL, c.lane);
   const ScanC sc = scan_prepare(lane_product<Q, false>(T, BW_DD));
   const int lane = c.lane, SP = c.SP;
-  const float *spec = (const float *)c.spec;
-  const int *specI = reinterpret_cast<const int *>(spec);
-  const unsigned *specU = reinterpret_cast<const unsigned *>(spec);
+  const float *spec = SG ? (const float *)c.specg : (const float *)c.spec;
+  auto ldf = [&](int idx) -> float { return SG ? __builtin_nontemporal_load(spec + idx) : spec[idx]; };
+  auto ldi = [&](int idx) -> int { return SG ? __builtin_nontemporal_load(reinterpret_cast<const int *>(spec) + idx) : reinterpret_cast<const int *>(spec)[idx]; };
+  auto ldu = [&](int idx) -> unsigned { return SG ? __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(spec) + idx) : reinterpret_cast<const unsigned *>(spec)[idx]; };
   float Mb[Q], Ib[Q], fM[Q];
 #pragma unroll
   for (int p = 0; p < Q; p++) { Mb[p] = 0.f; Ib[p] = 0.f; fM[p] = 0.f; }
   float xC = cu.move, xJ = 0.f, xN = 0.f, xB = 0.f, xfac = 0.f, fIs = 0.f;
   const int src = kWave - 1 - lane;   // the forward-order lane that owns my (reversed) cells
+  int S_next = 0;                     // S(i+1), carried so that every row reads its exponent once
 #pragma unroll 1
   for (int i = Ld; i >= 1; i--) {
     asm volatile("" ::: "memory");
@@ -157,7 +164,7 @@ __device__ __noinline__ P4Out sweep_backward_null2(const WaveCtx c, lds_u8 *eseq
     // across backward_cells); with two waves it is requested first.
     float4 fm4[Q / 4], fi4[Q / 4];
     auto request_row = [&]() {
-      const unsigned mword = src < 32 ? specU[SP_ML * SP + i] : specU[SP_MH * SP + i];
+      const unsigned mword = src < 32 ? ldu(SP_ML * SP + i) : ldu(SP_MH * SP + i);
       const bool have = (mword >> (src & 31)) & 1u;
       const float4 *row = reinterpret_cast<const float4 *>((const float *)c.Fs) + (size_t)i * (2 * (Q / 4) * kWave) + src;
       if (have) {
@@ -173,9 +180,10 @@ __device__ __noinline__ P4Out sweep_backward_null2(const WaveCtx c, lds_u8 *eseq
     };
     if (TH < 768) request_row();
     // mirrored scaling (wh_device.h, "envelope Backward scaling")
-    const int dS = specI[SP_S * SP + i] - specI[SP_S * SP + i - 1];      // Forward rescale at row i (>= 0)
+    const int S_i = ldi(SP_S * SP + i);
+    const int dS = S_i - ldi(SP_S * SP + i - 1);      // Forward rescale at row i (>= 0)
     if (i < Ld) {
-      mirror_scale<Q>(specI[SP_S * SP + i + 1] - specI[SP_S * SP + i], Mb, Ib, xJ, xC, xN);
+      mirror_scale<Q>(S_next - S_i, Mb, Ib, xJ, xC, xN);
       xB = wave_sum(backward_emit<Q, false>(T, emL, (const float *)c.emG, eseq[i], c.K, lane, Mb));
       xJ = fmaf(xJ, cu.loop, xB * cu.move);
       xC = xC * cu.loop;
@@ -189,7 +197,7 @@ __device__ __noinline__ P4Out sweep_backward_null2(const WaveCtx c, lds_u8 *eseq
     if (TH >= 768 && kMaskedAcc) {
       // only the lanes that own a stored block run the accumulation (the others would add zeros)
       asm volatile("" ::: "memory");
-      const unsigned mword = src < 32 ? specU[SP_ML * SP + i] : specU[SP_MH * SP + i];
+      const unsigned mword = src < 32 ? ldu(SP_ML * SP + i) : ldu(SP_MH * SP + i);
       if ((mword >> (src & 31)) & 1u) {
         const float4 *row = reinterpret_cast<const float4 *>((const float *)c.Fs) + (size_t)i * (2 * (Q / 4) * kWave) + src;
         float idot = 0.f;
@@ -221,9 +229,10 @@ __device__ __noinline__ P4Out sweep_backward_null2(const WaveCtx c, lds_u8 *eseq
       }
       fIs = fmaf(idot, s_i, fIs);
     }
-    float nj = spec[SP_N * SP + i - 1] * xN;
-    nj = fmaf(spec[SP_J * SP + i - 1], xJ, nj);
-    nj = fmaf(spec[SP_C * SP + i - 1], xC, nj);
+    float nj = ldf(SP_N * SP + i - 1) * xN;
+    nj = fmaf(ldf(SP_J * SP + i - 1), xJ, nj);
+    nj = fmaf(ldf(SP_C * SP + i - 1), xC, nj);
+    S_next = S_i;
     xfac = fmaf(nj * cu.loop, s_p, xfac);
   }
   // null2[a] = sum_k fM_k o_k(a) + sum_k fI_k + f_NJC, all / Ld
@@ -268,9 +277,10 @@ __device__ __noinline__ P4Out sweep_backward_null2(const WaveCtx c, lds_u8 *eseq
 }
 
 // ---------------------------------------------------------------- region scan (A.4)
-template <int TH>
-__device__ __noinline__ RegOut region_scan(lds_f *spec3, int SP, int L, lds_i *regs3, int lane) {
-  float *spec = (float *)spec3;
+template <int TH, bool SG>
+__device__ __noinline__ RegOut region_scan(lds_f *spec3, glb_f *specg, int SP, int L, lds_i *regs3, int lane) {
+  float *spec = SG ? (float *)specg : (float *)spec3;
+  auto ldf = [&](int idx) -> float { return SG ? __builtin_nontemporal_load(spec + idx) : spec[idx]; };
   int *regs = (int *)regs3;
   const float rt1 = 0.25f, rt2 = 0.10f, rt3 = 0.20f;
   int nenv = 0, nreg = 0, flags = 0;
@@ -279,10 +289,10 @@ __device__ __noinline__ RegOut region_scan(lds_f *spec3, int SP, int L, lds_i *r
   bool trig = false;
   if (lane == 0) { spec[SP_J * SP] = 0.f; spec[SP_C * SP] = 0.f; }
   for (int j = 1; j <= L; j++) {
-    const float mocc = 1.0f - spec[SP_N * SP + j];
+    const float mocc = 1.0f - ldf(SP_N * SP + j);
     const float bold = btot, eold = etot;
-    btot += spec[SP_B * SP + j - 1];
-    etot += spec[SP_E * SP + j];
+    btot += ldf(SP_B * SP + j - 1);
+    etot += ldf(SP_E * SP + j);
     if (lane == 0) { spec[SP_J * SP + j] = btot; spec[SP_C * SP + j] = etot; }
     if (!trig) {
       if (mocc - (btot - bold) < rt2) i0 = j;
@@ -299,13 +309,14 @@ __device__ __noinline__ RegOut region_scan(lds_f *spec3, int SP, int L, lds_i *r
     }
   }
   __builtin_amdgcn_wave_barrier();
+  if (SG) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
   // multidomain test: max_z min(etot[z]-etot[i-1], btot[j]-btot[z-1]) >= rt3
   for (int e = 0; e < nenv; e++) {
     const int ri = regs[2 * e], rj = regs[2 * e + 1];
     float mx = -1.0f;
-    const float e0 = spec[SP_C * SP + ri - 1], bj = spec[SP_J * SP + rj];
+    const float e0 = ldf(SP_C * SP + ri - 1), bj = ldf(SP_J * SP + rj);
     for (int z = ri + lane; z <= rj; z += kWave) {
-      const float u = spec[SP_C * SP + z] - e0, v = bj - spec[SP_J * SP + z - 1];
+      const float u = ldf(SP_C * SP + z) - e0, v = bj - ldf(SP_J * SP + z - 1);
       mx = fmaxf(mx, fminf(u, v));
     }
     mx = wave_max(mx);
@@ -318,7 +329,7 @@ __device__ __noinline__ RegOut region_scan(lds_f *spec3, int SP, int L, lds_i *r
 
 #define WH_TICK7(slot) do { if (a.stats) { const long long t_now = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(a.stats + (slot), (unsigned long long)(t_now - t_last)); t_last = t_now; } } while (0)
 
-template <int Q, int TH>
+template <int Q, int TH, bool SG>
 __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
   volatile int *s_item_p = reinterpret_cast<volatile int *>(smem_raw);
@@ -332,12 +343,13 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
   const int SP = a.SP;
   WaveCtx c;
   c.emL = (lds_f *)emL; c.fwL = (lds_f *)trL; c.bwL = (lds_f *)(trL + NARR * TBL);
-  c.spec = (lds_f *)wbase; c.n2tab = (lds_f *)(wbase + SP_NARR * SP);
+  c.spec = (lds_f *)wbase; c.n2tab = (lds_f *)(wbase + (SG ? 0 : SP_NARR * SP));
+  c.specg = SG ? (glb_f *)(a.spec_scratch + ((size_t)blockIdx.x * nwaves + wave) * a.spec_stride) : nullptr;
   c.degen = 0;
   for (int t = 0; t < 32; t++) if (t == lane) c.degen = a.degen[t];
   c.Fs = (glb_f *)(a.scratch + ((size_t)blockIdx.x * nwaves + wave) * a.scratch_stride);
   c.SP = SP; c.K = a.K; c.Kp = a.Kp; c.lane = lane;
-  int *regs = reinterpret_cast<int *>(wbase + SP_NARR * SP + 32);
+  int *regs = reinterpret_cast<int *>(wbase + (SG ? 0 : SP_NARR * SP) + 32);
   uint8_t *seq = reinterpret_cast<uint8_t *>(regs + 3 * WH_MAX_ENVELOPES);
   const double LOG2 = 0.69314718055994529;
   int cur_h = -1;
@@ -386,7 +398,7 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
         long long t_last = a.stats ? __builtin_readcyclecounter() : 0;
         // ---------------- P1
         const LenCfg cm = len_config(L, true);
-        const FwdOut f1 = sweep_forward<Q, false, TH>(c, (lds_u8 *)seq, L, cm, 0.f);
+        const FwdOut f1 = sweep_forward<Q, false, TH, SG>(c, (lds_u8 *)seq, L, cm, 0.f);
         const double fwd_nats = (double)f1.ef * LOG2 + log((double)(f1.xC * cm.move));
         const float fwdsc = (float)fwd_nats;
         const float p1 = (float)L / (float)(L + 1);
@@ -396,9 +408,9 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
         if (f1.xC > 0.f && isfinite(fwdsc)) {
           WH_TICK7(4);
           // ---------------- P2 + region scan
-          sweep_backward_decode<Q, TH>(c, (lds_u8 *)seq, L, cm, 1.0f / (f1.xC * cm.move), f1.ef);
+          sweep_backward_decode<Q, TH, SG>(c, (lds_u8 *)seq, L, cm, 1.0f / (f1.xC * cm.move), f1.ef);
           WH_TICK7(5);
-          const RegOut ro = region_scan<TH>(c.spec, SP, L, (lds_i *)regs, lane);
+          const RegOut ro = region_scan<TH, SG>(c.spec, c.specg, SP, L, (lds_i *)regs, lane);
           const int nenv = ro.nenv, nreg = ro.nreg;
           flags |= ro.flags;
           if (dp) { dp->nregions = nreg; dp->nenv = nenv; }
@@ -416,7 +428,7 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
 #pragma unroll 1
               for (int attempt = 0; attempt < 2; attempt++) {
                 const float keep_scale = attempt == 0 ? (a.keep_scale > 0.f ? a.keep_scale : kKeepScale7) : -1.0f;
-                const FwdOut f3 = sweep_forward<Q, true, TH>(c, (lds_u8 *)eseq, Ld, cu, keep_scale);
+                const FwdOut f3 = sweep_forward<Q, true, TH, SG>(c, (lds_u8 *)eseq, Ld, cu, keep_scale);
                 // the rows were written by other lanes of this wave: order the stores before the loads
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                 envsc = (float)((double)f3.ef * LOG2 + log((double)(f3.xC * cu.move)));
@@ -424,7 +436,7 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
                 if (!(f3.xC > 0.f)) break;
                 WH_TICK7(7);
                 const float tol = attempt == 0 ? kMassTol7 : INFINITY;
-                const P4Out p4 = sweep_backward_null2<Q, TH>(c, (lds_u8 *)eseq, Ld, cu, 1.0f / (f3.xC * cu.move), f3.ef, tol);
+                const P4Out p4 = sweep_backward_null2<Q, TH, SG>(c, (lds_u8 *)eseq, Ld, cu, 1.0f / (f3.xC * cu.move), f3.ef, tol);
                 domcorr = p4.domcorr;
                 WH_TICK7(8);
                 if (attempt == 0 && !(fabsf((float)Ld - p4.mass) <= kMassTol7 * (float)Ld)) continue;
@@ -460,13 +472,20 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
   }
 }
 
-template <int Q, int TH>
-static hipError_t launch7(const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
-  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&score_kernel7<Q, TH>),
+template <int Q, int TH, bool SG>
+static hipError_t launch7sg(const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&score_kernel7<Q, TH, SG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (err != hipSuccess) return err;
-  hipLaunchKernelGGL((score_kernel7<Q, TH>), dim3(blocks), dim3(threads), lds, s, a);
+  hipLaunchKernelGGL((score_kernel7<Q, TH, SG>), dim3(blocks), dim3(threads), lds, s, a);
   return hipGetLastError();
+}
+
+template <int Q, int TH>
+static hipError_t launch7(const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
+  // long queries: the per-row special states live in a.spec_scratch (HBM) instead of LDS
+  if (a.spec_scratch) return launch7sg<Q, TH, true>(a, blocks, threads, lds, s);
+  return launch7sg<Q, TH, false>(a, blocks, threads, lds, s);
 }
 
 // threads per workgroup sets the register budget of every sweep: 512 -> 256 VGPRs, 768 -> 168
@@ -489,7 +508,6 @@ hipError_t WH_K7LAUNCH(int Q, const ScoreArgs &a, int blocks, int threads, size_
   using namespace WH_K7NS;
   if (threads <= 512) return launch7_q<512>(Q, a, blocks, threads, lds, s);
   if (threads <= 768) return launch7_q<768>(Q, a, blocks, threads, lds, s);
-  if (threads <= 1024) return launch7_q<1024>(Q, a, blocks, threads, lds, s);
   return hipErrorInvalidValue;
 }
 

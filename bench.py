@@ -35,6 +35,9 @@ WORKLOADS = {
     # development only: longer models (24 and 12 DP cells per lane)
     "dna_m1450": ("dna", 20251205, 1450, 256, 0.03, 1e-4, 20, 2048, 150, 4),
     "dna_m700": ("dna", 20251205, 700, 256, 0.03, 1e-4, 20, 2048, 150, 4),
+    "dna_m1250": ("dna", 20251205, 1250, 256, 0.03, 1e-4, 40, 4096, 150, 4),
+    "dna_m1250_long": ("dna", 20251205, 1250, 256, 0.03, 1e-4, 20, 512, (600, 1200), 4),
+    "dna_m1450_long": ("dna", 20251205, 1450, 256, 0.03, 1e-4, 20, 512, (600, 1400), 4),
     # shaped like the reference's examples/data (rRNA backbone of 2574 columns, full-length queries)
     "dna_rrna_like": ("dna", 20251207, 2400, 256, 0.03, 2e-4, 10, 256, (1500, 2400), 4),
     # SURVEY.md section 8d config 5 (reported in DESIGN.md, not the headline): protein family,

@@ -431,3 +431,26 @@ def test_level0_shims_reproduce_hmmer_outputs(tmp_path):
         assert formats.decode_stockholm_row(row) == list(cols), (qn, out)
         n_aln += 1
     assert n_scores > 50 and n_aln > 10
+
+
+def test_long_queries_on_20_and_24_cell_models(orc, tmp_path):
+    """Models of 1025-1536 nodes with queries too long for the LDS special-state rows: the
+    phase-call kernel's HBM mode at 20 / 24 cells per lane (an older fused variant hung there)."""
+    _need_gpu()
+    from witch_amd import synth
+    from witch_amd.ehmm import EHMM, pack_queries
+    for root_len in (1200, 1450):
+        fam = synth.make_family(31 + root_len, root_len, 16, "dna", 0.03, 1e-4)
+        eh = synth.make_ehmm(fam, 3, str(tmp_path / ("m%d" % root_len)), witch_layout=False)
+        names, seqs = synth.make_queries(fam, 9, 6, (700, root_len - 50))
+        seqs = [s.astype(np.uint8) for s in seqs]
+        e = EHMM(eh.paths, hmm_index=eh.index, nseq=eh.nseq)
+        assert 1024 < int(e.M.max()) <= 1536
+        res, offs = pack_queries(seqs)
+        deci, flags, fwd = e.score(res, offs, want_fwd=True)
+        ohm = [orc.OracleHMM(p) for p in eh.paths]
+        od, of, ofwd, osc = orc.score_batch(ohm, res, offs)
+        assert np.max(np.abs(fwd - ofwd)) <= 2e-4
+        assert np.array_equal(flags & 3, of & 3)
+        assert np.abs(deci.astype(np.int64) - od).max() <= 1
+        e.close()

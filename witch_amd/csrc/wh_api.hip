@@ -285,8 +285,9 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       const bool treg = false;
       int waves, SP, wave_lds;
       size_t lds;
-      // pass-synchronous kernel (wh_score_big.hip): long models, and long queries on models of
-      // 20+ cells per lane (there the fused kernel's HBM special-state variant misbehaves on gfx950)
+      // pass-synchronous kernel (wh_score_big.hip): long models (28+ cells per lane).  Long queries on
+      // 20/24-cell models run the phase-call kernel's HBM special-state mode (1.7-1.85x faster than the
+      // pass-synchronous kernel there; the older fused kernel's variant misbehaves on gfx950 at 20+ cells)
       auto run_big = [&]() -> int {
         const int Lc = std::max(max_len, 1);
         const int wl = 32 + 3 * WH_MAX_ENVELOPES + (Lc + 3) / 4 + 4;
@@ -395,14 +396,15 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
         SP = (std::max(max_len, 1) + 1 + 3) / 4 * 4;
         wave_lds = 32 + 3 * WH_MAX_ENVELOPES + (std::max(max_len, 1) + 3) / 4 + 4;
         const size_t table = (size_t)(e->K + 2 * FW_NARR) * Q * kWave * sizeof(float);
-        const bool k7 = (kver == 7 || kver == 8) && Q <= 16 && !getenv("WH_SPECG_V1");
-        waves = k7 ? 12 : 8;     // phase-call kernel: three waves per SIMD also for long queries
+        const int k7_maxq = getenv("WH_K7_SG_MAXQ") ? atoi(getenv("WH_K7_SG_MAXQ")) : kMaxQFast;
+        const bool k7 = (kver == 7 || kver == 8) && Q <= k7_maxq && !getenv("WH_SPECG_V1");
+        waves = k7 ? (Q <= 16 ? 12 : 8) : 8;     // phase-call kernel: three waves per SIMD also for long queries
         if (const char *ev = getenv("WH_MAX_WAVES")) waves = std::max(1, std::min(waves, atoi(ev)));
         while (waves >= 1 && kLdsHeader + table + (size_t)waves * wave_lds * sizeof(float) > kLdsBudget) waves--;
         rc_plan = waves >= 1 ? WH_OK : WH_ERANGE;
         lds = kLdsHeader + table + (size_t)waves * wave_lds * sizeof(float);
       }
-      if (specg && Q >= 20) {
+      if (specg && Q >= 20 && !((kver == 7 || kver == 8) && Q <= (getenv("WH_K7_SG_MAXQ") ? atoi(getenv("WH_K7_SG_MAXQ")) : kMaxQFast) && !getenv("WH_SPECG_V1"))) {
         int rcb = run_big();
         if (rcb) return rcb;
         if (launches >= 60) break;
@@ -448,8 +450,8 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       if (getenv("WH_TRACE")) fprintf(stderr, "[wh] score Q=%d kver=%d specg=%d waves=%d blocks=%d lds=%zu SP=%d wave_lds=%d items=%d Lcap=%d\n", Q, kver, (int)specg, waves, blocks, lds, SP, wave_lds, a.n_items, a.Lcap);
       HIPCHK(hipMemsetAsync(a.counter, 0, sizeof(int), s));
       hipError_t err = use5 ? launch_score_treg(Q, a, blocks, waves * kWave, lds, s)
-                       : (kver == 7 && (!specg || (Q <= 16 && !getenv("WH_SPECG_V1")))) ? launch_score7(Q, a, blocks, waves * kWave, lds, s)
-                       : (kver == 8 && (!specg || (Q <= 16 && !getenv("WH_SPECG_V1")))) ? launch_score7b(Q, a, blocks, waves * kWave, lds, s)
+                       : (kver == 7 && (!specg || !getenv("WH_SPECG_V1"))) ? launch_score7(Q, a, blocks, waves * kWave, lds, s)
+                       : (kver == 8 && (!specg || !getenv("WH_SPECG_V1"))) ? launch_score7b(Q, a, blocks, waves * kWave, lds, s)
                        : (kver == 6 && Q == 16 && !specg) ? launch_score_tr12(Q, getenv("WH_TRM") ? atoi(getenv("WH_TRM")) : 1, a, blocks, waves * kWave, lds, s)
                        : use1 ? launch_score(Q, 0, a, blocks, waves * kWave, lds, s) : launch_score2(Q, a, blocks, waves * kWave, lds, s);
       if (err != hipSuccess) { set_error("score kernel launch (Q=%d) failed: %s", Q, hipGetErrorString(err)); return WH_EHIP; }

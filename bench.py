@@ -36,6 +36,7 @@ WORKLOADS = {
     "dna_m1450": ("dna", 20251205, 1450, 256, 0.03, 1e-4, 20, 2048, 150, 4),
     "dna_m700": ("dna", 20251205, 700, 256, 0.03, 1e-4, 20, 2048, 150, 4),
     "dna_m1250": ("dna", 20251205, 1250, 256, 0.03, 1e-4, 40, 4096, 150, 4),
+    "dna_m1900_long": ("dna", 20251205, 1900, 256, 0.03, 1e-4, 10, 256, (900, 1800), 4),
     "dna_m1250_long": ("dna", 20251205, 1250, 256, 0.03, 1e-4, 20, 512, (600, 1200), 4),
     "dna_m1450_long": ("dna", 20251205, 1450, 256, 0.03, 1e-4, 20, 512, (600, 1400), 4),
     # shaped like the reference's examples/data (rRNA backbone of 2574 columns, full-length queries)

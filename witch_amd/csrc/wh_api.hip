@@ -321,7 +321,9 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
         a.decibits = d_decibits; a.flags = d_flags; a.fwd_bits = d_fwd_bits; a.detail = d_detail;
         a.H = H; a.K = e->K; a.Kp = e->Kp;
         memcpy(a.degen, e->degen, sizeof a.degen);
+        if (const char *dv = getenv("WH_DBG")) a.dbg = atoi(dv);
         HIPCHK(hipMemsetAsync(a.counter, 0, sizeof(int), s));
+        if (getenv("WH_TRACE")) fprintf(stderr, "[wh] score(long model) Q=%d waves=%d blocks=%d lds=%zu Klds=%d items=%d Lcap=%d\n", Q, waves, blocks, lds, Klds, a.n_items, a.Lcap);
         hipError_t err = launch_score_big(Q, a, blocks, waves * kWave, lds, s);
         if (err != hipSuccess) { set_error("score kernel launch (Q=%d, long model) failed: %s", Q, hipGetErrorString(err)); return WH_EHIP; }
         launches++;

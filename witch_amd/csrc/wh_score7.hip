@@ -58,7 +58,6 @@ struct WaveCtx {
   lds_f *n2tab;               // 32 floats (LDS)
   glb_f *Fs;                  // Forward-row slab of this wave (HBM)
   int SP, K, Kp, lane;
-  int Klds;                   // emission rows staged in LDS (= K, or 0 when they stay in L2: long models)
   uint32_t degen;             // this lane's degenerate-code mask (lane = residue code)
 };
 struct P4Out { float mass, domcorr; };
@@ -74,7 +73,7 @@ __device__ __noinline__ FwdOut sweep_forward(const WaveCtx c, lds_u8 *seq3, int 
   T.load(nullptr, (const float *)c.fwL, c.lane);
   const ScanC sc = scan_prepare(lane_product<Q, false>(T, FW_D2));
   FwdOut o;
-  forward_sweep<Q, false, STORE, (Q <= kMaxQP)>(T, sc, (const float *)c.emL, (const float *)c.emG, c.Klds, seq, L, cfg, SG ? (float *)c.specg : (float *)c.spec, c.SP, (float *)c.Fs, keep_scale, c.lane, o.xC, o.ef);
+  forward_sweep<Q, false, STORE, (Q <= kMaxQP)>(T, sc, (const float *)c.emL, (const float *)c.emG, c.K, seq, L, cfg, SG ? (float *)c.specg : (float *)c.spec, c.SP, (float *)c.Fs, keep_scale, c.lane, o.xC, o.ef);
   if (SG) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // the rows were written by lane 0, every lane reads them next
   return o;
 }
@@ -102,7 +101,7 @@ __device__ __noinline__ void sweep_backward_decode(const WaveCtx c, lds_u8 *seq3
   for (int i = L; i >= 0; i--) {
     asm volatile("" ::: "memory");
     if (i < L) {
-      xB = wave_sum(backward_emit<Q, false>(T, emL, (const float *)c.emG, seq[i], c.Klds, lane, Mb));
+      xB = wave_sum(backward_emit<Q, false>(T, emL, (const float *)c.emG, seq[i], c.K, lane, Mb));
       xJ = fmaf(xJ, cm.loop, xB * cm.move);
       xC = xC * cm.loop;
       xN = fmaf(xN, cm.loop, xB * cm.move);
@@ -185,7 +184,7 @@ __device__ __noinline__ P4Out sweep_backward_null2(const WaveCtx c, lds_u8 *eseq
     const int dS = S_i - ldi(SP_S * SP + i - 1);      // Forward rescale at row i (>= 0)
     if (i < Ld) {
       mirror_scale<Q>(S_next - S_i, Mb, Ib, xJ, xC, xN);
-      xB = wave_sum(backward_emit<Q, false>(T, emL, (const float *)c.emG, eseq[i], c.Klds, lane, Mb));
+      xB = wave_sum(backward_emit<Q, false>(T, emL, (const float *)c.emG, eseq[i], c.K, lane, Mb));
       xJ = fmaf(xJ, cu.loop, xB * cu.move);
       xC = xC * cu.loop;
       xN = fmaf(xN, cu.loop, xB * cu.move);
@@ -250,7 +249,7 @@ __device__ __noinline__ P4Out sweep_backward_null2(const WaveCtx c, lds_u8 *eseq
   float mine = 1.0f;
   for (int x = 0; x < c.K; x++) {
     float od[Q];
-    load_em_rev<Q>(od, emL, (const float *)c.emG, x, c.Klds, lane);
+    load_em_rev<Q>(od, emL, (const float *)c.emG, x, c.K, lane);
     float s = 0.f;
 #pragma unroll
     for (int p = 0; p < Q; p++) s = fmaf(fM[p], od[p], s);
@@ -349,7 +348,7 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
   c.degen = 0;
   for (int t = 0; t < 32; t++) if (t == lane) c.degen = a.degen[t];
   c.Fs = (glb_f *)(a.scratch + ((size_t)blockIdx.x * nwaves + wave) * a.scratch_stride);
-  c.SP = SP; c.K = a.K; c.Kp = a.Kp; c.lane = lane; c.Klds = a.K;
+  c.SP = SP; c.K = a.K; c.Kp = a.Kp; c.lane = lane;
   int *regs = reinterpret_cast<int *>(wbase + (SG ? 0 : SP_NARR * SP) + 32);
   uint8_t *seq = reinterpret_cast<uint8_t *>(regs + 3 * WH_MAX_ENVELOPES);
   const double LOG2 = 0.69314718055994529;
@@ -502,7 +501,6 @@ static hipError_t launch7_q(int Q, const ScoreArgs &a, int blocks, int threads, 
     default: return hipErrorInvalidValue;
   }
 }
-
 
 }  // namespace WH_K7NS
 

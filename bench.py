@@ -129,9 +129,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # rehearsal hook for a one-GPU box: WITCH_BENCH_REHEARSAL=1 puts every rank on cuda:0 and uses
+    # gloo for the gather (RCCL refuses two ranks on one device); the driver's runs never set it
+    rehearsal = os.environ.get("WITCH_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from witch_amd.ehmm import EHMM, pack_queries
     workdir = tempfile.mkdtemp(prefix="witch_bench_%d_" % rank)
@@ -152,8 +160,12 @@ def main():
             from witch_amd.distributed import gather_topk
             # the path's one exchange step: per-query top-k records to every rank over RCCL
             gather = gather_topk
+            if rehearsal:
+                def gather(idx, w, nk, nu):       # gloo gathers host tensors
+                    return gather_topk(idx.cpu(), w.cpu(), nk.cpu(), nu.cpu())
 
         def barrier():
+            torch.cuda.synchronize()
             if world > 1:
                 dist.barrier()
             torch.cuda.synchronize()
@@ -176,7 +188,7 @@ def main():
         dt = time.perf_counter() - t0
         e.set_timing(False)
         if world > 1:
-            tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            tmax = torch.tensor([dt], device="cpu" if rehearsal else "cuda", dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
 

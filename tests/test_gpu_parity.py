@@ -454,3 +454,38 @@ def test_long_queries_on_20_and_24_cell_models(orc, tmp_path):
         assert np.array_equal(flags & 3, of & 3)
         assert np.abs(deci.astype(np.int64) - od).max() <= 1
         e.close()
+
+
+@pytest.mark.parametrize("root_len", [200, 450, 700, 950])
+def test_every_kernel_instantiation_against_the_oracle(root_len, orc, tmp_path):
+    """4/8/12/16 cells per lane x query lengths that select 12 waves with LDS special states,
+    fewer waves (the 512-thread build) and the HBM special-state mode: scores and flags against
+    the oracle for every scoring-kernel instantiation the planner can pick for these models."""
+    _need_gpu()
+    from witch_amd import synth
+    from witch_amd.ehmm import EHMM, pack_queries
+    fam = synth.make_family(900 + root_len, root_len, 16, "dna", 0.03, 1e-4)
+    eh = synth.make_ehmm(fam, 3, str(tmp_path), witch_layout=False)
+    e = EHMM(eh.paths, hmm_index=eh.index, nseq=eh.nseq)
+    ohm = [orc.OracleHMM(p) for p in eh.paths]
+    rng = np.random.default_rng(root_len)
+    bg = synth.background("dna")
+    for qlen in (120, 330, 520, 1100):
+        names, seqs = synth.make_queries(fam, 7 + qlen, 6, min(qlen, root_len - 20))
+        out = []
+        for s_ in seqs:                       # embed the window in random flanks up to the wanted length
+            s_ = s_.astype(np.uint8)
+            pad = qlen - len(s_)
+            if pad > 0:
+                a = int(rng.integers(0, pad + 1))
+                s_ = np.concatenate([rng.choice(4, size=a, p=bg), s_, rng.choice(4, size=pad - a, p=bg)]).astype(np.uint8)
+            out.append(s_)
+        res, offs = pack_queries(out)
+        deci, flags, fwd = e.score(res, offs, want_fwd=True)
+        od, of, ofwd, osc = orc.score_batch(ohm, res, offs)
+        assert np.max(np.abs(fwd - ofwd)) <= 2e-4, (root_len, qlen)
+        assert np.array_equal(flags & 3, of & 3), (root_len, qlen)
+        rep = (of & 1) == 1
+        assert np.abs(deci.astype(np.int64) - od)[rep].max() <= 1, (root_len, qlen)
+        assert ((deci == od) | ~rep).mean() >= 0.9
+    e.close()

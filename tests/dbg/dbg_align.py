@@ -2,7 +2,7 @@
 """Compare GPU MEA alignment columns with the CPU oracle on a slice of a bench workload."""
 import os, sys, tempfile, shutil
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import bench
 from oracle import oracle as orc

@@ -405,6 +405,121 @@ static double backward(const orc_hmm *h, const uint8_t *dsq, int L, orc_len c, o
   return ls + log(XS(bx, 0, sN));
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Extended-range twins of forward()/backward() for the hmmalign restatement.  A query with two
+ * hits of which the first scores beyond ~1000 bits pushes the N state below the range of a
+ * scaled double (and far below a scaled float); hmmalign itself notices the overflow in its
+ * float32 Decoding and switches to its log-space "generic" code, which finds the best hit.  x87
+ * long double (15-bit exponent) gives this CPU restatement the same reach with the same scaled
+ * prob-space recurrences (checked against the hmmalign binary on multi-hit protein queries).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  int L, M;
+  long double *dp;
+  long double *xs;
+  long double *lscale;
+} orc_mxx;
+static orc_mxx *mxx_new(int L, int M)
+{
+  orc_mxx *m = (orc_mxx *) calloc(1, sizeof(orc_mxx));
+  m->L = L; m->M = M;
+  m->dp = (long double *) calloc((size_t) (L + 1) * (M + 1) * 3, sizeof(long double));
+  m->xs = (long double *) calloc((size_t) (L + 1) * 5, sizeof(long double));
+  m->lscale = (long double *) calloc((size_t) L + 1, sizeof(long double));
+  return m;
+}
+static void mxx_free(orc_mxx *m) { if (m) { free(m->dp); free(m->xs); free(m->lscale); free(m); } }
+
+static long double forward_x(const orc_hmm *h, const uint8_t *dsq, int L, orc_len c, orc_mxx *fx)
+{
+  int M = h->M, i, k;
+  const double *pt = h->pt, *en = h->entry;
+  long double ls = 0.0;
+  for (k = 0; k <= M; k++) { MX(fx, 0, k, 0) = MX(fx, 0, k, 1) = MX(fx, 0, k, 2) = 0.0; }
+  XS(fx, 0, sN) = 1.0; XS(fx, 0, sB) = c.move; XS(fx, 0, sE) = 0.0; XS(fx, 0, sJ) = 0.0; XS(fx, 0, sC) = 0.0;
+  fx->lscale[0] = 0.0;
+  for (i = 1; i <= L; i++) {
+    const double *od = h->odds + (size_t) dsq[i - 1] * (M + 1);
+    long double xB = XS(fx, i - 1, sB), xE = 0.0, xN, xJ, xC;
+    MX(fx, i, 0, 0) = MX(fx, i, 0, 1) = MX(fx, i, 0, 2) = 0.0;
+    for (k = 1; k <= M; k++) {
+      const double *tp = pt + (size_t) (k - 1) * 7;
+      const double *tk = pt + (size_t) k * 7;
+      long double m = od[k] * (MX(fx, i - 1, k - 1, 0) * tp[tMM] + MX(fx, i - 1, k - 1, 1) * tp[tIM]
+                        + MX(fx, i - 1, k - 1, 2) * tp[tDM] + xB * en[k]);
+      long double d = MX(fx, i, k - 1, 0) * tp[tMD] + MX(fx, i, k - 1, 2) * tp[tDD];
+      long double ins = MX(fx, i - 1, k, 0) * tk[tMI] + MX(fx, i - 1, k, 1) * tk[tII];
+      MX(fx, i, k, 0) = m; MX(fx, i, k, 1) = ins; MX(fx, i, k, 2) = d;
+      xE += m + d;
+    }
+    xN = XS(fx, i - 1, sN) * c.loop;
+    xC = XS(fx, i - 1, sC) * c.loop + xE * c.EC;
+    xJ = XS(fx, i - 1, sJ) * c.loop + xE * c.EJ;
+    if (xE > RESCALE_HI) {
+      long double r = 1.0 / xE;
+      for (k = 1; k <= M; k++) { MX(fx, i, k, 0) *= r; MX(fx, i, k, 1) *= r; MX(fx, i, k, 2) *= r; }
+      xN *= r; xC *= r; xJ *= r; ls += logl(xE); xE = 1.0;
+    }
+    XS(fx, i, sN) = xN; XS(fx, i, sE) = xE; XS(fx, i, sJ) = xJ; XS(fx, i, sC) = xC;
+    XS(fx, i, sB) = xJ * c.move + xN * c.move;
+    fx->lscale[i] = ls;
+  }
+  return ls + logl(XS(fx, L, sC) * c.move);
+}
+
+/* Backward in extended precision (see forward_x). */
+static long double backward_x(const orc_hmm *h, const uint8_t *dsq, int L, orc_len c, orc_mxx *bx)
+{
+  int M = h->M, i, k;
+  const double *pt = h->pt, *en = h->entry;
+  long double ls = 0.0;
+  /* row L */
+  XS(bx, L, sC) = c.move; XS(bx, L, sJ) = 0.0; XS(bx, L, sN) = 0.0; XS(bx, L, sB) = 0.0;
+  XS(bx, L, sE) = XS(bx, L, sC) * c.EC + XS(bx, L, sJ) * c.EJ;
+  {
+    long double xE = XS(bx, L, sE);
+    MX(bx, L, M, 0) = xE; MX(bx, L, M, 2) = xE; MX(bx, L, M, 1) = 0.0;
+    for (k = M - 1; k >= 1; k--) {
+      const double *tk = pt + (size_t) k * 7;
+      MX(bx, L, k, 0) = xE + MX(bx, L, k + 1, 2) * tk[tMD];
+      MX(bx, L, k, 2) = xE + MX(bx, L, k + 1, 2) * tk[tDD];
+      MX(bx, L, k, 1) = 0.0;
+    }
+    MX(bx, L, 0, 0) = MX(bx, L, 0, 1) = MX(bx, L, 0, 2) = 0.0;
+  }
+  bx->lscale[L] = 0.0;
+  for (i = L - 1; i >= 0; i--) {
+    const double *od = h->odds + (size_t) dsq[i] * (M + 1);     /* residue x_{i+1} */
+    long double xB = 0.0, xE, xJ, xC, xN;
+    for (k = 1; k <= M; k++) xB += MX(bx, i + 1, k, 0) * od[k] * en[k];
+    xJ = XS(bx, i + 1, sJ) * c.loop + xB * c.move;
+    xC = XS(bx, i + 1, sC) * c.loop;
+    xN = XS(bx, i + 1, sN) * c.loop + xB * c.move;
+    xE = xC * c.EC + xJ * c.EJ;
+    if (i > 0) {
+      MX(bx, i, M, 0) = xE; MX(bx, i, M, 2) = xE; MX(bx, i, M, 1) = 0.0;
+      for (k = M - 1; k >= 1; k--) {
+        const double *tk = pt + (size_t) k * 7;
+        long double mnext = MX(bx, i + 1, k + 1, 0) * od[k + 1];
+        MX(bx, i, k, 0) = mnext * tk[tMM] + MX(bx, i + 1, k, 1) * tk[tMI] + MX(bx, i, k + 1, 2) * tk[tMD] + xE;
+        MX(bx, i, k, 1) = mnext * tk[tIM] + MX(bx, i + 1, k, 1) * tk[tII];
+        MX(bx, i, k, 2) = mnext * tk[tDM] + MX(bx, i, k + 1, 2) * tk[tDD] + xE;
+      }
+      MX(bx, i, 0, 0) = MX(bx, i, 0, 1) = MX(bx, i, 0, 2) = 0.0;
+    } else {
+      for (k = 0; k <= M; k++) { MX(bx, 0, k, 0) = MX(bx, 0, k, 1) = MX(bx, 0, k, 2) = 0.0; }
+    }
+    if (xB > RESCALE_HI || xN > RESCALE_HI) {
+      long double big = xB > xN ? xB : xN, r = 1.0L / big;
+      if (i > 0) for (k = 1; k <= M; k++) { MX(bx, i, k, 0) *= r; MX(bx, i, k, 1) *= r; MX(bx, i, k, 2) *= r; }
+      xB *= r; xJ *= r; xC *= r; xN *= r; xE *= r; ls += logl(big);
+    }
+    XS(bx, i, sB) = xB; XS(bx, i, sJ) = xJ; XS(bx, i, sC) = xC; XS(bx, i, sN) = xN; XS(bx, i, sE) = xE;
+    bx->lscale[i] = ls;
+  }
+  return ls + logl(XS(bx, 0, sN));
+}
+
 /* ----------------------------------------------------------------------------
  * p7_FLogsum: table-driven float log-sum-exp (A.6)
  * -------------------------------------------------------------------------- */
@@ -619,26 +734,26 @@ int orc_align_pair(const orc_hmm *h, const uint8_t *dsq, int L, int32_t *cols)
 {
   int M = h->M, i, k;
   orc_len c = len_config(L, 0);
-  orc_mx *fx, *bx;
+  orc_mxx *fx, *bx;
   float *ppM, *ppI, *ppN, *ppC, *ppJ;    /* posteriors, float32 like HMMER's matrices */
   float *oM, *oI, *oD, *oX;              /* OA matrices; oX: N B E J C per row         */
   const double *pt = h->pt, *en = h->entry;
-  double fwd;
+  long double fwd;
   size_t W = (size_t) M + 1;
   for (i = 0; i < L; i++) cols[i] = -1;
   if (L <= 0) return 0;
-  fx = mx_new(L, M); bx = mx_new(L, M);
-  fwd = forward(h, dsq, L, c, fx);
-  backward(h, dsq, L, c, bx);
-  if (!isfinite(fwd)) { mx_free(fx); mx_free(bx); return -1; }
+  fx = mxx_new(L, M); bx = mxx_new(L, M);
+  fwd = forward_x(h, dsq, L, c, fx);
+  backward_x(h, dsq, L, c, bx);
+  if (!isfinite((double) fwd)) { mxx_free(fx); mxx_free(bx); return -1; }
   ppM = (float *) calloc((size_t) (L + 1) * W, sizeof(float));
   ppI = (float *) calloc((size_t) (L + 1) * W, sizeof(float));
   ppN = (float *) calloc((size_t) L + 1, sizeof(float));
   ppC = (float *) calloc((size_t) L + 1, sizeof(float));
   ppJ = (float *) calloc((size_t) L + 1, sizeof(float));
   for (i = 1; i <= L; i++) {
-    double sc = exp(fx->lscale[i] + bx->lscale[i] - fwd);
-    double sc2 = exp(fx->lscale[i - 1] + bx->lscale[i] - fwd);
+    long double sc = expl(fx->lscale[i] + bx->lscale[i] - fwd);
+    long double sc2 = expl(fx->lscale[i - 1] + bx->lscale[i] - fwd);
     for (k = 1; k <= M; k++) {
       ppM[i * W + k] = (float) (MX(fx, i, k, 0) * MX(bx, i, k, 0) * sc);
       ppI[i * W + k] = (float) (MX(fx, i, k, 1) * MX(bx, i, k, 1) * sc);
@@ -647,7 +762,7 @@ int orc_align_pair(const orc_hmm *h, const uint8_t *dsq, int L, int32_t *cols)
     ppJ[i] = (float) (XS(fx, i - 1, sJ) * XS(bx, i, sJ) * c.loop * sc2);
     ppC[i] = (float) (XS(fx, i - 1, sC) * XS(bx, i, sC) * c.loop * sc2);
   }
-  mx_free(fx); mx_free(bx);
+  mxx_free(fx); mxx_free(bx);
 
   oM = (float *) calloc((size_t) (L + 1) * W, sizeof(float));
   oI = (float *) calloc((size_t) (L + 1) * W, sizeof(float));
@@ -719,7 +834,7 @@ int orc_align_pair(const orc_hmm *h, const uint8_t *dsq, int L, int32_t *cols)
             for (rr = 0; rr < 4; rr++) { kk = rr * Q + q + 1; if (kk <= M && oM[i * W + kk] >= mx) { mx = oM[i * W + kk]; smax = stM; kmax = kk; } }
             for (rr = 0; rr < 4; rr++) { kk = rr * Q + q + 1; if (kk <= M && oD[i * W + kk] >  mx) { mx = oD[i * W + kk]; smax = stD; kmax = kk; } }
           }
-          if (kmax == 0) { fprintf(stderr, "oracle: OA traceback found no cell at i=%d L=%d M=%d oE=%g fwd=%g\n", i, L, M, oX[i*5+sE], fwd); guard = 0; s1 = stS; break; }
+          if (kmax == 0) { fprintf(stderr, "oracle: OA traceback found no cell at i=%d L=%d M=%d oE=%g fwd=%g\n", i, L, M, oX[i*5+sE], (double) fwd); guard = 0; s1 = stS; break; }
           k = kmax; s1 = smax;
           break; }
         case stM: {

@@ -357,23 +357,16 @@ def test_long_protein_queries_with_several_hits(orc, tmp_path):
     diff = np.abs(deci.astype(np.int64) - od)
     assert diff.max() <= 1, diff.max()        # long envelopes: float32 vs float64 null2 sums, one deci-bit at most
     assert (diff == 0).mean() >= 0.9
-    # alignment of the same queries: where the best hit is not the first one, HMMER leaves float32
-    # (its Decoding overflows and it switches to its log-space code); this path saturates and
-    # aligns the hit its float32 Forward reached (float32-range class).  Everything
-    # else must equal the oracle; before the mirrored scaling almost half of these pairs did not.
+    # alignment of the same queries: where the best hit is not the first one the scaled float32
+    # sweeps cannot represent it (HMMER's Decoding overflows there and hmmalign switches to its
+    # log-space code); the kernel detects the same condition and redoes those pairs in log space
+    # (wh_align_log.h).  Every pair must equal the oracle; before this fallback a quarter did not.
     pq = [q for q in range(8) for _ in range(e.H)]
     ph = [h for q in range(8) for h in range(e.H)]
     cols, co = e.align(res, offs, pq, ph)
-    bad = 0
     for p in range(len(pq)):
         want = ohm[ph[p]].align(seqs[pq[p]])
-        got = cols[co[p]:co[p + 1]]
-        if not np.array_equal(got, want):
-            bad += 1
-            # still a clean local alignment: match columns strictly increasing
-            m = got[got >= 0]
-            assert len(m) > 0 and np.all(np.diff(m) > 0)
-    assert bad <= 0.35 * len(pq), (bad, len(pq))
+        assert np.array_equal(cols[co[p]:co[p + 1]], want), (pq[p], ph[p])
     e.close()
 
 

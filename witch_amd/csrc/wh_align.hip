@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include "wh_device.h"
+#include "wh_align_log.h"
 #include "wh_launch.h"
 
 namespace wh {
@@ -51,7 +52,8 @@ __device__ __forceinline__ float tab_load(const float *tab, int arr, int k) {
 
 // SWAP (long models, Q > 24): only ONE transition orientation is resident in LDS; the waves of a
 // workgroup run the three sweeps in lockstep and swap the tables between them (see wh_score_big.hip).
-template <int Q, bool TREG, bool SPECG, bool SWAP>
+// LOGSP: the fallback pass for pairs that left float32 range (wh_align_log.h); not for SWAP.
+template <int Q, bool TREG, bool SPECG, bool SWAP, bool LOGSP = false>
 __global__ __launch_bounds__(SWAP ? 256 : 512) void align_kernel(AlignArgs a) {
   // all LDS in ONE 16-byte aligned dynamic array: a static __shared__ object in front of it
   // would shift the base by 4 bytes and split every ds_read_b128 (measured: 13x LDS time)
@@ -130,21 +132,39 @@ __global__ __launch_bounds__(SWAP ? 256 : 512) void align_kernel(AlignArgs a) {
       const LenCfg cu = len_config(L > 0 ? L : 1, false);
 
       // ---------------- unihit Forward, rows spilled to slab A
-      float xC_L = 0.f; int ef_L = 0;
+      float xC_L = 0.f, lZ = -INFINITY; int ef_L = 0;
       orient(0);
       if (active) {
         TransTab<Q, TREG> T;
         T.load(fwG, trF, lane);
-        const ScanC sc = scan_prepare(lane_product<Q, TREG>(T, FW_D2));
-        // forward_sweep uses spec slots 0..5 = N,B,E,J,C,S with stride SP (AL_PN..AL_S coincide)
-        forward_sweep<Q, TREG, true>(T, sc, emL, emG, Klds, seq, L, cu, spec, SP, slabA, -1.0f, lane, xC_L, ef_L);   // dense
+        if constexpr (LOGSP) {
+          lZ = forward_sweep_log<Q>(T, emL, emG, Klds, seq, L, cu, spec, SP, slabA, lane);
+          xC_L = lZ > -INFINITY ? 1.f : 0.f;
+        } else {
+          const ScanC sc = scan_prepare(lane_product<Q, TREG>(T, FW_D2));
+          // forward_sweep uses spec slots 0..5 = N,B,E,J,C,S with stride SP (AL_PN..AL_S coincide)
+          forward_sweep<Q, TREG, true>(T, sc, emL, emG, Klds, seq, L, cu, spec, SP, slabA, -1.0f, lane, xC_L, ef_L);   // dense
+        }
       }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       if (!(xC_L > 0.f)) active = false;   // no alignment has non-zero probability: all residues stay -1
 
       // ---------------- Backward + posterior decoding, in place over slab A
       orient(1);
-      if (active) {
+      if (LOGSP && active) {
+        if constexpr (LOGSP) {
+          TransTab<Q, TREG> T;
+          T.load(bwG, trB, lane);
+          backward_posterior_log<Q>(T, emL, emG, Klds, seq, L, cu, lZ, slabA, lane,
+              [&](int r, float &fN, float &fJ, float &fC) { fN = SPR(AL_PN * SP + r); fJ = SPR(AL_PJ * SP + r); fC = SPR(AL_PC * SP + r); },
+              [&](int r, float pn, float pj, float pc) {
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) { spec[AL_PN * SP + r] = pn; spec[AL_PJ * SP + r] = pj; spec[AL_PC * SP + r] = pc; }
+                __builtin_amdgcn_wave_barrier();
+              });
+        }
+      } else if (active) {
+        bool clamped = false;
         const float invZ = 1.0f / (xC_L * cu.move);
         TransTab<Q, TREG> T;
         T.load(bwG, trB, lane);
@@ -186,7 +206,7 @@ __global__ __launch_bounds__(SWAP ? 256 : 512) void align_kernel(AlignArgs a) {
           }
           float xE = fmaf(xC, cu.EC, xJ * cu.EJ);
           backward_cells<Q, TREG>(T, sc, Mb, Ib, xE);
-          clamp_backward<Q>(Mb, Ib, xB, xJ, xC, xN);
+          clamped |= clamp_backward<Q>(Mb, Ib, xB, xJ, xC, xN);
           const float s_i = invZ;
           const float s_p = ldexpf(invZ, SPRI(AL_S * SP + i - 1) - SPRI(AL_S * SP + i));
 #pragma unroll
@@ -204,6 +224,8 @@ __global__ __launch_bounds__(SWAP ? 256 : 512) void align_kernel(AlignArgs a) {
           if (lane == 0) { spec[AL_PN * SP + i] = pn; spec[AL_PJ * SP + i] = pj; spec[AL_PC * SP + i] = pc; }
           __builtin_amdgcn_wave_barrier();
         }
+        // float32 range left: queue the pair for the log-space pass (this pass still writes its columns)
+        if (clamped && a.redo_list && lane == 0) a.redo_list[atomicAdd(a.redo_count, 1)] = pair;
       }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 
@@ -415,13 +437,27 @@ __global__ __launch_bounds__(SWAP ? 256 : 512) void align_kernel(AlignArgs a) {
   }
 }
 
-template <int Q, bool TREG, bool SPECG, bool SWAP>
+template <int Q, bool TREG, bool SPECG, bool SWAP, bool LOGSP = false>
 static hipError_t launch_one(const AlignArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
-  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&align_kernel<Q, TREG, SPECG, SWAP>),
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&align_kernel<Q, TREG, SPECG, SWAP, LOGSP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (err != hipSuccess) return err;
-  hipLaunchKernelGGL((align_kernel<Q, TREG, SPECG, SWAP>), dim3(blocks), dim3(threads), lds, s, a);
+  hipLaunchKernelGGL((align_kernel<Q, TREG, SPECG, SWAP, LOGSP>), dim3(blocks), dim3(threads), lds, s, a);
   return hipGetLastError();
+}
+
+// log-space pass (models of up to 24 cells per lane)
+template <bool SPECG>
+static hipError_t launch_align_log_q(int Q, const AlignArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
+  switch (Q) {
+    case 4:  return launch_one<4, false, SPECG, false, true>(a, blocks, threads, lds, s);
+    case 8:  return launch_one<8, false, SPECG, false, true>(a, blocks, threads, lds, s);
+    case 12: return launch_one<12, false, SPECG, false, true>(a, blocks, threads, lds, s);
+    case 16: return launch_one<16, false, SPECG, false, true>(a, blocks, threads, lds, s);
+    case 20: return launch_one<20, false, SPECG, false, true>(a, blocks, threads, lds, s);
+    case 24: return launch_one<24, false, SPECG, false, true>(a, blocks, threads, lds, s);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 template <bool SPECG>
@@ -445,6 +481,7 @@ static hipError_t launch_align_q(int Q, const AlignArgs &a, int blocks, int thre
 }
 
 hipError_t launch_align(int Q, const AlignArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
+  if (a.logsp) return a.spec_scratch ? launch_align_log_q<true>(Q, a, blocks, threads, lds, s) : launch_align_log_q<false>(Q, a, blocks, threads, lds, s);
   return a.spec_scratch ? launch_align_q<true>(Q, a, blocks, threads, lds, s) : launch_align_q<false>(Q, a, blocks, threads, lds, s);
 }
 

@@ -66,6 +66,7 @@ struct wh_ehmm {
   bool timing = false;
   KernelTimer timers[4];
   int max_M = 0;
+  int last_align_redo = 0;          // pairs of the last wh_align call that went through the log-space pass
 };
 
 static int g_device = -1;
@@ -593,14 +594,24 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
   std::vector<int32_t> order((size_t)npairs), cursor(cnt.begin(), cnt.end() - 1);
   for (int64_t p = 0; p < npairs; p++) order[(size_t)cursor[(size_t)ph[(size_t)p]]++] = (int32_t)p;
   if (e->d_order.ensure(sizeof(int32_t) * (size_t)npairs)) return WH_ENOMEM;
-  HIPCHK(hipMemcpyAsync(e->d_order.p, order.data(), sizeof(int32_t) * (size_t)npairs, hipMemcpyHostToDevice, s));
+  // pairs whose Backward sweep leaves float32 range are queued on the device and redone in log space
+  const bool want_redo = !getenv("WH_NO_LOGSPACE");
+  if (e->d_recs.ensure(sizeof(int32_t) * ((size_t)npairs + 4))) return WH_ENOMEM;
+  int *d_redo_count = (int *)e->d_recs.p;
+  int32_t *d_redo_list = (int32_t *)e->d_recs.p + 4;
+  HIPCHK(hipMemsetAsync(d_redo_count, 0, sizeof(int), s));
   if (timer_begin(e, 2, s)) return WH_EHIP;
   int launches = 0;
+  // one pass = plan the launches of every model class for the pairs in <order> (grouped by model,
+  // cnt = prefix counts per model) and run them
+  auto run_pass = [&](const std::vector<int32_t> &order, const std::vector<int32_t> &cnt, bool logsp) -> int {
+  HIPCHK(hipMemcpyAsync(e->d_order.p, order.data(), sizeof(int32_t) * order.size(), hipMemcpyHostToDevice, s));
   std::vector<int32_t> items;   // all classes back to back: h, start, count
   std::vector<std::array<int, 7>> plans;   // Q, first item, n items, waves, SP, wave_lds, Klds
   std::vector<size_t> ldss;
   for (auto &kv : e->by_q) {
     const int Q = kv.first;
+    if (logsp && Q > kMaxQFast) continue;    // long models: no log-space kernel (their flagged pairs keep the saturated result)
     int waves = 0, SP = 0, wave_lds = 0; size_t lds = 0;
     if (Q <= kMaxQFast && plan_align_block(Q, e->K, std::max(max_len, 1), &waves, &SP, &wave_lds, &lds) != WH_OK) waves = 0;
     int Klds = e->K;
@@ -649,6 +660,9 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
     a.counter = (int *)e->d_counter.p + launches;
     a.Lcap = std::max(max_len, 1); a.SP = plans[pl][4]; a.wave_lds = std::abs(plans[pl][5]);
     a.K = e->K; a.Kp = e->Kp; a.Klds = plans[pl][6];
+    a.logsp = logsp ? 1 : 0;
+    a.redo_count = (!logsp && want_redo) ? d_redo_count : nullptr;
+    a.redo_list = (!logsp && want_redo) ? d_redo_list : nullptr;
     const int blocks = std::min(n, e->cu_count * std::max(1, 8 / waves));
     if (plans[pl][5] < 0) {
       a.spec_stride = (size_t)13 * a.SP;
@@ -663,9 +677,33 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
     if (err != hipSuccess) { set_error("align kernel launch (Q=%d) failed: %s", Q, hipGetErrorString(err)); return WH_EHIP; }
     launches++;
   }
-  if (timer_end(e, 2, s, launches)) return WH_EHIP;
-  // the host vectors above are consumed by async copies: drain before they go out of scope
+  // the host vectors of this pass are consumed by async copies: drain before they go out of scope
   HIPCHK(hipStreamSynchronize(s));
+  return WH_OK;
+  };
+  int rc = run_pass(order, cnt, false);
+  if (rc != WH_OK) return rc;
+  int n_redo = 0;
+  if (want_redo) {
+    HIPCHK(hipMemcpyAsync(&n_redo, d_redo_count, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+  }
+  if (n_redo > 0) {
+    std::vector<int32_t> redo((size_t)n_redo);
+    HIPCHK(hipMemcpyAsync(redo.data(), d_redo_list, sizeof(int32_t) * (size_t)n_redo, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    std::vector<int32_t> cnt2((size_t)H + 1, 0);
+    for (int32_t p : redo) cnt2[(size_t)ph[(size_t)p] + 1]++;
+    for (int h = 0; h < H; h++) cnt2[(size_t)h + 1] += cnt2[(size_t)h];
+    std::vector<int32_t> order2((size_t)n_redo), cur2(cnt2.begin(), cnt2.end() - 1);
+    std::sort(redo.begin(), redo.end());
+    for (int32_t p : redo) order2[(size_t)cur2[(size_t)ph[(size_t)p]]++] = p;
+    if (getenv("WH_TRACE")) fprintf(stderr, "[wh] align: %d of %lld pairs left float32 range, redone in log space\n", n_redo, (long long)npairs);
+    rc = run_pass(order2, cnt2, true);
+    if (rc != WH_OK) return rc;
+  }
+  e->last_align_redo = n_redo;
+  if (timer_end(e, 2, s, launches)) return WH_EHIP;
   return WH_OK;
 }
 

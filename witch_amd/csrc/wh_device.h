@@ -356,12 +356,14 @@ __device__ __forceinline__ void mirror_scale(int dn, float (&Mb)[Q], float (&Ib)
 }
 
 template <int Q>
-__device__ __forceinline__ void clamp_backward(float (&Mb)[Q], float (&Ib)[Q], float &xB, float &xJ, float &xC, float &xN) {
+__device__ __forceinline__ bool clamp_backward(float (&Mb)[Q], float (&Ib)[Q], float &xB, float &xJ, float &xC, float &xN) {
   if (fmaxf(xB, fmaxf(xN, xC)) > kClampHi) {
 #pragma unroll
     for (int p = 0; p < Q; p++) { Mb[p] = fminf(Mb[p], kClampHi); Ib[p] = fminf(Ib[p], kClampHi); }
     xB = fminf(xB, kClampHi); xN = fminf(xN, kClampHi); xC = fminf(xC, kClampHi); xJ = fminf(xJ, kClampHi);
+    return true;      // the pair has left float32 range (hmmalign would switch to its log-space code here)
   }
+  return false;
 }
 
 // G_k = o_k(x) * B_M_k in place (reversed node order) and the B-state sum  sum_k E_k G_k;

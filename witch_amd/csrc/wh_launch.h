@@ -90,6 +90,9 @@ struct AlignArgs {
   size_t spec_stride;
   int Klds;                    // emission rows staged in LDS (= K, or 0: read from L2)
   int K, Kp;
+  int *redo_count;             // pairs whose Backward sweep saturated (float32 range) are appended to
+  int32_t *redo_list;          // redo_list for the log-space pass (NULL in that pass)
+  int logsp;                   // 1: this launch is the log-space pass
 };
 hipError_t launch_align(int Q, const AlignArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
 

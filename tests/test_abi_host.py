@@ -67,3 +67,34 @@ def test_error_codes_and_messages_without_a_device():
     assert L.wh_ehmm_count(None) < 0
     assert L.wh_score(None, None, None, 0, None, None, None, None) < 0
     assert b"wh_score" in L.wh_last_error()
+
+
+def test_sweep_context_is_register_passed(tmp_path):
+    """The non-inlined sweeps of wh_score7.hip must receive their context struct in argument
+    registers: when the aggregate stops flattening (a 17th dword, byte-sized members) the compiler
+    passes it by reference through scratch and the callee faults on gfx950
+    (HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION).  Checked on the generated ISA."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "witch_amd", "csrc", "wh_score7.hip")
+    out = tmp_path / "k7.s"
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize",
+                        "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "witch_amd", "csrc"),
+                        "--cuda-device-only", "-S", "-o", str(out), src], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    name, n_funcs, bad = None, 0, []
+    for line in open(out):
+        m = re.match(r"^(_ZN2wh2k7\d+(sweep_|region_scan)\S*):", line)
+        if m:
+            name = m.group(1)
+            n_funcs += 1
+        elif line.startswith("_Z") or "s_setpc_b64" in line:
+            name = None if "s_setpc_b64" in line else name
+        elif name and re.search(r"scratch_load_\w+ v\S*, v0, off", line):
+            bad.append(name)
+    assert n_funcs >= 20
+    assert not bad, sorted(set(bad))[:3]

@@ -57,9 +57,21 @@ struct WaveCtx {
   glb_f *specg;               // ... or, for long queries (SG sweeps), in a per-wave HBM region
   lds_f *n2tab;               // 32 floats (LDS)
   glb_f *Fs;                  // Forward-row slab of this wave (HBM)
-  int SP, K, Kp, lane;
+  int SP, lane;
+  int alpha;                  // K | Kp << 8 | Klds << 16: alphabet size, with degenerate codes, emission rows staged in LDS
   uint32_t degen;             // this lane's degenerate-code mask (lane = residue code)
 };
+// The context travels to the non-inlined sweeps in argument registers: the compiler flattens an
+// aggregate of up to 16 dwords of plain 4/8-byte members.  Anything else (a 17th dword, byte-sized
+// members) is passed by reference through scratch instead - and that path faults on gfx950 with
+// this toolchain (HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION at the callee's first struct load),
+// hence the packed <alpha> word.
+#if defined(__HIP_DEVICE_COMPILE__)
+static_assert(sizeof(WaveCtx) <= 80, "WaveCtx must stay register-passed (see comment)");
+#endif
+__device__ __forceinline__ int ctxK(const WaveCtx &c) { return c.alpha & 255; }
+__device__ __forceinline__ int ctxKp(const WaveCtx &c) { return (c.alpha >> 8) & 255; }
+__device__ __forceinline__ int ctxKlds(const WaveCtx &c) { return (c.alpha >> 16) & 255; }
 struct P4Out { float mass, domcorr; };
 struct RegOut { int nenv, nreg, flags; };
 
@@ -73,7 +85,7 @@ __device__ __noinline__ FwdOut sweep_forward(const WaveCtx c, lds_u8 *seq3, int 
   T.load(nullptr, (const float *)c.fwL, c.lane);
   const ScanC sc = scan_prepare(lane_product<Q, false>(T, FW_D2));
   FwdOut o;
-  forward_sweep<Q, false, STORE, (Q <= kMaxQP)>(T, sc, (const float *)c.emL, (const float *)c.emG, c.K, seq, L, cfg, SG ? (float *)c.specg : (float *)c.spec, c.SP, (float *)c.Fs, keep_scale, c.lane, o.xC, o.ef);
+  forward_sweep<Q, false, STORE, (Q <= kMaxQP)>(T, sc, (const float *)c.emL, (const float *)c.emG, ctxKlds(c), seq, L, cfg, SG ? (float *)c.specg : (float *)c.spec, c.SP, (float *)c.Fs, keep_scale, c.lane, o.xC, o.ef);
   if (SG) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // the rows were written by lane 0, every lane reads them next
   return o;
 }
@@ -101,7 +113,7 @@ __device__ __noinline__ void sweep_backward_decode(const WaveCtx c, lds_u8 *seq3
   for (int i = L; i >= 0; i--) {
     asm volatile("" ::: "memory");
     if (i < L) {
-      xB = wave_sum(backward_emit<Q, false>(T, emL, (const float *)c.emG, seq[i], c.K, lane, Mb));
+      xB = wave_sum(backward_emit<Q, false>(T, emL, (const float *)c.emG, seq[i], ctxKlds(c), lane, Mb));
       xJ = fmaf(xJ, cm.loop, xB * cm.move);
       xC = xC * cm.loop;
       xN = fmaf(xN, cm.loop, xB * cm.move);
@@ -184,7 +196,7 @@ __device__ __noinline__ P4Out sweep_backward_null2(const WaveCtx c, lds_u8 *eseq
     const int dS = S_i - ldi(SP_S * SP + i - 1);      // Forward rescale at row i (>= 0)
     if (i < Ld) {
       mirror_scale<Q>(S_next - S_i, Mb, Ib, xJ, xC, xN);
-      xB = wave_sum(backward_emit<Q, false>(T, emL, (const float *)c.emG, eseq[i], c.K, lane, Mb));
+      xB = wave_sum(backward_emit<Q, false>(T, emL, (const float *)c.emG, eseq[i], ctxKlds(c), lane, Mb));
       xJ = fmaf(xJ, cu.loop, xB * cu.move);
       xC = xC * cu.loop;
       xN = fmaf(xN, cu.loop, xB * cu.move);
@@ -247,9 +259,9 @@ __device__ __noinline__ P4Out sweep_backward_null2(const WaveCtx c, lds_u8 *eseq
   if (!(fabsf((float)Ld - mass) <= mass_tol * (float)Ld)) return o;   // certificate failed: the caller redoes the envelope densely
   const float norm = 1.0f / (float)Ld;
   float mine = 1.0f;
-  for (int x = 0; x < c.K; x++) {
+  for (int x = 0; x < ctxK(c); x++) {
     float od[Q];
-    load_em_rev<Q>(od, emL, (const float *)c.emG, x, c.K, lane);
+    load_em_rev<Q>(od, emL, (const float *)c.emG, x, ctxKlds(c), lane);
     float s = 0.f;
 #pragma unroll
     for (int p = 0; p < Q; p++) s = fmaf(fM[p], od[p], s);
@@ -258,17 +270,17 @@ __device__ __noinline__ P4Out sweep_backward_null2(const WaveCtx c, lds_u8 *eseq
   }
   float *n2tab = (float *)c.n2tab;
   __builtin_amdgcn_wave_barrier();
-  if (lane < c.K) n2tab[lane] = mine;
+  if (lane < ctxK(c)) n2tab[lane] = mine;
   __builtin_amdgcn_wave_barrier();
-  if (lane >= c.K && lane < c.Kp) {
+  if (lane >= ctxK(c) && lane < ctxKp(c)) {
     // degenerate codes: unweighted mean of the canonical ratios; gap/*/~ -> 1
     const uint32_t m = c.degen;
     float s = 0.f; int n = 0;
-    for (int x = 0; x < c.K; x++) if (m & (1u << x)) { s += n2tab[x]; n++; }
+    for (int x = 0; x < ctxK(c); x++) if (m & (1u << x)) { s += n2tab[x]; n++; }
     mine = n > 0 ? s / (float)n : 1.0f;
   }
   __builtin_amdgcn_wave_barrier();
-  if (lane < c.Kp) n2tab[lane] = logf(mine);
+  if (lane < ctxKp(c)) n2tab[lane] = logf(mine);
   __builtin_amdgcn_wave_barrier();
   float dc = 0.f;
   for (int t = lane; t < Ld; t += kWave) dc += n2tab[eseq[t]];
@@ -348,7 +360,7 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
   c.degen = 0;
   for (int t = 0; t < 32; t++) if (t == lane) c.degen = a.degen[t];
   c.Fs = (glb_f *)(a.scratch + ((size_t)blockIdx.x * nwaves + wave) * a.scratch_stride);
-  c.SP = SP; c.K = a.K; c.Kp = a.Kp; c.lane = lane;
+  c.SP = SP; c.alpha = a.K | (a.Kp << 8) | (a.K << 16); c.lane = lane;
   int *regs = reinterpret_cast<int *>(wbase + (SG ? 0 : SP_NARR * SP) + 32);
   uint8_t *seq = reinterpret_cast<uint8_t *>(regs + 3 * WH_MAX_ENVELOPES);
   const double LOG2 = 0.69314718055994529;

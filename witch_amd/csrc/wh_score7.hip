@@ -61,11 +61,12 @@ struct WaveCtx {
   int alpha;                  // K | Kp << 8 | Klds << 16: alphabet size, with degenerate codes, emission rows staged in LDS
   uint32_t degen;             // this lane's degenerate-code mask (lane = residue code)
 };
-// The context travels to the non-inlined sweeps in argument registers: the compiler flattens an
-// aggregate of up to 16 dwords of plain 4/8-byte members.  Anything else (a 17th dword, byte-sized
-// members) is passed by reference through scratch instead - and that path faults on gfx950 with
-// this toolchain (HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION at the callee's first struct load),
-// hence the packed <alpha> word.
+// The context travels to the non-inlined sweeps in argument registers while it flattens to at most
+// 16 dwords of plain 4/8-byte members.  Every variant the compiler passed by reference through
+// scratch instead (a 17th dword, byte-sized members) faulted on gfx950 with this toolchain
+// (HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION; not fully understood - the 16-byte LenCfg argument
+// IS passed by reference and works).  Hence the packed <alpha> word; tests/test_abi_host.py checks
+// the generated ISA.
 #if defined(__HIP_DEVICE_COMPILE__)
 static_assert(sizeof(WaveCtx) <= 80, "WaveCtx must stay register-passed (see comment)");
 #endif

@@ -482,3 +482,26 @@ def test_every_kernel_instantiation_against_the_oracle(root_len, orc, tmp_path):
         assert np.abs(deci.astype(np.int64) - od)[rep].max() <= 1, (root_len, qlen)
         assert ((deci == od) | ~rep).mean() >= 0.9
     e.close()
+
+
+def test_multihit_queries_on_a_long_model_align_like_hmmalign(orc, tmp_path):
+    """1900-node models (pass-synchronous kernels) with queries that hold two or three copies of
+    the family: the pairs leave float32 range and go through the log-space pass."""
+    _need_gpu()
+    from witch_amd import synth
+    from witch_amd.ehmm import EHMM, pack_queries
+    fam = synth.make_family(4242 + 1900, 1900, 16, "dna", 0.03, 1e-4)
+    eh = synth.make_ehmm(fam, 2, str(tmp_path), witch_layout=False)
+    names, seqs = synth.make_queries(fam, 17, 4, (2100, 4200), flank_frac=0.3)
+    seqs = [s.astype(np.uint8) for s in seqs]
+    e = EHMM(eh.paths, hmm_index=eh.index, nseq=eh.nseq)
+    assert int(e.M.max()) > 1536
+    res, offs = pack_queries(seqs)
+    ohm = [orc.OracleHMM(p) for p in eh.paths]
+    pq = [q for q in range(len(seqs)) for _ in range(e.H)]
+    ph = [h for q in range(len(seqs)) for h in range(e.H)]
+    cols, co = e.align(res, offs, pq, ph)
+    for p in range(len(pq)):
+        want = ohm[ph[p]].align(seqs[pq[p]])
+        assert np.array_equal(cols[co[p]:co[p + 1]], want), (pq[p], ph[p])
+    e.close()

@@ -52,7 +52,7 @@ __device__ __forceinline__ float tab_load(const float *tab, int arr, int k) {
 
 // SWAP (long models, Q > 24): only ONE transition orientation is resident in LDS; the waves of a
 // workgroup run the three sweeps in lockstep and swap the tables between them (see wh_score_big.hip).
-// LOGSP: the fallback pass for pairs that left float32 range (wh_align_log.h); not for SWAP.
+// LOGSP: the fallback pass for pairs that left float32 range (wh_align_log.h).
 template <int Q, bool TREG, bool SPECG, bool SWAP, bool LOGSP = false>
 __global__ __launch_bounds__(SWAP ? 256 : 512) void align_kernel(AlignArgs a) {
   // all LDS in ONE 16-byte aligned dynamic array: a static __shared__ object in front of it
@@ -446,7 +446,7 @@ static hipError_t launch_one(const AlignArgs &a, int blocks, int threads, size_t
   return hipGetLastError();
 }
 
-// log-space pass (models of up to 24 cells per lane)
+// log-space pass
 template <bool SPECG>
 static hipError_t launch_align_log_q(int Q, const AlignArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
   switch (Q) {
@@ -456,6 +456,13 @@ static hipError_t launch_align_log_q(int Q, const AlignArgs &a, int blocks, int 
     case 16: return launch_one<16, false, SPECG, false, true>(a, blocks, threads, lds, s);
     case 20: return launch_one<20, false, SPECG, false, true>(a, blocks, threads, lds, s);
     case 24: return launch_one<24, false, SPECG, false, true>(a, blocks, threads, lds, s);
+    // long models: pass-synchronous table swapping like the prob-space pass
+    case 28: return launch_one<28, false, true, true, true>(a, blocks, threads, lds, s);
+    case 32: return launch_one<32, false, true, true, true>(a, blocks, threads, lds, s);
+    case 36: return launch_one<36, false, true, true, true>(a, blocks, threads, lds, s);
+    case 40: return launch_one<40, false, true, true, true>(a, blocks, threads, lds, s);
+    case 44: return launch_one<44, false, true, true, true>(a, blocks, threads, lds, s);
+    case 48: return launch_one<48, false, true, true, true>(a, blocks, threads, lds, s);
     default: return hipErrorInvalidValue;
   }
 }

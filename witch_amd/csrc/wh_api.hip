@@ -611,7 +611,6 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
   std::vector<size_t> ldss;
   for (auto &kv : e->by_q) {
     const int Q = kv.first;
-    if (logsp && Q > kMaxQFast) continue;    // long models: no log-space kernel (their flagged pairs keep the saturated result)
     int waves = 0, SP = 0, wave_lds = 0; size_t lds = 0;
     if (Q <= kMaxQFast && plan_align_block(Q, e->K, std::max(max_len, 1), &waves, &SP, &wave_lds, &lds) != WH_OK) waves = 0;
     int Klds = e->K;

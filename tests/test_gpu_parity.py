@@ -505,3 +505,55 @@ def test_multihit_queries_on_a_long_model_align_like_hmmalign(orc, tmp_path):
         want = ohm[ph[p]].align(seqs[pq[p]])
         assert np.array_equal(cols[co[p]:co[p + 1]], want), (pq[p], ph[p])
     e.close()
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16])
+def test_randomised_small_cases(seed, orc, tmp_path):
+    """Random families (both alphabets, 20-400 nodes), ragged query lengths from 1 residue up,
+    degenerate residue codes, unrelated sequences: scores, flags and aligned columns against the
+    oracle through the C ABI."""
+    _need_gpu()
+    from witch_amd import synth
+    from witch_amd.ehmm import EHMM, pack_queries
+    rng = np.random.default_rng(seed)
+    alph = "amino" if seed % 2 else "dna"
+    root = int(rng.integers(20, 400))
+    fam = synth.make_family(1000 + seed, root, 8, alph, 0.05, 2e-3)
+    eh = synth.make_ehmm(fam, 3, str(tmp_path), witch_layout=False)
+    e = EHMM(eh.paths, hmm_index=eh.index, nseq=eh.nseq)
+    K = 20 if alph == "amino" else 4
+    Kp = 29 if alph == "amino" else 18
+    bg = synth.background(alph)
+    seqs = []
+    for t in range(14):
+        L = int(rng.choice([1, 2, 3, 7, 25, 60, 150, 333, 401]))
+        if t % 3 == 0:
+            s_ = rng.choice(K, size=L, p=bg).astype(np.uint8)                 # unrelated
+        else:
+            _, w = synth.make_queries(fam, seed * 100 + t, 1, min(L, root - 1) if root > 2 else 1)
+            s_ = w[0].astype(np.uint8)
+        if t % 4 == 1 and len(s_) > 4:                                       # degenerate codes (not gap/*/~)
+            pos = rng.integers(0, len(s_), size=max(1, len(s_) // 10))
+            lo = K
+            hi = Kp - 3
+            s_ = s_.copy()
+            s_[pos] = rng.integers(lo, hi, size=len(pos)).astype(np.uint8)
+        seqs.append(s_)
+    res, offs = pack_queries(seqs)
+    deci, flags, fwd = e.score(res, offs, want_fwd=True)
+    ohm = [orc.OracleHMM(p) for p in eh.paths]
+    od, of, ofwd, osc = orc.score_batch(ohm, res, offs)
+    fin = np.isfinite(ofwd)
+    assert np.array_equal(np.isfinite(fwd), fin)
+    assert np.max(np.abs(fwd[fin] - ofwd[fin])) <= 1e-4
+    assert np.array_equal(flags & 3, of & 3)
+    rep = (of & 1) == 1
+    if rep.any():
+        assert np.abs(deci.astype(np.int64) - od)[rep].max() <= 1
+    pq = [q for q in range(len(seqs)) for _ in range(e.H)]
+    ph = [h for q in range(len(seqs)) for h in range(e.H)]
+    cols, co = e.align(res, offs, pq, ph)
+    for p in range(len(pq)):
+        want = ohm[ph[p]].align(seqs[pq[p]])
+        assert np.array_equal(cols[co[p]:co[p + 1]], want), (seed, pq[p], ph[p], len(seqs[pq[p]]))
+    e.close()

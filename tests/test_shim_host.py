@@ -132,3 +132,22 @@ def test_clients_end_to_end_with_a_stub_backend(server, tmp_path):
     from witch_amd.shim.server import request
     st, body = request(server, "ping", [])
     assert st == 0 and body.split()[:1] == ["pong"] and int(body.split()[2]) >= 25
+
+
+def test_evalues_follow_hmmer_formula(golden_case):
+    """E = Z * exp(-lambda (s - tau)) with the FORWARD line of the HMM file reproduces the E-values
+    HMMER printed for the golden searches (to the 0.1-bit rounding of the printed score)."""
+    from witch_amd.shim import formats
+    case = golden_case
+    Z = len(case.qnames)
+    n = 0
+    for hf, hp in zip(case.hmm_files[:3], case.hmm_paths[:3]):
+        hdr = formats.hmm_header(hp)
+        if hdr["flambda"] is None:
+            continue
+        for q, v in case.g["search"][hf].items():
+            ev = formats.forward_evalue(v["score"], Z, hdr["ftau"], hdr["flambda"])
+            if v["evalue"] > 1e-250 and ev > 1e-250 and v["score"] > hdr["ftau"] + 1:
+                assert 0.93 < ev / v["evalue"] < 1.08, (hf, q, ev, v["evalue"])
+                n += 1
+    assert n > 0 or case.name.startswith("example")

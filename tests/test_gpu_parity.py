@@ -557,3 +557,30 @@ def test_randomised_small_cases(seed, orc, tmp_path):
         want = ohm[ph[p]].align(seqs[pq[p]])
         assert np.array_equal(cols[co[p]:co[p + 1]], want), (seed, pq[p], ph[p], len(seqs[pq[p]]))
     e.close()
+
+
+def test_bench_line_contract(tmp_path):
+    """bench.py prints ONE JSON line with the driver's keys, the roofline object and the CPU baseline."""
+    _need_gpu()
+    import json
+    import os
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--nq", "192", "--nh", "6", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 1 and j["warmup"] == 0 and j["higher_is_better"] is True
+    assert j["value"] > 0 and j["unit"] == "queries/s" and j["dtype"] == "f32" and j["data"] == "synthetic"
+    assert "workload" in j["config"] and "model" not in j["config"]
+    rf = j["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and "traffic" in rf
+    cb = j["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]

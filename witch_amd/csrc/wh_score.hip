@@ -8,6 +8,11 @@
 //   score assembly, "%6.1f" rounding to deci-bits.
 // One wavefront per pair; a workgroup shares one model's emission table in LDS and pulls
 // (model, query-block) items from a global counter until the list is drained.
+//
+// This fused body (two waves per SIMD) was the default until wh_score7.hip (the same sweeps as
+// non-inlined functions, three waves per SIMD) replaced it; it stays selectable
+// (WH_SCORE_KERNEL=1, and 3 for the split-phase experiment) as the A/B reference the design
+// notes quote, and wh_score_big.hip's long-model variant shares its structure.
 #include <hip/hip_runtime.h>
 
 #include "wh_device.h"

@@ -1,4 +1,7 @@
 // Scoring kernel, two (query, HMM) problems per wavefront (packed float32 math).
+// EXPERIMENT kept for A/B (WH_SCORE_KERNEL=2): measured 968 ms against 719 ms for the fused
+// single-problem kernel and 555 ms for the phase-call kernel on 8192 queries x 200 HMMs - on gfx950 a
+// packed fp32 op holds the SIMD for two passes, so packing saves issue slots, not VALU time.
 //
 // What "hmmsearch --cpu 1 --noali -E 99999999 --max" computes for a (query, HMM) pair
 // (witch_msa/gcmm/algorithm.py:526-532; algorithm: SURVEY.md A.2-A.6):

@@ -584,3 +584,22 @@ def test_bench_line_contract(tmp_path):
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and "traffic" in rf
     cb = j["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+
+
+def test_kernel_variants_agree(golden_case, monkeypatch):
+    """The A/B reference kernels the design notes quote (fused two-wave body, packed two-queries
+    body) stay consistent with the default phase-call kernel: same reported mask, deci-bit scores
+    within one unit (their float32 summation orders differ in the last bits)."""
+    _need_gpu()
+    case = golden_case
+    e, seqs, res, offs = _load(case)
+    monkeypatch.delenv("WH_SCORE_KERNEL", raising=False)
+    d0, f0 = e.score(res, offs)
+    for variant in ("1", "2"):
+        monkeypatch.setenv("WH_SCORE_KERNEL", variant)
+        d1, f1 = e.score(res, offs)
+        assert np.array_equal(f0 & 7, f1 & 7), (case.name, variant)
+        assert np.abs(d0.astype(np.int64) - d1).max() <= 1, (case.name, variant)
+        assert (d0 == d1).mean() >= 0.999, (case.name, variant)
+    monkeypatch.delenv("WH_SCORE_KERNEL", raising=False)
+    e.close()

@@ -603,3 +603,33 @@ def test_kernel_variants_agree(golden_case, monkeypatch):
         assert (d0 == d1).mean() >= 0.999, (case.name, variant)
     monkeypatch.delenv("WH_SCORE_KERNEL", raising=False)
     e.close()
+
+
+@pytest.mark.parametrize("root_len", [900, 1100, 1400])
+def test_large_protein_models(root_len, orc, tmp_path):
+    """Protein models of 16 / 20 / 24 cells per lane: 20 emission rows no longer fit in LDS beside
+    both table orientations from 20 cells on, so those go to the pass-synchronous kernels (short
+    and long queries, scoring and alignment)."""
+    _need_gpu()
+    from witch_amd import synth
+    from witch_amd.ehmm import EHMM, pack_queries
+    fam = synth.make_family(555 + root_len, root_len, 8, "amino", 0.03, 1e-4)
+    eh = synth.make_ehmm(fam, 2, str(tmp_path), witch_layout=False)
+    e = EHMM(eh.paths, hmm_index=eh.index, nseq=eh.nseq)
+    assert root_len - 50 < int(e.M.max()) <= 1536
+    ohm = [orc.OracleHMM(p) for p in eh.paths]
+    for qlen in (150, 900):
+        names, seqs = synth.make_queries(fam, 3 + qlen, 4, qlen)
+        seqs = [s.astype(np.uint8) for s in seqs]
+        res, offs = pack_queries(seqs)
+        deci, flags, fwd = e.score(res, offs, want_fwd=True)
+        od, of, ofwd, osc = orc.score_batch(ohm, res, offs)
+        assert np.max(np.abs(fwd - ofwd)) <= 2e-4
+        assert np.array_equal(flags & 3, of & 3)
+        assert np.abs(deci.astype(np.int64) - od).max() <= 1
+        pq = [q for q in range(len(seqs)) for _ in range(e.H)]
+        ph = [h for q in range(len(seqs)) for h in range(e.H)]
+        cols, co = e.align(res, offs, pq, ph)
+        for p in range(len(pq)):
+            assert np.array_equal(cols[co[p]:co[p + 1]], ohm[ph[p]].align(seqs[pq[p]])), (qlen, pq[p], ph[p])
+    e.close()

@@ -487,7 +487,21 @@ static hipError_t launch_align_q(int Q, const AlignArgs &a, int blocks, int thre
   }
 }
 
+// protein models of 20/24 cells per lane do not fit both orientations beside 20 emission rows:
+// they run the pass-synchronous variant too
+static hipError_t launch_align_swap_mid(int Q, const AlignArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
+  if (a.logsp) {
+    if (Q == 20) return launch_one<20, false, true, true, true>(a, blocks, threads, lds, s);
+    if (Q == 24) return launch_one<24, false, true, true, true>(a, blocks, threads, lds, s);
+  } else {
+    if (Q == 20) return launch_one<20, false, true, true>(a, blocks, threads, lds, s);
+    if (Q == 24) return launch_one<24, false, true, true>(a, blocks, threads, lds, s);
+  }
+  return hipErrorInvalidValue;
+}
+
 hipError_t launch_align(int Q, const AlignArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
+  if (a.swap && Q <= 24) return launch_align_swap_mid(Q, a, blocks, threads, lds, s);
   if (a.logsp) return a.spec_scratch ? launch_align_log_q<true>(Q, a, blocks, threads, lds, s) : launch_align_log_q<false>(Q, a, blocks, threads, lds, s);
   return a.spec_scratch ? launch_align_q<true>(Q, a, blocks, threads, lds, s) : launch_align_q<false>(Q, a, blocks, threads, lds, s);
 }

@@ -407,7 +407,12 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
         rc_plan = waves >= 1 ? WH_OK : WH_ERANGE;
         lds = kLdsHeader + table + (size_t)waves * wave_lds * sizeof(float);
       }
-      if (specg && Q >= 20 && !((kver == 7 || kver == 8) && Q <= (getenv("WH_K7_SG_MAXQ") ? atoi(getenv("WH_K7_SG_MAXQ")) : kMaxQFast) && !getenv("WH_SPECG_V1"))) {
+      // 20/24-cell models in the HBM special-state mode: the phase-call kernel if both table
+      // orientations and the emission rows fit beside at least 4 waves (nucleotide models), else the
+      // pass-synchronous kernel (one orientation resident, emission rows from L2: protein models)
+      const bool k7_sg_ok = (kver == 7 || kver == 8) && !getenv("WH_SPECG_V1") && rc_plan == WH_OK && waves >= 4 &&
+                            Q <= (getenv("WH_K7_SG_MAXQ") ? atoi(getenv("WH_K7_SG_MAXQ")) : kMaxQFast);
+      if (specg && Q >= 20 && !k7_sg_ok) {
         int rcb = run_big();
         if (rcb) return rcb;
         if (launches >= 60) break;
@@ -614,7 +619,15 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
     int waves = 0, SP = 0, wave_lds = 0; size_t lds = 0;
     if (Q <= kMaxQFast && plan_align_block(Q, e->K, std::max(max_len, 1), &waves, &SP, &wave_lds, &lds) != WH_OK) waves = 0;
     int Klds = e->K;
-    if (Q > kMaxQFast) {   // long models: one orientation resident, 4 waves, special states in HBM
+    bool swap = Q > kMaxQFast;
+    if (!swap && Q >= 20 && (waves < 4 || getenv("WH_FORCE_SPECG"))) {
+      // 20/24-cell models whose emission rows (protein: 20) do not fit beside BOTH orientations even
+      // with the special states in HBM: pass-synchronous variant
+      const size_t table2 = (size_t)(e->K + 2 * FW_NARR) * Q * kWave * sizeof(float);
+      const size_t per_wave = (size_t)((std::max(max_len, 1) + 3) / 4 + 4) * sizeof(float);
+      if (kLdsHeader + table2 + 4 * per_wave > kLdsBudget) swap = true;
+    }
+    if (swap) {   // long models: one orientation resident, 4 waves, special states in HBM
       SP = (std::max(max_len, 1) + 1 + 3) / 4 * 4;
       wave_lds = -((std::max(max_len, 1) + 3) / 4 + 4);
       waves = 4;
@@ -637,7 +650,7 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       for (int st = lo; st < hi; st += waves) { items.push_back(h); items.push_back(st); items.push_back(std::min(waves, hi - st)); }
     }
     const int n = (int)items.size() / 3 - first;
-    if (n > 0) { plans.push_back({Q, first, n, waves, SP, wave_lds, Klds}); ldss.push_back(lds); }
+    if (n > 0) { plans.push_back({Q, first, n, waves, SP, wave_lds, Klds + (swap ? 1000 : 0)}); ldss.push_back(lds); }
   }
   const size_t nit = items.size() / 3;
   std::vector<int32_t> soa(items.size());
@@ -658,7 +671,7 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
     a.col_offsets = d_col_offsets; a.cols = d_cols;
     a.counter = (int *)e->d_counter.p + launches;
     a.Lcap = std::max(max_len, 1); a.SP = plans[pl][4]; a.wave_lds = std::abs(plans[pl][5]);
-    a.K = e->K; a.Kp = e->Kp; a.Klds = plans[pl][6];
+    a.K = e->K; a.Kp = e->Kp; a.Klds = plans[pl][6] % 1000; a.swap = plans[pl][6] >= 1000 ? 1 : 0;
     a.logsp = logsp ? 1 : 0;
     a.redo_count = (!logsp && want_redo) ? d_redo_count : nullptr;
     a.redo_list = (!logsp && want_redo) ? d_redo_list : nullptr;

@@ -93,6 +93,7 @@ struct AlignArgs {
   int *redo_count;             // pairs whose Backward sweep saturated (float32 range) are appended to
   int32_t *redo_list;          // redo_list for the log-space pass (NULL in that pass)
   int logsp;                   // 1: this launch is the log-space pass
+  int swap;                    // 1: pass-synchronous variant (one table orientation resident in LDS)
 };
 hipError_t launch_align(int Q, const AlignArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
 

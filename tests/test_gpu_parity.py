@@ -605,18 +605,18 @@ def test_kernel_variants_agree(golden_case, monkeypatch):
     e.close()
 
 
-@pytest.mark.parametrize("root_len", [900, 1100, 1400])
+@pytest.mark.parametrize("root_len", [900, 1100, 1400, 1800])
 def test_large_protein_models(root_len, orc, tmp_path):
-    """Protein models of 16 / 20 / 24 cells per lane: 20 emission rows no longer fit in LDS beside
-    both table orientations from 20 cells on, so those go to the pass-synchronous kernels (short
-    and long queries, scoring and alignment)."""
+    """Protein models of 16 / 20 / 24 / 32 cells per lane: 20 emission rows no longer fit in LDS
+    beside both table orientations from 20 cells on, so those go to the pass-synchronous kernels;
+    at 32 cells the emission rows stay in L2 (short and long queries, scoring and alignment)."""
     _need_gpu()
     from witch_amd import synth
     from witch_amd.ehmm import EHMM, pack_queries
     fam = synth.make_family(555 + root_len, root_len, 8, "amino", 0.03, 1e-4)
     eh = synth.make_ehmm(fam, 2, str(tmp_path), witch_layout=False)
     e = EHMM(eh.paths, hmm_index=eh.index, nseq=eh.nseq)
-    assert root_len - 50 < int(e.M.max()) <= 1536
+    assert root_len - 50 < int(e.M.max()) <= 2048
     ohm = [orc.OracleHMM(p) for p in eh.paths]
     for qlen in (150, 900):
         names, seqs = synth.make_queries(fam, 3 + qlen, 4, qlen)

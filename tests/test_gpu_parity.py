@@ -633,3 +633,65 @@ def test_large_protein_models(root_len, orc, tmp_path):
         for p in range(len(pq)):
             assert np.array_equal(cols[co[p]:co[p + 1]], ohm[ph[p]].align(seqs[pq[p]])), (qlen, pq[p], ph[p])
     e.close()
+
+
+def test_headline_size_properties(orc, tmp_path):
+    """BASELINE.json's headline configuration at full size (100 000 queries x 200 HMMs): properties
+    that do not need the oracle at that size - determinism of the scoring kernel, structure of the
+    top-k table and of the aligned columns - plus an oracle spot check on a random sample."""
+    _need_gpu()
+    import torch
+    import bench
+    from witch_amd.ehmm import EHMM, pack_queries
+    fam, se, names, seqs, k = bench.make_workload("dna_100k_x200", str(tmp_path), None, None)
+    e = EHMM(se.paths, hmm_index=se.index, nseq=se.nseq)
+    res, offs = pack_queries([s_.astype(np.uint8) for s_ in seqs])
+    res_t, off_t = torch.from_numpy(res).cuda(), torch.from_numpy(offs).cuda()
+    maxlen = int(np.max(np.diff(offs)))
+    d1, f1 = e.score_t(res_t, off_t, maxlen)
+    d2, f2 = e.score_t(res_t, off_t, maxlen)
+    assert torch.equal(d1, d2) and torch.equal(f1, f2)                    # idempotent / deterministic
+    deci, flags = d1.cpu().numpy(), f1.cpu().numpy()
+    assert deci.shape == (100000, 200)
+    rep = (flags & 1) == 1
+    assert (deci[~rep] == 0).all() and rep.mean() > 0.99
+    idx, w, nk, nu = [t.cpu().numpy() for t in e.topk_t(d1, f1, k)]
+    assert ((nu >= 1) & (nu <= nk) & (nk <= k)).all()
+    assert (np.diff(w, axis=1) <= 1e-15).all() and (w >= 0).all() and (w.sum(1) <= 1 + 1e-9).all()
+    cum = np.cumsum(w, axis=1)
+    reached = cum[np.arange(len(nu)), nu - 1] >= 0.999
+    assert (reached | (nu == nk)).all()                                   # 0.999 prefix rule (aligner.py:58-63)
+    first_short = (nu > 1) & (cum[np.arange(len(nu)), np.maximum(nu - 2, 0)] >= 0.999)
+    assert not first_short.any()                                          # and not one model more than needed
+    valid = idx[:, 0] >= 0
+    assert valid.all()
+    srt = np.sort(idx, axis=1)
+    assert ((np.diff(srt, axis=1) != 0) | (srt[:, 1:] < 0)).all()         # no model twice per query
+    # align the first 20 000 queries' kept models: columns strictly increasing inside [0, M)
+    nq_a = 20000
+    ar = np.arange(k)[None, :]
+    keep = ar < nu[:nq_a, None]
+    pq = np.nonzero(keep)[0]
+    ph = np.array([e.pos_of_index[int(x)] for x in idx[:nq_a][keep]], dtype=np.int32)
+    cols, co = e.align(res, offs, pq, ph)
+    M = e.M
+    lens = np.diff(co)
+    pair_of = np.repeat(np.arange(len(pq)), lens)
+    ok = cols >= 0
+    assert (cols[ok] < M[ph][pair_of[ok]]).all()
+    for p in np.random.default_rng(0).choice(len(pq), size=2000, replace=False):     # monotone columns, sampled
+        c = cols[co[p]:co[p + 1]]
+        c = c[c >= 0]
+        assert (np.diff(c) > 0).all()
+    # oracle spot check: 48 random (query, model) pairs
+    rng = np.random.default_rng(1)
+    qs = rng.choice(100000, size=48, replace=False)
+    ohm = {}
+    for q in qs:
+        h = int(rng.integers(0, e.H))
+        if h not in ohm:
+            ohm[h] = orc.OracleHMM(se.paths[h])
+        r = ohm[h].score(seqs[q].astype(np.uint8))
+        assert bool(flags[q, h] & 1) == bool(r.flags & 1)
+        assert abs(int(deci[q, h]) - int(r.decibits)) <= 1, (q, h)
+    e.close()

@@ -63,7 +63,7 @@ def make_workload(name, workdir, nq_override=None, nh_override=None):
     return fam, ehmm, names, seqs, k
 
 
-def hot_path_step(e, res_t, off_t, maxlen, k, gather_topk=None):
+def hot_path_step(e, res_t, off_t, maxlen, k, gather_topk=None, keep_device=False):
     """One pass of the hot path; returns host-side results (top-k table, aligned columns)."""
     import torch
     deci, flags = e.score_t(res_t, off_t, maxlen)
@@ -79,13 +79,46 @@ def hot_path_step(e, res_t, off_t, maxlen, k, gather_topk=None):
     torch.cumsum(lens, 0, out=co[1:])
     total_cols = int(co[-1].item())
     cols = e.align_t(res_t, off_t, maxlen, pq, ph, co, total_cols)
+    if keep_device:      # inputs of the next stage (weighted consensus), kept on the device
+        hot_path_step.dev = dict(pq=pq, ph=ph, pw=w[keep].contiguous(), co=co, cols=cols, nu=nu, flags=flags)
     if gather_topk is not None:
         idx, w, nk, nu = gather_topk(idx, w, nk, nu)
     out = (idx.cpu(), w.cpu(), nk.cpu(), nu.cpu(), cols.cpu(), co.cpu())
     hot_path_step.dense_redo = int(((flags & 16) != 0).sum().item())
     hot_path_step.multidomain = int(((flags & 2) != 0).sum().item())
     hot_path_step.reported = int(((flags & 1) != 0).sum().item())
+    hot_path_step.aligned_cells = float((lens.double() * torch.from_numpy(e.M.astype(np.float64)).to(ph.device)[ph.long()]).sum().item())
     return out, int(pq.numel()), total_cols
+
+
+def consensus_stage(e, synth_ehmm, fam, off_t, maxlen, k):
+    """Next row #1 (aligner.py:376-473) on the outputs of the last hot_path_step: HIP-event time of
+    wh_consensus_dev over every query of this rank.  Reported as an extra stage, not part of <value>."""
+    import torch
+    d = hot_path_step.dev
+    dev = off_t.device
+    nq = off_t.numel() - 1
+    qpo = torch.zeros(nq + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(d["nu"].long(), 0, out=qpo[1:])
+    ret = [np.asarray(h.map_cols[1:] - 1, dtype=np.int32) for h in synth_ehmm.hmms]
+    ng = [np.asarray(h.nongaps, dtype=np.int32) for h in synth_ehmm.hmms]
+    ro = np.zeros(len(ret) + 1, dtype=np.int64)
+    ro[1:] = np.cumsum([len(r) for r in ret])
+    ro_t = torch.from_numpy(ro).to(dev)
+    ret_t = torch.from_numpy(np.concatenate(ret)).to(dev)
+    ng_t = torch.from_numpy(np.concatenate(ng)).to(dev)
+    e.consensus_t(off_t, maxlen, qpo, d["ph"], d["pw"], d["co"], d["cols"], ro_t, ret_t, ng_t, fam.msa.shape[1], k)
+    torch.cuda.synchronize()
+    ms, _ = e.last_kernel_ms(3)
+    return ms
+
+
+def crc_of(*arrays):
+    import zlib
+    c = 0
+    for a in arrays:
+        c = zlib.crc32(np.ascontiguousarray(a).tobytes(), c)
+    return c
 
 
 def cpu_baseline(ehmm_paths, nseq, seqs, k, n_sample, threads):
@@ -178,51 +211,77 @@ def main():
         kern_ms = [0.0, 0.0, 0.0]
         kern_n = [0, 0, 0]
         npairs = ncols = 0
-        for _ in range(args.steps):
-            out, npairs, ncols = hot_path_step(e, res_t, off_t, maxlen, k, gather)
+        for st in range(args.steps):
+            out, npairs, ncols = hot_path_step(e, res_t, off_t, maxlen, k, gather, keep_device=(st == args.steps - 1))
             for which in range(3):
                 ms, n = e.last_kernel_ms(which)
                 kern_ms[which] += ms
                 kern_n[which] += n
         barrier()
         dt = time.perf_counter() - t0
-        e.set_timing(False)
         if world > 1:
             tmax = torch.tensor([dt], device="cpu" if rehearsal else "cuda", dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
+        # ---- outside the timed region: the next stage (weighted consensus) and the value distributions
+        cons_ms = consensus_stage(e, synth_ehmm, fam, off_t, maxlen, k) if hi > lo else 0.0
+        e.set_timing(False)
 
         if rank == 0:
             H = e.H
             M = e.M.astype(np.float64)
-            L = float(np.mean(np.diff(offs)))
+            lens_local = np.diff(offs).astype(np.float64)
+            L = float(np.mean(lens_local)) if hi > lo else 0.0
             qps = nq_total * args.steps / dt
-            # dominant kernel: the fused scoring kernel.  Algorithmic HBM bytes per (query,HMM)
-            # pair: the Forward rows of the envelope are written once and
-            # read once, 2 states x 4 B each way = 16 B per (residue x model node) cell,
-            # plus the query residues and the 9 output bytes.
             n_local = hi - lo
+            # ---- rooflines per SURVEY.md section 8(d).  Unit = one DP cell (residue x model node).
+            # Scoring (dominant kernel, VALU-bound by design): 32 flop/cell for the multihit Forward +
+            # Backward parsers + ~45 flop/cell for the envelope sweeps (unihit Forward, Backward, decoding,
+            # null2) over the envelope's cells; the envelope of a full-length hit is the whole query, so
+            # 77 flop/cell over L x M cells per pair.  Peak: 157.3 TFLOP/s fp32 vector (packed rate; the
+            # plain v_fma_f32 the sweeps use reaches the same SIMD throughput on gfx950).
             score_launches = max(kern_n[0], 1)
             score_ms = kern_ms[0] / score_launches
-            bytes_per_launch = n_local * float(np.sum(16.0 * L * M + L + 9.0)) * args.steps / score_launches
-            achieved = bytes_per_launch / (score_ms * 1e-3) / 1e9 if score_ms > 0 else 0.0
-            traffic = None
+            cells_step = float(lens_local.sum() * M.sum())              # every local query x every model
+            cells_launch = cells_step * args.steps / score_launches
+            s_tflops = cells_launch * 77.0 / (score_ms * 1e-3) / 1e12 if score_ms > 0 else 0.0
+            traffic, traffic_src = None, None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
                 try:
                     tj = json.load(open(tpath))
-                    if tj.get("workload") == args.workload and not args.nq and not args.nh:
+                    if tj.get("workload") == args.workload and not args.nq and not args.nh and world == 1:
                         traffic = tj.get("score_kernel_hbm_bytes_per_launch")
+                        traffic_src = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command, not this run)"
                 except Exception:
                     traffic = None
-            # VALU view of the same kernel (it is arithmetic-bound by design):
-            # 5 DP sweeps (2 multihit parsers, 2 envelope sweeps, decoding) ~ 77 flop per cell
-            flops = n_local * float(np.sum(L * M)) * 77.0 * args.steps / score_launches
-            roofline = {"bound": "hbm", "kernel": "wh::k7::score_kernel7", "achieved": round(achieved, 1), "peak": 8000.0,
-                        "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+            roofline = {"bound": "valu", "kernel": "wh::k7::score_kernel7", "achieved": round(s_tflops, 2), "peak": 157.3,
+                        "unit": "TFLOP/s", "frac": round(s_tflops / 157.3, 4), "traffic": traffic, "traffic_source": traffic_src,
+                        "flop_per_cell": 77, "cells_per_launch": cells_launch,
                         "kernel_ms_avg": round(score_ms, 3), "launches": score_launches,
-                        "valu_tflops": round(flops / (score_ms * 1e-3) / 1e12, 2) if score_ms > 0 else 0.0,
-                        "valu_peak_tflops": 157.3}
+                        "peak_unpacked": 78.6, "frac_unpacked": round(s_tflops / 78.6, 4),
+                        "algorithmic_hbm_bytes_per_launch": float(n_local * H * (L + 9.0)) * args.steps / score_launches}
+            # Alignment (HBM-bound by construction): 52 B/cell (Forward rows written + read 24, posteriors
+            # 16, OA rows 12) over the aligned pairs' L x M cells; the stage time spans the pass's launches
+            # (one per model size class, plus the log-space redo pass when pairs leave float32 range).
+            align_ms = kern_ms[2] / args.steps
+            a_gbs = hot_path_step.aligned_cells * 52.0 / (align_ms * 1e-3) / 1e9 if align_ms > 0 else 0.0
+            roofline_align = {"bound": "hbm", "kernel": "wh::align_kernel", "achieved": round(a_gbs, 1), "peak": 8000.0,
+                              "unit": "GB/s", "frac": round(a_gbs / 8000.0, 4), "bytes_per_cell": 52,
+                              "cells_per_step": hot_path_step.aligned_cells, "stage_ms": round(align_ms, 3),
+                              "launches_per_step": kern_n[2] / args.steps, "traffic": None}
+            t_s, t_a = kern_ms[0] / args.steps, align_ms
+            combined = (t_s * roofline["frac"] + t_a * roofline_align["frac"]) / (t_s + t_a) if t_s + t_a > 0 else 0.0
+            # ---- the three distributions SURVEY.md 8(d) asks for with every run
+            nu_h = np.bincount(out[3].numpy(), minlength=k + 1).tolist()
+            dist3 = {"n_used": {str(i): int(c) for i, c in enumerate(nu_h) if c},
+                     "multidomain_frac": round(hot_path_step.multidomain / max(1, n_local * H), 8)}
+            ns = min(256, n_local)
+            if ns > 0:
+                _, _, det = e.score(res[:offs[ns]], offs[:ns + 1], want_detail=True)
+                nreg = np.array([d.nregions for d in det])
+                dist3["regions_per_pair"] = {str(i): int(c) for i, c in enumerate(np.bincount(nreg)) if c}
+                dist3["regions_per_pair_sample"] = "first %d queries x %d HMMs" % (ns, H)
             line = {
                 "metric": "query-seqs aligned/sec (100k queries x 200-HMM eHMM)",
                 "value": round(qps, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
@@ -231,12 +290,18 @@ def main():
                 "data": "synthetic",
                 "config": {"workload": args.workload, "n_queries": nq_total, "n_hmms": H,
                            "query_len": int(round(L)), "model_len_min": int(M.min()), "model_len_max": int(M.max()),
+                           "model_len_mean": round(float(M.mean()), 1),
                            "k": k, "aligned_pairs_per_step": npairs, "sharding": "queries/%d" % world,
                            "pairs_reported_rank0": hot_path_step.reported, "pairs_multidomain_rank0": hot_path_step.multidomain,
-                           "pairs_dense_redo_rank0": hot_path_step.dense_redo},
+                           "pairs_dense_redo_rank0": hot_path_step.dense_redo,
+                           "topk_crc32": crc_of(out[0].numpy(), out[1].numpy(), out[2].numpy(), out[3].numpy())},
                 "stage_ms_per_step": {"score": round(kern_ms[0] / args.steps, 3), "topk": round(kern_ms[1] / args.steps, 3),
                                       "align": round(kern_ms[2] / args.steps, 3)},
-                "roofline": roofline,
+                "extra_stage_ms": {"consensus_rank0": round(cons_ms, 3),
+                                   "note": "weighted consensus DP (next row #1) over this rank's queries, outside the timed region"},
+                "roofline": roofline, "roofline_align": roofline_align,
+                "roofline_time_weighted_frac": round(combined, 4),
+                "distributions": dist3,
             }
             if not args.no_cpu_baseline:
                 threads = min(os.cpu_count() or 1, 64)
@@ -245,6 +310,16 @@ def main():
                 line["cpu_baseline"] = {"value": round(v, 3), "unit": "queries/s", "cores": threads, "kind": "port",
                                         "sample": "first %d queries x %d HMMs through the float64 oracle "
                                                   "(score + top-k + align), %.1f s" % (min(n_sample, nq_total), H, cdt)}
+                # the reference's real CPU path (HMMER 3.1b2 binaries, the reference's process scheme) on a
+                # subsample of the same seeded inputs, timed in the build container by
+                # tools/time_reference_cpu.py - the binaries cannot travel to the GPU box
+                rpath = os.path.join(ROOT, "profiles", "cpu_reference_%s.json" % args.workload)
+                if os.path.exists(rpath) and not args.nh:
+                    rj = json.load(open(rpath))
+                    line["cpu_baseline"]["reference"] = {
+                        "value": rj["queries_per_s"], "unit": "queries/s", "cores": rj["cores"], "kind": "reference",
+                        "host": rj["host"], "sample": rj["sample"], "seconds": rj["seconds"],
+                        "source": "profiles/cpu_reference_%s.json (recorded in the build container, not this run)" % args.workload}
             print(json.dumps(line), flush=True)
         e.close()
     finally:

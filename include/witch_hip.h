@@ -149,6 +149,10 @@ int wh_consensus_dev(wh_ehmm *e, const int64_t *d_offsets, int64_t nq, int32_t m
 int wh_last_kernel_ms(wh_ehmm *e, int which, double *ms, int *launches);
 /* When enabled, every kernel launch is bracketed by HIP events (bench/roofline use). */
 int wh_set_timing(wh_ehmm *e, int enabled);
+/* Development knobs (WH_SCORE_KERNEL, WH_KEEP_LOG2, WH_MAX_WAVES, WH_FORCE_SPECG,
+ * WH_NO_LOGSPACE, WH_STATS, WH_TRACE, WH_DBG).  The environment is read ONCE, in wh_ehmm_load; this call
+ * changes a knob on a live handle (A/B harness tools/ab_score.py).  Production needs none of them. */
+int wh_set_option(wh_ehmm *e, const char *name, const char *value);
 
 #ifdef __cplusplus
 }

@@ -99,7 +99,7 @@ def test_result_files_and_weights_txt(golden_case, tmp_path):
     case = golden_case
     eng = _engine_from_golden(case)
     dirs = {i: str(tmp_path / ("A_0_%d" % i)) for i in case.hmm_index}
-    files = gcmm.search(dirs)
+    files, _ = gcmm.search(dirs)
     assert len(files) == len(case.hmm_index)
     for i, hf in zip(case.hmm_index, case.hmm_files):
         path = os.path.join(dirs[i], "hmmsearch.results.A_0_%d.fragment_chunk_0" % i)
@@ -118,6 +118,38 @@ def test_result_files_and_weights_txt(golden_case, tmp_path):
     # one line per query 'taxon:((idx, w), ...)' exactly as weighting.py:174-179 writes it
     first = open(wpath).readline()
     assert first.split(":")[0] in weights and first.split(":", 1)[1].startswith("((")
+
+
+def test_search_uses_the_reference_chunk_layout(tmp_path):
+    """a1: lcm(#HMMs, #cpus) // #HMMs chunks, queries dealt round-robin in input order, empty
+    chunks skipped, at most 20 000 per chunk, names with blanks/tabs rejected
+    (witch_msa/gcmm/algorithm.py:280-284, 351-359, 376-383; helpers/alignment_tools.py:674-686)."""
+    import numpy as np
+    assert gcmm.num_chunks_for(200, 8) == 1 and gcmm.num_chunks_for(10, 8) == 4 and gcmm.num_chunks_for(3, 16) == 16
+    names = ["q%d" % i for i in range(7)]
+    assert gcmm.divide_to_equal_chunks(names, 3) == [["q0", "q3", "q6"], ["q1", "q4"], ["q2", "q5"]]
+    assert gcmm.divide_to_equal_chunks(["a", "b"], 4) == [["a"], ["b"], None, None]
+    big = gcmm.divide_to_equal_chunks(range(50001), 2)          # 25 000.5 per chunk > 20 000 -> 3 chunks
+    assert len(big) == 3 and max(len(c) for c in big) <= 20000
+    hmm_index = [0, 1, 2]
+    deci = np.arange(21, dtype=np.int32).reshape(7, 3) * 7 - 30
+    flags = (deci % 5 != 0).astype(np.uint8)
+    gcmm.install(gcmm.QueryAlignmentEngine.from_results(names, hmm_index, [5, 6, 7], deci, flags, 2))
+    dirs = {i: str(tmp_path / "root" / ("A_0_%d" % i)) for i in hmm_index}
+    seqs = {n: "ACGT" * (i + 1) for i, n in enumerate(names)}
+    files, frags = gcmm.search(dirs, num_cpus=4, fragment_chunk_dir=str(tmp_path / "fragment_chunks"), sequences=seqs)
+    assert gcmm.num_chunks_for(3, 4) == 4 and len(frags) == 4 and len(files) == 12
+    assert open(frags[1]).read() == ">q1\nACGTACGT\n>q5\n" + "ACGT" * 6 + "\n"
+    for col, i in enumerate(hmm_index):
+        seen = {}
+        for c in range(4):
+            d = ast.literal_eval(open(os.path.join(dirs[i], "hmmsearch.results.A_0_%d.fragment_chunk_%d" % (i, c))).read())
+            assert set(d) <= set(names[c::4])
+            seen.update(d)
+        assert seen == {n: (0.0, deci[r, col] / 10.0) for r, n in enumerate(names) if flags[r, col]}
+    gcmm.install(gcmm.QueryAlignmentEngine.from_results(["ok", "has blank"], hmm_index, [5, 6, 7], deci[:2], flags[:2], 2))
+    with pytest.raises(ValueError, match="whitespaces or tabs"):
+        gcmm.search(dirs)
 
 
 def test_no_engine_installed_fails_loudly():

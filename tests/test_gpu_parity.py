@@ -43,6 +43,26 @@ def _near_boundary(score):
     return abs((frac % 1.0) - 0.5) < BOUNDARY_EPS * 10.0
 
 
+LONG_EPS = 0.02       # bits; SURVEY.md D-8's gate ("0 whenever the float64 restatement is >= 0.02 bit from a
+                      # rounding boundary"): used where the envelopes are hundreds to thousands of rows long and
+                      # the float32 null2 sums differ from the float64 oracle by more than a few ulp
+
+
+def _near_boundary_eps(score, eps):
+    frac = abs(float(score)) * 10.0
+    return abs((frac % 1.0) - 0.5) < eps * 10.0
+
+
+def _check_decibits(deci, od, osc, rep, ctx, eps=BOUNDARY_EPS):
+    """deci-bit scores equal the oracle's, except that a pair whose float score
+    lies within <eps> bit of a "%6.1f" rounding boundary may differ by exactly one unit."""
+    bad = np.argwhere((deci != od) & rep)
+    for qi, hj in bad:
+        assert abs(int(deci[qi, hj]) - int(od[qi, hj])) == 1, (ctx, int(qi), int(hj), int(deci[qi, hj]), int(od[qi, hj]))
+        assert _near_boundary_eps(osc[qi, hj], eps), (ctx, int(qi), int(hj), float(osc[qi, hj]), int(deci[qi, hj]), int(od[qi, hj]))
+    return len(bad)
+
+
 def test_score_against_oracle_and_golden(golden_case, orc):
     _need_gpu()
     case = golden_case
@@ -354,9 +374,11 @@ def test_long_protein_queries_with_several_hits(orc, tmp_path):
     for d in det:
         for t in range(d.nenv):
             assert np.isfinite(d.domcorr[t]) and np.isfinite(d.envsc[t])
+    single = (of & 2) == 0                    # multi-hit envelopes (flag 2) are the stochastic class of HMMER itself
+    n_bad = _check_decibits(deci, od, osc, ((of & 1) == 1) & single, "long protein", LONG_EPS)
     diff = np.abs(deci.astype(np.int64) - od)
-    assert diff.max() <= 1, diff.max()        # long envelopes: float32 vs float64 null2 sums, one deci-bit at most
-    assert (diff == 0).mean() >= 0.9
+    assert diff.max() <= 1, diff.max()
+    print("\n[long protein] %d of %d single-domain pairs one deci-bit off (all within %.2f bit of a boundary)" % (n_bad, int(single.sum()), LONG_EPS))
     # alignment of the same queries: where the best hit is not the first one the scaled float32
     # sweeps cannot represent it (HMMER's Decoding overflows there and hmmalign switches to its
     # log-space code); the kernel detects the same condition and redoes those pairs in log space
@@ -379,7 +401,7 @@ def test_level0_shims_reproduce_hmmer_outputs(tmp_path):
     import subprocess
     import threading
     from tests.conftest import load_case, ROOT
-    from witch_amd.gcmm.algorithm import evalHMMSearchOutput
+    from tests.refparse import evalHMMSearchOutput
     from witch_amd.shim import formats
     from witch_amd.shim.server import Server, GpuBackend
     bindir = os.path.join(ROOT, "witch_amd", "shim", "bin")
@@ -445,7 +467,7 @@ def test_long_queries_on_20_and_24_cell_models(orc, tmp_path):
         od, of, ofwd, osc = orc.score_batch(ohm, res, offs)
         assert np.max(np.abs(fwd - ofwd)) <= 2e-4
         assert np.array_equal(flags & 3, of & 3)
-        assert np.abs(deci.astype(np.int64) - od).max() <= 1
+        _check_decibits(deci, od, osc, (of & 1) == 1, ("20/24-cell long", root_len), LONG_EPS)
         e.close()
 
 
@@ -478,9 +500,7 @@ def test_every_kernel_instantiation_against_the_oracle(root_len, orc, tmp_path):
         od, of, ofwd, osc = orc.score_batch(ohm, res, offs)
         assert np.max(np.abs(fwd - ofwd)) <= 2e-4, (root_len, qlen)
         assert np.array_equal(flags & 3, of & 3), (root_len, qlen)
-        rep = (of & 1) == 1
-        assert np.abs(deci.astype(np.int64) - od)[rep].max() <= 1, (root_len, qlen)
-        assert ((deci == od) | ~rep).mean() >= 0.9
+        _check_decibits(deci, od, osc, (of & 1) == 1, (root_len, qlen), BOUNDARY_EPS if qlen <= 330 else LONG_EPS)
     e.close()
 
 
@@ -547,9 +567,7 @@ def test_randomised_small_cases(seed, orc, tmp_path):
     assert np.array_equal(np.isfinite(fwd), fin)
     assert np.max(np.abs(fwd[fin] - ofwd[fin])) <= 1e-4
     assert np.array_equal(flags & 3, of & 3)
-    rep = (of & 1) == 1
-    if rep.any():
-        assert np.abs(deci.astype(np.int64) - od)[rep].max() <= 1
+    _check_decibits(deci, od, osc, (of & 1) == 1, ("random", seed))
     pq = [q for q in range(len(seqs)) for _ in range(e.H)]
     ph = [h for q in range(len(seqs)) for h in range(e.H)]
     cols, co = e.align(res, offs, pq, ph)
@@ -580,28 +598,32 @@ def test_bench_line_contract(tmp_path):
     assert j["value"] > 0 and j["unit"] == "queries/s" and j["dtype"] == "f32" and j["data"] == "synthetic"
     assert "workload" in j["config"] and "model" not in j["config"]
     rf = j["roofline"]
-    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s")
+    assert rf["bound"] == "valu" and rf["unit"] == "TFLOP/s" and rf["peak"] == 157.3
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and "traffic" in rf
+    assert abs(rf["achieved"] - rf["cells_per_launch"] * 77 / (rf["kernel_ms_avg"] * 1e-3) / 1e12) < 0.02 * rf["achieved"] + 0.01
+    ra = j["roofline_align"]
+    assert ra["bound"] == "hbm" and ra["unit"] == "GB/s" and abs(ra["frac"] - ra["achieved"] / 8000.0) < 1e-3
+    assert set(j["distributions"]) >= {"n_used", "multidomain_frac", "regions_per_pair"}
+    assert j["extra_stage_ms"]["consensus_rank0"] > 0
     cb = j["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
 
 
-def test_kernel_variants_agree(golden_case, monkeypatch):
-    """The A/B reference kernels the design notes quote (fused two-wave body, packed two-queries
-    body) stay consistent with the default phase-call kernel: same reported mask, deci-bit scores
-    within one unit (their float32 summation orders differ in the last bits)."""
+def test_ab_slot_kernel_agrees(golden_case):
+    """The A/B slot (the phase-call kernel compiled a second time, option WH_SCORE_KERNEL=8) and the
+    development knobs that change the launch plan give the default kernel's results."""
     _need_gpu()
     case = golden_case
     e, seqs, res, offs = _load(case)
-    monkeypatch.delenv("WH_SCORE_KERNEL", raising=False)
     d0, f0 = e.score(res, offs)
-    for variant in ("1", "2"):
-        monkeypatch.setenv("WH_SCORE_KERNEL", variant)
+    for name, value in (("WH_SCORE_KERNEL", "8"), ("WH_MAX_WAVES", "4"), ("WH_FORCE_SPECG", "1")):
+        e.set_option(name, value)
         d1, f1 = e.score(res, offs)
-        assert np.array_equal(f0 & 7, f1 & 7), (case.name, variant)
-        assert np.abs(d0.astype(np.int64) - d1).max() <= 1, (case.name, variant)
-        assert (d0 == d1).mean() >= 0.999, (case.name, variant)
-    monkeypatch.delenv("WH_SCORE_KERNEL", raising=False)
+        e.set_option(name, "")
+        assert np.array_equal(f0, f1), (case.name, name)
+        assert np.array_equal(d0, d1), (case.name, name)
+    with pytest.raises(Exception):
+        e.set_option("WH_SCORE_KERNEL", "2")      # removed experiment kernels are refused, not ignored
     e.close()
 
 
@@ -626,7 +648,7 @@ def test_large_protein_models(root_len, orc, tmp_path):
         od, of, ofwd, osc = orc.score_batch(ohm, res, offs)
         assert np.max(np.abs(fwd - ofwd)) <= 2e-4
         assert np.array_equal(flags & 3, of & 3)
-        assert np.abs(deci.astype(np.int64) - od).max() <= 1
+        _check_decibits(deci, od, osc, (of & 1) == 1, ("large protein", root_len, qlen), BOUNDARY_EPS if qlen <= 330 else LONG_EPS)
         pq = [q for q in range(len(seqs)) for _ in range(e.H)]
         ph = [h for q in range(len(seqs)) for h in range(e.H)]
         cols, co = e.align(res, offs, pq, ph)
@@ -695,3 +717,166 @@ def test_headline_size_properties(orc, tmp_path):
         assert bool(flags[q, h] & 1) == bool(r.flags & 1)
         assert abs(int(deci[q, h]) - int(r.decibits)) <= 1, (q, h)
     e.close()
+
+
+def _oracle_topk_and_pairs(orc, hmm_index, nseq, od, of, k):
+    """rank -> calculateWeights -> 0.999 prefix with the numpy restatement (oracle side)."""
+    size_of = dict(zip(hmm_index, nseq))
+    tables, pairs = [], []
+    for qi in range(od.shape[0]):
+        ranked = orc.rank_bitscores(hmm_index, od[qi], of[qi] & 1)
+        if not ranked:
+            tables.append(([], 0))
+            continue
+        idxs = [r[0] for r in ranked]
+        w = orc.calculate_weights(idxs, [r[1] for r in ranked], [size_of[i] for i in idxs], k)
+        nu = orc.adaptive_cut(w)
+        tables.append((w, nu))
+        pairs += [(qi, i) for i, _ in w[:nu]]
+    return tables, pairs
+
+
+def test_config2_dna_1k_x10_at_its_stated_size(orc, tmp_path):
+    """BASELINE.json configs[1] in full: 1 000 synthetic 150-nt queries x 10-HMM ensemble, k = 4 - flags,
+    deci-bits (rounding-boundary rule), top-k tables and every aligned column against the oracle."""
+    _need_gpu()
+    import bench
+    from witch_amd.ehmm import EHMM, pack_queries
+    fam, se, names, seqs, k = bench.make_workload("dna_1k_x10", str(tmp_path))
+    assert len(seqs) == 1000 and len(se.paths) == 10 and k == 4
+    seqs = [s_.astype(np.uint8) for s_ in seqs]
+    e = EHMM(se.paths, hmm_index=se.index, nseq=se.nseq)
+    res, offs = pack_queries(seqs)
+    deci, flags, fwd = e.score(res, offs, want_fwd=True)
+    ohm = [orc.OracleHMM(p) for p in se.paths]
+    od, of, ofwd, osc = orc.score_batch(ohm, res, offs, nthreads=16)
+    assert np.max(np.abs(fwd - ofwd)) <= 1e-4
+    assert np.array_equal(flags & 7, of & 7)
+    n_off = _check_decibits(deci, od, osc, (of & 1) == 1, "dna_1k_x10")
+    idx, w, nk, nu = e.topk(deci, flags, k)
+    tables, _ = _oracle_topk_and_pairs(orc, se.index, se.nseq, deci, flags, k)     # same scores in: tables must be identical
+    for qi, (ow, onu) in enumerate(tables):
+        assert nk[qi] == len(ow) and nu[qi] == onu, qi
+        assert idx[qi, :nk[qi]].tolist() == [i for i, _ in ow], qi
+        assert np.allclose(w[qi, :nk[qi]], [x for _, x in ow], rtol=1e-12, atol=0), qi
+    pq = [q for q in range(len(seqs)) for _ in range(int(nu[q]))]
+    ph = [e.pos_of_index[int(idx[q, j])] for q in range(len(seqs)) for j in range(int(nu[q]))]
+    cols, co = e.align(res, offs, pq, ph)
+    ocols, oco = orc.align_batch(ohm, res, offs, pq, ph, nthreads=16)
+    assert np.array_equal(co, oco) and np.array_equal(cols, ocols), int((cols != ocols).sum())
+    print("\n[dna_1k_x10] %d pairs scored, %d one deci-bit off at a rounding boundary, %d pairs aligned identically"
+          % (deci.size, n_off, len(pq)))
+    e.close()
+
+
+def test_config5_shape_all_500_hmms(orc, tmp_path):
+    """BASELINE.json configs[4] shape (aa_50k_x500): ALL 500 protein HMMs (more than 256 candidates per
+    query: the multi-slot path of the top-k kernel) x 64 mixed-length queries (50-2000 residues) against
+    the oracle, then the structural properties of the top-k table and the aligned columns at 10 000 queries."""
+    _need_gpu()
+    import torch
+    import bench
+    from witch_amd.ehmm import EHMM, pack_queries
+    fam, se, names, seqs, k = bench.make_workload("aa_50k_x500", str(tmp_path), 10000, None)
+    assert len(se.paths) == 500 and k == 10
+    seqs = [s_.astype(np.uint8) for s_ in seqs]
+    e = EHMM(se.paths, hmm_index=se.index, nseq=se.nseq)
+    # ---- 64 queries x 500 HMMs against the oracle
+    sub = seqs[:64]
+    assert min(len(s_) for s_ in sub) < 400 and max(len(s_) for s_ in sub) > 1500
+    res, offs = pack_queries(sub)
+    deci, flags, fwd = e.score(res, offs, want_fwd=True)
+    ohm = [orc.OracleHMM(p) for p in se.paths]
+    od, of, ofwd, osc = orc.score_batch(ohm, res, offs, nthreads=16)
+    fin = np.isfinite(ofwd)
+    assert np.max(np.abs(fwd[fin] - ofwd[fin]) / np.maximum(1.0, np.abs(ofwd[fin]) / 1000)) <= 2e-4
+    assert np.array_equal(flags & 3, of & 3)
+    single = (of & 3) == 1
+    n_off = _check_decibits(deci, od, osc, single, "aa_50k_x500", LONG_EPS)
+    assert np.abs(deci.astype(np.int64) - od)[(of & 1) == 1].max() <= 1
+    idx, w, nk, nu = e.topk(deci, flags, k)
+    tables, _ = _oracle_topk_and_pairs(orc, se.index, se.nseq, deci, flags, k)
+    for qi, (ow, onu) in enumerate(tables):
+        assert nk[qi] == len(ow) and nu[qi] == onu, qi
+        got_i, ref_i = idx[qi, :nk[qi]].tolist(), [i for i, _ in ow]
+        assert np.allclose(w[qi, :nk[qi]], [x for _, x in ow], rtol=1e-12, atol=0), qi
+        for a, b, wa, wb in zip(got_i, ref_i, w[qi], [x for _, x in ow]):     # order identical up to 1e-12 weight ties
+            assert a == b or abs(wa - wb) <= 1e-12 * max(wa, wb), (qi, got_i, ref_i)
+    pq = [q for q in range(len(sub)) for _ in range(int(nu[q]))]
+    ph = [e.pos_of_index[int(idx[q, j])] for q in range(len(sub)) for j in range(int(nu[q]))]
+    cols, co = e.align(res, offs, pq, ph)
+    ocols, oco = orc.align_batch(ohm, res, offs, pq, ph, nthreads=16)
+    assert np.array_equal(cols, ocols), int((cols != ocols).sum())
+    print("\n[aa_50k_x500] 64 x 500 pairs: %d single-domain pairs one deci-bit off (boundary), %d multidomain pairs, %d pairs aligned identically"
+          % (n_off, int(((of & 2) != 0).sum()), len(pq)))
+    # ---- 10 000 queries x 500 HMMs: size-independent properties
+    res, offs = pack_queries(seqs)
+    res_t, off_t = torch.from_numpy(res).cuda(), torch.from_numpy(offs).cuda()
+    maxlen = int(np.max(np.diff(offs)))
+    d1, f1 = e.score_t(res_t, off_t, maxlen)
+    d2, f2 = e.score_t(res_t, off_t, maxlen)
+    assert torch.equal(d1, d2) and torch.equal(f1, f2)
+    assert torch.equal(d1[:64].cpu(), torch.from_numpy(deci)) and torch.equal(f1[:64].cpu(), torch.from_numpy(flags))   # batch-size independent
+    idx, w, nk, nu = [t.cpu().numpy() for t in e.topk_t(d1, f1, k)]
+    fl = f1.cpu().numpy()
+    rep_n = ((fl & 1) == 1).sum(1)
+    assert (nk == np.minimum(rep_n, k)).all()
+    has = nk > 0
+    assert ((nu >= 1) & (nu <= nk))[has].all() and (nu[~has] == 0).all()
+    assert (np.diff(w, axis=1) <= 1e-15).all() and (w >= 0).all() and (w.sum(1) <= 1 + 1e-9).all()
+    cum = np.cumsum(w, axis=1)
+    rows = np.nonzero(has)[0]
+    assert ((cum[rows, nu[rows] - 1] >= 0.999) | (nu[rows] == nk[rows])).all()
+    srt = np.sort(idx, axis=1)
+    assert ((np.diff(srt, axis=1) != 0) | (srt[:, 1:] < 0)).all()
+    dd = d1.cpu().numpy()
+    pos = np.array([e.pos_of_index.get(int(x), 0) for x in idx[:, 0]])
+    best = np.where((fl & 1) == 1, dd, -10**9)
+    # the first model has the largest weight n_i 2^{s_i}: no reported model may beat it on both score and size
+    top_s = dd[np.arange(len(pos)), pos]
+    assert ((best.max(1) - top_s)[has] <= 10 * np.log2(e.nseq.max() / e.nseq.min()) + 1).all()
+    nq_a = 1500
+    keep = np.arange(k)[None, :] < nu[:nq_a, None]
+    pq = np.nonzero(keep)[0]
+    ph = np.array([e.pos_of_index[int(x)] for x in idx[:nq_a][keep]], dtype=np.int32)
+    cols, co = e.align(res, offs, pq, ph)
+    lens = np.diff(co)
+    pair_of = np.repeat(np.arange(len(pq)), lens)
+    ok = cols >= 0
+    assert (cols[ok] < e.M[ph][pair_of[ok]]).all()
+    for p in np.random.default_rng(0).choice(len(pq), size=min(1000, len(pq)), replace=False):
+        c = cols[co[p]:co[p + 1]]
+        assert (np.diff(c[c >= 0]) > 0).all()
+    e.close()
+
+
+def test_two_rank_rehearsal_equals_one_rank(tmp_path):
+    """BASELINE.json configs[3] rehearsed on one GPU: bench.py under torch.distributed.run with two ranks
+    (WITCH_BENCH_REHEARSAL=1: both on cuda:0, gloo gather) must gather exactly the 1-rank top-k table."""
+    _need_gpu()
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    common = ["--steps", "1", "--warmup", "0", "--nq", "3001", "--nh", "12", "--no-cpu-baseline"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common,
+                        capture_output=True, text=True, timeout=900, env=env)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    env2 = dict(env, WITCH_BENCH_REHEARSAL="1")
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                         "--master-addr", "127.0.0.1", "--master-port", str(port),
+                         os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common,
+                        capture_output=True, text=True, timeout=900, env=env2)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    j1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][0])
+    j2 = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][0])
+    assert j2["n_gpus"] == 2 and j2["config"]["sharding"] == "queries/2"
+    assert j1["config"]["topk_crc32"] == j2["config"]["topk_crc32"]
+    assert j1["distributions"]["n_used"] == j2["distributions"]["n_used"]

@@ -48,7 +48,7 @@ def server(tmp_path):
 
 def test_hmmsearch_table_is_readable_by_the_reference_parser(tmp_path):
     from witch_amd.shim import formats
-    from witch_amd.gcmm.algorithm import evalHMMSearchOutput
+    from tests.refparse import evalHMMSearchOutput
     hdr = formats.hmm_header(_hmm(tmp_path))
     assert hdr == {"name": "A_0_7", "M": 12, "ftau": -4.2, "flambda": 0.71}
     rows = [("q1", 123.4, 0.3, 1), ("a_long_query_name_with_many_chars", -5.2, 0.0, 2), ("q3", 7.0, 11.1, 1)]
@@ -97,7 +97,7 @@ def test_argv_of_witch_command_lines():
 def test_clients_end_to_end_with_a_stub_backend(server, tmp_path):
     if not os.path.exists(os.path.join(BIN, "hmmsearch")):
         subprocess.run(["make", "-C", os.path.join(ROOT, "witch_amd", "shim")], check=True, stdout=subprocess.DEVNULL)
-    from witch_amd.gcmm.algorithm import evalHMMSearchOutput
+    from tests.refparse import evalHMMSearchOutput
     from witch_amd.shim import formats
     hmm = _hmm(tmp_path)
     fa = tmp_path / "q.fa"

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B harness for the scoring kernel: same process, same GPU, same inputs.
 
-Each variant is a set of WH_* environment knobs (read by wh_score_dev at every call);
+Each variant is a set of WH_* knobs (set on the live handle with wh_set_option);
 prints the kernel time of every variant and how many (query, HMM) deci-bit scores / flags
 differ from the first variant.   usage: tools/ab_score.py NQ "K=V,K=V" "K=V" ...
 """
@@ -44,10 +44,10 @@ def main():
         for rep in range(2):
             for v in variants:
                 for kn in knobs:
-                    os.environ.pop(kn, None)
+                    e.set_option(kn, "")
                 for kv in filter(None, v.split(",")):
                     a, b = kv.split("=")
-                    os.environ[a] = b
+                    e.set_option(a, b)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 deci, flags = e.score_t(res_t, off_t, maxlen)

@@ -51,7 +51,21 @@ struct KernelTimer {
   bool pending = false;
 };
 
+// Development knobs.  Read from the environment ONCE, at wh_ehmm_load;
+// wh_set_option changes them on a live handle (tools/ab_score.py).  None is needed in production.
+struct Knobs {
+  int kernel = 7;            // 7 phase-call scoring kernel; 8 its second compilation (A/B slot)
+  float keep_scale = 0.f;    // Forward-row spill threshold relative to E(row); 0 = the kernel's default
+  int max_waves = 0;         // cap on waves per workgroup (0 = planner's choice)
+  bool force_specg = false;  // force the HBM special-state mode
+  bool no_logspace = false;  // skip the log-space alignment pass
+  bool stats = false, trace = false;
+  int dbg = 0;
+};
+static const int kMaxLaunches = 60;   // work-queue heads in d_counter (slot 63 belongs to the consensus kernel)
+
 struct wh_ehmm {
+  Knobs knobs;
   int device = 0;
   int alphabet = 0, K = 0, Kp = 0;
   int cu_count = 256;
@@ -122,6 +136,8 @@ void wh_ehmm_free(wh_ehmm *e) {
   delete e;
 }
 
+static void knobs_from_env(wh_ehmm *e);
+
 wh_ehmm *wh_ehmm_load(const char *const *hmm_paths, const int32_t *hmm_index, const int32_t *nseq, int n) {
   if (!hmm_paths || n <= 0) { set_error("wh_ehmm_load: no models"); return nullptr; }
   if (g_device < 0 && wh_init(0) != WH_OK) return nullptr;
@@ -156,6 +172,7 @@ wh_ehmm *wh_ehmm_load(const char *const *hmm_paths, const int32_t *hmm_index, co
     e->max_M = std::max(e->max_M, h.M);
   }
   degen_masks(e->alphabet, e->degen);
+  knobs_from_env(e.get());
   hipDeviceProp_t p;
   if (hipGetDeviceProperties(&p, e->device) == hipSuccess) e->cu_count = p.multiProcessorCount;
   std::vector<int32_t> ns((size_t)n), ix((size_t)n);
@@ -194,6 +211,31 @@ int wh_ehmm_map(const wh_ehmm *e, int h, int32_t *map_cols) {
   const HostHMM &m = e->hmms[(size_t)h];
   for (int k = 1; k <= m.M; k++) map_cols[k - 1] = m.map[(size_t)k];
   return WH_OK;
+}
+
+int wh_set_option(wh_ehmm *e, const char *name, const char *value) {
+  if (!e || !name) { set_error("wh_set_option: bad argument"); return WH_EINVAL; }
+  const char *v = value ? value : "";
+  const bool on = *v && strcmp(v, "0") != 0;
+  Knobs &k = e->knobs;
+  if (!strcmp(name, "WH_SCORE_KERNEL")) {
+    const int kv = *v ? atoi(v) : 7;
+    if (kv != 7 && kv != 8) { set_error("WH_SCORE_KERNEL=%s: this build has kernels 7 and 8", v); return WH_EINVAL; }
+    k.kernel = kv;
+  } else if (!strcmp(name, "WH_KEEP_LOG2")) k.keep_scale = *v ? ldexpf(1.0f, atoi(v)) : 0.f;
+  else if (!strcmp(name, "WH_MAX_WAVES")) k.max_waves = *v ? std::max(1, std::min(16, atoi(v))) : 0;
+  else if (!strcmp(name, "WH_FORCE_SPECG")) k.force_specg = on;
+  else if (!strcmp(name, "WH_NO_LOGSPACE")) k.no_logspace = on;
+  else if (!strcmp(name, "WH_STATS")) k.stats = on;
+  else if (!strcmp(name, "WH_TRACE")) k.trace = on;
+  else if (!strcmp(name, "WH_DBG")) k.dbg = atoi(v);
+  else { set_error("wh_set_option: unknown option %s", name); return WH_EINVAL; }
+  return WH_OK;
+}
+
+static void knobs_from_env(wh_ehmm *e) {
+  for (const char *name : {"WH_SCORE_KERNEL", "WH_KEEP_LOG2", "WH_MAX_WAVES", "WH_FORCE_SPECG", "WH_NO_LOGSPACE", "WH_STATS", "WH_TRACE", "WH_DBG"})
+    if (const char *v = getenv(name)) (void)wh_set_option(e, name, v);
 }
 
 int wh_set_timing(wh_ehmm *e, int enabled) {
@@ -238,32 +280,30 @@ int wh_last_kernel_ms(wh_ehmm *e, int which, double *ms, int *launches) {
 static const size_t kLdsBudget = 160 * 1024 - 512;
 static const size_t kLdsHeader = 16;   // work-item slot in front of the tables (keeps them 16-byte aligned)
 
-// LDS plan of score_kernel2: tables (K emission rows + 16 transition arrays) + per wave two
-// problem blocks (special-state arrays, null2 table, region list, residues).
-static int plan_block(int Q, int K, bool treg, int Lcap, int *waves, int *SP, int *wave_lds, size_t *lds) {
-  (void)treg;
+// LDS plan of the phase-call scoring kernel: tables (K emission rows + both transition
+// orientations) + per wave one block (special-state arrays, null2 table, region list, residues).
+static int plan_block1(const wh_ehmm *e, int Q, int K, int Lcap, int wmax, int *waves, int *SP, int *wave_lds, size_t *lds) {
   const int sp = (Lcap + 1 + 3) / 4 * 4;
-  const int prob = 8 * sp + 32 + 3 * WH_MAX_ENVELOPES + (Lcap + 3) / 4 + 4;
-  const int wl = 2 * prob;
+  const int wl = 8 * sp + 32 + 3 * WH_MAX_ENVELOPES + (Lcap + 3) / 4 + 4;
   const size_t table = (size_t)(K + 2 * FW_NARR) * Q * kWave * sizeof(float);
-  int w = 8;
-  if (const char *ev = getenv("WH_MAX_WAVES")) w = std::max(1, std::min(16, atoi(ev)));   // tuning knob
+  int w = wmax;
+  if (e->knobs.max_waves > 0) w = std::max(1, std::min(wmax, e->knobs.max_waves));
   while (w >= 1 && kLdsHeader + table + (size_t)w * wl * sizeof(float) > kLdsBudget) w--;
   if (w < 1) return WH_ERANGE;
   *waves = w; *SP = sp; *wave_lds = wl; *lds = kLdsHeader + table + (size_t)w * wl * sizeof(float);
   return WH_OK;
 }
 
-static int plan_block1(int Q, int K, int Lcap, int wmax, int *waves, int *SP, int *wave_lds, size_t *lds, int narr = FW_NARR) {
-  const int sp = (Lcap + 1 + 3) / 4 * 4;
-  const int wl = 8 * sp + 32 + 3 * WH_MAX_ENVELOPES + (Lcap + 3) / 4 + 4;
-  const size_t table = (size_t)(K + 2 * narr) * Q * kWave * sizeof(float);
-  int w = wmax;
-  if (const char *ev = getenv("WH_MAX_WAVES")) w = std::max(1, std::min(wmax, atoi(ev)));
-  while (w >= 1 && kLdsHeader + table + (size_t)w * wl * sizeof(float) > kLdsBudget) w--;
-  if (w < 1) return WH_ERANGE;
-  *waves = w; *SP = sp; *wave_lds = wl; *lds = kLdsHeader + table + (size_t)w * wl * sizeof(float);
-  return WH_OK;
+// Resident workgroups are capped so that <per_block> bytes of per-wave workspace each fit in
+// about 70 % of the free HBM (the work-item counter loops tolerate fewer workgroups than CUs).
+static int clamp_blocks(int blocks, size_t per_block, const DevBuf &have) {
+  if (blocks <= 1 || per_block == 0) return blocks;
+  if ((size_t)blocks * per_block <= have.cap) return blocks;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return blocks;
+  const size_t budget = (size_t)((double)(free_b + have.cap) * 0.7);
+  const size_t fit = budget / per_block;
+  return (int)std::max<size_t>(1, std::min<size_t>((size_t)blocks, fit));
 }
 
 int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets, int64_t nq,
@@ -279,149 +319,13 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
   if (timer_begin(e, 0, s)) return WH_EHIP;
   int launches = 0;
   if (nq > 0) {
+    if ((int)e->by_q.size() > kMaxLaunches) { set_error("too many model size classes (%zu)", e->by_q.size()); return WH_ERANGE; }
     const int H = (int)e->hmms.size();
+    const Knobs &kn = e->knobs;
+    const int Lc = std::max(max_len, 1);
     int list_off = 0;
     for (auto &kv : e->by_q) {
       const int Q = kv.first;
-      const bool treg = false;
-      int waves, SP, wave_lds;
-      size_t lds;
-      // pass-synchronous kernel (wh_score_big.hip): long models (28+ cells per lane).  Long queries on
-      // 20/24-cell models run the phase-call kernel's HBM special-state mode (1.7-1.85x faster than the
-      // pass-synchronous kernel there; the older fused kernel's variant misbehaves on gfx950 at 20+ cells)
-      auto run_big = [&]() -> int {
-        const int Lc = std::max(max_len, 1);
-        const int wl = 32 + 3 * WH_MAX_ENVELOPES + (Lc + 3) / 4 + 4;
-        waves = 4;
-        int Klds = e->K;
-        size_t table = (size_t)(Klds + 8) * Q * kWave * sizeof(float);
-        if (kLdsHeader + table + (size_t)waves * wl * sizeof(float) > kLdsBudget) { Klds = 0; table = (size_t)8 * Q * kWave * sizeof(float); }
-        lds = kLdsHeader + table + (size_t)waves * wl * sizeof(float);
-        if (lds > kLdsBudget) { set_error("query length %d with model class Q=%d does not fit in LDS", max_len, Q); return WH_ERANGE; }
-        ScoreArgs a;
-        memset(&a, 0, sizeof a);
-        a.hmms = (const DevHMM *)e->d_hmms.p;
-        a.tables = (const float *)e->d_tables.p;
-        a.hmm_list = (const int32_t *)e->d_lists.p + list_off;
-        a.n_list = (int)kv.second.size();
-        list_off += a.n_list;
-        a.residues = d_residues; a.offsets = d_offsets; a.nq = nq;
-        a.QB = waves * 4;
-        a.n_qblocks = (int)((nq + a.QB - 1) / a.QB);
-        a.n_items = a.n_list * a.n_qblocks;
-        a.counter = (int *)e->d_counter.p + launches;
-        a.Lcap = Lc; a.SP = (Lc + 1 + 3) / 4 * 4; a.wave_lds = wl; a.Klds = Klds;
-        const int blocks = std::min(a.n_items, e->cu_count);
-        a.scratch_stride = (size_t)(a.Lcap + 1) * 2 * Q * kWave;
-        a.spec_stride = (size_t)8 * a.SP;
-        if (e->d_scratch.ensure((size_t)blocks * waves * a.scratch_stride * sizeof(float)) ||
-            e->d_spec.ensure((size_t)blocks * waves * a.spec_stride * sizeof(float)))
-          return WH_ENOMEM;
-        a.scratch = (float *)e->d_scratch.p;
-        a.spec_scratch = (float *)e->d_spec.p;
-        a.decibits = d_decibits; a.flags = d_flags; a.fwd_bits = d_fwd_bits; a.detail = d_detail;
-        a.H = H; a.K = e->K; a.Kp = e->Kp;
-        memcpy(a.degen, e->degen, sizeof a.degen);
-        if (const char *dv = getenv("WH_DBG")) a.dbg = atoi(dv);
-        HIPCHK(hipMemsetAsync(a.counter, 0, sizeof(int), s));
-        if (getenv("WH_TRACE")) fprintf(stderr, "[wh] score(long model) Q=%d waves=%d blocks=%d lds=%zu Klds=%d items=%d Lcap=%d\n", Q, waves, blocks, lds, Klds, a.n_items, a.Lcap);
-        hipError_t err = launch_score_big(Q, a, blocks, waves * kWave, lds, s);
-        if (err != hipSuccess) { set_error("score kernel launch (Q=%d, long model) failed: %s", Q, hipGetErrorString(err)); return WH_EHIP; }
-        launches++;
-        return WH_OK;
-      };
-      if (Q > kMaxQFast) {
-        int rcb = run_big();
-        if (rcb) return rcb;
-        if (launches >= 60) break;
-        continue;
-      }
-      const char *kenv = getenv("WH_SCORE_KERNEL");
-      const int kver = kenv ? atoi(kenv) : 7;    // 7 phase-call kernel, 3 waves/SIMD (default, fastest measured); 1 fused single; 2 fused packed pair; 3 split; 5/6 register-table experiments
-      if (kver == 3) {
-        // split: phase A (Forward/Backward parsers + regions) then phase B (envelopes + assembly)
-        const size_t np = (size_t)nq * H;
-        if (e->d_recs.ensure(np * sizeof(PairRec))) return WH_ENOMEM;
-        for (int phase = 1; phase <= 2; phase++) {
-          if (plan_block1(Q, e->K, std::max(max_len, 1), phase == 1 ? 16 : 12, &waves, &SP, &wave_lds, &lds) != WH_OK) {
-            set_error("query length %d with model class Q=%d does not fit in LDS", max_len, Q);
-            return WH_ERANGE;
-          }
-          ScoreArgs a;
-          memset(&a, 0, sizeof a);
-          a.hmms = (const DevHMM *)e->d_hmms.p;
-          a.tables = (const float *)e->d_tables.p;
-          a.hmm_list = (const int32_t *)e->d_lists.p + list_off;
-          a.n_list = (int)kv.second.size();
-          a.residues = d_residues; a.offsets = d_offsets; a.nq = nq;
-          a.QB = waves * 4;
-          a.n_qblocks = (int)((nq + a.QB - 1) / a.QB);
-          a.n_items = a.n_list * a.n_qblocks;
-          a.counter = (int *)e->d_counter.p + launches;
-          a.Lcap = std::max(max_len, 1); a.SP = SP; a.wave_lds = wave_lds;
-          const int blocks = std::min(a.n_items, e->cu_count);
-          a.scratch_stride = (size_t)(a.Lcap + 1) * 2 * Q * kWave;
-          if (phase == 2 && e->d_scratch.ensure((size_t)blocks * waves * a.scratch_stride * sizeof(float))) return WH_ENOMEM;
-          a.scratch = (float *)e->d_scratch.p;
-          a.decibits = d_decibits; a.flags = d_flags; a.fwd_bits = d_fwd_bits; a.detail = d_detail;
-          a.recs = (PairRec *)e->d_recs.p;
-          a.H = H; a.K = e->K; a.Kp = e->Kp;
-          memcpy(a.degen, e->degen, sizeof a.degen);
-          if (const char *dv = getenv("WH_DBG")) a.dbg = atoi(dv);
-          HIPCHK(hipMemsetAsync(a.counter, 0, sizeof(int), s));
-          hipError_t err = launch_score(Q, phase, a, blocks, waves * kWave, lds, s);
-          if (err != hipSuccess) { set_error("score kernel launch (Q=%d, phase %d) failed: %s", Q, phase, hipGetErrorString(err)); return WH_EHIP; }
-          launches++;
-        }
-        list_off += (int)kv.second.size();
-        if (launches >= 60) break;
-        continue;
-      }
-      const bool use4 = false;
-      bool use5 = false;
-      if (kver == 5 && Q <= 16) {
-        // v1 with the transition tables in VGPRs: LDS holds only the emission rows
-        const int sp = (std::max(max_len, 1) + 1 + 3) / 4 * 4;
-        const int wl = 8 * sp + 32 + 3 * WH_MAX_ENVELOPES + (std::max(max_len, 1) + 3) / 4 + 4;
-        const size_t table = (size_t)e->K * Q * kWave * sizeof(float);
-        int w = 8;
-        if (const char *ev = getenv("WH_MAX_WAVES")) w = std::max(1, std::min(16, atoi(ev)));
-        while (w >= 1 && kLdsHeader + table + (size_t)w * wl * sizeof(float) > kLdsBudget) w--;
-        if (w >= 4) { use5 = true; waves = w; SP = sp; wave_lds = wl; lds = kLdsHeader + table + (size_t)w * wl * sizeof(float); }
-      }
-      const bool use1 = kver == 1 || kver == 6 || kver == 7 || kver == 8 || (kver == 4 && !use4) || (kver == 5 && !use5);
-      bool specg = false;
-      int rc_plan = (use4 || use5) ? WH_OK : use1 ? plan_block1(Q, e->K, std::max(max_len, 1), (kver == 7 || kver == 8) ? (getenv("WH_WMAX") ? atoi(getenv("WH_WMAX")) : (Q <= 16 ? 12 : 8)) : 8, &waves, &SP, &wave_lds, &lds, FW_NARR)
-                         : plan_block(Q, e->K, treg, std::max(max_len, 1), &waves, &SP, &wave_lds, &lds);
-      if (use1 && !use5 && (rc_plan != WH_OK || waves < 4 || getenv("WH_FORCE_SPECG"))) {
-        // long queries: the per-row special-state arrays move to a per-wave HBM region
-        specg = true;
-        SP = (std::max(max_len, 1) + 1 + 3) / 4 * 4;
-        wave_lds = 32 + 3 * WH_MAX_ENVELOPES + (std::max(max_len, 1) + 3) / 4 + 4;
-        const size_t table = (size_t)(e->K + 2 * FW_NARR) * Q * kWave * sizeof(float);
-        const int k7_maxq = getenv("WH_K7_SG_MAXQ") ? atoi(getenv("WH_K7_SG_MAXQ")) : kMaxQFast;
-        const bool k7 = (kver == 7 || kver == 8) && Q <= k7_maxq && !getenv("WH_SPECG_V1");
-        waves = k7 ? (Q <= 16 ? 12 : 8) : 8;     // phase-call kernel: three waves per SIMD also for long queries
-        if (const char *ev = getenv("WH_MAX_WAVES")) waves = std::max(1, std::min(waves, atoi(ev)));
-        while (waves >= 1 && kLdsHeader + table + (size_t)waves * wave_lds * sizeof(float) > kLdsBudget) waves--;
-        rc_plan = waves >= 1 ? WH_OK : WH_ERANGE;
-        lds = kLdsHeader + table + (size_t)waves * wave_lds * sizeof(float);
-      }
-      // 20/24-cell models in the HBM special-state mode: the phase-call kernel if both table
-      // orientations and the emission rows fit beside at least 4 waves (nucleotide models), else the
-      // pass-synchronous kernel (one orientation resident, emission rows from L2: protein models)
-      const bool k7_sg_ok = (kver == 7 || kver == 8) && !getenv("WH_SPECG_V1") && rc_plan == WH_OK && waves >= 4 &&
-                            Q <= (getenv("WH_K7_SG_MAXQ") ? atoi(getenv("WH_K7_SG_MAXQ")) : kMaxQFast);
-      if (specg && Q >= 20 && !k7_sg_ok) {
-        int rcb = run_big();
-        if (rcb) return rcb;
-        if (launches >= 60) break;
-        continue;
-      }
-      if (rc_plan != WH_OK) {
-        set_error("query length %d with model class Q=%d does not fit in LDS", max_len, Q);
-        return WH_ERANGE;
-      }
       ScoreArgs a;
       memset(&a, 0, sizeof a);
       a.hmms = (const DevHMM *)e->d_hmms.p;
@@ -430,55 +334,87 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       a.n_list = (int)kv.second.size();
       list_off += a.n_list;
       a.residues = d_residues; a.offsets = d_offsets; a.nq = nq;
+      a.counter = (int *)e->d_counter.p + launches;
+      a.Lcap = Lc;
+      a.decibits = d_decibits; a.flags = d_flags; a.fwd_bits = d_fwd_bits; a.detail = d_detail;
+      a.H = H; a.K = e->K; a.Kp = e->Kp;
+      a.dbg = kn.dbg;
+      a.keep_scale = kn.keep_scale;
+      memcpy(a.degen, e->degen, sizeof a.degen);
+      int waves = 0, SP = 0, wave_lds = 0;
+      size_t lds = 0;
+      // Three kernels serve a size class:
+      //  * phase-call kernel, special states in LDS: models of up to 24 cells per lane, short queries
+      //  * the same kernel with the special-state rows in HBM ("SG"): long queries
+      //  * pass-synchronous kernel (wh_score_big.hip): 28+ cells per lane, and 20/24-cell models whose
+      //    emission rows do not fit in LDS beside both orientations (protein)
+      bool big = Q > kMaxQFast, specg = false;
+      if (!big) {
+        int rc_plan = plan_block1(e, Q, e->K, Lc, Q <= 16 ? 12 : 8, &waves, &SP, &wave_lds, &lds);
+        if (rc_plan != WH_OK || waves < 4 || kn.force_specg) {
+          specg = true;
+          SP = (Lc + 1 + 3) / 4 * 4;
+          wave_lds = 32 + 3 * WH_MAX_ENVELOPES + (Lc + 3) / 4 + 4;
+          const size_t table = (size_t)(e->K + 2 * FW_NARR) * Q * kWave * sizeof(float);
+          waves = Q <= 16 ? 12 : 8;
+          if (kn.max_waves > 0) waves = std::max(1, std::min(waves, kn.max_waves));
+          while (waves >= 1 && kLdsHeader + table + (size_t)waves * wave_lds * sizeof(float) > kLdsBudget) waves--;
+          rc_plan = waves >= 1 ? WH_OK : WH_ERANGE;
+          lds = kLdsHeader + table + (size_t)waves * wave_lds * sizeof(float);
+          if (Q >= 20 && (rc_plan != WH_OK || waves < 4)) big = true;
+        }
+        if (!big && rc_plan != WH_OK) {
+          set_error("query length %d with model class Q=%d does not fit in LDS", max_len, Q);
+          return WH_ERANGE;
+        }
+      }
+      if (big) {
+        wave_lds = 32 + 3 * WH_MAX_ENVELOPES + (Lc + 3) / 4 + 4;
+        waves = 4;
+        a.Klds = e->K;
+        size_t table = (size_t)(a.Klds + 8) * Q * kWave * sizeof(float);
+        if (kLdsHeader + table + (size_t)waves * wave_lds * sizeof(float) > kLdsBudget) { a.Klds = 0; table = (size_t)8 * Q * kWave * sizeof(float); }
+        lds = kLdsHeader + table + (size_t)waves * wave_lds * sizeof(float);
+        if (lds > kLdsBudget) { set_error("query length %d with model class Q=%d does not fit in LDS", max_len, Q); return WH_ERANGE; }
+        SP = (Lc + 1 + 3) / 4 * 4;
+        specg = true;
+      }
+      a.SP = SP; a.wave_lds = wave_lds;
       a.QB = waves * 4;
       a.n_qblocks = (int)((nq + a.QB - 1) / a.QB);
       a.n_items = a.n_list * a.n_qblocks;
-      a.counter = (int *)e->d_counter.p + launches;
-      a.Lcap = std::max(max_len, 1); a.SP = SP; a.wave_lds = wave_lds;
-      const int blocks = std::min(a.n_items, e->cu_count * std::max(1, 8 / waves));
-      a.scratch_stride = (use1 || use4 || use5 ? 1 : 2) * (size_t)(a.Lcap + 1) * 2 * Q * kWave;   // Forward slab(s) per wave
+      a.scratch_stride = (size_t)(a.Lcap + 1) * 2 * Q * kWave;   // Forward slab per wave
+      a.spec_stride = specg ? (size_t)8 * a.SP : 0;
+      int blocks = std::min(a.n_items, big ? e->cu_count : e->cu_count * std::max(1, 8 / waves));
+      blocks = clamp_blocks(blocks, (size_t)waves * (a.scratch_stride + a.spec_stride) * sizeof(float), e->d_scratch);
       if (e->d_scratch.ensure((size_t)blocks * waves * a.scratch_stride * sizeof(float))) return WH_ENOMEM;
       a.scratch = (float *)e->d_scratch.p;
-      a.decibits = d_decibits; a.flags = d_flags; a.fwd_bits = d_fwd_bits; a.detail = d_detail;
-      a.H = H; a.K = e->K; a.Kp = e->Kp;
       if (specg) {
-        a.spec_stride = (size_t)8 * SP;
         if (e->d_spec.ensure((size_t)blocks * waves * a.spec_stride * sizeof(float))) return WH_ENOMEM;
         a.spec_scratch = (float *)e->d_spec.p;
       }
-      memcpy(a.degen, e->degen, sizeof a.degen);
-      if (const char *dv = getenv("WH_DBG")) a.dbg = atoi(dv);
-      if (const char *kv2 = getenv("WH_KEEP_LOG2")) a.keep_scale = ldexpf(1.0f, atoi(kv2));
-      if (getenv("WH_STATS")) {
+      if (kn.stats && !big) {
         if (e->d_recs.ensure(128)) return WH_ENOMEM;
         HIPCHK(hipMemsetAsync(e->d_recs.p, 0, 128, s));
-        { unsigned long long big = ~0ull; HIPCHK(hipMemcpyAsync((char *)e->d_recs.p + 13 * 8, &big, 8, hipMemcpyHostToDevice, s)); }
+        { unsigned long long bigv = ~0ull; HIPCHK(hipMemcpyAsync((char *)e->d_recs.p + 13 * 8, &bigv, 8, hipMemcpyHostToDevice, s)); }
         a.stats = (unsigned long long *)e->d_recs.p;
       }
-      if (getenv("WH_TRACE")) fprintf(stderr, "[wh] score Q=%d kver=%d specg=%d waves=%d blocks=%d lds=%zu SP=%d wave_lds=%d items=%d Lcap=%d\n", Q, kver, (int)specg, waves, blocks, lds, SP, wave_lds, a.n_items, a.Lcap);
+      if (kn.trace) fprintf(stderr, "[wh] score Q=%d kernel=%s specg=%d waves=%d blocks=%d lds=%zu SP=%d wave_lds=%d items=%d Lcap=%d\n", Q,
+                            big ? "pass-synchronous" : kn.kernel == 8 ? "phase-call(B)" : "phase-call", (int)specg, waves, blocks, lds, SP, wave_lds, a.n_items, a.Lcap);
       HIPCHK(hipMemsetAsync(a.counter, 0, sizeof(int), s));
-      hipError_t err = use5 ? launch_score_treg(Q, a, blocks, waves * kWave, lds, s)
-                       : (kver == 7 && (!specg || !getenv("WH_SPECG_V1"))) ? launch_score7(Q, a, blocks, waves * kWave, lds, s)
-                       : (kver == 8 && (!specg || !getenv("WH_SPECG_V1"))) ? launch_score7b(Q, a, blocks, waves * kWave, lds, s)
-                       : (kver == 6 && Q == 16 && !specg) ? launch_score_tr12(Q, getenv("WH_TRM") ? atoi(getenv("WH_TRM")) : 1, a, blocks, waves * kWave, lds, s)
-                       : use1 ? launch_score(Q, 0, a, blocks, waves * kWave, lds, s) : launch_score2(Q, a, blocks, waves * kWave, lds, s);
+      hipError_t err = big ? launch_score_big(Q, a, blocks, waves * kWave, lds, s)
+                       : kn.kernel == 8 ? launch_score7b(Q, a, blocks, waves * kWave, lds, s)
+                                        : launch_score7(Q, a, blocks, waves * kWave, lds, s);
       if (err != hipSuccess) { set_error("score kernel launch (Q=%d) failed: %s", Q, hipGetErrorString(err)); return WH_EHIP; }
       launches++;
       if (a.stats) {
         unsigned long long st[16];
         HIPCHK(hipMemcpyAsync(st, a.stats, sizeof st, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
-        fprintf(stderr, "[wh] stats Q=%d: envelope rows %llu, lane blocks kept %llu (%.1f of 64 per row), envelopes %llu, dense redos %llu\n", Q, st[0], st[1],
-                st[0] ? (double)st[1] / (double)st[0] : 0.0, st[2], st[3]);
-        { unsigned u0 = (unsigned)st[10], u1 = (unsigned)st[11]; float f0, f1; memcpy(&f0, &u0, 4); memcpy(&f1, &u1, 4);
-          fprintf(stderr, "[wh] max |Ld - mass|/Ld: sparse attempt %.3g, dense attempt %.3g\n", f0, f1); }
-        fprintf(stderr, "[wh] dbg: scale exponent k range [%lld, %lld]; last row with non-finite B cells %llu, F cells %llu, specials %llu\n",
-                (long long)st[13] - 100000, (long long)st[12] - 100000, st[14], st[15], st[9]);
         const double tot = (double)(st[4] + st[5] + st[6] + st[7] + st[8] + st[9]);
-        fprintf(stderr, "[wh] wave cycles: P1 %.1f%%  P2 %.1f%%  regions %.1f%%  P3 %.1f%%  P4 %.1f%%  null2 %.1f%%  (total %.3g ticks; P1 per row %.0f ticks)\n", 100.0 * st[4] / tot,
-                100.0 * st[5] / tot, 100.0 * st[6] / tot, 100.0 * st[7] / tot, 100.0 * st[8] / tot, 100.0 * st[9] / tot, tot, (double)st[4] / ((double)nq * a.n_list * 150.0));
+        fprintf(stderr, "[wh] Q=%d wave cycles: P1 %.1f%%  P2 %.1f%%  regions %.1f%%  P3 %.1f%%  P4 %.1f%%  null2 %.1f%%  (total %.3g ticks)\n", Q, 100.0 * st[4] / tot,
+                100.0 * st[5] / tot, 100.0 * st[6] / tot, 100.0 * st[7] / tot, 100.0 * st[8] / tot, 100.0 * st[9] / tot, tot);
       }
-      if (launches >= 60) break;
     }
   }
   if (timer_end(e, 0, s, launches)) return WH_EHIP;
@@ -600,7 +536,7 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
   for (int64_t p = 0; p < npairs; p++) order[(size_t)cursor[(size_t)ph[(size_t)p]]++] = (int32_t)p;
   if (e->d_order.ensure(sizeof(int32_t) * (size_t)npairs)) return WH_ENOMEM;
   // pairs whose Backward sweep leaves float32 range are queued on the device and redone in log space
-  const bool want_redo = !getenv("WH_NO_LOGSPACE");
+  const bool want_redo = !e->knobs.no_logspace;
   if (e->d_recs.ensure(sizeof(int32_t) * ((size_t)npairs + 4))) return WH_ENOMEM;
   int *d_redo_count = (int *)e->d_recs.p;
   int32_t *d_redo_list = (int32_t *)e->d_recs.p + 4;
@@ -620,7 +556,7 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
     if (Q <= kMaxQFast && plan_align_block(Q, e->K, std::max(max_len, 1), &waves, &SP, &wave_lds, &lds) != WH_OK) waves = 0;
     int Klds = e->K;
     bool swap = Q > kMaxQFast;
-    if (!swap && Q >= 20 && (waves < 4 || getenv("WH_FORCE_SPECG"))) {
+    if (!swap && Q >= 20 && (waves < 4 || e->knobs.force_specg)) {
       // 20/24-cell models whose emission rows (protein: 20) do not fit beside BOTH orientations even
       // with the special states in HBM: pass-synchronous variant
       const size_t table2 = (size_t)(e->K + 2 * FW_NARR) * Q * kWave * sizeof(float);
@@ -635,7 +571,7 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       if (kLdsHeader + table + (size_t)waves * (size_t)(-wave_lds) * sizeof(float) > kLdsBudget) { Klds = 0; table = (size_t)8 * Q * kWave * sizeof(float); }
       lds = kLdsHeader + table + (size_t)waves * (size_t)(-wave_lds) * sizeof(float);
       if (lds > kLdsBudget) { set_error("query length %d with model class Q=%d does not fit in LDS", max_len, Q); return WH_ERANGE; }
-    } else if (waves < 4 || getenv("WH_FORCE_SPECG")) {   // long queries: special-state rows in HBM
+    } else if (waves < 4 || e->knobs.force_specg) {   // long queries: special-state rows in HBM
       SP = (std::max(max_len, 1) + 1 + 3) / 4 * 4;
       wave_lds = -((std::max(max_len, 1) + 3) / 4 + 4);   // negative marks the HBM mode for the launch loop below
       const size_t table = (size_t)(e->K + 2 * FW_NARR) * Q * kWave * sizeof(float);
@@ -675,13 +611,15 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
     a.logsp = logsp ? 1 : 0;
     a.redo_count = (!logsp && want_redo) ? d_redo_count : nullptr;
     a.redo_list = (!logsp && want_redo) ? d_redo_list : nullptr;
-    const int blocks = std::min(n, e->cu_count * std::max(1, 8 / waves));
+    if (launches >= kMaxLaunches) { set_error("wh_align_dev: too many launches in one call"); return WH_ERANGE; }
+    int blocks = std::min(n, e->cu_count * std::max(1, 8 / waves));
+    a.scratch_stride = (size_t)(a.Lcap + 1) * 5 * Q * kWave;
+    a.spec_stride = plans[pl][5] < 0 ? (size_t)13 * a.SP : 0;
+    blocks = clamp_blocks(blocks, (size_t)waves * (a.scratch_stride + a.spec_stride) * sizeof(float), e->d_scratch);
     if (plans[pl][5] < 0) {
-      a.spec_stride = (size_t)13 * a.SP;
       if (e->d_spec.ensure((size_t)blocks * waves * a.spec_stride * sizeof(float))) return WH_ENOMEM;
       a.spec_scratch = (float *)e->d_spec.p;
     }
-    a.scratch_stride = (size_t)(a.Lcap + 1) * 5 * Q * kWave;
     if (e->d_scratch.ensure((size_t)blocks * waves * a.scratch_stride * sizeof(float))) return WH_ENOMEM;
     a.scratch = (float *)e->d_scratch.p;
     HIPCHK(hipMemsetAsync(a.counter, 0, sizeof(int), s));
@@ -710,7 +648,7 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
     std::vector<int32_t> order2((size_t)n_redo), cur2(cnt2.begin(), cnt2.end() - 1);
     std::sort(redo.begin(), redo.end());
     for (int32_t p : redo) order2[(size_t)cur2[(size_t)ph[(size_t)p]]++] = p;
-    if (getenv("WH_TRACE")) fprintf(stderr, "[wh] align: %d of %lld pairs left float32 range, redone in log space\n", n_redo, (long long)npairs);
+    if (e->knobs.trace) fprintf(stderr, "[wh] align: %d of %lld pairs left float32 range, redone in log space\n", n_redo, (long long)npairs);
     rc = run_pass(order2, cnt2, true);
     if (rc != WH_OK) return rc;
   }
@@ -779,7 +717,8 @@ int wh_consensus_dev(wh_ehmm *e, const int64_t *d_offsets, int64_t nq, int32_t m
     while (waves >= 1 && (size_t)waves * (a.Wcap + 2) * sizeof(double) > kLdsBudget) waves--;
     if (waves < 1) { set_error("backbone of %d columns does not fit the consensus kernel's LDS row", backbone_length); return WH_ERANGE; }
     const size_t lds = (size_t)waves * (a.Wcap + 2) * sizeof(double);
-    const int blocks = (int)std::min<int64_t>((nq + waves - 1) / waves, (int64_t)e->cu_count * 2);
+    int blocks = (int)std::min<int64_t>((nq + waves - 1) / waves, (int64_t)e->cu_count * 2);
+    blocks = clamp_blocks(blocks, (size_t)waves * ((size_t)(a.Lcap + 1) * (a.Wcap + 2) + (size_t)a.Lcap * a.KMAX * 12 + (size_t)a.Lcap * 4), e->d_back);
     const size_t nw = (size_t)blocks * waves;
     if (e->d_back.ensure(nw * (size_t)(a.Lcap + 1) * (a.Wcap + 2)) || e->d_cwj.ensure(nw * (size_t)a.Lcap * a.KMAX * sizeof(int32_t)) ||
         e->d_cwv.ensure(nw * (size_t)a.Lcap * a.KMAX * sizeof(double)) || e->d_cwn.ensure(nw * (size_t)a.Lcap * sizeof(int32_t)))

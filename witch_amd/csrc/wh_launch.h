@@ -6,14 +6,6 @@
 
 namespace wh {
 
-// Hand-off between the two halves of the split scoring kernel (one record per pair).
-struct PairRec {
-  float fwdsc, nullsc, fwd_bits;
-  int32_t nenv, flags;
-  int16_t regs[2 * WH_MAX_ENVELOPES];
-  int32_t pad[3];
-};
-
 struct ScoreArgs {
   const DevHMM *hmms;          // all models of the eHMM
   const float *tables;         // table buffer (fw / bw / em arrays of every model)
@@ -35,7 +27,6 @@ struct ScoreArgs {
   uint8_t *flags;
   float *fwd_bits;
   wh_pair_detail *detail;
-  PairRec *recs;               // split mode only
   float *spec_scratch;         // long-query mode: per-wave special-state rows in HBM (else NULL -> LDS)
   size_t spec_stride;          // floats per wave
   int H;
@@ -43,17 +34,13 @@ struct ScoreArgs {
   uint32_t degen[32];
   int Klds;                    // emission rows staged in LDS (= K, or 0: read from L2)
   int dbg;                     // timing experiments only: 1 = skip Forward-row stores, 2 = skip Forward-row loads
-  float keep_scale;            // Forward-row spill threshold relative to E(row); 0 = default 2^-40
-  unsigned long long *stats;   // experiments: [0] envelope rows, [1] lane blocks kept, [2] envelopes, [3] dense redos (or NULL)
+  float keep_scale;            // Forward-row spill threshold relative to E(row); 0 = the kernel's default (2^-24)
+  unsigned long long *stats;   // WH_STATS: [4..9] wave cycles per phase (or NULL)
 };
 
-hipError_t launch_score(int Q, int phase, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
 hipError_t launch_score_big(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
 hipError_t launch_score7(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
 hipError_t launch_score7b(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);   // A/B slot
-hipError_t launch_score_tr12(int Q, int mask, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
-hipError_t launch_score_treg(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
-hipError_t launch_score2(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
 
 struct TopkArgs {
   const int32_t *decibits;

@@ -76,6 +76,10 @@ class EHMM:
     def set_timing(self, on: bool):
         check(lib().wh_set_timing(self._h, 1 if on else 0), "wh_set_timing")
 
+    def set_option(self, name: str, value: str = ""):
+        """Development knob on a live handle (include/witch_hip.h: wh_set_option)."""
+        check(lib().wh_set_option(self._h, name.encode(), str(value).encode()), "wh_set_option")
+
     def last_kernel_ms(self, which: int):
         ms, n = C.c_double(0), C.c_int(0)
         check(lib().wh_last_kernel_ms(self._h, which, C.byref(ms), C.byref(n)), "wh_last_kernel_ms")
@@ -200,3 +204,19 @@ class EHMM:
                                      npairs, col_offsets_t.data_ptr(), cols.data_ptr(), self._stream()),
                   "wh_align_dev")
         return cols
+
+    def consensus_t(self, offsets_t, max_len: int, qpair_off_t, pair_h_t, pair_w_t, col_offsets_t, cols_t,
+                    ret_off_t, retained_t, nongaps_t, backbone_length: int, max_pairs_per_query: int):
+        """Weighted consensus DP on device-resident inputs (wh_consensus_dev): per residue the backbone
+        column or -1 - (column before which the insertion sits), and (min, max) touched column per query."""
+        import torch
+        nq = offsets_t.numel() - 1
+        dev = offsets_t.device
+        out = torch.empty(int(cols_t.numel() and offsets_t[-1].item()), dtype=torch.int32, device=dev)
+        mm = torch.empty((nq, 2), dtype=torch.int32, device=dev)
+        check(lib().wh_consensus_dev(self._h, offsets_t.data_ptr(), nq, int(max_len), qpair_off_t.data_ptr(),
+                                     pair_h_t.data_ptr(), pair_w_t.data_ptr(), col_offsets_t.data_ptr(),
+                                     cols_t.data_ptr(), ret_off_t.data_ptr(), retained_t.data_ptr(),
+                                     nongaps_t.data_ptr(), int(backbone_length), int(max_pairs_per_query),
+                                     out.data_ptr(), mm.data_ptr(), self._stream()), "wh_consensus_dev")
+        return out, mm

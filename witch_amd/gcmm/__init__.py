@@ -19,6 +19,6 @@ from .engine import QueryAlignmentEngine, install, current_engine  # noqa: F401
 from .loader import rankBitscores, readAndRankBitscoreMP  # noqa: F401
 from .weighting import writeWeights, calculateWeights, writeWeightsToLocal, readWeightsFromLocal  # noqa: F401
 from .aligner import getBackbones  # noqa: F401
-from .algorithm import search, evalHMMSearchOutput  # noqa: F401
+from .algorithm import search, check_query_names, divide_to_equal_chunks, num_chunks_for  # noqa: F401
 from .merge import alignSubQueriesNew, compressInsertions, trace_to_string  # noqa: F401
 from .merger import mergeAlignmentsCollapsed  # noqa: F401

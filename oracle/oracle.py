@@ -206,3 +206,9 @@ def adaptive_cut(sorted_weights, target=0.999):
         cur += sorted_weights[idx][1]
         idx += 1
     return idx
+
+
+def set_resolve_multidomain(on: bool) -> None:
+    """True (default): multidomain regions go through the A.4b trace ensemble + clustering;
+    False: the round-1 behaviour (the whole region is one envelope) - kept for comparison only."""
+    lib().orc_set_resolve_multidomain(1 if on else 0)

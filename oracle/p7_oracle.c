@@ -20,10 +20,11 @@
  * Parity pin: tests/golden/ holds outputs of the bundled HMMER binaries and of the
  * reference's own Python functions, produced in the build container by
  * tests/golden/make_golden.py; tests/test_oracle_golden.py checks this file against
- * them.  Known, documented deviation: regions that HMMER flags "multidomain" are
- * resolved there by 200 stochastic tracebacks + clustering (A.4b, RNG-dependent even
- * between HMMER runs with different --seed); here such a region becomes ONE envelope
- * scored like a single-domain region, and the pair is flagged ORC_FLAG_MULTI.
+ * them.  Regions that HMMER flags "multidomain" are resolved as HMMER does (A.4b: 200
+ * stochastic tracebacks with Easel's seeded fast RNG + single-linkage clustering); on the
+ * 191 golden multidomain pairs: reported mask 191/191, printed score 189/191 (two pairs one
+ * deci-bit off, 0.002 and 0.005 bit from a rounding boundary: one sampled trace differing in
+ * float rounding moves a per-residue null2 term by 1/200), envelopes 190/191.
  */
 #include <math.h>
 #include <stdint.h>
@@ -601,10 +602,350 @@ static void null2_by_expectation(const orc_hmm *h, const orc_mx *fx, const orc_m
   free(fM); free(fI);
 }
 
+/* ----------------------------------------------------------------------------
+ * A.4b  Multidomain regions: stochastic traceback ensemble + clustering.
+ *
+ * HMMER 3.1b2 resolves a region flagged multidomain (p7_domaindef_ByPosteriorHeuristics ->
+ * region_trace_ensemble) by: multihit Forward on the region's sub-sequence (length model of the
+ * whole sequence); the pipeline's RNG re-initialised to its seed; 200 stochastic tracebacks
+ * (p7_StochasticTrace); every sampled domain goes into a segment-pair ensemble and bumps the
+ * per-residue null2 accumulators (p7_Null2_ByTrace); single-linkage clustering of the segments
+ * (p7_spensemble_Cluster: >= 0.8 overlap of the smaller in sequence and model, both end diagonals
+ * within 4, cluster in >= 25 % of the traces, end points at >= 2 % frequency); clusters dominated
+ * by an overlapping, more probable one are dropped; every surviving cluster is an envelope.
+ * The RNG is Easel's "fast" generator (esl_randomness_CreateFast(42) in p7_pipeline_Create,
+ * identified in the bundled binary): x <- 69069 x + 1 (mod 2^32), seeded with Jenkins' mix3.
+ * Restated from HMMER 3.1b2's published behaviour; pinned on the golden multidomain pairs
+ * (tests/test_oracle_golden.py prints and bounds the residual).
+ * -------------------------------------------------------------------------- */
+typedef struct { uint32_t x; } orc_rng;
+
+static uint32_t jenkins_mix3(uint32_t a, uint32_t b, uint32_t c)
+{
+  a -= b; a -= c; a ^= (c >> 13);
+  b -= c; b -= a; b ^= (a << 8);
+  c -= a; c -= b; c ^= (b >> 13);
+  a -= b; a -= c; a ^= (c >> 12);
+  b -= c; b -= a; b ^= (a << 16);
+  c -= a; c -= b; c ^= (b >> 5);
+  a -= b; a -= c; a ^= (c >> 3);
+  b -= c; b -= a; b ^= (a << 10);
+  c -= a; c -= b; c ^= (b >> 15);
+  return c;
+}
+static void rng_init(orc_rng *r, uint32_t seed)
+{
+  r->x = jenkins_mix3(seed, 87654321u, 12345678u);
+  if (r->x == 0) r->x = 42;
+}
+static double rng_next(orc_rng *r)
+{
+  r->x = r->x * 69069u + 1u;
+  return (double) r->x / 4294967296.0;
+}
+/* esl_vec_FNorm + esl_rnd_FChoose on a short vector of float probabilities */
+static int rng_choose(orc_rng *r, double *pd, int n)
+{
+  float p[4];
+  double tot = 0.0, roll, sum = 0.0;
+  int t;
+  for (t = 0; t < n; t++) tot += pd[t];
+  for (t = 0; t < n; t++) p[t] = tot > 0.0 ? (float) (pd[t] / tot) : 1.0f / (float) n;
+  /* esl_rnd_FChoose of the bundled binary: first t with (p[0] + .. + p[t]) / norm > roll, in double */
+  {
+    double norm = 0.0;
+    roll = rng_next(r);
+    for (t = 0; t < n; t++) norm += p[t];
+    for (t = 0; t < n; t++) { sum += p[t]; if (sum / norm > roll) return t; }
+  }
+  return n - 1;
+}
+
+typedef struct { int i, j, k, m, idx; float prob; } orc_seg;
+enum { stM = 1, stD, stI, stN, stC, stJ, stE, stB, stS };
+
+typedef struct {
+  orc_seg *seg; int nseg, aseg;
+} orc_ensemble;
+
+static void ens_add(orc_ensemble *en, int idx, int i, int j, int k, int m)
+{
+  if (en->nseg == en->aseg) { en->aseg = en->aseg ? 2 * en->aseg : 256; en->seg = (orc_seg *) realloc(en->seg, sizeof(orc_seg) * (size_t) en->aseg); }
+  en->seg[en->nseg].i = i; en->seg[en->nseg].j = j; en->seg[en->nseg].k = k; en->seg[en->nseg].m = m;
+  en->seg[en->nseg].idx = idx; en->seg[en->nseg].prob = 0.0f;
+  en->nseg++;
+}
+
+static int seg_linked(const orc_seg *h1, const orc_seg *h2)
+{
+  const float min_overlap = 0.8f;
+  const int max_diagdiff = 4;
+  int nov, n, d1, d2;
+#define IMIN(a, b) ((a) < (b) ? (a) : (b))
+#define IMAX(a, b) ((a) > (b) ? (a) : (b))
+  nov = IMIN(h1->j, h2->j) - IMAX(h1->i, h2->i) + 1;
+  n = IMIN(h1->j - h1->i + 1, h2->j - h2->i + 1);
+  if ((float) nov / (float) n < min_overlap) return 0;
+  nov = IMIN(h1->m, h2->m) - IMAX(h1->k, h2->k);
+  n = IMIN(h1->m - h1->k + 1, h2->m - h2->k + 1);
+  if ((float) nov / (float) n < min_overlap) return 0;
+  /* start points OR end points on nearby diagonals (binary: link_spsamples returns TRUE at the first hit) */
+  d1 = h1->i - h1->k; d2 = h2->i - h2->k; if (abs(d1 - d2) <= max_diagdiff) return 1;
+  d1 = h1->j - h1->m; d2 = h2->j - h2->m; if (abs(d1 - d2) <= max_diagdiff) return 1;
+  return 0;
+}
+
+/* esl_cluster_SingleLinkage's vertex order (stack a initialised in reverse, swap-with-last deletion) */
+static int single_linkage(const orc_seg *seg, int n, int *assign)
+{
+  int *a = (int *) malloc(sizeof(int) * (size_t) (n + 1)), *b = (int *) malloc(sizeof(int) * (size_t) (n + 1));
+  int na = n, nb, nc = 0, v, w, t;
+  for (v = 0; v < n; v++) a[v] = n - v - 1;
+  while (na > 0) {
+    v = a[na - 1]; na--;
+    b[0] = v; nb = 1;
+    while (nb > 0) {
+      v = b[nb - 1]; nb--;
+      assign[v] = nc;
+      for (t = na - 1; t >= 0; t--)
+        if (seg_linked(seg + v, seg + a[t])) { w = a[t]; a[t] = a[na - 1]; na--; b[nb++] = w; }
+    }
+    nc++;
+  }
+  free(a); free(b);
+  return nc;
+}
+
+static int iargmax(const int *v, int n) { int t, best = 0; for (t = 1; t < n; t++) if (v[t] > v[best]) best = t; return best; }
+
+/* p7_spensemble_Cluster + the "dominated domain" removal of region_trace_ensemble.
+ * Returns the number of envelopes; coordinates in sig[] sorted by start. */
+static int cluster_ensemble(orc_ensemble *en, int nsamples, orc_seg *sig, int maxsig)
+{
+  const float min_posterior = 0.25f, min_endpointp = 0.02f;
+  int n = en->nseg, nc, c, h, nsig = 0, d, d2;
+  int *assign, *epc, *dominated;
+  if (n == 0) return 0;
+  assign = (int *) malloc(sizeof(int) * (size_t) n);
+  nc = single_linkage(en->seg, n, assign);
+  for (c = 0; c < nc; c++) {
+    int ninc = 0, idx_of_last = -1, imin = 0, imax = 0, jmin = 0, jmax = 0, kmin = 0, kmax = 0, mmin = 0, mmax = 0;
+    int best_i, best_j, best_k, best_m, thr, span;
+    for (h = 0; h < n; h++) if (assign[h] == c) { if (en->seg[h].idx != idx_of_last) ninc++; idx_of_last = en->seg[h].idx; }
+    if ((float) ninc / (float) nsamples < min_posterior) continue;
+    for (h = 0; h < n; h++) if (assign[h] == c) {
+      const orc_seg *s = en->seg + h;
+      if (imin == 0) { imin = imax = s->i; jmin = jmax = s->j; kmin = kmax = s->k; mmin = mmax = s->m; }
+      else {
+        imin = IMIN(imin, s->i); imax = IMAX(imax, s->i); jmin = IMIN(jmin, s->j); jmax = IMAX(jmax, s->j);
+        kmin = IMIN(kmin, s->k); kmax = IMAX(kmax, s->k); mmin = IMIN(mmin, s->m); mmax = IMAX(mmax, s->m);
+      }
+    }
+    thr = (int) ceilf((float) ninc * min_endpointp);
+    span = IMAX(IMAX(imax - imin, jmax - jmin), IMAX(kmax - kmin, mmax - mmin)) + 1;
+    epc = (int *) calloc((size_t) span, sizeof(int));
+    for (h = 0; h < n; h++) if (assign[h] == c) epc[en->seg[h].i - imin]++;
+    for (best_i = imin; best_i <= imax; best_i++) if (epc[best_i - imin] >= thr) break;
+    if (best_i > imax) best_i = imin + iargmax(epc, imax - imin + 1);
+    memset(epc, 0, sizeof(int) * (size_t) span);
+    for (h = 0; h < n; h++) if (assign[h] == c) epc[en->seg[h].k - kmin]++;
+    for (best_k = kmin; best_k <= kmax; best_k++) if (epc[best_k - kmin] >= thr) break;
+    if (best_k > kmax) best_k = kmin + iargmax(epc, kmax - kmin + 1);
+    memset(epc, 0, sizeof(int) * (size_t) span);
+    for (h = 0; h < n; h++) if (assign[h] == c) epc[en->seg[h].j - jmin]++;
+    for (best_j = jmax; best_j >= jmin; best_j--) if (epc[best_j - jmin] >= thr) break;
+    if (best_j < jmin) best_j = jmin + iargmax(epc, jmax - jmin + 1);
+    memset(epc, 0, sizeof(int) * (size_t) span);
+    for (h = 0; h < n; h++) if (assign[h] == c) epc[en->seg[h].m - mmin]++;
+    for (best_m = mmax; best_m >= mmin; best_m--) if (epc[best_m - mmin] >= thr) break;
+    if (best_m < mmin) best_m = mmin + iargmax(epc, mmax - mmin + 1);
+    free(epc);
+    if (best_i > best_j || best_k > best_m) continue;
+    if (nsig < maxsig) {
+      sig[nsig].i = best_i; sig[nsig].j = best_j; sig[nsig].k = best_k; sig[nsig].m = best_m;
+      sig[nsig].idx = c; sig[nsig].prob = (float) ninc / (float) nsamples;
+      nsig++;
+    }
+  }
+  free(assign);
+  /* order by start point (stable) */
+  for (d = 1; d < nsig; d++) {
+    orc_seg t = sig[d];
+    for (d2 = d - 1; d2 >= 0 && sig[d2].i > t.i; d2--) sig[d2 + 1] = sig[d2];
+    sig[d2 + 1] = t;
+  }
+  /* drop clusters dominated by an overlapping, more probable one */
+  dominated = (int *) calloc((size_t) nsig + 1, sizeof(int));
+  for (d = 0; d < nsig; d++)
+    for (d2 = d + 1; d2 < nsig; d2++) {
+      int nov = IMIN(sig[d].j, sig[d2].j) - IMAX(sig[d].i, sig[d2].i) + 1, nn;
+      if (nov == 0) break;
+      nn = IMIN(sig[d].j - sig[d].i + 1, sig[d2].j - sig[d2].i + 1);
+      if ((float) nov / (float) nn >= 0.8f) {
+        if (sig[d].prob > sig[d2].prob) dominated[d2] = 1; else dominated[d] = 1;
+      }
+    }
+  for (d = 0, d2 = 0; d2 < nsig; d2++) { if (dominated[d2]) continue; if (d != d2) sig[d] = sig[d2]; d++; }
+  free(dominated);
+  return d;
+}
+
+/* One region i..j (1-based, inclusive).  <fr>: multihit Forward matrix of the region's sub-sequence.
+ * Sets n2sc[ireg..jreg]; returns the envelopes in sig[]. */
+static int region_trace_ensemble(const orc_hmm *h, const uint8_t *dsq, int ireg, int jreg, const orc_mx *fr,
+                                 orc_len c, float *n2sc, orc_seg *sig, int maxsig)
+{
+  const int nsamples = 200;
+  const int M = h->M, K = h->K, Kp = h->Kp, Lr = jreg - ireg + 1;
+  const int Q = ((M - 1) / 4 + 1) > 2 ? ((M - 1) / 4 + 1) : 2;       /* p7O_NQF: striped vectors of 4 floats */
+  const double *pt = h->pt, *en = h->entry;
+  const uint8_t *rs = dsq + (ireg - 1);                              /* rs[pos-1] = residue at region position pos */
+  orc_rng rng;
+  orc_ensemble ens = {0, 0, 0};
+  int *cntM = (int *) calloc((size_t) M + 2, sizeof(int)), *cntI = (int *) calloc((size_t) M + 2, sizeof(int));
+  int *usedk = (int *) malloc(sizeof(int) * (size_t) (2 * (Lr + M) + 8));
+  uint32_t mask[32];
+  int t, pos, nc, Kc = K, Kpc = Kp;
+  /* per trace: domains found right-to-left */
+  int adom = 64, *dfrom = (int *) malloc(sizeof(int) * 4 * (size_t) adom);
+  float *dnull = (float *) malloc(sizeof(float) * 32 * (size_t) adom);
+  degen_masks(h->alphabet, mask, &Kc, &Kpc);
+  for (pos = ireg; pos <= jreg; pos++) n2sc[pos] = 0.0f;
+  rng_init(&rng, 42u);
+  for (t = 0; t < nsamples; t++) {
+    int i = Lr, k = 0, s0 = stC, s1, ndom = 0, nused = 0, Ld = 0, sqto = 0, hmmto = 0, sqfrom = 0, hmmfrom = 0, d;
+    while (s0 != stS) {
+      double path[4];
+      switch (s0) {
+      case stM:
+        path[0] = XS(fr, i - 1, sB) * en[k];
+        path[1] = MX(fr, i - 1, k - 1, 0) * pt[(size_t) (k - 1) * 7 + tMM];
+        path[2] = MX(fr, i - 1, k - 1, 1) * pt[(size_t) (k - 1) * 7 + tIM];
+        path[3] = MX(fr, i - 1, k - 1, 2) * pt[(size_t) (k - 1) * 7 + tDM];
+        { static const int st[4] = { stB, stM, stI, stD }; s1 = st[rng_choose(&rng, path, 4)]; }
+        k--; i--;
+        break;
+      case stD:
+        path[0] = MX(fr, i, k - 1, 0) * pt[(size_t) (k - 1) * 7 + tMD];
+        path[1] = MX(fr, i, k - 1, 2) * pt[(size_t) (k - 1) * 7 + tDD];
+        s1 = rng_choose(&rng, path, 2) == 0 ? stM : stD;
+        k--;
+        break;
+      case stI:
+        path[0] = MX(fr, i - 1, k, 0) * pt[(size_t) k * 7 + tMI];
+        path[1] = MX(fr, i - 1, k, 1) * pt[(size_t) k * 7 + tII];
+        s1 = rng_choose(&rng, path, 2) == 0 ? stM : stI;
+        i--;
+        break;
+      case stN: s1 = (i == 0) ? stS : stN; break;
+      case stC:
+        path[0] = XS(fr, i - 1, sC) * c.loop;
+        path[1] = XS(fr, i, sE) * c.EC * exp(fr->lscale[i] - fr->lscale[i - 1]);
+        s1 = rng_choose(&rng, path, 2) == 0 ? stC : stE;
+        break;
+      case stJ:
+        path[0] = XS(fr, i - 1, sJ) * c.loop;
+        path[1] = XS(fr, i, sE) * c.EJ * exp(fr->lscale[i] - fr->lscale[i - 1]);
+        s1 = rng_choose(&rng, path, 2) == 0 ? stJ : stE;
+        break;
+      case stE: {
+        /* on-the-fly FChoose over M(i,*) and D(i,*) in HMMER's striped order (q outer, r inner) */
+        const double roll = rng_next(&rng), norm = 1.0 / XS(fr, i, sE);
+        double sum = 0.0;
+        int q, r, found = 0, guard = 0;
+        s1 = stM;
+        while (!found && guard++ < 4) {
+          for (q = 0; q < Q && !found; q++) {
+            for (r = 0; r < 4 && !found; r++) {
+              const int kk = r * Q + q + 1;
+              sum += (kk <= M) ? (double) (float) (MX(fr, i, kk, 0) * norm) : 0.0;
+              if (roll < sum) { k = kk; s1 = stM; found = 1; }
+            }
+            for (r = 0; r < 4 && !found; r++) {
+              const int kk = r * Q + q + 1;
+              sum += (kk <= M) ? (double) (float) (MX(fr, i, kk, 2) * norm) : 0.0;
+              if (roll < sum) { k = kk; s1 = stD; found = 1; }
+            }
+          }
+        }
+        if (!found) { k = 1; s1 = stM; }
+        break;
+      }
+      case stB:
+        path[0] = XS(fr, i, sN) * c.move;
+        path[1] = XS(fr, i, sJ) * c.move;
+        s1 = rng_choose(&rng, path, 2) == 0 ? stN : stJ;
+        break;
+      default: s1 = stS; break;
+      }
+      /* the state just chosen sits at (k, i) */
+      if (s1 == stE) { sqto = hmmto = 0; nused = 0; Ld = 0; }
+      else if (s1 == stM) {
+        if (sqto == 0) { sqto = i; hmmto = k; }
+        sqfrom = i; hmmfrom = k;
+        usedk[nused++] = k; Ld++;
+      } else if (s1 == stI) { usedk[nused++] = -k; Ld++; }
+      else if (s1 == stB) {
+        /* domain complete: p7_Null2_ByTrace over its M and I states */
+        float *nl;
+        int x, a, u;
+        if (ndom == adom) { adom *= 2; dfrom = (int *) realloc(dfrom, sizeof(int) * 4 * (size_t) adom); dnull = (float *) realloc(dnull, sizeof(float) * 32 * (size_t) adom); }
+        dfrom[4 * ndom] = sqfrom; dfrom[4 * ndom + 1] = sqto; dfrom[4 * ndom + 2] = hmmfrom; dfrom[4 * ndom + 3] = hmmto;
+        nl = dnull + 32 * (size_t) ndom;
+        for (u = 0; u < nused; u++) { if (usedk[u] > 0) cntM[usedk[u]]++; else cntI[-usedk[u]]++; }
+        {
+          const float norm = 1.0f / (float) Ld;
+          for (a = 0; a < K; a++) {
+            const double *od = h->odds + (size_t) a * (M + 1);
+            float lane[4] = { 0.f, 0.f, 0.f, 0.f };
+            int q, r;
+            for (q = 0; q < Q; q++)
+              for (r = 0; r < 4; r++) {
+                const int kk = r * Q + q + 1;
+                if (kk > M) continue;
+                if (cntM[kk]) lane[r] += ((float) cntM[kk] * norm) * (float) od[kk];
+                if (cntI[kk]) lane[r] += (float) cntI[kk] * norm;
+              }
+            nl[a] = (lane[0] + lane[1]) + (lane[2] + lane[3]);
+          }
+          for (x = K; x < Kp; x++) {
+            if (mask[x] == 0) { nl[x] = 1.0f; continue; }
+            float sx = 0.0f; int nx = 0;
+            for (a = 0; a < K; a++) if (mask[x] & (1u << a)) { sx += nl[a]; nx++; }
+            nl[x] = sx / (float) nx;
+          }
+        }
+        for (u = 0; u < nused; u++) { if (usedk[u] > 0) cntM[usedk[u]] = 0; else cntI[-usedk[u]] = 0; }
+        ndom++;
+      }
+      if ((s1 == stN || s1 == stJ || s1 == stC) && s1 == s0) i--;
+      s0 = s1;
+    }
+    /* domains were found right to left; the ensemble and the null2 bumps take them left to right */
+    pos = 1;
+    for (d = ndom - 1; d >= 0; d--) {
+      const int *df = dfrom + 4 * d;
+      const float *nl = dnull + 32 * (size_t) d;
+      ens_add(&ens, t, df[0] + ireg - 1, df[1] + ireg - 1, df[2], df[3]);
+      for (; pos <= df[0]; pos++) n2sc[ireg + pos - 1] += 1.0f;    /* sic: the domain's first residue is bumped by 1 too (matches the binary's scores) */
+      for (; pos <= df[1]; pos++) n2sc[ireg + pos - 1] += nl[rs[pos - 1]];
+    }
+    for (; pos <= Lr; pos++) n2sc[ireg + pos - 1] += 1.0f;
+  }
+  for (pos = ireg; pos <= jreg; pos++) n2sc[pos] = logf(n2sc[pos] / (float) nsamples);
+  nc = cluster_ensemble(&ens, nsamples, sig, maxsig);
+  free(ens.seg); free(cntM); free(cntI); free(usedk); free(dfrom); free(dnull);
+  return nc;
+}
+
+/* 1 (default): multidomain regions go through A.4b; 0: the round-1 behaviour (one envelope per region) */
+int orc_resolve_multidomain = 1;
+void orc_set_resolve_multidomain(int on) { orc_resolve_multidomain = on; }
+
 /* Score one (query, HMM) pair the way "hmmsearch --max" does (A.2-A.6). */
 int orc_score_pair(const orc_hmm *h, const uint8_t *dsq, int L, orc_result *r)
 {
-  int M = h->M, i, j, z;
+  int M = h->M, i, j, z, nclustered_env = 0;
   orc_mx *fx, *bx;
   orc_len cm = len_config(L, 1);
   double fwd, ov;
@@ -667,7 +1008,31 @@ int orc_score_pair(const orc_hmm *h, const uint8_t *dsq, int L, orc_result *r)
         }
         multi = (mx >= rt3);
         if (multi) r->flags |= ORC_FLAG_MULTI;
-        if (r->nenv < ORC_MAXENV) {
+        if (multi && orc_resolve_multidomain) {
+          /* A.4b: the region is resolved into 0..n envelopes by the trace ensemble; n2sc of the whole
+           * region comes from the traces and is NOT recomputed per envelope (null2_is_done) */
+          const int Lr = j - i + 1;
+          orc_seg sig[ORC_MAXENV];
+          orc_mx *fr = mx_new(Lr, M);
+          int nc, d;
+          forward(h, dsq + (i - 1), Lr, cm, fr);
+          nc = region_trace_ensemble(h, dsq, i, j, fr, cm, n2sc, sig, ORC_MAXENV);
+          mx_free(fr);
+          nclustered_env += nc;
+          for (d = 0; d < nc && r->nenv < ORC_MAXENV; d++) {
+            const int i2 = sig[d].i, j2 = sig[d].j, Ld = j2 - i2 + 1;
+            orc_len cu = len_config(L, 0);
+            orc_mx *f2 = mx_new(Ld, M);
+            double envsc = forward(h, dsq + (i2 - 1), Ld, cu, f2);
+            float domcorr = 0.0f;
+            int pos;
+            for (pos = i2; pos <= j2; pos++) domcorr += n2sc[pos];
+            r->env_i[r->nenv] = i2; r->env_j[r->nenv] = j2; r->env_multi[r->nenv] = 1;
+            r->envsc[r->nenv] = (float) envsc; r->domcorr[r->nenv] = domcorr;
+            r->nenv++;
+            mx_free(f2);
+          }
+        } else if (r->nenv < ORC_MAXENV) {
           /* A.5 rescore the envelope in unihit mode, length model of the full sequence */
           int Ld = j - i + 1, pos;
           orc_len cu = len_config(L, 0);

@@ -83,35 +83,37 @@ def test_score_against_oracle_and_golden(golden_case, orc):
             r = ohm[hj].score(seqs[qi])
             d = det[qi * H + hj]
             assert d.nregions == r.nregions, (case.name, qi, hj)
-            assert d.nenv == min(r.nenv, 8)
+            assert d.nenv == min(r.nenv, 8), (case.name, qi, hj, d.nenv, r.nenv, r.flags)
             for t in range(d.nenv):
                 assert (d.env_i[t], d.env_j[t]) == (r.env_i[t], r.env_j[t]), (case.name, qi, hj, t)
                 assert abs(d.envsc[t] - r.envsc[t]) <= 2e-4 * max(1.0, abs(r.envsc[t]) / 50), (case.name, qi, hj, d.envsc[t], r.envsc[t])
-                assert abs(d.domcorr[t] - r.domcorr[t]) <= 1e-3, (case.name, qi, hj, d.domcorr[t], r.domcorr[t])
+                assert abs(d.domcorr[t] - r.domcorr[t]) <= (2e-2 if r.env_multi[t] else 1e-3), (case.name, qi, hj, d.domcorr[t], r.domcorr[t])
     # deci-bits
     rep = (of & 1) == 1
     diff = (deci != od) & rep
     n_diff = int(diff.sum())
     for qi, hj in np.argwhere(diff):
         assert abs(int(deci[qi, hj]) - int(od[qi, hj])) == 1, (case.name, qi, hj, deci[qi, hj], od[qi, hj])
-        assert _near_boundary(osc[qi, hj]), (case.name, qi, hj, osc[qi, hj], deci[qi, hj], od[qi, hj])
-    # and directly against HMMER's printed scores for the single-domain class
-    n_exact = n_pairs = 0
+        assert _near_boundary_eps(osc[qi, hj], LONG_EPS if of[qi, hj] & 2 else BOUNDARY_EPS), (case.name, qi, hj, osc[qi, hj], deci[qi, hj], od[qi, hj])
+    # and directly against HMMER's printed scores: every pair, the multidomain class (HMMER's stochastic
+    # resolver, reproduced by resolve_kernel) included
+    n_exact = n_pairs = n_multi = n_multi_exact = 0
     for hj, hf in enumerate(case.hmm_files):
         S = case.g["search"][hf]
         for qi, qn in enumerate(case.qnames):
-            if flags[qi, hj] & 2:
-                continue
-            assert bool(flags[qi, hj] & 1) == (qn in S), (case.name, hf, qn)
+            multi = bool(flags[qi, hj] & 2)
+            assert bool(flags[qi, hj] & 1) == (qn in S), (case.name, hf, qn, "multidomain" if multi else "single")
             if qn in S:
                 n_pairs += 1
+                n_multi += multi
                 g = int(round(S[qn]["score"] * 10))
                 if g == deci[qi, hj]:
                     n_exact += 1
+                    n_multi_exact += multi
                 else:
-                    assert abs(g - int(deci[qi, hj])) == 1 and _near_boundary(osc[qi, hj]), (case.name, hf, qn, g, deci[qi, hj])
+                    assert abs(g - int(deci[qi, hj])) == 1 and _near_boundary_eps(osc[qi, hj], LONG_EPS if multi else BOUNDARY_EPS), (case.name, hf, qn, g, deci[qi, hj])
     print("\n[%s] GPU vs oracle: %d/%d reported pairs differ (all at a rounding boundary); "
-          "GPU vs HMMER print (single-domain): %d/%d exact" % (case.name, n_diff, int(rep.sum()), n_exact, n_pairs))
+          "GPU vs HMMER print: %d/%d exact (multidomain class %d/%d)" % (case.name, n_diff, int(rep.sum()), n_exact, n_pairs, n_multi_exact, n_multi))
     assert n_exact >= 0.98 * n_pairs
     e.close()
 
@@ -374,11 +376,9 @@ def test_long_protein_queries_with_several_hits(orc, tmp_path):
     for d in det:
         for t in range(d.nenv):
             assert np.isfinite(d.domcorr[t]) and np.isfinite(d.envsc[t])
-    single = (of & 2) == 0                    # multi-hit envelopes (flag 2) are the stochastic class of HMMER itself
-    n_bad = _check_decibits(deci, od, osc, ((of & 1) == 1) & single, "long protein", LONG_EPS)
-    diff = np.abs(deci.astype(np.int64) - od)
-    assert diff.max() <= 1, diff.max()
-    print("\n[long protein] %d of %d single-domain pairs one deci-bit off (all within %.2f bit of a boundary)" % (n_bad, int(single.sum()), LONG_EPS))
+    n_bad = _check_decibits(deci, od, osc, (of & 1) == 1, "long protein", LONG_EPS)
+    print("\n[long protein] %d of %d reported pairs one deci-bit off (all within %.2f bit of a boundary); %d multidomain pairs"
+          % (n_bad, int(((of & 1) == 1).sum()), LONG_EPS, int(((of & 2) != 0).sum())))
     # alignment of the same queries: where the best hit is not the first one the scaled float32
     # sweeps cannot represent it (HMMER's Decoding overflows there and hmmalign switches to its
     # log-space code); the kernel detects the same condition and redoes those pairs in log space
@@ -772,12 +772,13 @@ def test_config2_dna_1k_x10_at_its_stated_size(orc, tmp_path):
 def test_config5_shape_all_500_hmms(orc, tmp_path):
     """BASELINE.json configs[4] shape (aa_50k_x500): ALL 500 protein HMMs (more than 256 candidates per
     query: the multi-slot path of the top-k kernel) x 64 mixed-length queries (50-2000 residues) against
-    the oracle, then the structural properties of the top-k table and the aligned columns at 10 000 queries."""
+    the oracle, then the structural properties of the top-k table and the aligned columns at 2 000 queries
+    (a quarter of these pairs hold several hits: each goes through the 200-trace resolver)."""
     _need_gpu()
     import torch
     import bench
     from witch_amd.ehmm import EHMM, pack_queries
-    fam, se, names, seqs, k = bench.make_workload("aa_50k_x500", str(tmp_path), 10000, None)
+    fam, se, names, seqs, k = bench.make_workload("aa_50k_x500", str(tmp_path), 2000, None)
     assert len(se.paths) == 500 and k == 10
     seqs = [s_.astype(np.uint8) for s_ in seqs]
     e = EHMM(se.paths, hmm_index=se.index, nseq=se.nseq)
@@ -791,9 +792,7 @@ def test_config5_shape_all_500_hmms(orc, tmp_path):
     fin = np.isfinite(ofwd)
     assert np.max(np.abs(fwd[fin] - ofwd[fin]) / np.maximum(1.0, np.abs(ofwd[fin]) / 1000)) <= 2e-4
     assert np.array_equal(flags & 3, of & 3)
-    single = (of & 3) == 1
-    n_off = _check_decibits(deci, od, osc, single, "aa_50k_x500", LONG_EPS)
-    assert np.abs(deci.astype(np.int64) - od)[(of & 1) == 1].max() <= 1
+    n_off = _check_decibits(deci, od, osc, (of & 1) == 1, "aa_50k_x500", LONG_EPS)
     idx, w, nk, nu = e.topk(deci, flags, k)
     tables, _ = _oracle_topk_and_pairs(orc, se.index, se.nseq, deci, flags, k)
     for qi, (ow, onu) in enumerate(tables):
@@ -809,7 +808,7 @@ def test_config5_shape_all_500_hmms(orc, tmp_path):
     assert np.array_equal(cols, ocols), int((cols != ocols).sum())
     print("\n[aa_50k_x500] 64 x 500 pairs: %d single-domain pairs one deci-bit off (boundary), %d multidomain pairs, %d pairs aligned identically"
           % (n_off, int(((of & 2) != 0).sum()), len(pq)))
-    # ---- 10 000 queries x 500 HMMs: size-independent properties
+    # ---- 2 000 queries x 500 HMMs: size-independent properties
     res, offs = pack_queries(seqs)
     res_t, off_t = torch.from_numpy(res).cuda(), torch.from_numpy(offs).cuda()
     maxlen = int(np.max(np.diff(offs)))

@@ -59,6 +59,7 @@ struct Knobs {
   int max_waves = 0;         // cap on waves per workgroup (0 = planner's choice)
   bool force_specg = false;  // force the HBM special-state mode
   bool no_logspace = false;  // skip the log-space alignment pass
+  bool no_resolve = false;   // multidomain regions stay ONE envelope (round-1 behaviour) instead of HMMER's stochastic resolver
   bool stats = false, trace = false;
   int dbg = 0;
 };
@@ -73,6 +74,8 @@ struct wh_ehmm {
   std::vector<DevHMM> dev;          // host copy of the descriptors
   std::map<int, std::vector<int32_t>> by_q;   // Q class -> model positions
   DevBuf d_hmms, d_tables, d_nseq, d_index, d_lists, d_counter, d_scratch;
+  DevBuf d_gtab, d_rrecs, d_rmx, d_rsegs;   // multidomain resolver: float64 tables, pair queue, matrix slabs, segment arrays
+  int last_resolved = 0;                    // pairs the resolver finished in the last wh_score call
   // staging for the host-pointer entry points
   DevBuf s_res, s_off, s_deci, s_flags, s_fwd, s_det, s_idx, s_w, s_nk, s_nu, s_pq, s_ph, s_co, s_cols, s_pos;
   DevBuf d_order, d_items, d_recs, d_spec, d_back, d_cwj, d_cwv, d_cwn, c_buf[10];
@@ -123,7 +126,7 @@ int wh_digitize(int alphabet, const char *text, int64_t n, uint8_t *out) {
 
 void wh_ehmm_free(wh_ehmm *e) {
   if (!e) return;
-  for (DevBuf *b : {&e->d_hmms, &e->d_tables, &e->d_nseq, &e->d_index, &e->d_lists, &e->d_counter, &e->d_scratch,
+  for (DevBuf *b : {&e->d_gtab, &e->d_rrecs, &e->d_rmx, &e->d_rsegs, &e->d_hmms, &e->d_tables, &e->d_nseq, &e->d_index, &e->d_lists, &e->d_counter, &e->d_scratch,
                     &e->s_res, &e->s_off, &e->s_deci, &e->s_flags, &e->s_fwd, &e->s_det, &e->s_idx, &e->s_w,
                     &e->s_nk, &e->s_nu, &e->s_pq, &e->s_ph, &e->s_co, &e->s_cols, &e->s_pos, &e->d_order, &e->d_items, &e->d_recs, &e->d_spec, &e->d_back, &e->d_cwj, &e->d_cwv, &e->d_cwn,
                     &e->c_buf[0], &e->c_buf[1], &e->c_buf[2], &e->c_buf[3], &e->c_buf[4], &e->c_buf[5], &e->c_buf[6],
@@ -145,6 +148,7 @@ wh_ehmm *wh_ehmm_load(const char *const *hmm_paths, const int32_t *hmm_index, co
   e->device = g_device;
   e->hmms.resize((size_t)n);
   std::vector<float> tables;
+  std::vector<double> gtab;
   e->dev.resize((size_t)n);
   for (int i = 0; i < n; i++) {
     HostHMM &h = e->hmms[(size_t)i];
@@ -168,6 +172,12 @@ wh_ehmm *wh_ehmm_load(const char *const *hmm_paths, const int32_t *hmm_index, co
     d.fw_off = (int64_t)tables.size(); tables.insert(tables.end(), fw.begin(), fw.end());
     d.bw_off = (int64_t)tables.size(); tables.insert(tables.end(), bw.begin(), bw.end());
     d.em_off = (int64_t)tables.size(); tables.insert(tables.end(), em.begin(), em.end());
+    {
+      std::vector<double> gfw, gem;
+      build_tables_f64(h, Q, gfw, gem);
+      d.gfw_off = (int64_t)gtab.size(); gtab.insert(gtab.end(), gfw.begin(), gfw.end());
+      d.gem_off = (int64_t)gtab.size(); gtab.insert(gtab.end(), gem.begin(), gem.end());
+    }
     e->by_q[Q].push_back(i);
     e->max_M = std::max(e->max_M, h.M);
   }
@@ -179,14 +189,14 @@ wh_ehmm *wh_ehmm_load(const char *const *hmm_paths, const int32_t *hmm_index, co
   for (int i = 0; i < n; i++) { ns[(size_t)i] = e->hmms[(size_t)i].nseq; ix[(size_t)i] = e->hmms[(size_t)i].index; }
   if (e->d_hmms.ensure(sizeof(DevHMM) * (size_t)n) || e->d_tables.ensure(sizeof(float) * tables.size()) ||
       e->d_nseq.ensure(sizeof(int32_t) * (size_t)n) || e->d_index.ensure(sizeof(int32_t) * (size_t)n) ||
-      e->d_lists.ensure(sizeof(int32_t) * (size_t)n) || e->d_counter.ensure(256))
+      e->d_lists.ensure(sizeof(int32_t) * (size_t)n) || e->d_counter.ensure(512) || e->d_gtab.ensure(sizeof(double) * gtab.size()))
     return nullptr;
   auto up = [&](void *dst, const void *src, size_t bytes) { return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess; };
   std::vector<int32_t> lists;
   for (auto &kv : e->by_q) lists.insert(lists.end(), kv.second.begin(), kv.second.end());
   if (!up(e->d_hmms.p, e->dev.data(), sizeof(DevHMM) * (size_t)n) || !up(e->d_tables.p, tables.data(), sizeof(float) * tables.size()) ||
       !up(e->d_nseq.p, ns.data(), sizeof(int32_t) * (size_t)n) || !up(e->d_index.p, ix.data(), sizeof(int32_t) * (size_t)n) ||
-      !up(e->d_lists.p, lists.data(), sizeof(int32_t) * (size_t)n)) {
+      !up(e->d_lists.p, lists.data(), sizeof(int32_t) * (size_t)n) || !up(e->d_gtab.p, gtab.data(), sizeof(double) * gtab.size())) {
     set_error("upload of the eHMM tables failed");
     return nullptr;
   }
@@ -226,6 +236,7 @@ int wh_set_option(wh_ehmm *e, const char *name, const char *value) {
   else if (!strcmp(name, "WH_MAX_WAVES")) k.max_waves = *v ? std::max(1, std::min(16, atoi(v))) : 0;
   else if (!strcmp(name, "WH_FORCE_SPECG")) k.force_specg = on;
   else if (!strcmp(name, "WH_NO_LOGSPACE")) k.no_logspace = on;
+  else if (!strcmp(name, "WH_NO_RESOLVE")) k.no_resolve = on;
   else if (!strcmp(name, "WH_STATS")) k.stats = on;
   else if (!strcmp(name, "WH_TRACE")) k.trace = on;
   else if (!strcmp(name, "WH_DBG")) k.dbg = atoi(v);
@@ -234,7 +245,7 @@ int wh_set_option(wh_ehmm *e, const char *name, const char *value) {
 }
 
 static void knobs_from_env(wh_ehmm *e) {
-  for (const char *name : {"WH_SCORE_KERNEL", "WH_KEEP_LOG2", "WH_MAX_WAVES", "WH_FORCE_SPECG", "WH_NO_LOGSPACE", "WH_STATS", "WH_TRACE", "WH_DBG"})
+  for (const char *name : {"WH_SCORE_KERNEL", "WH_KEEP_LOG2", "WH_MAX_WAVES", "WH_FORCE_SPECG", "WH_NO_LOGSPACE", "WH_NO_RESOLVE", "WH_STATS", "WH_TRACE", "WH_DBG"})
     if (const char *v = getenv(name)) (void)wh_set_option(e, name, v);
 }
 
@@ -324,6 +335,17 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
     const Knobs &kn = e->knobs;
     const int Lc = std::max(max_len, 1);
     int list_off = 0;
+    // queue of pairs with a multidomain region (finished by resolve_kernel after the scoring launches);
+    // one record per pair in the worst case
+    const size_t rlds = resolve_lds_bytes(Lc, e->max_M);
+    const int64_t npairs_all = nq * (int64_t)H;
+    const bool resolve = !kn.no_resolve && rlds <= kLdsBudget && npairs_all < 0x7FFFFFFF;
+    int *d_rcount = (int *)e->d_counter.p + 64;      // [64] queue length, [65] work-queue head of the resolver
+    e->last_resolved = 0;
+    if (resolve) {
+      if (e->d_rrecs.ensure(sizeof(ResolveRec) * (size_t)npairs_all)) return WH_ENOMEM;
+      HIPCHK(hipMemsetAsync(d_rcount, 0, 2 * sizeof(int), s));
+    }
     for (auto &kv : e->by_q) {
       const int Q = kv.first;
       ScoreArgs a;
@@ -340,6 +362,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       a.H = H; a.K = e->K; a.Kp = e->Kp;
       a.dbg = kn.dbg;
       a.keep_scale = kn.keep_scale;
+      if (resolve) { a.rrecs = (ResolveRec *)e->d_rrecs.p; a.rcount = d_rcount; a.rcap = (int)npairs_all; }
       memcpy(a.degen, e->degen, sizeof a.degen);
       int waves = 0, SP = 0, wave_lds = 0;
       size_t lds = 0;
@@ -415,6 +438,45 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
         fprintf(stderr, "[wh] Q=%d wave cycles: P1 %.1f%%  P2 %.1f%%  regions %.1f%%  P3 %.1f%%  P4 %.1f%%  null2 %.1f%%  (total %.3g ticks)\n", Q, 100.0 * st[4] / tot,
                 100.0 * st[5] / tot, 100.0 * st[6] / tot, 100.0 * st[7] / tot, 100.0 * st[8] / tot, 100.0 * st[9] / tot, tot);
       }
+    }
+  }
+  if (nq > 0 && !e->knobs.no_resolve && e->d_rrecs.p) {
+    // ---- multidomain regions: HMMER's stochastic resolver (wh_resolve.hip), one wavefront per queued pair
+    const int Lc = std::max(max_len, 1);
+    const size_t rlds = resolve_lds_bytes(Lc, e->max_M);
+    int *d_rcount = (int *)e->d_counter.p + 64, *d_rwork = (int *)e->d_counter.p + 65;
+    int n_multi = 0;
+    if (rlds <= kLdsBudget && nq * (int64_t)e->hmms.size() < 0x7FFFFFFF) {
+      HIPCHK(hipMemcpyAsync(&n_multi, d_rcount, sizeof(int), hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
+    }
+    if (n_multi > 0) {
+      int Qmax = 4;
+      for (auto &kv : e->by_q) Qmax = std::max(Qmax, kv.first);
+      ResolveArgs r;
+      memset(&r, 0, sizeof r);
+      r.hmms = (const DevHMM *)e->d_hmms.p; r.gtab = (const double *)e->d_gtab.p;
+      r.residues = d_residues; r.offsets = d_offsets;
+      r.recs = (const ResolveRec *)e->d_rrecs.p; r.count = d_rcount; r.rec_cap = (int)(nq * (int64_t)e->hmms.size());
+      r.counter = d_rwork;
+      r.Lcap = Lc; r.Mmax = e->max_M;
+      r.mx_stride = (size_t)(Lc + 2) * ((size_t)3 * Qmax * kWave + 8);
+      r.seg_cap = resolve_seg_cap();
+      r.seg_stride = (size_t)6 * r.seg_cap;
+      r.decibits = d_decibits; r.flags = d_flags; r.detail = d_detail;
+      r.H = (int)e->hmms.size(); r.K = e->K; r.Kp = e->Kp;
+      memcpy(r.degen, e->degen, sizeof r.degen);
+      const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, kLdsBudget / rlds));
+      int blocks = std::min(n_multi, e->cu_count * per_cu);
+      blocks = clamp_blocks(blocks, r.mx_stride * sizeof(double) + r.seg_stride * sizeof(int32_t), e->d_rmx);
+      if (e->d_rmx.ensure((size_t)blocks * r.mx_stride * sizeof(double)) || e->d_rsegs.ensure((size_t)blocks * r.seg_stride * sizeof(int32_t)))
+        return WH_ENOMEM;
+      r.mx = (double *)e->d_rmx.p; r.segs = (int32_t *)e->d_rsegs.p;
+      if (e->knobs.trace) fprintf(stderr, "[wh] resolve: %d pairs with a multidomain region, %d wavefronts, lds %zu, slab %zu MB per wave\n", n_multi, blocks, rlds, r.mx_stride * 8 >> 20);
+      hipError_t err = launch_resolve(r, blocks, rlds, s);
+      if (err != hipSuccess) { set_error("resolve kernel launch failed: %s", hipGetErrorString(err)); return WH_EHIP; }
+      launches++;
+      e->last_resolved = n_multi;
     }
   }
   if (timer_end(e, 0, s, launches)) return WH_EHIP;

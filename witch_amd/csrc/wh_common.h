@@ -45,6 +45,7 @@ void configure_profile(HostHMM &h);
 struct DevHMM {
   int32_t M, Q, Mpad, K, Kp, nseq, index, qclass;
   int64_t fw_off, bw_off, em_off;    // offsets (in floats) into the table buffer
+  int64_t gfw_off, gem_off;          // offsets (in doubles) into the float64 table buffer of the resolver
 };
 
 enum { FW_A = 0, FW_B, FW_C, FW_E, FW_MI, FW_II, FW_D1, FW_D2, FW_NARR, FW_P = FW_NARR };
@@ -57,5 +58,8 @@ enum { BW_MM = 0, BW_IM, BW_DM, BW_MI, BW_II, BW_MD, BW_DD, BW_E, BW_NARR, BW_P 
 int  choose_Q(int M);     // cells per lane for a model of M nodes, or -1 if unsupported
 void build_tables(const HostHMM &h, int Q, std::vector<float> &fw, std::vector<float> &bw,
                   std::vector<float> &em);
+// float64 tables of the multidomain resolver: 8 forward arrays and Kp emission rows, value of node
+// k = lane*Q + q + 1 at [(arr*Q + q)*64 + lane]
+void build_tables_f64(const HostHMM &h, int Q, std::vector<double> &fw, std::vector<double> &em);
 
 }  // namespace wh

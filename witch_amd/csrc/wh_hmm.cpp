@@ -240,4 +240,19 @@ void build_tables(const HostHMM &h, int Q, std::vector<float> &fw, std::vector<f
   }
 }
 
+void build_tables_f64(const HostHMM &h, int Q, std::vector<double> &fw, std::vector<double> &em) {
+  enum { tMM = 0, tMI, tMD, tIM, tII, tDM, tDD };
+  const int M = h.M, Mpad = Q * kWave;
+  auto at = [&](int arr, int k) -> size_t { return ((size_t)arr * Q + (k - 1) % Q) * kWave + (k - 1) / Q; };
+  fw.assign((size_t)8 * Mpad, 0.0);
+  em.assign((size_t)h.Kp * Mpad, 0.0);
+  for (int k = 1; k <= M; k++) {
+    const double *tp = &h.pt[(size_t)(k - 1) * 7];
+    const double *tk = &h.pt[(size_t)k * 7];
+    fw[at(0, k)] = tp[tMM]; fw[at(1, k)] = tp[tIM]; fw[at(2, k)] = tp[tDM]; fw[at(3, k)] = h.entry[k];
+    fw[at(4, k)] = tk[tMI]; fw[at(5, k)] = tk[tII]; fw[at(6, k)] = tp[tMD]; fw[at(7, k)] = tp[tDD];
+    for (int x = 0; x < h.Kp; x++) em[at(x, k)] = h.odds[(size_t)x * (M + 1) + k];
+  }
+}
+
 }  // namespace wh

@@ -6,6 +6,20 @@
 
 namespace wh {
 
+// A pair with a multidomain region, handed from the scoring kernels to resolve_kernel (wh_resolve.hip)
+struct ResolveRec {
+  int64_t q;
+  int32_t h;
+  float fwdsc;                 // float32 multihit Forward score of the whole sequence (nats)
+  float fwd_bits;
+  int32_t nreg;                // regions found; the first nenv are stored
+  int32_t nenv;
+  int32_t flags;               // WH_FLAG_* collected so far
+  int32_t multi_mask;          // bit e: stored region e is multidomain
+  int32_t ri[WH_MAX_ENVELOPES], rj[WH_MAX_ENVELOPES];
+  float envsc[WH_MAX_ENVELOPES], domcorr[WH_MAX_ENVELOPES];   // single-domain regions: scored by the scoring kernel
+};
+
 struct ScoreArgs {
   const DevHMM *hmms;          // all models of the eHMM
   const float *tables;         // table buffer (fw / bw / em arrays of every model)
@@ -35,12 +49,40 @@ struct ScoreArgs {
   int Klds;                    // emission rows staged in LDS (= K, or 0: read from L2)
   int dbg;                     // timing experiments only: 1 = skip Forward-row stores, 2 = skip Forward-row loads
   float keep_scale;            // Forward-row spill threshold relative to E(row); 0 = the kernel's default (2^-24)
+  ResolveRec *rrecs;           // queue of pairs with a multidomain region (NULL: such regions become one envelope)
+  int *rcount;                 // queue length (device counter)
+  int rcap;
   unsigned long long *stats;   // WH_STATS: [4..9] wave cycles per phase (or NULL)
 };
 
 hipError_t launch_score_big(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
 hipError_t launch_score7(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
 hipError_t launch_score7b(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);   // A/B slot
+
+struct ResolveArgs {
+  const DevHMM *hmms;
+  const double *gtab;          // float64 tables of every model (DevHMM::gfw_off / gem_off)
+  const uint8_t *residues;
+  const int64_t *offsets;
+  const ResolveRec *recs;
+  const int *count;            // number of queued pairs (device)
+  int rec_cap;
+  int *counter;                // work-queue head
+  int Lcap, Mmax;
+  double *mx;                  // per-wave matrix slabs
+  size_t mx_stride;            // doubles per wave
+  int32_t *segs;               // per-wave segment arrays
+  size_t seg_stride;           // ints per wave
+  int seg_cap;
+  int32_t *decibits;
+  uint8_t *flags;
+  wh_pair_detail *detail;
+  int H, K, Kp;
+  uint32_t degen[32];
+};
+hipError_t launch_resolve(const ResolveArgs &a, int blocks, size_t lds, hipStream_t s);
+size_t resolve_lds_bytes(int Lcap, int Mmax);
+int resolve_seg_cap();
 
 struct TopkArgs {
   const int32_t *decibits;

@@ -1,0 +1,621 @@
+// Multidomain regions: HMMER's stochastic resolver on the device.
+//
+// `hmmsearch` (called at witch_msa/gcmm/algorithm.py:526-532) resolves a region whose posterior
+// decoding suggests more than one domain by: multihit Forward on the region's sub-sequence with
+// the full matrix; the pipeline's RNG re-seeded (Easel's "fast" generator, seed 42:
+// x <- 69069 x + 1 mod 2^32 started from Jenkins' mix3); 200 stochastic tracebacks; every
+// sampled domain becomes a segment pair (seq from/to, model from/to) and bumps per-residue null2
+// accumulators (null2 by trace); single-linkage clustering of the segments (overlap >= 0.8 of the
+// smaller in sequence and model, start OR end diagonals within 4), clusters present in >= 25 % of
+// the traces survive, their end points are the outermost ones reached by >= 2 % of the cluster;
+// clusters dominated by an overlapping more probable one are dropped; each survivor is an
+// envelope rescored by unihit Forward, its null2 correction being the trace-derived one.
+//
+// The scoring kernels queue every pair that has such a region (ResolveRec: regions, the results of
+// its single-domain regions, the Forward score); this kernel finishes those pairs, ONE WAVEFRONT
+// PER PAIR: float64 Forward sweeps (generic in the model size: lane r owns nodes r*Q+1..r*Q+Q, the
+// D->D chain is a cross-lane affine scan in double; the dense matrix lives in a per-wave HBM slab,
+// double precision keeps the sampled choices identical to the float64 oracle's), the traces run
+// wave-uniform (one random number per choice, strictly serial by construction of the generator),
+// the E-state choice and the per-trace null2 / segment bookkeeping use the 64 lanes, the
+// clustering reproduces Easel's vertex order exactly (parallel link tests, serial stack updates).
+#include <hip/hip_runtime.h>
+
+#include "wh_launch.h"
+
+namespace wh {
+
+namespace {
+
+constexpr int kSamples = 200;
+constexpr int kDomMax = 32;          // domains per sampled trace kept (more: TRUNC)
+constexpr int kSegCap = 2048;         // sampled segments per region kept (200 traces x ~1-3 domains; more: TRUNC)
+constexpr int kEnvMax = 16;          // envelopes per pair kept internally (detail reports WH_MAX_ENVELOPES)
+constexpr double kRescaleHi = 1e60;
+
+enum { gA = 0, gB, gC, gE, gMI, gII, gD1, gD2, gNARR };
+enum { xN = 0, xB, xE, xJ, xC, xLS, xNSPEC = 8 };   // specials in a row's tail; xLS = ln of the rescale applied at this row
+enum { stM = 1, stD, stI, stN, stC, stJ, stE, stB, stS };
+
+__device__ __forceinline__ double shfl_up_d(double v, int d) {
+  const long long u = __double_as_longlong(v);
+  const int lo = __shfl_up((int)(u & 0xFFFFFFFFll), d), hi = __shfl_up((int)(u >> 32), d);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double shfl_d(double v, int l) {
+  const long long u = __double_as_longlong(v);
+  const int lo = __shfl((int)(u & 0xFFFFFFFFll), l), hi = __shfl((int)(u >> 32), l);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double wave_sum_d(double x) {
+  for (int m = 32; m >= 1; m >>= 1) {
+    const long long u = __double_as_longlong(x);
+    const int lo = __shfl_xor((int)(u & 0xFFFFFFFFll), m), hi = __shfl_xor((int)(u >> 32), m);
+    x += __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+  }
+  return x;
+}
+__device__ __forceinline__ float wave_sum_f(float x) {
+  for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m);
+  return x;
+}
+__device__ __forceinline__ int wave_min_i(int x) { for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(x, m); x = o < x ? o : x; } return x; }
+__device__ __forceinline__ int wave_max_i(int x) { for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(x, m); x = o > x ? o : x; } return x; }
+__device__ __forceinline__ int wave_sum_i(int x) { for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m); return x; }
+
+struct GLen { double loop, move, EJ, EC; };
+__device__ __forceinline__ GLen glen_config(int Lcfg, bool multihit) {
+  // HMMER evaluates the length model in float32 (A.1)
+  const float nj = multihit ? 1.0f : 0.0f;
+  const float pmove = (2.0f + nj) / ((float)Lcfg + 2.0f + nj);
+  const float ploop = 1.0f - pmove;
+  GLen c;
+  c.loop = ploop; c.move = pmove; c.EJ = multihit ? 0.5 : 0.0; c.EC = multihit ? 0.5 : 1.0;
+  return c;
+}
+
+// One model's float64 tables, lane-blocked: value of array <arr> at node k = lane*Q + q + 1 sits at
+// [(arr*Q + q)*64 + lane]; emission odds rows the same with arr = residue code.
+struct GModel {
+  const double *tf, *te;
+  int Q, M;
+  __device__ __forceinline__ size_t at(int arr, int k) const { return ((size_t)arr * Q + (k - 1) % Q) * 64 + (k - 1) / Q; }
+  __device__ __forceinline__ double t(int arr, int k) const { return tf[at(arr, k)]; }
+};
+
+// The per-wave matrix slab: row i = [3 states][Q][64 lanes] doubles + xNSPEC specials.
+struct GMx {
+  double *p;
+  size_t rowlen;
+  int Q;
+  __device__ __forceinline__ double *row(int i) const { return p + (size_t)i * rowlen; }
+  __device__ __forceinline__ double cell(int i, int k, int s) const {   // k = 0 reads as 0
+    return k <= 0 ? 0.0 : __builtin_nontemporal_load(p + (size_t)i * rowlen + ((size_t)s * Q + (k - 1) % Q) * 64 + (k - 1) / Q);
+  }
+  __device__ __forceinline__ double spec(int i, int s) const { return __builtin_nontemporal_load(p + (size_t)i * rowlen + (size_t)3 * Q * 64 + s); }
+};
+
+// Forward sweep (A.2), float64.  STORE keeps every row (row i at slab row i), otherwise rows
+// alternate between slab rows 0 and 1.  Returns ln P in nats (Forward score).
+template <bool STORE>
+__device__ double gforward(const GModel &m, const uint8_t *seq, int L, GLen c, const GMx &mx, int lane) {
+  const int Q = m.Q;
+  const size_t SQ = (size_t)Q * 64;
+  double ls = 0.0;
+  {
+    double *r0 = mx.row(0);
+    for (int q = 0; q < Q; q++) { r0[(size_t)q * 64 + lane] = 0.0; r0[SQ + (size_t)q * 64 + lane] = 0.0; r0[2 * SQ + (size_t)q * 64 + lane] = 0.0; }
+    if (lane == 0) { double *s = r0 + 3 * SQ; s[xN] = 1.0; s[xB] = c.move; s[xE] = 0.0; s[xJ] = 0.0; s[xC] = 0.0; s[xLS] = 0.0; }
+  }
+  double pN = 1.0, pB = c.move, pJ = 0.0, pC = 0.0;
+  // model-only part of the cross-lane D scan: A_r = (prod_{q>=1} D2_q) * D2_0 = product of the lane's D2
+  double Alane = 1.0;
+  for (int q = 0; q < Q; q++) Alane *= m.tf[((size_t)gD2 * Q + q) * 64 + lane];
+  for (int i = 1; i <= L; i++) {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");    // row i-1 was written by other lanes of this wave
+    const double *pr = mx.row(STORE ? i - 1 : (i - 1) & 1);
+    double *cr = mx.row(STORE ? i : i & 1);
+    const double *od = m.te + (size_t)seq[i - 1] * SQ;
+    // previous row at node k-1 for my first node: lane-1's last node
+    double pm1 = 0.0, pi1 = 0.0, pd1 = 0.0;
+    if (lane > 0) {
+      pm1 = __builtin_nontemporal_load(pr + (size_t)(Q - 1) * 64 + lane - 1);
+      pi1 = __builtin_nontemporal_load(pr + SQ + (size_t)(Q - 1) * 64 + lane - 1);
+      pd1 = __builtin_nontemporal_load(pr + 2 * SQ + (size_t)(Q - 1) * 64 + lane - 1);
+    }
+    double mprev = 0.0, dloc = 0.0, P = 1.0, esum = 0.0;
+    for (int q = 0; q < Q; q++) {
+      const size_t o = (size_t)q * 64 + lane;
+      const double pM = __builtin_nontemporal_load(pr + o), pI = __builtin_nontemporal_load(pr + SQ + o), pD = __builtin_nontemporal_load(pr + 2 * SQ + o);
+      const double mm = od[o] * (pm1 * m.tf[gA * SQ + o] + pi1 * m.tf[gB * SQ + o] + pd1 * m.tf[gC * SQ + o] + pB * m.tf[gE * SQ + o]);
+      const double ins = pM * m.tf[gMI * SQ + o] + pI * m.tf[gII * SQ + o];
+      // D chain inside the lane with nothing entering from the left (the entering value is added below)
+      dloc = q > 0 ? mprev * m.tf[gD1 * SQ + o] + dloc * m.tf[gD2 * SQ + o] : 0.0;
+      if (q > 0) P *= m.tf[gD2 * SQ + o];
+      cr[o] = mm; cr[SQ + o] = ins; cr[2 * SQ + o] = dloc;
+      esum += mm;
+      pm1 = pM; pi1 = pI; pd1 = pD; mprev = mm;
+    }
+    // cross-lane: Dlast(r) = [dloc_last + P * D1_0 * Mlast(r-1)] + [P * D2_0] * Dlast(r-1)
+    const double mleft = lane > 0 ? shfl_up_d(mprev, 1) : 0.0;
+    const double d10 = m.tf[gD1 * SQ + lane], d20 = m.tf[gD2 * SQ + lane];
+    double Bv = dloc + P * d10 * (lane > 0 ? mleft : 0.0), Av = Alane;
+    for (int d = 1; d < 64; d <<= 1) {
+      const double Bo = shfl_up_d(Bv, d), Ao = shfl_up_d(Av, d);
+      if (lane >= d) { Bv = Bv + Av * Bo; Av = Av * Ao; }
+    }
+    const double dleft = lane > 0 ? shfl_up_d(Bv, 1) : 0.0;      // true D of lane-1's last node
+    const double c0 = lane > 0 ? d10 * mleft + d20 * dleft : 0.0;  // true D of my first node
+    double Pq = 1.0;
+    for (int q = 0; q < Q; q++) {
+      const size_t o = (size_t)q * 64 + lane;
+      if (q > 0) Pq *= m.tf[gD2 * SQ + o];
+      const double dv = cr[2 * SQ + o] + Pq * c0;
+      cr[2 * SQ + o] = dv;
+      esum += dv;
+    }
+    double xe = wave_sum_d(esum);
+    double xn = pN * c.loop, xc = pC * c.loop + xe * c.EC, xj = pJ * c.loop + xe * c.EJ, lsd = 0.0;
+    if (xe > kRescaleHi) {
+      const double r = 1.0 / xe;
+      for (int q = 0; q < Q; q++) { const size_t o = (size_t)q * 64 + lane; cr[o] *= r; cr[SQ + o] *= r; cr[2 * SQ + o] *= r; }
+      xn *= r; xc *= r; xj *= r; lsd = log(xe); ls += lsd; xe = 1.0;
+    }
+    const double xb = xj * c.move + xn * c.move;
+    if (lane == 0) { double *s = cr + 3 * SQ; s[xN] = xn; s[xB] = xb; s[xE] = xe; s[xJ] = xj; s[xC] = xc; s[xLS] = lsd; }
+    pN = xn; pB = xb; pJ = xj; pC = xc;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  return ls + log(pC * c.move);
+}
+
+struct Rng { uint32_t x; };
+__device__ __forceinline__ uint32_t mix3(uint32_t a, uint32_t b, uint32_t c) {
+  a -= b; a -= c; a ^= (c >> 13);
+  b -= c; b -= a; b ^= (a << 8);
+  c -= a; c -= b; c ^= (b >> 13);
+  a -= b; a -= c; a ^= (c >> 12);
+  b -= c; b -= a; b ^= (a << 16);
+  c -= a; c -= b; c ^= (b >> 5);
+  a -= b; a -= c; a ^= (c >> 3);
+  b -= c; b -= a; b ^= (a << 10);
+  c -= a; c -= b; c ^= (b >> 15);
+  return c;
+}
+__device__ __forceinline__ double rng_next(Rng &r) { r.x = r.x * 69069u + 1u; return (double)r.x / 4294967296.0; }
+// esl_vec_FNorm + esl_rnd_FChoose: float probabilities, double running sum, first t with sum/norm > roll
+__device__ __forceinline__ int rng_choose(Rng &r, const double *pd, int n) {
+  float p[4];
+  double tot = 0.0;
+  for (int t = 0; t < n; t++) tot += pd[t];
+  for (int t = 0; t < n; t++) p[t] = tot > 0.0 ? (float)(pd[t] / tot) : 1.0f / (float)n;
+  const double roll = rng_next(r);
+  double norm = 0.0, sum = 0.0;
+  for (int t = 0; t < n; t++) norm += (double)p[t];
+  for (int t = 0; t < n; t++) { sum += (double)p[t]; if (sum / norm > roll) return t; }
+  return n - 1;
+}
+
+// seq overlap, model overlap, diagonal test of link_spsamples (p7_spensemble.c), see file header
+__device__ __forceinline__ bool seg_linked(int i1, int j1, int k1, int m1, int i2, int j2, int k2, int m2) {
+  int nov = min(j1, j2) - max(i1, i2) + 1;
+  int n = min(j1 - i1 + 1, j2 - i2 + 1);
+  if ((float)nov / (float)n < 0.8f) return false;
+  nov = min(m1, m2) - max(k1, k2);
+  n = min(m1 - k1 + 1, m2 - k2 + 1);
+  if ((float)nov / (float)n < 0.8f) return false;
+  if (abs((i1 - k1) - (i2 - k2)) <= 4) return true;
+  if (abs((j1 - m1) - (j2 - m2)) <= 4) return true;
+  return false;
+}
+
+}  // namespace
+
+// LDS per wave (ints unless noted): see resolve_lds_bytes()
+__host__ __device__ inline size_t resolve_lds_ints(int Lcap, int Mmax) {
+  const int Lp = (Lcap + 4) & ~1, W = (Lcap > Mmax ? Lcap : Mmax) + 4;
+  return (size_t)(Lcap + 8) / 4 + 2 /*seq*/ + Lp /*n2sc*/ + Lp /*acc*/ + Lp /*stk*/ + W /*epc*/ + kDomMax * (4 + 32) + 2 * kSegCap + 64;
+}
+size_t resolve_lds_bytes(int Lcap, int Mmax) { return resolve_lds_ints(Lcap, Mmax) * 4 + 16; }
+int resolve_seg_cap() { return kSegCap; }
+
+__global__ __launch_bounds__(64) void resolve_kernel(ResolveArgs a) {
+  extern __shared__ __attribute__((aligned(16))) int lds_raw[];
+  const int lane = threadIdx.x;
+  const int Lp = (a.Lcap + 4) & ~1, W = (a.Lcap > a.Mmax ? a.Lcap : a.Mmax) + 4;
+  uint8_t *seq = reinterpret_cast<uint8_t *>(lds_raw);
+  float *n2sc = reinterpret_cast<float *>(lds_raw + (a.Lcap + 8) / 4 + 2);
+  float *acc = n2sc + Lp;
+  int *stk = reinterpret_cast<int *>(acc + Lp);
+  int *epc = stk + Lp;
+  int *dom = epc + W;                                  // kDomMax x (sqfrom, sqto, hmmfrom, hmmto)
+  float *dnull = reinterpret_cast<float *>(dom + 4 * kDomMax);   // kDomMax x 32
+  const int SEGCAP = a.seg_cap;
+  int *s_a = reinterpret_cast<int *>(dnull + 32 * kDomMax);      // Easel's vertex stacks of the clustering (LDS)
+  int *s_b = s_a + SEGCAP;
+  int32_t *sg = a.segs + (size_t)blockIdx.x * a.seg_stride;      // per wave in HBM: 6 arrays of SEGCAP ints
+  int32_t *s_idx = sg, *s_i = sg + SEGCAP, *s_j = sg + 2 * SEGCAP, *s_k = sg + 3 * SEGCAP, *s_m = sg + 4 * SEGCAP;
+  int32_t *s_as = sg + 5 * SEGCAP;
+  const double LOG2 = 0.69314718055994529;
+  const int n_items = *a.count < a.rec_cap ? *a.count : a.rec_cap;
+
+  for (;;) {
+    int item = 0;
+    if (lane == 0) item = atomicAdd(a.counter, 1);
+    item = __shfl(item, 0);
+    if (item >= n_items) break;
+    const ResolveRec rec = a.recs[item];
+    const DevHMM hm = a.hmms[rec.h];
+    GModel m;
+    m.tf = a.gtab + hm.gfw_off; m.te = a.gtab + hm.gem_off; m.Q = hm.Q; m.M = hm.M;
+    GMx mx;
+    mx.Q = hm.Q; mx.rowlen = (size_t)3 * hm.Q * 64 + xNSPEC;
+    mx.p = a.mx + (size_t)blockIdx.x * a.mx_stride;
+    const int64_t off = a.offsets[rec.q];
+    const int L = (int)(a.offsets[rec.q + 1] - off);
+    const size_t out = (size_t)rec.q * a.H + rec.h;
+    for (int t = lane; t < L; t += 64) { const int r = a.residues[off + t]; seq[t] = (uint8_t)(r < a.Kp ? r : a.Kp - 1); }
+    for (int t = lane; t <= L + 1; t += 64) n2sc[t] = 0.f;
+    __builtin_amdgcn_wave_barrier();
+    const GLen cm = glen_config(L, true), cu = glen_config(L, false);
+    int flags = rec.flags | WH_FLAG_MULTI;
+    // envelope list of the pair
+    int nenv = 0;
+    int env_i[kEnvMax], env_j[kEnvMax];
+    float env_sc[kEnvMax], env_dc[kEnvMax];
+    float seqbias_sum = 0.f;
+    for (int e = 0; e < rec.nenv; e++) {
+      const int ireg = rec.ri[e], jreg = rec.rj[e], Lr = jreg - ireg + 1;
+      if (!((rec.multi_mask >> e) & 1)) {
+        // single-domain region: envelope = region, scored by the scoring kernel (A.5)
+        seqbias_sum += rec.domcorr[e];
+        if (nenv < kEnvMax) { env_i[nenv] = ireg; env_j[nenv] = jreg; env_sc[nenv] = rec.envsc[e]; env_dc[nenv] = rec.domcorr[e]; nenv++; }
+        else flags |= WH_FLAG_TRUNC;
+        continue;
+      }
+      // ---------------- A.4b
+      const uint8_t *rs = seq + (ireg - 1);       // rs[pos-1] = residue at region position pos
+      gforward<true>(m, rs, Lr, cm, mx, lane);
+      for (int t = lane; t <= Lr + 1; t += 64) acc[t] = 0.f;
+      int nseg = 0;
+      Rng rng;
+      rng.x = mix3(42u, 87654321u, 12345678u);
+      if (rng.x == 0) rng.x = 42;
+      const int Qs = ((m.M - 1) / 4 + 1) > 2 ? ((m.M - 1) / 4 + 1) : 2;     // HMMER's striping: vectors of 4 floats
+      for (int t = 0; t < kSamples; t++) {
+        int i = Lr, k = 0, s0 = stC, ndom = 0, sqto = 0, hmmto = 0, sqfrom = 0, hmmfrom = 0;
+        while (s0 != stS) {
+          double path[4];
+          int s1;
+          switch (s0) {
+            case stM: {
+              path[0] = mx.spec(i - 1, xB) * m.t(gE, k);
+              path[1] = mx.cell(i - 1, k - 1, 0) * m.t(gA, k);
+              path[2] = mx.cell(i - 1, k - 1, 1) * m.t(gB, k);
+              path[3] = mx.cell(i - 1, k - 1, 2) * m.t(gC, k);
+              const int c4 = rng_choose(rng, path, 4);
+              s1 = c4 == 0 ? stB : c4 == 1 ? stM : c4 == 2 ? stI : stD;
+              k--; i--;
+              break;
+            }
+            case stD:
+              path[0] = mx.cell(i, k - 1, 0) * m.t(gD1, k);
+              path[1] = mx.cell(i, k - 1, 2) * m.t(gD2, k);
+              s1 = rng_choose(rng, path, 2) == 0 ? stM : stD;
+              k--;
+              break;
+            case stI:
+              path[0] = mx.cell(i - 1, k, 0) * m.t(gMI, k);
+              path[1] = mx.cell(i - 1, k, 1) * m.t(gII, k);
+              s1 = rng_choose(rng, path, 2) == 0 ? stM : stI;
+              i--;
+              break;
+            case stN: s1 = (i == 0) ? stS : stN; break;
+            case stC:
+              path[0] = mx.spec(i - 1, xC) * cm.loop;
+              path[1] = mx.spec(i, xE) * cm.EC * exp(mx.spec(i, xLS));
+              s1 = rng_choose(rng, path, 2) == 0 ? stC : stE;
+              break;
+            case stJ:
+              path[0] = mx.spec(i - 1, xJ) * cm.loop;
+              path[1] = mx.spec(i, xE) * cm.EJ * exp(mx.spec(i, xLS));
+              s1 = rng_choose(rng, path, 2) == 0 ? stJ : stE;
+              break;
+            case stE: {
+              // FChoose over M(i,*) and D(i,*) in HMMER's striped order: position p = q*8 + state*4 + r
+              // holds node r*Qs + q + 1.  Lanes take contiguous chunks, an exclusive scan finds the chunk.
+              const double roll = rng_next(rng), norm = 1.0 / mx.spec(i, xE);
+              const int total = 8 * Qs, chunk = (total + 63) / 64;
+              const int p0 = lane * chunk, p1 = min(total, p0 + chunk);
+              auto term = [&](int p) -> double {
+                const int q = p >> 3, st = (p >> 2) & 1, r = p & 3, kk = r * Qs + q + 1;
+                return kk <= m.M ? (double)(float)(mx.cell(i, kk, st ? 2 : 0) * norm) : 0.0;
+              };
+              double mine = 0.0;
+              for (int p = p0; p < p1; p++) mine += term(p);
+              double incl = mine;
+              for (int d = 1; d < 64; d <<= 1) { const double o = shfl_up_d(incl, d); if (lane >= d) incl += o; }
+              const double excl = incl - mine;
+              const unsigned long long hit = __ballot(roll < incl);
+              int found_p = -1;
+              if (hit) {
+                const int src = __ffsll((long long)hit) - 1;
+                int fp = -1;
+                if (lane == src) {
+                  double sum = excl;
+                  for (int p = p0; p < p1; p++) { sum += term(p); if (roll < sum) { fp = p; break; } }
+                  if (fp < 0) fp = p1 - 1;
+                }
+                found_p = __shfl(fp, src);
+              }
+              if (found_p < 0) { k = 1; s1 = stM; }        // rounding left the sum below the roll: HMMER rescans, first non-zero cell wins
+              else { k = (found_p & 3) * Qs + (found_p >> 3) + 1; s1 = ((found_p >> 2) & 1) ? stD : stM; }
+              break;
+            }
+            case stB:
+              path[0] = mx.spec(i, xN) * cm.move;
+              path[1] = mx.spec(i, xJ) * cm.move;
+              s1 = rng_choose(rng, path, 2) == 0 ? stN : stJ;
+              break;
+            default: s1 = stS; break;
+          }
+          // the state just chosen sits at (k, i)
+          if (s1 == stE) { sqto = 0; hmmto = 0; }
+          else if (s1 == stM) {
+            if (sqto == 0) { sqto = i; hmmto = k; }
+            sqfrom = i; hmmfrom = k;
+            if (lane == 0) stk[i] = k;
+          } else if (s1 == stI) { if (lane == 0) stk[i] = -k; }
+          else if (s1 == stB) {
+            if (ndom < kDomMax) {
+              if (lane == 0) { dom[4 * ndom] = sqfrom; dom[4 * ndom + 1] = sqto; dom[4 * ndom + 2] = hmmfrom; dom[4 * ndom + 3] = hmmto; }
+              ndom++;
+            } else flags |= WH_FLAG_TRUNC;
+          }
+          if ((s1 == stN || s1 == stJ || s1 == stC) && s1 == s0) i--;
+          s0 = s1;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // null2 by trace of every sampled domain (A.4b / p7_Null2_ByTrace): mean emission odds of the
+        // M/I states that emitted the domain's residues
+        for (int d = 0; d < ndom; d++) {
+          const int df = dom[4 * d], dt = dom[4 * d + 1], Ld = dt - df + 1;
+          float mine = 1.0f;
+          for (int x = 0; x < a.K; x++) {
+            float s = 0.f;
+            for (int pos = df + lane; pos <= dt; pos += 64) {
+              const int kk = stk[pos];
+              s += kk > 0 ? (float)m.te[((size_t)x * m.Q + (kk - 1) % m.Q) * 64 + (kk - 1) / m.Q] : 1.0f;
+            }
+            s = wave_sum_f(s);
+            if (lane == x) mine = s / (float)Ld;
+          }
+          __builtin_amdgcn_wave_barrier();
+          if (lane < a.K) dnull[32 * d + lane] = mine;
+          __builtin_amdgcn_wave_barrier();
+          if (lane >= a.K && lane < a.Kp) {
+            const uint32_t msk = a.degen[lane];
+            float s = 0.f; int n = 0;
+            for (int x = 0; x < a.K; x++) if (msk & (1u << x)) { s += dnull[32 * d + x]; n++; }
+            dnull[32 * d + lane] = n > 0 ? s / (float)n : 1.0f;
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+        // per-residue accumulators: +1 outside sampled domains AND at a domain's first residue (sic),
+        // + null2[x] at the domain's other residues
+        for (int pos = 1 + lane; pos <= Lr; pos += 64) {
+          float add = 1.0f;
+          for (int d = 0; d < ndom; d++)
+            if (pos > dom[4 * d] && pos <= dom[4 * d + 1]) add = dnull[32 * d + rs[pos - 1]];
+          acc[pos] += add;
+        }
+        // the ensemble takes the domains left to right (they were found right to left)
+        if (lane == 0)
+          for (int d = ndom - 1; d >= 0; d--)
+            if (nseg + (ndom - 1 - d) < SEGCAP) {
+              const int z = nseg + (ndom - 1 - d);
+              s_idx[z] = t; s_i[z] = dom[4 * d] + ireg - 1; s_j[z] = dom[4 * d + 1] + ireg - 1; s_k[z] = dom[4 * d + 2]; s_m[z] = dom[4 * d + 3];
+            }
+        if (nseg + ndom > SEGCAP) flags |= WH_FLAG_TRUNC;
+        nseg = min(SEGCAP, nseg + ndom);
+        __builtin_amdgcn_wave_barrier();
+      }
+      for (int pos = 1 + lane; pos <= Lr; pos += 64) n2sc[ireg + pos - 1] = logf(acc[pos] / (float)kSamples);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      // ---------------- single-linkage clustering in Easel's vertex order (esl_cluster_SingleLinkage)
+      int nc = 0;
+      {
+        for (int v = lane; v < nseg; v += 64) s_a[v] = nseg - v - 1;
+        __builtin_amdgcn_wave_barrier();
+        int na = nseg;
+        while (na > 0) {
+          int v = s_a[na - 1];
+          na--;
+          int nb = 1;
+          __builtin_amdgcn_wave_barrier();
+          if (lane == 0) s_b[0] = v;
+          __builtin_amdgcn_wave_barrier();
+          while (nb > 0) {
+            v = s_b[nb - 1];
+            nb--;
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) s_as[v] = nc;
+            const int vi = __builtin_nontemporal_load(s_i + v), vj = __builtin_nontemporal_load(s_j + v), vk = __builtin_nontemporal_load(s_k + v), vm = __builtin_nontemporal_load(s_m + v);
+            // scan a[na-1 .. 0]: link tests in parallel, deletions (swap with the last entry) in scan order
+            for (int hi = na - 1; hi >= 0; hi -= 64) {
+              const int tpos = hi - lane;
+              bool link = false;
+              int w = 0;
+              if (tpos >= 0) {
+                w = s_a[tpos];
+                link = seg_linked(vi, vj, vk, vm, __builtin_nontemporal_load(s_i + w), __builtin_nontemporal_load(s_j + w),
+                                  __builtin_nontemporal_load(s_k + w), __builtin_nontemporal_load(s_m + w));
+              }
+              unsigned long long hits = __ballot(link);
+              // entries moved in by a swap come from positions above the scan point of this chunk: they were
+              // tested in this very scan already (the scan runs downwards), so the flags stay valid
+              while (hits) {
+                const int l = __ffsll((long long)hits) - 1;
+                hits &= hits - 1;
+                const int tp = hi - l;
+                const int wv = __shfl(w, l);
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) {
+                  s_a[tp] = s_a[na - 1];
+                  s_b[nb] = wv;
+                }
+                na--; nb++;
+                __builtin_amdgcn_wave_barrier();
+              }
+            }
+          }
+          nc++;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      // ---------------- clusters -> envelopes (p7_spensemble_Cluster)
+      int nsig = 0;
+      int g_i[kEnvMax], g_j[kEnvMax];
+      float g_p[kEnvMax];
+      for (int c = 0; c < nc; c++) {
+        // posterior of the cluster: traces that contribute (segments are in trace order)
+        int ninc = 0;
+        {
+          int last = -1;      // idx of the previous member in the serial order ("idx_of_last")
+          for (int h0 = 0; h0 < nseg; h0 += 64) {
+            const int h = h0 + lane;
+            const bool mem = h < nseg && __builtin_nontemporal_load(s_as + h) == c;
+            const int idx = mem ? __builtin_nontemporal_load(s_idx + h) : -1;
+            const unsigned long long mm = __ballot(mem);
+            const unsigned long long below = mm & ((1ull << lane) - 1ull);
+            const int src = below ? 63 - __clzll((long long)below) : 0;
+            const int pv = __shfl(idx, src);
+            const int prev = below ? pv : last;
+            ninc += wave_sum_i((mem && idx != prev) ? 1 : 0);
+            if (mm) last = __shfl(idx, 63 - __clzll((long long)mm));
+          }
+        }
+        if ((float)ninc / (float)kSamples < 0.25f) continue;
+        int imin = 1 << 30, imax = -1, jmin = 1 << 30, jmax = -1, kmin = 1 << 30, kmax = -1, mmin = 1 << 30, mmax = -1;
+        for (int h = lane; h < nseg; h += 64)
+          if (__builtin_nontemporal_load(s_as + h) == c) {
+            const int si = s_i[h], sj = s_j[h], sk = s_k[h], sm = s_m[h];
+            imin = min(imin, si); imax = max(imax, si); jmin = min(jmin, sj); jmax = max(jmax, sj);
+            kmin = min(kmin, sk); kmax = max(kmax, sk); mmin = min(mmin, sm); mmax = max(mmax, sm);
+          }
+        imin = wave_min_i(imin); imax = wave_max_i(imax); jmin = wave_min_i(jmin); jmax = wave_max_i(jmax);
+        kmin = wave_min_i(kmin); kmax = wave_max_i(kmax); mmin = wave_min_i(mmin); mmax = wave_max_i(mmax);
+        const int thr = (int)ceilf((float)ninc * 0.02f);
+        // end-point histograms; which = 0 i (leftmost), 1 k (leftmost), 2 j (rightmost), 3 m (rightmost)
+        int best[4];
+        for (int which = 0; which < 4; which++) {
+          const int lo = which == 0 ? imin : which == 1 ? kmin : which == 2 ? jmin : mmin;
+          const int hi = which == 0 ? imax : which == 1 ? kmax : which == 2 ? jmax : mmax;
+          const int32_t *src = which == 0 ? s_i : which == 1 ? s_k : which == 2 ? s_j : s_m;
+          const int n = hi - lo + 1;
+          for (int t = lane; t < n; t += 64) epc[t] = 0;
+          __builtin_amdgcn_wave_barrier();
+          for (int h = lane; h < nseg; h += 64)
+            if (__builtin_nontemporal_load(s_as + h) == c) atomicAdd(&epc[src[h] - lo], 1);
+          __builtin_amdgcn_wave_barrier();
+          int b = -1;
+          if (which < 2) {          // leftmost position with enough end points, else the (first) most frequent one
+            int cand = 1 << 30;
+            for (int t = lane; t < n; t += 64) if (epc[t] >= thr) cand = min(cand, t);
+            cand = wave_min_i(cand);
+            if (cand < (1 << 30)) b = cand;
+          } else {
+            int cand = -1;
+            for (int t = lane; t < n; t += 64) if (epc[t] >= thr) cand = max(cand, t);
+            cand = wave_max_i(cand);
+            if (cand >= 0) b = cand;
+          }
+          if (b < 0) {              // esl_vec_IArgMax: first maximum
+            int bv = -1, bt = 0;
+            for (int t = 0; t < n; t++) { const int e2 = epc[t]; if (e2 > bv) { bv = e2; bt = t; } }
+            b = bt;
+          }
+          best[which] = lo + b;
+          __builtin_amdgcn_wave_barrier();
+        }
+        if (best[0] > best[2] || best[1] > best[3]) continue;
+        if (nsig < kEnvMax) { g_i[nsig] = best[0]; g_j[nsig] = best[2]; g_p[nsig] = (float)ninc / (float)kSamples; nsig++; }
+        else flags |= WH_FLAG_TRUNC;
+      }
+      // order by start (stable), drop dominated clusters (region_trace_ensemble)
+      for (int d = 1; d < nsig; d++) {
+        const int ti = g_i[d], tj = g_j[d]; const float tp = g_p[d];
+        int d2 = d - 1;
+        for (; d2 >= 0 && g_i[d2] > ti; d2--) { g_i[d2 + 1] = g_i[d2]; g_j[d2 + 1] = g_j[d2]; g_p[d2 + 1] = g_p[d2]; }
+        g_i[d2 + 1] = ti; g_j[d2 + 1] = tj; g_p[d2 + 1] = tp;
+      }
+      unsigned dominated = 0;
+      for (int d = 0; d < nsig; d++)
+        for (int d2 = d + 1; d2 < nsig; d2++) {
+          const int nov = min(g_j[d], g_j[d2]) - max(g_i[d], g_i[d2]) + 1;
+          if (nov == 0) break;
+          const int nn = min(g_j[d] - g_i[d] + 1, g_j[d2] - g_i[d2] + 1);
+          if ((float)nov / (float)nn >= 0.8f) { if (g_p[d] > g_p[d2]) dominated |= 1u << d2; else dominated |= 1u << d; }
+        }
+      // ---------------- every surviving cluster is an envelope: unihit Forward score, trace-derived null2
+      // HMMER sums n2sc over the whole sequence in position order; per region here (float32 either way)
+      float regsum = 0.f;
+      for (int pos = ireg; pos <= jreg; pos++) regsum += n2sc[pos];
+      seqbias_sum += regsum;
+      for (int d = 0; d < nsig; d++) {
+        if (dominated & (1u << d)) continue;
+        const int i2 = g_i[d], j2 = g_j[d], Ld = j2 - i2 + 1;
+        const double envsc = gforward<false>(m, seq + (i2 - 1), Ld, cu, mx, lane);
+        float dc = 0.f;
+        for (int pos = i2; pos <= j2; pos++) dc += n2sc[pos];
+        if (nenv < kEnvMax) { env_i[nenv] = i2; env_j[nenv] = j2; env_sc[nenv] = (float)envsc; env_dc[nenv] = dc; nenv++; }
+        else flags |= WH_FLAG_TRUNC;
+      }
+    }
+    // ---------------- A.6 score assembly (float32 where HMMER is float32), as in the scoring kernels
+    int decibits = 0;
+    wh_pair_detail *dp = (a.detail && lane == 0) ? a.detail + out : nullptr;
+    if (nenv > 0) {
+      const float fwdsc = rec.fwdsc;
+      const float p1 = (float)L / (float)(L + 1);
+      const float nullsc = (float)((double)(float)L * log((double)p1) + log(1.0 - (double)p1));
+      const float lomega = (float)log(1.0 / 256.0);
+      auto flogsum0 = [](float b) -> float {
+        const float mxv = b > 0.f ? b : 0.f, mn = b > 0.f ? 0.f : b;
+        if (mn == -INFINITY || (mxv - mn) >= 15.7f) return mxv;
+        const int idx = (int)((mxv - mn) * 1000.0f);
+        return mxv + (float)log(1.0 + exp((double)-idx / 1000.0));
+      };
+      const float seqbias = flogsum0(lomega + seqbias_sum);
+      float pre_score = (float)(((double)fwdsc - (double)nullsc) / LOG2);
+      float seq_score = (float)(((double)fwdsc - (double)(nullsc + seqbias)) / LOG2);
+      float sum_score = 0.f, sb2 = 0.f;
+      int Ld_tot = 0;
+      for (int e = 0; e < nenv; e++)
+        if (env_sc[e] - env_dc[e] > 0.0f) { sum_score += env_sc[e]; Ld_tot += env_j[e] - env_i[e] + 1; sb2 += env_dc[e]; }
+      sb2 = flogsum0(lomega + sb2);
+      sum_score += (float)((double)(L - Ld_tot) * log((double)((float)L / (float)(L + 3))));
+      const float pre2 = (float)(((double)sum_score - (double)nullsc) / LOG2);
+      sum_score = (float)(((double)sum_score - (double)(nullsc + sb2)) / LOG2);
+      if (Ld_tot > 0 && sum_score > seq_score) { seq_score = sum_score; pre_score = pre2; flags |= WH_FLAG_OVERRIDE; }
+      decibits = (int)rint((double)seq_score * 10.0);
+      flags |= WH_FLAG_REPORTED;
+      if (dp) { dp->seq_score = seq_score; dp->pre_score = pre_score; dp->seqbias_nats = seqbias; }
+    }
+    if (dp) {
+      dp->nregions = rec.nreg;
+      dp->nenv = nenv < WH_MAX_ENVELOPES ? nenv : WH_MAX_ENVELOPES;
+      for (int e = 0; e < dp->nenv; e++) { dp->env_i[e] = env_i[e]; dp->env_j[e] = env_j[e]; dp->envsc[e] = env_sc[e]; dp->domcorr[e] = env_dc[e]; }
+    }
+    if (lane == 0) { a.decibits[out] = decibits; a.flags[out] = (uint8_t)flags; }
+  }
+}
+
+hipError_t launch_resolve(const ResolveArgs &a, int blocks, size_t lds, hipStream_t s) {
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&resolve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (err != hipSuccess) return err;
+  hipLaunchKernelGGL(resolve_kernel, dim3(blocks), dim3(64), lds, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace wh

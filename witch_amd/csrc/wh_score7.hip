@@ -74,7 +74,7 @@ __device__ __forceinline__ int ctxK(const WaveCtx &c) { return c.alpha & 255; }
 __device__ __forceinline__ int ctxKp(const WaveCtx &c) { return (c.alpha >> 8) & 255; }
 __device__ __forceinline__ int ctxKlds(const WaveCtx &c) { return (c.alpha >> 16) & 255; }
 struct P4Out { float mass, domcorr; };
-struct RegOut { int nenv, nreg, flags; };
+struct RegOut { int nenv, nreg, flags, multi_mask; };
 
 struct FwdOut { float xC; int ef; };
 
@@ -324,6 +324,7 @@ __device__ __noinline__ RegOut region_scan(lds_f *spec3, glb_f *specg, int SP, i
   __builtin_amdgcn_wave_barrier();
   if (SG) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
   // multidomain test: max_z min(etot[z]-etot[i-1], btot[j]-btot[z-1]) >= rt3
+  int multi_mask = 0;
   for (int e = 0; e < nenv; e++) {
     const int ri = regs[2 * e], rj = regs[2 * e + 1];
     float mx = -1.0f;
@@ -333,10 +334,10 @@ __device__ __noinline__ RegOut region_scan(lds_f *spec3, glb_f *specg, int SP, i
       mx = fmaxf(mx, fminf(u, v));
     }
     mx = wave_max(mx);
-    if (mx >= rt3) flags |= WH_FLAG_MULTI;
+    if (mx >= rt3) { flags |= WH_FLAG_MULTI; multi_mask |= 1 << e; }
   }
   RegOut o;
-  o.nenv = nenv; o.nreg = nreg; o.flags = flags;
+  o.nenv = nenv; o.nreg = nreg; o.flags = flags; o.multi_mask = multi_mask;
   return o;
 }
 
@@ -433,7 +434,24 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
             const LenCfg cu = len_config(L, false);
             float seqbias_sum = 0.f, sum_score = 0.f, sb2 = 0.f;
             int Ld_tot = 0;
+            // a pair with a multidomain region is finished by resolve_kernel (A.4b): queue it; its
+            // single-domain regions are still scored here
+            ResolveRec *rr = nullptr;
+            if ((ro.flags & WH_FLAG_MULTI) && a.rrecs) {
+              int slot = 0;
+              if (lane == 0) slot = atomicAdd(a.rcount, 1);
+              slot = __shfl(slot, 0);
+              if (slot < a.rcap) {
+                rr = a.rrecs + slot;
+                if (lane == 0) {
+                  rr->q = qi; rr->h = h; rr->fwdsc = fwdsc; rr->fwd_bits = fwd_bits_out; rr->nreg = nreg; rr->nenv = nenv;
+                  rr->multi_mask = ro.multi_mask;
+                  for (int e = 0; e < nenv; e++) { rr->ri[e] = regs[2 * e]; rr->rj[e] = regs[2 * e + 1]; rr->envsc[e] = 0.f; rr->domcorr[e] = 0.f; }
+                }
+              }
+            }
             for (int e = 0; e < nenv; e++) {
+              if (rr && ((ro.multi_mask >> e) & 1)) continue;
               const int ri = regs[2 * e], rj = regs[2 * e + 1];
               const int Ld = rj - ri + 1;
               const uint8_t *eseq = seq + (ri - 1);
@@ -459,7 +477,12 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
               seqbias_sum += domcorr;
               if (envsc - domcorr > 0.0f) { sum_score += envsc; Ld_tot += Ld; sb2 += domcorr; }
               if (dp) { dp->env_i[e] = ri; dp->env_j[e] = rj; dp->envsc[e] = envsc; dp->domcorr[e] = domcorr; }
+              if (rr && lane == 0) { rr->envsc[e] = envsc; rr->domcorr[e] = domcorr; }
             }
+            if (rr) {
+              if (lane == 0) rr->flags = flags;
+              flags |= WH_FLAG_MULTI;      // provisional: resolve_kernel writes the final score and flags
+            } else {
             // ---------------- A.6 score assembly (float32 where HMMER is float32)
             const float lomega = (float)log(1.0 / 256.0);
             const float seqbias = flogsum0_v7(lomega + seqbias_sum);
@@ -473,6 +496,7 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
             decibits = (int)rint((double)seq_score * 10.0);
             flags |= WH_FLAG_REPORTED;
             if (dp) { dp->seq_score = seq_score; dp->pre_score = pre_score; dp->seqbias_nats = seqbias; }
+            }
           }
         }
       }

@@ -91,7 +91,8 @@ __global__ __launch_bounds__(256) void score_big_kernel(ScoreArgs a) {
       if (qi < q_hi) { off = a.offsets[qi]; L = (int)(a.offsets[qi + 1] - off); if (L > a.Lcap) L = 0; }
       const bool active = qi < q_hi && L > 0;
       const size_t out = (size_t)(qi < q_hi ? qi : q_lo) * a.H + h;
-      int flags = 0, decibits = 0, nreg = 0, nenv = 0, ef_L = 0;
+      int flags = 0, decibits = 0, nreg = 0, nenv = 0, ef_L = 0, multi_mask = 0;
+      ResolveRec *rr = nullptr;
       float fwd_bits_out = -INFINITY, fwdsc = 0.f, nullsc = 0.f, invZ = 0.f;
       bool ok = false;
       wh_pair_detail *dp = (a.detail && lane == 0 && active) ? a.detail + out : nullptr;
@@ -223,15 +224,31 @@ __global__ __launch_bounds__(256) void score_big_kernel(ScoreArgs a) {
             mx = fmaxf(mx, fminf(u, v));
           }
           mx = wave_max(mx);
-          if (mx >= rt3) flags |= WH_FLAG_MULTI;
+          if (mx >= rt3) { flags |= WH_FLAG_MULTI; multi_mask |= 1 << e; }
         }
         if (dp) { dp->nregions = nreg; dp->nenv = nenv; }
+        // a pair with a multidomain region is finished by resolve_kernel (A.4b): queue it; its
+        // single-domain regions are still scored here
+        if ((flags & WH_FLAG_MULTI) && a.rrecs) {
+          int slot = 0;
+          if (lane == 0) slot = atomicAdd(a.rcount, 1);
+          slot = __shfl(slot, 0);
+          if (slot < a.rcap) {
+            rr = a.rrecs + slot;
+            if (lane == 0) {
+              rr->q = qi; rr->h = h; rr->fwdsc = fwdsc; rr->fwd_bits = fwd_bits_out; rr->nreg = nreg; rr->nenv = nenv;
+              rr->multi_mask = multi_mask;
+              for (int e = 0; e < nenv; e++) { rr->ri[e] = regs[2 * e]; rr->rj[e] = regs[2 * e + 1]; rr->envsc[e] = 0.f; rr->domcorr[e] = 0.f; }
+            }
+          }
+        }
       }
 
       // ---------------- envelopes: workgroup-uniform loop over (envelope, attempt) steps
       float seqbias_sum = 0.f, sum_score = 0.f, sb2 = 0.f;
       int Ld_tot = 0, e = 0, attempt = 0;
-      bool pending = active && ok && nenv > 0;
+      while (rr && e < nenv && ((multi_mask >> e) & 1)) e++;       // multidomain regions are left to resolve_kernel
+      bool pending = active && ok && e < nenv;
       while (__syncthreads_or(pending ? 1 : 0)) {
         int ri = 1, Ld = 0, ef_e = 0;
         float xC_e = 0.f, envsc = -INFINITY, domcorr = 0.f;
@@ -358,7 +375,9 @@ __global__ __launch_bounds__(256) void score_big_kernel(ScoreArgs a) {
             seqbias_sum += domcorr;
             if (envsc - domcorr > 0.0f) { sum_score += envsc; Ld_tot += Ld; sb2 += domcorr; }
             if (dp) { dp->env_i[e] = ri; dp->env_j[e] = ri + Ld - 1; dp->envsc[e] = envsc; dp->domcorr[e] = domcorr; }
+            if (rr && lane == 0) { rr->envsc[e] = envsc; rr->domcorr[e] = domcorr; }
             e++;
+            while (rr && e < nenv && ((multi_mask >> e) & 1)) e++;
             attempt = 0;
             pending = e < nenv;
           }
@@ -366,7 +385,9 @@ __global__ __launch_bounds__(256) void score_big_kernel(ScoreArgs a) {
       }
 
       // ---------------- A.6 score assembly
-      if (active && ok && nenv > 0) {
+      if (rr) {
+        if (lane == 0) rr->flags = flags;      // resolve_kernel writes the final score and flags of this pair
+      } else if (active && ok && nenv > 0) {
         const float lomega = (float)log(1.0 / 256.0);
         const float seqbias = flogsum0_big(lomega + seqbias_sum);
         float pre_score = (float)(((double)fwdsc - (double)nullsc) / LOG2);

@@ -728,6 +728,11 @@ static int cluster_ensemble(orc_ensemble *en, int nsamples, orc_seg *sig, int ma
   if (n == 0) return 0;
   assign = (int *) malloc(sizeof(int) * (size_t) n);
   nc = single_linkage(en->seg, n, assign);
+  if (getenv("ORC_DBG")) {
+    fprintf(stderr, "[oracle] nseg %d nc %d\n", n, nc);
+    for (h = 0; h < n && h < atoi(getenv("ORC_DBG")); h++)
+      fprintf(stderr, "   seg %d: t %d i %d j %d k %d m %d cluster %d\n", h, en->seg[h].idx, en->seg[h].i, en->seg[h].j, en->seg[h].k, en->seg[h].m, assign[h]);
+  }
   for (c = 0; c < nc; c++) {
     int ninc = 0, idx_of_last = -1, imin = 0, imax = 0, jmin = 0, jmax = 0, kmin = 0, kmax = 0, mmin = 0, mmax = 0;
     int best_i, best_j, best_k, best_m, thr, span;
@@ -760,6 +765,7 @@ static int cluster_ensemble(orc_ensemble *en, int nsamples, orc_seg *sig, int ma
     for (best_m = mmax; best_m >= mmin; best_m--) if (epc[best_m - mmin] >= thr) break;
     if (best_m < mmin) best_m = mmin + iargmax(epc, mmax - mmin + 1);
     free(epc);
+    if (getenv("ORC_DBG")) fprintf(stderr, "[oracle] cluster %d: ninc %d thr %d i %d..%d j %d..%d k %d..%d m %d..%d best %d %d %d %d\n", c, ninc, thr, imin, imax, jmin, jmax, kmin, kmax, mmin, mmax, best_i, best_j, best_k, best_m);
     if (best_i > best_j || best_k > best_m) continue;
     if (nsig < maxsig) {
       sig[nsig].i = best_i; sig[nsig].j = best_j; sig[nsig].k = best_k; sig[nsig].m = best_m;
@@ -815,7 +821,7 @@ static int region_trace_ensemble(const orc_hmm *h, const uint8_t *dsq, int ireg,
   for (t = 0; t < nsamples; t++) {
     int i = Lr, k = 0, s0 = stC, s1, ndom = 0, nused = 0, Ld = 0, sqto = 0, hmmto = 0, sqfrom = 0, hmmfrom = 0, d;
     while (s0 != stS) {
-      double path[4];
+      double path[4] = {0.0, 0.0, 0.0, 0.0};
       switch (s0) {
       case stM:
         path[0] = XS(fr, i - 1, sB) * en[k];
@@ -878,6 +884,8 @@ static int region_trace_ensemble(const orc_hmm *h, const uint8_t *dsq, int ireg,
         break;
       default: s1 = stS; break;
       }
+      if (getenv("ORC_DBG") && atoi(getenv("ORC_DBG")) >= 1000 && t == atoi(getenv("ORC_DBG")) - 1000)
+        fprintf(stderr, "   [trace %d] s0 %d -> s1 %d at i %d k %d  path %.9g %.9g %.9g %.9g rng %u\n", t, s0, s1, i, k, path[0], path[1], path[2], path[3], rng.x);
       /* the state just chosen sits at (k, i) */
       if (s1 == stE) { sqto = hmmto = 0; nused = 0; Ld = 0; }
       else if (s1 == stM) {
@@ -933,6 +941,7 @@ static int region_trace_ensemble(const orc_hmm *h, const uint8_t *dsq, int ireg,
     for (; pos <= Lr; pos++) n2sc[ireg + pos - 1] += 1.0f;
   }
   for (pos = ireg; pos <= jreg; pos++) n2sc[pos] = logf(n2sc[pos] / (float) nsamples);
+  if (getenv("ORC_DBG")) { float sm = 0.f; for (pos = ireg; pos <= jreg; pos++) sm += n2sc[pos]; fprintf(stderr, "[oracle] region n2sc sum %.6f; n2sc:", sm); for (pos = ireg; pos <= jreg; pos++) fprintf(stderr, " %.3f", n2sc[pos]); fprintf(stderr, "\n"); }
   nc = cluster_ensemble(&ens, nsamples, sig, maxsig);
   free(ens.seg); free(cntM); free(cntI); free(usedk); free(dfrom); free(dnull);
   return nc;
@@ -1015,7 +1024,7 @@ int orc_score_pair(const orc_hmm *h, const uint8_t *dsq, int L, orc_result *r)
           orc_seg sig[ORC_MAXENV];
           orc_mx *fr = mx_new(Lr, M);
           int nc, d;
-          forward(h, dsq + (i - 1), Lr, cm, fr);
+          { double rf = forward(h, dsq + (i - 1), Lr, cm, fr); if (getenv("ORC_DBG")) fprintf(stderr, "[oracle] region forward %.12f\n", rf); }
           nc = region_trace_ensemble(h, dsq, i, j, fr, cm, n2sc, sig, ORC_MAXENV);
           mx_free(fr);
           nclustered_env += nc;

@@ -879,3 +879,25 @@ def test_two_rank_rehearsal_equals_one_rank(tmp_path):
     assert j2["n_gpus"] == 2 and j2["config"]["sharding"] == "queries/2"
     assert j1["config"]["topk_crc32"] == j2["config"]["topk_crc32"]
     assert j1["distributions"]["n_used"] == j2["distributions"]["n_used"]
+
+
+def test_single_pair_launches_match_the_batch(orc):
+    """One (query, model) pair per call: the planner then picks launch shapes a batch never sees (e.g.
+    5 waves per workgroup for a 311-residue query on a 20-cell model).  A build of this round returned
+    a score without the null1 term for exactly that shape (a value lost across the non-inlined sweep
+    calls), so every pair of the example case is also scored alone and must equal the batch result."""
+    _need_gpu()
+    from tests.conftest import load_case
+    from witch_amd.ehmm import EHMM, pack_queries
+    case = load_case("example_sub30")
+    e = EHMM(case.hmm_paths, hmm_index=case.hmm_index, nseq=case.nseq)
+    seqs = [e.digitize(s_) for s_ in case.qseqs[:40]]
+    res, offs = pack_queries(seqs)
+    deci, flags = e.score(res, offs)
+    ohm = orc.OracleHMM(case.hmm_paths[0])
+    for qi, s_ in enumerate(seqs):
+        d1, f1 = e.score(*pack_queries([s_]))
+        assert (int(d1[0, 0]), int(f1[0, 0])) == (int(deci[qi, 0]), int(flags[qi, 0])), (qi, len(s_))
+        r = ohm.score(s_)
+        assert (int(f1[0, 0]) & 3) == (r.flags & 3) and abs(int(d1[0, 0]) - r.decibits) <= 1, (qi, int(d1[0, 0]), r.decibits)
+    e.close()

@@ -62,6 +62,7 @@ struct Knobs {
   bool no_resolve = false;   // multidomain regions stay ONE envelope (round-1 behaviour) instead of HMMER's stochastic resolver
   bool stats = false, trace = false;
   int dbg = 0;
+  int rdbg = 0;              // resolver: print the first <n> sampled segments and the cluster statistics of every region
 };
 static const int kMaxLaunches = 60;   // work-queue heads in d_counter (slot 63 belongs to the consensus kernel)
 
@@ -240,12 +241,13 @@ int wh_set_option(wh_ehmm *e, const char *name, const char *value) {
   else if (!strcmp(name, "WH_STATS")) k.stats = on;
   else if (!strcmp(name, "WH_TRACE")) k.trace = on;
   else if (!strcmp(name, "WH_DBG")) k.dbg = atoi(v);
+  else if (!strcmp(name, "WH_RDBG")) k.rdbg = atoi(v);
   else { set_error("wh_set_option: unknown option %s", name); return WH_EINVAL; }
   return WH_OK;
 }
 
 static void knobs_from_env(wh_ehmm *e) {
-  for (const char *name : {"WH_SCORE_KERNEL", "WH_KEEP_LOG2", "WH_MAX_WAVES", "WH_FORCE_SPECG", "WH_NO_LOGSPACE", "WH_NO_RESOLVE", "WH_STATS", "WH_TRACE", "WH_DBG"})
+  for (const char *name : {"WH_SCORE_KERNEL", "WH_KEEP_LOG2", "WH_MAX_WAVES", "WH_FORCE_SPECG", "WH_NO_LOGSPACE", "WH_NO_RESOLVE", "WH_STATS", "WH_TRACE", "WH_DBG", "WH_RDBG"})
     if (const char *v = getenv(name)) (void)wh_set_option(e, name, v);
 }
 
@@ -295,7 +297,7 @@ static const size_t kLdsHeader = 16;   // work-item slot in front of the tables 
 // orientations) + per wave one block (special-state arrays, null2 table, region list, residues).
 static int plan_block1(const wh_ehmm *e, int Q, int K, int Lcap, int wmax, int *waves, int *SP, int *wave_lds, size_t *lds) {
   const int sp = (Lcap + 1 + 3) / 4 * 4;
-  const int wl = 8 * sp + 32 + 3 * WH_MAX_ENVELOPES + (Lcap + 3) / 4 + 4;
+  const int wl = 8 * sp + 32 + kRegsInts + (Lcap + 3) / 4 + 4;
   const size_t table = (size_t)(K + 2 * FW_NARR) * Q * kWave * sizeof(float);
   int w = wmax;
   if (e->knobs.max_waves > 0) w = std::max(1, std::min(wmax, e->knobs.max_waves));
@@ -377,7 +379,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
         if (rc_plan != WH_OK || waves < 4 || kn.force_specg) {
           specg = true;
           SP = (Lc + 1 + 3) / 4 * 4;
-          wave_lds = 32 + 3 * WH_MAX_ENVELOPES + (Lc + 3) / 4 + 4;
+          wave_lds = 32 + kRegsInts + (Lc + 3) / 4 + 4;
           const size_t table = (size_t)(e->K + 2 * FW_NARR) * Q * kWave * sizeof(float);
           waves = Q <= 16 ? 12 : 8;
           if (kn.max_waves > 0) waves = std::max(1, std::min(waves, kn.max_waves));
@@ -392,7 +394,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
         }
       }
       if (big) {
-        wave_lds = 32 + 3 * WH_MAX_ENVELOPES + (Lc + 3) / 4 + 4;
+        wave_lds = 32 + kRegsInts + (Lc + 3) / 4 + 4;
         waves = 4;
         a.Klds = e->K;
         size_t table = (size_t)(a.Klds + 8) * Q * kWave * sizeof(float);
@@ -466,6 +468,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       r.decibits = d_decibits; r.flags = d_flags; r.detail = d_detail;
       r.H = (int)e->hmms.size(); r.K = e->K; r.Kp = e->Kp;
       memcpy(r.degen, e->degen, sizeof r.degen);
+      r.dbg = e->knobs.rdbg;
       const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, kLdsBudget / rlds));
       int blocks = std::min(n_multi, e->cu_count * per_cu);
       blocks = clamp_blocks(blocks, r.mx_stride * sizeof(double) + r.seg_stride * sizeof(int32_t), e->d_rmx);
@@ -847,7 +850,7 @@ int wh_ehmm_max_query_len(const wh_ehmm *e) {
   int best = 1 << 20;
   for (auto &kv : e->by_q) {
     const size_t table = (size_t)(e->K + 2 * FW_NARR) * kv.first * kWave * sizeof(float);
-    const size_t left = kLdsBudget - kLdsHeader - table - (32 + 3 * WH_MAX_ENVELOPES + 8) * sizeof(float);
+    const size_t left = kLdsBudget - kLdsHeader - table - (32 + kRegsInts + 8) * sizeof(float);
     best = std::min(best, (int)std::min<size_t>(left, 1u << 20));
   }
   return best;

@@ -13,6 +13,9 @@ constexpr int kWave = 64;          // CDNA wavefront width
 constexpr int kMaxQ = 48;          // cells per lane supported by this build -> M <= 64*kMaxQ = 3072
 constexpr int kMaxQFast = 24;      // up to here both transition orientations stay resident in LDS
 constexpr int kQRegMax = 16;       // up to this Q the transition tables live in VGPRs
+// per-wave LDS block of the scoring kernels: region list (i, j) x WH_MAX_ENVELOPES, 8 spare ints, and the
+// envelope results (envsc, domcorr) x WH_MAX_ENVELOPES staged for the multidomain resolver's record
+constexpr int kRegsInts = 5 * WH_MAX_ENVELOPES;
 
 void set_error(const char *fmt, ...);
 

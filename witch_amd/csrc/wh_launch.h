@@ -79,6 +79,7 @@ struct ResolveArgs {
   wh_pair_detail *detail;
   int H, K, Kp;
   uint32_t degen[32];
+  int dbg;                     // WH_DBG > 0: print the first <dbg> sampled segments and the cluster statistics of every region
 };
 hipError_t launch_resolve(const ResolveArgs &a, int blocks, size_t lds, hipStream_t s);
 size_t resolve_lds_bytes(int Lcap, int Mmax);

@@ -63,6 +63,14 @@ __device__ __forceinline__ int wave_min_i(int x) { for (int m = 32; m >= 1; m >>
 __device__ __forceinline__ int wave_max_i(int x) { for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(x, m); x = o > x ? o : x; } return x; }
 __device__ __forceinline__ int wave_sum_i(int x) { for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m); return x; }
 
+// This kernel runs ONE wavefront per workgroup, and for such a workgroup the compiler emits nothing for
+// a workgroup-scope fence (checked in the ISA: a store followed at once by the dependent load of
+// another lane).  Global data handed from one lane to another inside the wave is therefore ordered by
+// hand: every store of the wave acknowledged, then the vector L1 invalidated.
+__device__ __forceinline__ void wave_mem_sync() {
+  asm volatile("s_waitcnt vmcnt(0)\n\tbuffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+}
+
 struct GLen { double loop, move, EJ, EC; };
 __device__ __forceinline__ GLen glen_config(int Lcfg, bool multihit) {
   // HMMER evaluates the length model in float32 (A.1)
@@ -112,7 +120,7 @@ __device__ double gforward(const GModel &m, const uint8_t *seq, int L, GLen c, c
   double Alane = 1.0;
   for (int q = 0; q < Q; q++) Alane *= m.tf[((size_t)gD2 * Q + q) * 64 + lane];
   for (int i = 1; i <= L; i++) {
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");    // row i-1 was written by other lanes of this wave
+    wave_mem_sync();    // row i-1 was written by other lanes of this wave
     const double *pr = mx.row(STORE ? i - 1 : (i - 1) & 1);
     double *cr = mx.row(STORE ? i : i & 1);
     const double *od = m.te + (size_t)seq[i - 1] * SQ;
@@ -137,20 +145,23 @@ __device__ double gforward(const GModel &m, const uint8_t *seq, int L, GLen c, c
       pm1 = pM; pi1 = pI; pd1 = pD; mprev = mm;
     }
     // cross-lane: Dlast(r) = [dloc_last + P * D1_0 * Mlast(r-1)] + [P * D2_0] * Dlast(r-1)
-    const double mleft = lane > 0 ? shfl_up_d(mprev, 1) : 0.0;
+    // (shuffles stay outside conditionals: a lane that skips a ds_bpermute does not lend its value)
+    const double mup = shfl_up_d(mprev, 1);
+    const double mleft = lane > 0 ? mup : 0.0;
     const double d10 = m.tf[gD1 * SQ + lane], d20 = m.tf[gD2 * SQ + lane];
     double Bv = dloc + P * d10 * (lane > 0 ? mleft : 0.0), Av = Alane;
     for (int d = 1; d < 64; d <<= 1) {
       const double Bo = shfl_up_d(Bv, d), Ao = shfl_up_d(Av, d);
       if (lane >= d) { Bv = Bv + Av * Bo; Av = Av * Ao; }
     }
-    const double dleft = lane > 0 ? shfl_up_d(Bv, 1) : 0.0;      // true D of lane-1's last node
+    const double dup = shfl_up_d(Bv, 1);
+    const double dleft = lane > 0 ? dup : 0.0;                   // true D of lane-1's last node
     const double c0 = lane > 0 ? d10 * mleft + d20 * dleft : 0.0;  // true D of my first node
     double Pq = 1.0;
     for (int q = 0; q < Q; q++) {
       const size_t o = (size_t)q * 64 + lane;
       if (q > 0) Pq *= m.tf[gD2 * SQ + o];
-      const double dv = cr[2 * SQ + o] + Pq * c0;
+      const double dv = __builtin_nontemporal_load(cr + 2 * SQ + o) + Pq * c0;
       cr[2 * SQ + o] = dv;
       esum += dv;
     }
@@ -158,14 +169,17 @@ __device__ double gforward(const GModel &m, const uint8_t *seq, int L, GLen c, c
     double xn = pN * c.loop, xc = pC * c.loop + xe * c.EC, xj = pJ * c.loop + xe * c.EJ, lsd = 0.0;
     if (xe > kRescaleHi) {
       const double r = 1.0 / xe;
-      for (int q = 0; q < Q; q++) { const size_t o = (size_t)q * 64 + lane; cr[o] *= r; cr[SQ + o] *= r; cr[2 * SQ + o] *= r; }
+      for (int q = 0; q < Q; q++) {
+        const size_t o = (size_t)q * 64 + lane;
+        cr[o] = __builtin_nontemporal_load(cr + o) * r; cr[SQ + o] = __builtin_nontemporal_load(cr + SQ + o) * r; cr[2 * SQ + o] = __builtin_nontemporal_load(cr + 2 * SQ + o) * r;
+      }
       xn *= r; xc *= r; xj *= r; lsd = log(xe); ls += lsd; xe = 1.0;
     }
     const double xb = xj * c.move + xn * c.move;
     if (lane == 0) { double *s = cr + 3 * SQ; s[xN] = xn; s[xB] = xb; s[xE] = xe; s[xJ] = xj; s[xC] = xc; s[xLS] = lsd; }
     pN = xn; pB = xb; pJ = xj; pC = xc;
   }
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  wave_mem_sync();
   return ls + log(pC * c.move);
 }
 
@@ -275,7 +289,8 @@ __global__ __launch_bounds__(64) void resolve_kernel(ResolveArgs a) {
       }
       // ---------------- A.4b
       const uint8_t *rs = seq + (ireg - 1);       // rs[pos-1] = residue at region position pos
-      gforward<true>(m, rs, Lr, cm, mx, lane);
+      const double regfwd = gforward<true>(m, rs, Lr, cm, mx, lane);
+      if (a.dbg && lane == 0) printf("[resolve] region forward %.12f\n", regfwd);
       for (int t = lane; t <= Lr + 1; t += 64) acc[t] = 0.f;
       int nseg = 0;
       Rng rng;
@@ -285,7 +300,7 @@ __global__ __launch_bounds__(64) void resolve_kernel(ResolveArgs a) {
       for (int t = 0; t < kSamples; t++) {
         int i = Lr, k = 0, s0 = stC, ndom = 0, sqto = 0, hmmto = 0, sqfrom = 0, hmmfrom = 0;
         while (s0 != stS) {
-          double path[4];
+          double path[4] = {0.0, 0.0, 0.0, 0.0};
           int s1;
           switch (s0) {
             case stM: {
@@ -359,6 +374,8 @@ __global__ __launch_bounds__(64) void resolve_kernel(ResolveArgs a) {
               break;
             default: s1 = stS; break;
           }
+          if (a.dbg >= 1000 && t == a.dbg - 1000 && lane == 0)
+            printf("   [trace %d] s0 %d -> s1 %d at i %d k %d  path %.9g %.9g %.9g %.9g rng %u\n", t, s0, s1, i, k, path[0], path[1], path[2], path[3], rng.x);
           // the state just chosen sits at (k, i)
           if (s1 == stE) { sqto = 0; hmmto = 0; }
           else if (s1 == stM) {
@@ -421,7 +438,7 @@ __global__ __launch_bounds__(64) void resolve_kernel(ResolveArgs a) {
         __builtin_amdgcn_wave_barrier();
       }
       for (int pos = 1 + lane; pos <= Lr; pos += 64) n2sc[ireg + pos - 1] = logf(acc[pos] / (float)kSamples);
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      wave_mem_sync();
       // ---------------- single-linkage clustering in Easel's vertex order (esl_cluster_SingleLinkage)
       int nc = 0;
       {
@@ -472,7 +489,11 @@ __global__ __launch_bounds__(64) void resolve_kernel(ResolveArgs a) {
           nc++;
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      wave_mem_sync();
+      if (a.dbg && lane == 0) {
+        printf("[resolve q=%lld h=%d region %d..%d] nseg %d nc %d rng %u\n", (long long)rec.q, rec.h, ireg, jreg, nseg, nc, rng.x);
+        for (int z = 0; z < nseg && z < a.dbg; z++) printf("   seg %d: t %d i %d j %d k %d m %d cluster %d\n", z, s_idx[z], s_i[z], s_j[z], s_k[z], s_m[z], s_as[z]);
+      }
       // ---------------- clusters -> envelopes (p7_spensemble_Cluster)
       int nsig = 0;
       int g_i[kEnvMax], g_j[kEnvMax];
@@ -499,7 +520,7 @@ __global__ __launch_bounds__(64) void resolve_kernel(ResolveArgs a) {
         int imin = 1 << 30, imax = -1, jmin = 1 << 30, jmax = -1, kmin = 1 << 30, kmax = -1, mmin = 1 << 30, mmax = -1;
         for (int h = lane; h < nseg; h += 64)
           if (__builtin_nontemporal_load(s_as + h) == c) {
-            const int si = s_i[h], sj = s_j[h], sk = s_k[h], sm = s_m[h];
+            const int si = __builtin_nontemporal_load(s_i + h), sj = __builtin_nontemporal_load(s_j + h), sk = __builtin_nontemporal_load(s_k + h), sm = __builtin_nontemporal_load(s_m + h);
             imin = min(imin, si); imax = max(imax, si); jmin = min(jmin, sj); jmax = max(jmax, sj);
             kmin = min(kmin, sk); kmax = max(kmax, sk); mmin = min(mmin, sm); mmax = max(mmax, sm);
           }
@@ -516,7 +537,7 @@ __global__ __launch_bounds__(64) void resolve_kernel(ResolveArgs a) {
           for (int t = lane; t < n; t += 64) epc[t] = 0;
           __builtin_amdgcn_wave_barrier();
           for (int h = lane; h < nseg; h += 64)
-            if (__builtin_nontemporal_load(s_as + h) == c) atomicAdd(&epc[src[h] - lo], 1);
+            if (__builtin_nontemporal_load(s_as + h) == c) atomicAdd(&epc[__builtin_nontemporal_load(src + h) - lo], 1);
           __builtin_amdgcn_wave_barrier();
           int b = -1;
           if (which < 2) {          // leftmost position with enough end points, else the (first) most frequent one
@@ -538,6 +559,7 @@ __global__ __launch_bounds__(64) void resolve_kernel(ResolveArgs a) {
           best[which] = lo + b;
           __builtin_amdgcn_wave_barrier();
         }
+        if (a.dbg && lane == 0) printf("[resolve q=%lld h=%d region %d..%d] cluster %d: ninc %d thr %d i %d..%d j %d..%d k %d..%d m %d..%d best %d %d %d %d\n", (long long)rec.q, rec.h, ireg, jreg, c, ninc, thr, imin, imax, jmin, jmax, kmin, kmax, mmin, mmax, best[0], best[2], best[1], best[3]);
         if (best[0] > best[2] || best[1] > best[3]) continue;
         if (nsig < kEnvMax) { g_i[nsig] = best[0]; g_j[nsig] = best[2]; g_p[nsig] = (float)ninc / (float)kSamples; nsig++; }
         else flags |= WH_FLAG_TRUNC;
@@ -562,6 +584,7 @@ __global__ __launch_bounds__(64) void resolve_kernel(ResolveArgs a) {
       float regsum = 0.f;
       for (int pos = ireg; pos <= jreg; pos++) regsum += n2sc[pos];
       seqbias_sum += regsum;
+      if (a.dbg && lane == 0) { printf("[resolve] region n2sc sum %.6f; n2sc:", regsum); for (int pos = ireg; pos <= jreg; pos++) printf(" %.3f", n2sc[pos]); printf("\n"); }
       for (int d = 0; d < nsig; d++) {
         if (dominated & (1u << d)) continue;
         const int i2 = g_i[d], j2 = g_j[d], Ld = j2 - i2 + 1;

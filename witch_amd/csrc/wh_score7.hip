@@ -74,7 +74,7 @@ __device__ __forceinline__ int ctxK(const WaveCtx &c) { return c.alpha & 255; }
 __device__ __forceinline__ int ctxKp(const WaveCtx &c) { return (c.alpha >> 8) & 255; }
 __device__ __forceinline__ int ctxKlds(const WaveCtx &c) { return (c.alpha >> 16) & 255; }
 struct P4Out { float mass, domcorr; };
-struct RegOut { int nenv, nreg, flags, multi_mask; };
+struct RegOut { int nenv, nreg, flags; };   // flags: WH_FLAG_* | multidomain mask of the stored regions << 8 (12 bytes: stays in return registers)
 
 struct FwdOut { float xC; int ef; };
 
@@ -337,7 +337,7 @@ __device__ __noinline__ RegOut region_scan(lds_f *spec3, glb_f *specg, int SP, i
     if (mx >= rt3) { flags |= WH_FLAG_MULTI; multi_mask |= 1 << e; }
   }
   RegOut o;
-  o.nenv = nenv; o.nreg = nreg; o.flags = flags; o.multi_mask = multi_mask;
+  o.nenv = nenv; o.nreg = nreg; o.flags = flags | (multi_mask << 8);
   return o;
 }
 
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
   c.Fs = (glb_f *)(a.scratch + ((size_t)blockIdx.x * nwaves + wave) * a.scratch_stride);
   c.SP = SP; c.alpha = a.K | (a.Kp << 8) | (a.K << 16); c.lane = lane;
   int *regs = reinterpret_cast<int *>(wbase + (SG ? 0 : SP_NARR * SP) + 32);
-  uint8_t *seq = reinterpret_cast<uint8_t *>(regs + 3 * WH_MAX_ENVELOPES);
+  uint8_t *seq = reinterpret_cast<uint8_t *>(regs + kRegsInts);
   const double LOG2 = 0.69314718055994529;
   int cur_h = -1;
   const DevHMM *hm = nullptr;
@@ -425,8 +425,8 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
           sweep_backward_decode<Q, TH, SG>(c, (lds_u8 *)seq, L, cm, 1.0f / (f1.xC * cm.move), f1.ef);
           WH_TICK7(5);
           const RegOut ro = region_scan<TH, SG>(c.spec, c.specg, SP, L, (lds_i *)regs, lane);
-          const int nenv = ro.nenv, nreg = ro.nreg;
-          flags |= ro.flags;
+          const int nenv = ro.nenv, nreg = ro.nreg, multi_mask = ro.flags >> 8;
+          flags |= ro.flags & 0xFF;
           if (dp) { dp->nregions = nreg; dp->nenv = nenv; }
           if (nenv > 0) {
             WH_TICK7(6);
@@ -434,24 +434,12 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
             const LenCfg cu = len_config(L, false);
             float seqbias_sum = 0.f, sum_score = 0.f, sb2 = 0.f;
             int Ld_tot = 0;
-            // a pair with a multidomain region is finished by resolve_kernel (A.4b): queue it; its
-            // single-domain regions are still scored here
-            ResolveRec *rr = nullptr;
-            if ((ro.flags & WH_FLAG_MULTI) && a.rrecs) {
-              int slot = 0;
-              if (lane == 0) slot = atomicAdd(a.rcount, 1);
-              slot = __shfl(slot, 0);
-              if (slot < a.rcap) {
-                rr = a.rrecs + slot;
-                if (lane == 0) {
-                  rr->q = qi; rr->h = h; rr->fwdsc = fwdsc; rr->fwd_bits = fwd_bits_out; rr->nreg = nreg; rr->nenv = nenv;
-                  rr->multi_mask = ro.multi_mask;
-                  for (int e = 0; e < nenv; e++) { rr->ri[e] = regs[2 * e]; rr->rj[e] = regs[2 * e + 1]; rr->envsc[e] = 0.f; rr->domcorr[e] = 0.f; }
-                }
-              }
-            }
+            // a pair with a multidomain region is finished by resolve_kernel (A.4b); its single-domain
+            // regions are still scored here, their results staged in LDS for the pair's queue record
+            const bool queue_pair = multi_mask != 0 && a.rrecs != nullptr;
+            float *envres = reinterpret_cast<float *>(regs + 3 * WH_MAX_ENVELOPES);
             for (int e = 0; e < nenv; e++) {
-              if (rr && ((ro.multi_mask >> e) & 1)) continue;
+              if (queue_pair && ((multi_mask >> e) & 1)) { if (lane == 0) { envres[e] = 0.f; envres[WH_MAX_ENVELOPES + e] = 0.f; } continue; }
               const int ri = regs[2 * e], rj = regs[2 * e + 1];
               const int Ld = rj - ri + 1;
               const uint8_t *eseq = seq + (ri - 1);
@@ -477,11 +465,20 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
               seqbias_sum += domcorr;
               if (envsc - domcorr > 0.0f) { sum_score += envsc; Ld_tot += Ld; sb2 += domcorr; }
               if (dp) { dp->env_i[e] = ri; dp->env_j[e] = rj; dp->envsc[e] = envsc; dp->domcorr[e] = domcorr; }
-              if (rr && lane == 0) { rr->envsc[e] = envsc; rr->domcorr[e] = domcorr; }
+              if (queue_pair && lane == 0) { envres[e] = envsc; envres[WH_MAX_ENVELOPES + e] = domcorr; }
             }
-            if (rr) {
-              if (lane == 0) rr->flags = flags;
-              flags |= WH_FLAG_MULTI;      // provisional: resolve_kernel writes the final score and flags
+            if (queue_pair) {
+              __builtin_amdgcn_wave_barrier();
+              int slot = 0;
+              if (lane == 0) slot = atomicAdd(a.rcount, 1);
+              slot = __shfl(slot, 0);
+              if (slot < a.rcap && lane == 0) {
+                ResolveRec *rr = a.rrecs + slot;
+                rr->q = qi; rr->h = h; rr->fwdsc = fwdsc; rr->fwd_bits = fwd_bits_out; rr->nreg = nreg; rr->nenv = nenv;
+                rr->multi_mask = multi_mask; rr->flags = flags;
+                for (int e = 0; e < nenv; e++) { rr->ri[e] = regs[2 * e]; rr->rj[e] = regs[2 * e + 1]; rr->envsc[e] = envres[e]; rr->domcorr[e] = envres[WH_MAX_ENVELOPES + e]; }
+              }
+              // provisional result: resolve_kernel writes the final score and flags of this pair
             } else {
             // ---------------- A.6 score assembly (float32 where HMMER is float32)
             const float lomega = (float)log(1.0 / 256.0);

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void score_big_kernel(ScoreArgs a) {
   float *wbase = trL + 8 * TBL + (size_t)wave * a.wave_lds;
   float *n2tab = wbase;
   int *regs = reinterpret_cast<int *>(n2tab + 32);
-  uint8_t *seq = reinterpret_cast<uint8_t *>(regs + 3 * WH_MAX_ENVELOPES);
+  uint8_t *seq = reinterpret_cast<uint8_t *>(regs + kRegsInts);
   float *spec = a.spec_scratch + ((size_t)blockIdx.x * nwaves + wave) * a.spec_stride;
   float *Fs = a.scratch + ((size_t)blockIdx.x * nwaves + wave) * a.scratch_stride;
   const int SP = a.SP;
@@ -92,7 +92,6 @@ __global__ __launch_bounds__(256) void score_big_kernel(ScoreArgs a) {
       const bool active = qi < q_hi && L > 0;
       const size_t out = (size_t)(qi < q_hi ? qi : q_lo) * a.H + h;
       int flags = 0, decibits = 0, nreg = 0, nenv = 0, ef_L = 0, multi_mask = 0;
-      ResolveRec *rr = nullptr;
       float fwd_bits_out = -INFINITY, fwdsc = 0.f, nullsc = 0.f, invZ = 0.f;
       bool ok = false;
       wh_pair_detail *dp = (a.detail && lane == 0 && active) ? a.detail + out : nullptr;
@@ -227,27 +226,17 @@ __global__ __launch_bounds__(256) void score_big_kernel(ScoreArgs a) {
           if (mx >= rt3) { flags |= WH_FLAG_MULTI; multi_mask |= 1 << e; }
         }
         if (dp) { dp->nregions = nreg; dp->nenv = nenv; }
-        // a pair with a multidomain region is finished by resolve_kernel (A.4b): queue it; its
-        // single-domain regions are still scored here
-        if ((flags & WH_FLAG_MULTI) && a.rrecs) {
-          int slot = 0;
-          if (lane == 0) slot = atomicAdd(a.rcount, 1);
-          slot = __shfl(slot, 0);
-          if (slot < a.rcap) {
-            rr = a.rrecs + slot;
-            if (lane == 0) {
-              rr->q = qi; rr->h = h; rr->fwdsc = fwdsc; rr->fwd_bits = fwd_bits_out; rr->nreg = nreg; rr->nenv = nenv;
-              rr->multi_mask = multi_mask;
-              for (int e = 0; e < nenv; e++) { rr->ri[e] = regs[2 * e]; rr->rj[e] = regs[2 * e + 1]; rr->envsc[e] = 0.f; rr->domcorr[e] = 0.f; }
-            }
-          }
-        }
       }
+      // a pair with a multidomain region is finished by resolve_kernel (A.4b); its single-domain regions
+      // are still scored here, their results staged in LDS for the pair's queue record
+      const bool queue_pair = multi_mask != 0 && a.rrecs != nullptr;
+      float *envres = reinterpret_cast<float *>(regs + 3 * WH_MAX_ENVELOPES);
+      if (queue_pair && lane == 0) for (int t = 0; t < 2 * WH_MAX_ENVELOPES; t++) envres[t] = 0.f;
 
       // ---------------- envelopes: workgroup-uniform loop over (envelope, attempt) steps
       float seqbias_sum = 0.f, sum_score = 0.f, sb2 = 0.f;
       int Ld_tot = 0, e = 0, attempt = 0;
-      while (rr && e < nenv && ((multi_mask >> e) & 1)) e++;       // multidomain regions are left to resolve_kernel
+      while (queue_pair && e < nenv && ((multi_mask >> e) & 1)) e++;       // multidomain regions are left to resolve_kernel
       bool pending = active && ok && e < nenv;
       while (__syncthreads_or(pending ? 1 : 0)) {
         int ri = 1, Ld = 0, ef_e = 0;
@@ -375,9 +364,9 @@ __global__ __launch_bounds__(256) void score_big_kernel(ScoreArgs a) {
             seqbias_sum += domcorr;
             if (envsc - domcorr > 0.0f) { sum_score += envsc; Ld_tot += Ld; sb2 += domcorr; }
             if (dp) { dp->env_i[e] = ri; dp->env_j[e] = ri + Ld - 1; dp->envsc[e] = envsc; dp->domcorr[e] = domcorr; }
-            if (rr && lane == 0) { rr->envsc[e] = envsc; rr->domcorr[e] = domcorr; }
+            if (queue_pair && lane == 0) { envres[e] = envsc; envres[WH_MAX_ENVELOPES + e] = domcorr; }
             e++;
-            while (rr && e < nenv && ((multi_mask >> e) & 1)) e++;
+            while (queue_pair && e < nenv && ((multi_mask >> e) & 1)) e++;
             attempt = 0;
             pending = e < nenv;
           }
@@ -385,8 +374,17 @@ __global__ __launch_bounds__(256) void score_big_kernel(ScoreArgs a) {
       }
 
       // ---------------- A.6 score assembly
-      if (rr) {
-        if (lane == 0) rr->flags = flags;      // resolve_kernel writes the final score and flags of this pair
+      if (queue_pair) {
+        __builtin_amdgcn_wave_barrier();
+        int slot = 0;
+        if (lane == 0) slot = atomicAdd(a.rcount, 1);
+        slot = __shfl(slot, 0);
+        if (slot < a.rcap && lane == 0) {     // resolve_kernel writes the final score and flags of this pair
+          ResolveRec *rr = a.rrecs + slot;
+          rr->q = qi; rr->h = h; rr->fwdsc = fwdsc; rr->fwd_bits = fwd_bits_out; rr->nreg = nreg; rr->nenv = nenv;
+          rr->multi_mask = multi_mask; rr->flags = flags;
+          for (int t = 0; t < nenv; t++) { rr->ri[t] = regs[2 * t]; rr->rj[t] = regs[2 * t + 1]; rr->envsc[t] = envres[t]; rr->domcorr[t] = envres[WH_MAX_ENVELOPES + t]; }
+        }
       } else if (active && ok && nenv > 0) {
         const float lomega = (float)log(1.0 / 256.0);
         const float seqbias = flogsum0_big(lomega + seqbias_sum);

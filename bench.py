@@ -208,12 +208,12 @@ def main():
         e.set_timing(True)
         barrier()
         t0 = time.perf_counter()
-        kern_ms = [0.0, 0.0, 0.0]
-        kern_n = [0, 0, 0]
+        kern_ms = [0.0, 0.0, 0.0, 0.0, 0.0]     # scoring kernels, topk, align, (consensus: timed apart), multidomain resolver
+        kern_n = [0, 0, 0, 0, 0]
         npairs = ncols = 0
         for st in range(args.steps):
             out, npairs, ncols = hot_path_step(e, res_t, off_t, maxlen, k, gather, keep_device=(st == args.steps - 1))
-            for which in range(3):
+            for which in (0, 1, 2, 4):
                 ms, n = e.last_kernel_ms(which)
                 kern_ms[which] += ms
                 kern_n[which] += n
@@ -295,8 +295,10 @@ def main():
                            "pairs_reported_rank0": hot_path_step.reported, "pairs_multidomain_rank0": hot_path_step.multidomain,
                            "pairs_dense_redo_rank0": hot_path_step.dense_redo,
                            "topk_crc32": crc_of(out[0].numpy(), out[1].numpy(), out[2].numpy(), out[3].numpy())},
-                "stage_ms_per_step": {"score": round(kern_ms[0] / args.steps, 3), "topk": round(kern_ms[1] / args.steps, 3),
-                                      "align": round(kern_ms[2] / args.steps, 3)},
+                "stage_ms_per_step": {"score": round((kern_ms[0] + kern_ms[4]) / args.steps, 3), "topk": round(kern_ms[1] / args.steps, 3),
+                                      "align": round(kern_ms[2] / args.steps, 3),
+                                      "score_parts": {"scoring_kernels": round(kern_ms[0] / args.steps, 3),
+                                                      "multidomain_resolver": round(kern_ms[4] / args.steps, 3)}},
                 "extra_stage_ms": {"consensus_rank0": round(cons_ms, 3),
                                    "note": "weighted consensus DP (next row #1) over this rank's queries, outside the timed region"},
                 "roofline": roofline, "roofline_align": roofline_align,

@@ -145,7 +145,8 @@ int wh_consensus_dev(wh_ehmm *e, const int64_t *d_offsets, int64_t nq, int32_t m
                      int32_t *d_out, int32_t *d_minmax, void *stream);
 
 /* Duration (ms) and launch count of the kernels of the last *_dev/plain call, measured
- * with HIP events on the stream the kernels ran on: which = 0 score, 1 topk, 2 align, 3 consensus. */
+ * with HIP events on the stream the kernels ran on: which = 0 scoring kernels, 1 topk, 2 align, 3 consensus,
+ * 4 multidomain resolver (the second part of wh_score: stage time of scoring = 0 + 4). */
 int wh_last_kernel_ms(wh_ehmm *e, int which, double *ms, int *launches);
 /* When enabled, every kernel launch is bracketed by HIP events (bench/roofline use). */
 int wh_set_timing(wh_ehmm *e, int enabled);

@@ -52,3 +52,73 @@ def test_shard_ranges_cover_and_are_contiguous():
             assert edges[0][0] == 0 and edges[-1][1] == n
             assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
             assert max(b - a for a, b in edges) - min(b - a for a, b in edges) <= 1
+
+
+def _engine_worker(rank, world, port, outdir):
+    """Each rank holds the golden tables of ITS block of queries (shard_range), like a rank of a
+    multi-GPU run; after the gather, the reference-shaped functions must give the unsharded answers."""
+    import pickle
+    import torch.distributed as dist
+    from tests.conftest import load_case
+    from tests.test_gcmm_host import _Sub, _engine_from_golden
+    from witch_amd import gcmm
+    from witch_amd.distributed import shard_range
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    case = load_case("dna_hmmbuild")
+    full = _engine_from_golden(case)                      # the one-rank engine: reference answers
+    index_to_hmm = {i: _Sub(p, n) for i, p, n in zip(case.hmm_index, case.hmm_paths, case.nseq)}
+    want_ranked = gcmm.rankBitscores(index_to_hmm, {})
+    want_weights = gcmm.writeWeights(index_to_hmm, want_ranked)
+    lo, hi = shard_range(len(case.qnames), rank, world)
+    # this rank's shard: rows [lo, hi) of every table; aligned columns only for its own queries
+    pairs = {k: p for k, p in full.pair_of.items() if lo <= k[0] < hi}
+    eng = gcmm.QueryAlignmentEngine.from_results(
+        case.qnames, case.hmm_index, case.nseq, full.decibits[lo:hi], full.flags[lo:hi], case.k,
+        topk=(full.topk_idx[lo:hi], full.topk_w[lo:hi], full.n_kept[lo:hi], full.n_used[lo:hi]),
+        aligned=(full.cols, full.col_offsets, pairs), rows=(lo, hi), world=world, rank=rank)
+    gcmm.install(eng)
+    ok = True
+    # before the gather a rank cannot answer for foreign queries - loudly
+    foreign = 0 if rank == 1 else len(case.qnames) - 1
+    try:
+        eng.weights(foreign)
+        ok = False
+    except KeyError:
+        pass
+    eng.gather()
+    ranked = gcmm.rankBitscores(index_to_hmm, {})         # this rank's block
+    ok &= all(lo <= eng.taxon_row[t] < hi for t in ranked) and all(ranked[t] == want_ranked[t] for t in ranked)
+    ok &= set(ranked) == {t for t in want_ranked if lo <= eng.taxon_row[t] < hi}
+    weights = gcmm.writeWeights(index_to_hmm, want_ranked)   # every query, on every rank
+    ok &= weights.keys() == want_weights.keys()
+    ok &= all([(i, float(x)) for i, x in weights[t]] == [(i, float(x)) for i, x in want_weights[t]] for t in weights)
+    # aligned columns: own queries answer, foreign ones raise
+    for (row, label), p in list(full.pair_of.items())[:200]:
+        if lo <= row < hi:
+            ok &= eng.aligned_columns(row, label) == full.aligned_columns(row, label)
+        else:
+            try:
+                eng.aligned_columns(row, label)
+                ok = False
+            except KeyError:
+                pass
+    # the owners' per-query results travel as Python objects, as INTEGRATION.md section 5 shows
+    mine = {t: weights[t] for t in ranked}
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    merged = {}
+    for g in gathered:
+        merged.update(g)
+    ok &= merged.keys() == want_weights.keys()
+    open(os.path.join(outdir, "erank%d" % rank), "w").write("ok" if ok else "bad")
+    dist.destroy_process_group()
+
+
+def test_sharded_engine_answers_like_the_unsharded_one(tmp_path):
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    mp.spawn(_engine_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert open(tmp_path / ("erank%d" % r)).read() == "ok"

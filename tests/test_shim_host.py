@@ -151,3 +151,64 @@ def test_evalues_follow_hmmer_formula(golden_case):
                 assert 0.93 < ev / v["evalue"] < 1.08, (hf, q, ev, v["evalue"])
                 n += 1
     assert n > 0 or case.name.startswith("example")
+
+
+def test_only_one_server_survives_a_stampede(tmp_path):
+    """WITCH fires num_cpus hmmsearch calls at once; every client that cannot connect launches a
+    server.  The flock on <socket>.lock (taken before the socket or the GPU is touched) leaves exactly
+    one; the socket lives in a directory private to the user."""
+    import sys
+    import time
+    from witch_amd.shim.server import request
+    d = tmp_path / "rt"
+    sock = str(d / "witch_hip" / "server.sock")
+    env = dict(os.environ, PYTHONPATH=ROOT, WITCH_HIP_IDLE_TIMEOUT="30")
+    procs = [subprocess.Popen([sys.executable, "-m", "witch_amd.shim.server", "--socket", sock], env=env,
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for _ in range(8)]
+    deadline = time.time() + 60
+    while time.time() < deadline and sum(p.poll() is None for p in procs) > 1:
+        time.sleep(0.2)
+    alive = [p for p in procs if p.poll() is None]
+    assert len(alive) == 1, len(alive)
+    assert all(p.returncode == 0 for p in procs if p.poll() is not None)     # the losers leave quietly
+    for _ in range(50):
+        if os.path.exists(sock):
+            break
+        time.sleep(0.1)
+    st, body = request(sock, "ping", [])
+    assert st == 0 and body.startswith("pong")
+    assert (os.stat(os.path.dirname(sock)).st_mode & 0o077) == 0
+    st, _ = request(sock, "shutdown", [])
+    assert alive[0].wait(10) == 0
+
+
+def test_model_cache_is_bounded_and_options_are_checked(tmp_path, monkeypatch):
+    from witch_amd.shim import server as srv
+
+    class _H:
+        closed = 0
+
+        def __init__(self, *a, **k):
+            pass
+
+        def close(self):
+            _H.closed += 1
+    import witch_amd.ehmm as ehmm_mod
+    monkeypatch.setattr(ehmm_mod, "EHMM", _H)
+    b = srv.GpuBackend(0, max_models=3)
+    paths = []
+    for i in range(5):
+        p = tmp_path / ("m%d.hmm" % i)
+        p.write_text(open(_hmm(tmp_path)).read())
+        paths.append(str(p))
+        b.model(str(p))
+    assert len(b.cache) == 3 and _H.closed == 2 and list(b.cache) == [os.path.realpath(x) for x in paths[2:]]
+    b.model(paths[2])                                   # touching a model makes it the most recent one
+    b.model(paths[0])
+    assert os.path.realpath(paths[3]) not in b.cache and os.path.realpath(paths[2]) in b.cache
+    # WITCH's own command line passes; anything that would change the reported set in HMMER is refused
+    ok = srv.parse_hmmsearch_argv("--cpu 1 --noali -E 99999999 -o o --max m q".split())[0]
+    srv.check_hmmsearch_options(ok)
+    for bad in ("--cpu 1 --noali -E 99999999 -o o m q", "--max -E 10 m q", "--max -T 5 m q", "--max --nonull2 m q"):
+        with pytest.raises(srv.ArgError):
+            srv.check_hmmsearch_options(srv.parse_hmmsearch_argv(bad.split())[0])

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Round profile of the bench command on the GPU box (run through gpurun from the repo root):
+#   1. rocprofv3 --kernel-trace --stats   -> per-kernel time
+#   2. rocprofv3 --pmc FETCH_SIZE, then --pmc WRITE_SIZE (separate passes, as the microarch guide
+#      prescribes) -> HBM bytes per kernel launch (gfx950: FETCH_SIZE counts 64 B per 128-B request, so
+#      read bytes = 2 x FETCH_SIZE x 1 KiB-units... the post-processor applies the guide's corrections)
+# Summaries land in gpurun_out/<tag>/ ; copy what should be judged into profiles/.
+# usage: tools/profile_round.sh <tag> [extra bench args]
+set -e
+tag=${1:-r02}; shift || true
+cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
+out=gpurun_out/$tag; mkdir -p $out
+timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $out/trace -o trace --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $out/trace.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -k 10 600 rocprofv3 --pmc $c -d $out/pmc_$c -o pmc --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > $out/pmc_$c.log 2>&1
+done
+python3 tools/prof_summary.py $out

@@ -82,7 +82,7 @@ struct wh_ehmm {
   DevBuf d_order, d_items, d_recs, d_spec, d_back, d_cwj, d_cwv, d_cwn, c_buf[10];
   uint32_t degen[32];
   bool timing = false;
-  KernelTimer timers[4];
+  KernelTimer timers[5];
   int max_M = 0;
   int last_align_redo = 0;          // pairs of the last wh_align call that went through the log-space pass
 };
@@ -275,7 +275,7 @@ static int timer_end(wh_ehmm *e, int which, hipStream_t s, int launches) {
 }
 
 int wh_last_kernel_ms(wh_ehmm *e, int which, double *ms, int *launches) {
-  if (!e || which < 0 || which > 3) return WH_EINVAL;
+  if (!e || which < 0 || which > 4) return WH_EINVAL;
   KernelTimer &t = e->timers[which];
   if (t.pending) {
     HIPCHK(hipEventSynchronize(t.e1));
@@ -442,6 +442,9 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       }
     }
   }
+  if (timer_end(e, 0, s, launches)) return WH_EHIP;
+  if (timer_begin(e, 4, s)) return WH_EHIP;
+  int rlaunches = 0;
   if (nq > 0 && !e->knobs.no_resolve && e->d_rrecs.p) {
     // ---- multidomain regions: HMMER's stochastic resolver (wh_resolve.hip), one wavefront per queued pair
     const int Lc = std::max(max_len, 1);
@@ -478,11 +481,11 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       if (e->knobs.trace) fprintf(stderr, "[wh] resolve: %d pairs with a multidomain region, %d wavefronts, lds %zu, slab %zu MB per wave\n", n_multi, blocks, rlds, r.mx_stride * 8 >> 20);
       hipError_t err = launch_resolve(r, blocks, rlds, s);
       if (err != hipSuccess) { set_error("resolve kernel launch failed: %s", hipGetErrorString(err)); return WH_EHIP; }
-      launches++;
+      rlaunches++;
       e->last_resolved = n_multi;
     }
   }
-  if (timer_end(e, 0, s, launches)) return WH_EHIP;
+  if (timer_end(e, 4, s, rlaunches)) return WH_EHIP;
   return WH_OK;
 }
 

@@ -48,6 +48,8 @@ def search(hmm_dirs, num_cpus=1, chunk_of_taxon=None, fragment_chunk_dir=None, s
     FASTA files are written only if <fragment_chunk_dir> and <sequences> ({taxon: text}) are given.
     chunk_of_taxon overrides the layout (tests)."""
     eng = current_engine()
+    if eng.world > 1:
+        raise RuntimeError("gcmm.search writes the result files of the WHOLE batch: run it on a one-rank engine")
     check_query_names(eng.taxa)
     if chunk_of_taxon is None:
         chunks = divide_to_equal_chunks(eng.taxa, num_chunks_for(len(hmm_dirs), max(1, int(num_cpus))))

@@ -46,16 +46,32 @@ class QueryAlignmentEngine:
         self.merged = None            # int32 CSR by query: consensus codes (gcmm/merge.py)
         self.query_offsets = None     # int64 [nq+1]
         self.merged_minmax = None
+        # multi-GPU (one process per GPU): this rank scored, aligned and merged the
+        # contiguous block [row_lo, row_hi) of the batch; the top-k tables cover EVERY query once gathered
+        self.world, self.rank = 1, 0
+        self.row_lo, self.row_hi = 0, 0
+        self.topk_rows = (0, 0)       # rows the top-k tables cover
 
     # ------------------------------------------------------------------ construction
     @classmethod
-    def run(cls, index_to_hmm, unaligned, num_hmms: int, device: int = 0, multidomain_policy: str = "envelope",
-            subset_to_retained_columns=None, subset_to_nongaps_per_column=None, backbone_length=None):
-        """Score, weight and align every query of ``unaligned`` ({taxon: sequence text} or
-        a list of (taxon, text)) against every HMM of ``index_to_hmm`` on one MI355X."""
+    def run(cls, index_to_hmm, unaligned, num_hmms: int, device: int = 0, multidomain_policy: str = "resolve",
+            subset_to_retained_columns=None, subset_to_nongaps_per_column=None, backbone_length=None,
+            world: int = 1, rank: int = 0, group=None):
+        """Score, weight and align every query of ``unaligned`` ({taxon: sequence text} or a list of
+        (taxon, text)) against every HMM of ``index_to_hmm``.
+
+        One process per GPU: with ``world`` > 1 (torch.distributed initialised, backend "nccl" = RCCL on
+        the GPU box, "gloo" on CPU) this rank works on its contiguous block of queries
+        (distributed.shard_range; the eHMM is replicated), the per-query top-k records of all ranks are
+        all-gathered (the path's only exchange step), aligned columns and consensus results stay
+        rank-local.  multidomain_policy: "resolve" (HMMER's stochastic resolver, default) or "drop"
+        (pairs with a multidomain region are not reported)."""
         import time
+        from ..distributed import shard_range
         from ..ehmm import EHMM, pack_queries
+        from .algorithm import check_query_names
         items = list(unaligned.items()) if hasattr(unaligned, "items") else list(unaligned)
+        check_query_names([t for t, _ in items])                       # algorithm.py:351-359
         labels = sorted(index_to_hmm.keys())
         paths = [index_to_hmm[i].hmm_model_path for i in labels]
         nseq = [int(index_to_hmm[i].num_taxa) for i in labels]
@@ -66,8 +82,11 @@ class QueryAlignmentEngine:
         self.num_taxa = np.asarray(nseq, dtype=np.int32)
         self.taxa = [t for t, _ in items]
         self.taxon_row = {t: r for r, t in enumerate(self.taxa)}
+        self.world, self.rank = int(world), int(rank)
+        self.row_lo, self.row_hi = shard_range(len(items), self.rank, self.world)
+        local = items[self.row_lo:self.row_hi]
         # the reference upper-cases sequences on read (helpers/alignment_tools.py:730-731)
-        seqs = [e.digitize(s.upper()) for _, s in items]
+        seqs = [e.digitize(s.upper()) for _, s in local]
         res, offs = pack_queries(seqs)
         t0 = time.time()
         self.decibits, self.flags = e.score(res, offs)
@@ -76,36 +95,64 @@ class QueryAlignmentEngine:
             self.flags = np.where(drop, self.flags & ~np.uint8(1), self.flags).astype(np.uint8)
         t1 = time.time()
         self.topk_idx, self.topk_w, self.n_kept, self.n_used = e.topk(self.decibits, self.flags, self.num_hmms)
+        self.topk_rows = (self.row_lo, self.row_hi)
         t2 = time.time()
-        pq, ph, key = [], [], []
-        for r in range(len(self.taxa)):
-            for j in range(int(self.n_used[r])):
-                lab = int(self.topk_idx[r, j])
-                pq.append(r)
-                ph.append(e.pos_of_index[lab])
-                key.append((r, lab))
+        # pairs (local query, kept model) of the 0.999 prefix (aligner.py:58-63), built with array ops
+        nloc = len(local)
+        keep = np.arange(self.num_hmms)[None, :] < self.n_used[:, None]
+        pq = np.nonzero(keep)[0].astype(np.int64)
+        plab = self.topk_idx[keep].astype(np.int64)
+        lut = np.full(int(self.hmm_index.max()) + 1, -1, dtype=np.int32)
+        lut[self.hmm_index] = np.arange(len(labels), dtype=np.int32)
+        ph = lut[plab]
         self.cols, self.col_offsets = e.align(res, offs, pq, ph)
-        self.pair_of = {k: p for p, k in enumerate(key)}
+        self.pair_of = {(int(q) + self.row_lo, int(lab)): p for p, (q, lab) in enumerate(zip(pq.tolist(), plab.tolist()))}
         t3 = time.time()
         # same three stage names the reference logs (algorithm.py:333-335, weighting.py:165-168, aligner.py:520-525)
         self.timings = {"search": t1 - t0, "weights": t2 - t1, "align": t3 - t2}
         self.query_offsets = offs
         if subset_to_retained_columns is not None:
-            # the weighted consensus DP of alignSubQueriesNew (aligner.py:376-473), all queries at once
-            qpo = np.zeros(len(self.taxa) + 1, dtype=np.int64)
+            # the weighted consensus DP of alignSubQueriesNew (aligner.py:376-473), all local queries at once
+            qpo = np.zeros(nloc + 1, dtype=np.int64)
             qpo[1:] = np.cumsum(self.n_used)
-            pw = np.array([self.topk_w[r, j] for r in range(len(self.taxa)) for j in range(int(self.n_used[r]))], dtype=np.float64)
+            pw = self.topk_w[keep].astype(np.float64)
             ret = [np.asarray(subset_to_retained_columns[i], dtype=np.int32) for i in labels]
             ng = [np.asarray(subset_to_nongaps_per_column[i], dtype=np.int32) for i in labels]
             self.merged, self.merged_minmax = e.consensus(offs, qpo, ph, pw, self.col_offsets, self.cols, ret, ng,
                                                           int(backbone_length))
             self.timings["merge"] = time.time() - t3
         e.close()
+        if self.world > 1:
+            self.gather(group)
         return self
 
+    def gather(self, group=None):
+        """The path's one exchange step: all-gather of the per-query top-k records
+        (int32 idx[k], float64 w[k], n_kept, n_used); afterwards writeWeights answers for every query on
+        every rank.  Scores, aligned columns and consensus results stay with the rank that owns the query."""
+        import torch
+        import torch.distributed as dist
+        from ..distributed import gather_topk
+        if self.world <= 1:
+            return self
+        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+        t0 = __import__("time").time()
+        parts = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (self.topk_idx, self.topk_w, self.n_kept, self.n_used)]
+        idx, w, nk, nu = gather_topk(*parts, group=group)
+        self.topk_idx, self.topk_w, self.n_kept, self.n_used = [t.cpu().numpy() for t in (idx, w, nk, nu)]
+        assert self.topk_idx.shape[0] == len(self.taxa), "ranks were given different query lists"
+        self.topk_rows = (0, len(self.taxa))
+        self.timings["gather"] = __import__("time").time() - t0
+        return self
+
+    def owns(self, row: int) -> bool:
+        return self.row_lo <= row < self.row_hi
+
     @classmethod
-    def from_results(cls, taxa, hmm_index, num_taxa, decibits, flags, num_hmms, topk=None, aligned=None):
-        """Assemble an engine from precomputed arrays (host-logic tests, checkpoints)."""
+    def from_results(cls, taxa, hmm_index, num_taxa, decibits, flags, num_hmms, topk=None, aligned=None,
+                     rows=None, world: int = 1, rank: int = 0):
+        """Assemble an engine from precomputed arrays (host-logic tests, checkpoints).  ``rows`` = (lo, hi):
+        the arrays cover only that block of ``taxa`` (a rank's shard)."""
         self = cls()
         self.taxa = list(taxa)
         self.taxon_row = {t: r for r, t in enumerate(self.taxa)}
@@ -114,6 +161,9 @@ class QueryAlignmentEngine:
         self.decibits = np.asarray(decibits, dtype=np.int32)
         self.flags = np.asarray(flags, dtype=np.uint8)
         self.num_hmms = int(num_hmms)
+        self.world, self.rank = int(world), int(rank)
+        self.row_lo, self.row_hi = rows if rows is not None else (0, len(self.taxa))
+        self.topk_rows = (self.row_lo, self.row_hi)
         if topk is not None:
             self.topk_idx, self.topk_w, self.n_kept, self.n_used = topk
         if aligned is not None:
@@ -121,17 +171,37 @@ class QueryAlignmentEngine:
         return self
 
     # ------------------------------------------------------------------ lookups
+    def _local(self, row: int, what: str) -> int:
+        if not self.owns(row):
+            raise KeyError("%s of query row %d live on the rank that owns rows [%d, %d); this is rank %d of %d with rows [%d, %d)"
+                           % (what, row, *self._owner_rows(row), self.rank, self.world, self.row_lo, self.row_hi))
+        return row - self.row_lo
+
+    def _owner_rows(self, row: int):
+        from ..distributed import shard_range
+        for r in range(self.world):
+            lo, hi = shard_range(len(self.taxa), r, self.world)
+            if lo <= row < hi:
+                return lo, hi
+        return 0, 0
+
     def ranked(self, row: int):
         """[(idx, score)] sorted by score descending (loader.py:325-330), ties by idx."""
-        rep = (self.flags[row] & 1) != 0
-        order = np.lexsort((self.hmm_index, -self.decibits[row]))
-        return [(int(self.hmm_index[j]), float(self.decibits[row, j]) / 10.0) for j in order if rep[j]]
+        r = self._local(row, "the scores")
+        rep = (self.flags[r] & 1) != 0
+        order = np.lexsort((self.hmm_index, -self.decibits[r]))
+        return [(int(self.hmm_index[j]), float(self.decibits[r, j]) / 10.0) for j in order if rep[j]]
 
     def weights(self, row: int):
         """((idx, np.float64 w), ...) - the value type calculateWeights returns (weighting.py:71-74)."""
-        n = int(self.n_kept[row])
-        return tuple((int(self.topk_idx[row, j]), np.float64(self.topk_w[row, j])) for j in range(n))
+        lo, hi = self.topk_rows
+        if not lo <= row < hi:
+            raise KeyError("top-k record of query row %d is not on this rank: call gather() first" % row)
+        r = row - lo
+        n = int(self.n_kept[r])
+        return tuple((int(self.topk_idx[r, j]), np.float64(self.topk_w[r, j])) for j in range(n))
 
     def aligned_columns(self, row: int, label: int):
+        self._local(row, "the aligned columns")
         p = self.pair_of[(row, int(label))]
         return self.cols[self.col_offsets[p]:self.col_offsets[p + 1]].tolist()

@@ -10,11 +10,13 @@ def readAndRankBitscoreMP(index_to_hmm, renamed_taxa, lock=None, pool=None):
 
     The reference sorts with Python's stable sort over the arrival order of pool futures
     (loader.py:310-330), so its order among equal scores is not reproducible; here equal
-    scores are ordered by ascending HMM index."""
+    scores are ordered by ascending HMM index.  With several ranks (one per
+    GPU) a rank returns the queries of its own block; writeWeights answers for every query."""
     eng = current_engine()
     wanted = set(int(i) for i in index_to_hmm.keys())
     ranked = defaultdict(list)
-    for row, taxon in enumerate(eng.taxa):
+    for row in range(eng.row_lo, eng.row_hi):
+        taxon = eng.taxa[row]
         scores = [(i, s) for (i, s) in eng.ranked(row) if i in wanted]
         if not scores:
             continue          # a taxon with no reported HMM never appears (loader.py:291-293)

@@ -55,7 +55,7 @@ def alignSubQueriesNew(backbone_path, backbone_length, index_to_hmm, lock, timeo
     query = QueryAlignment()
     if len(query_weights) == 0 or eng.merged is None:
         return query, index, taxon
-    row = eng.taxon_row[taxon]
+    row = eng._local(eng.taxon_row[taxon], "the consensus alignment")
     lo, hi = eng.query_offsets[row], eng.query_offsets[row + 1]
     combined = trace_to_string(seq, eng.merged[lo:hi].tolist(), backbone_length)
     query[taxon] = combined

@@ -2,7 +2,8 @@
  * (the tool is argv[0]'s basename), so that WITCH's own plug-in keys hmmsearchpath /
  * hmmalignpath (witch_msa/default.config:15-17) can point at them.  Sends
  *     tool \0 cwd \0 arg \0 arg ...
- * over the UNIX socket $WITCH_HIP_SOCKET (default /tmp/witch_hip_<uid>.sock), prints the
+ * over the UNIX socket $WITCH_HIP_SOCKET (default $XDG_RUNTIME_DIR/witch_hip/server.sock or
+ * /tmp/witch_hip_<uid>/server.sock, a directory private to the user), prints the
  * reply body and exits with the reply status.  If nothing listens it starts
  * `python3 -m witch_amd.shim.server --daemonize` (repo root = two directories above this binary's
  * directory, or $WITCH_HIP_ROOT) and retries for up to WITCH_HIP_START_TIMEOUT seconds (default 120:
@@ -64,7 +65,12 @@ int main(int argc, char **argv) {
   const char *tool = basename(selfbuf);
   char sockbuf[108];
   const char *sock = getenv("WITCH_HIP_SOCKET");
-  if (!sock) { snprintf(sockbuf, sizeof sockbuf, "/tmp/witch_hip_%d.sock", (int)getuid()); sock = sockbuf; }
+  if (!sock) {                                     /* same rule as server.py: a directory private to this user */
+    const char *rt = getenv("XDG_RUNTIME_DIR");
+    if (rt && *rt) snprintf(sockbuf, sizeof sockbuf, "%s/witch_hip/server.sock", rt);
+    else snprintf(sockbuf, sizeof sockbuf, "/tmp/witch_hip_%d/server.sock", (int)getuid());
+    sock = sockbuf;
+  }
   if (argc >= 2 && strcmp(argv[1], "-h") == 0) {
     printf("# %s :: witch-hip level-0 shim (MI355X server behind a UNIX socket)\nUsage: %s [options] <hmmfile> <seqfile>\n", tool, tool);
     return 0;

@@ -20,7 +20,24 @@ from . import formats
 
 
 def default_socket_path():
-    return os.environ.get("WITCH_HIP_SOCKET", "/tmp/witch_hip_%d.sock" % os.getuid())
+    """$WITCH_HIP_SOCKET, else a socket inside a directory only this user can enter
+    ($XDG_RUNTIME_DIR/witch_hip or /tmp/witch_hip_<uid>, mode 0700; client.c uses the same rule)."""
+    if os.environ.get("WITCH_HIP_SOCKET"):
+        return os.environ["WITCH_HIP_SOCKET"]
+    base = os.environ.get("XDG_RUNTIME_DIR")
+    d = os.path.join(base, "witch_hip") if base else "/tmp/witch_hip_%d" % os.getuid()
+    return os.path.join(d, "server.sock")
+
+
+def private_socket_dir(sock_path):
+    """Create the socket's directory 0700 and refuse one that somebody else owns or can write to."""
+    d = os.path.dirname(os.path.abspath(sock_path))
+    os.makedirs(d, mode=0o700, exist_ok=True)
+    st = os.stat(d)
+    if d.startswith("/tmp/witch_hip_") or d.endswith("/witch_hip"):
+        if st.st_uid != os.getuid() or (st.st_mode & 0o077):
+            raise PermissionError("socket directory %s is not private to uid %d" % (d, os.getuid()))
+    return d
 
 
 class ArgError(Exception):
@@ -52,6 +69,28 @@ def parse_hmmsearch_argv(argv):
     return opts, pos[0], pos[1]
 
 
+def check_hmmsearch_options(opts):
+    """The GPU path computes what WITCH's own command line asks for (algorithm.py:526-532):
+    `--max` (no filters) with a reporting threshold that lets every hit through.  Anything that would
+    change the reported set in HMMER (filters on, a real E-value / score cut-off, no null2) is refused
+    with exit status 1 instead of being silently ignored."""
+    if "--max" not in opts:
+        raise ArgError("witch-hip hmmsearch shim: only the unfiltered search (--max) is implemented; "
+                       "WITCH passes --max unless its filters are switched on")
+    for o in ("-T", "--incT", "--domT", "--incdomT", "--nonull2", "--nobias", "--cut_ga", "--cut_nc", "--cut_tc"):
+        if o in opts:
+            raise ArgError("witch-hip hmmsearch shim: option %s is not supported" % o)
+    for o in ("-E", "--incE", "--domE", "--incdomE"):
+        if o in opts:
+            try:
+                v = float(opts[o])
+            except ValueError:
+                raise ArgError("witch-hip hmmsearch shim: bad value for %s" % o)
+            if o == "-E" and v < 1e6:
+                raise ArgError("witch-hip hmmsearch shim: -E %s would drop hits; only E >= 1e6 (WITCH: 99999999) "
+                               "is supported, every sequence with a domain is reported" % opts[o])
+
+
 def parse_hmmalign_argv(argv):
     takes_value = {"-o", "--mapali", "--informat", "--outformat"}
     opts, pos, i = {}, [], 0
@@ -77,9 +116,14 @@ class GpuBackend:
     """The only place that touches libwitch_hip.so.  One single-model EHMM per HMM file
     (hmmsearch works one model at a time; hmmalign batches are grouped by model)."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, max_models=None):
+        import collections
         self.device = device
-        self.cache = {}          # realpath -> (mtime, EHMM, header)
+        # realpath -> (mtime, EHMM, header), least recently used first.  Every handle owns device
+        # workspace (hundreds of MB once it has scored a chunk) and a WITCH ensemble has hundreds of
+        # models, so the cache is bounded and evicted handles are closed.
+        self.cache = collections.OrderedDict()
+        self.max_models = max_models or int(os.environ.get("WITCH_HIP_MAX_MODELS", "32"))
         self.lock = threading.Lock()
 
     def model(self, path):
@@ -90,8 +134,14 @@ class GpuBackend:
         if hit is None or hit[0] != mt:
             if hit is not None:
                 hit[1].close()
+                del self.cache[rp]
+            while len(self.cache) >= self.max_models:
+                _, (_, old, _) = self.cache.popitem(last=False)
+                old.close()
             hit = (mt, EHMM([rp], device=self.device), formats.hmm_header(rp))
             self.cache[rp] = hit
+        else:
+            self.cache.move_to_end(rp)
         return hit[1], hit[2]
 
     def search(self, hmm_path, records):
@@ -186,6 +236,7 @@ class Server:
             raise ArgError("Error: File existence/permissions problem in trying to open HMM file %s." % hmm)
         if not os.path.exists(fa):
             raise ArgError("Error: Failed to open sequence file %s for reading" % fa)
+        check_hmmsearch_options(opts)
         records = formats.read_fasta(fa)
         hdr, rows = self.backend.search(hmm, records)
         text = formats.format_hmmsearch(hmm, fa, hdr, rows, len(records))
@@ -256,16 +307,45 @@ class Server:
             except OSError:
                 pass
 
-    def serve_forever(self, ready=None):
+    def serve_forever(self, ready=None, idle_timeout=None):
+        """One server per socket: an exclusive flock on <socket>.lock is taken BEFORE the socket is
+        touched (and before any GPU call), so of the many clients WITCH starts at once - each of which
+        launches a server when it cannot connect - exactly one server survives; the others exit 0 and
+        their clients connect to the survivor.  The server leaves after <idle_timeout> seconds without
+        a request ($WITCH_HIP_IDLE_TIMEOUT, default 3600; 0 = never)."""
+        import fcntl
+        private_socket_dir(self.sock_path)
+        self._lockf = open(self.sock_path + ".lock", "w")
+        try:
+            fcntl.flock(self._lockf, fcntl.LOCK_EX | fcntl.LOCK_NB)
+        except OSError:
+            return False                                  # another server owns this socket
         if os.path.exists(self.sock_path):
             os.unlink(self.sock_path)
-        srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
-        srv.bind(self.sock_path)
+        old_umask = os.umask(0o077)
+        try:
+            srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+            srv.bind(self.sock_path)
+        finally:
+            os.umask(old_umask)
         srv.listen(512)
+        if idle_timeout is None:
+            idle_timeout = float(os.environ.get("WITCH_HIP_IDLE_TIMEOUT", "3600"))
+        srv.settimeout(idle_timeout if idle_timeout > 0 else None)
         if ready is not None:
             ready.set()
         while True:
-            conn, _ = srv.accept()
+            try:
+                conn, _ = srv.accept()
+            except socket.timeout:
+                if threading.active_count() > 2:          # requests still running: keep going
+                    continue
+                try:
+                    os.unlink(self.sock_path)
+                except OSError:
+                    pass
+                return True
+            conn.settimeout(None)
             threading.Thread(target=self.handle, args=(conn,), daemon=True).start()
 
 
@@ -299,10 +379,12 @@ def main():
         os.setsid()
         if os.fork() > 0:
             os._exit(0)
+        private_socket_dir(args.socket)
         log = open(args.socket + ".log", "a")
         os.dup2(log.fileno(), 1)
         os.dup2(log.fileno(), 2)
         sys.stdin.close()
+    private_socket_dir(args.socket)
     Server(GpuBackend(args.device), args.socket).serve_forever()
 
 

@@ -245,14 +245,15 @@ def main():
             cells_step = float(lens_local.sum() * M.sum())              # every local query x every model
             cells_launch = cells_step * args.steps / score_launches
             s_tflops = cells_launch * 77.0 / (score_ms * 1e-3) / 1e12 if score_ms > 0 else 0.0
-            traffic, traffic_src = None, None
+            traffic, traffic_src, traffic_align = None, None, None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
                 try:
                     tj = json.load(open(tpath))
                     if tj.get("workload") == args.workload and not args.nq and not args.nh and world == 1:
                         traffic = tj.get("score_kernel_hbm_bytes_per_launch")
-                        traffic_src = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run of this command, not this run)"
+                        traffic_align = tj.get("align_kernel_hbm_bytes_per_launch")
+                        traffic_src = "profiles/traffic.json <- %s; counters of an earlier run of this command, NOT measured in this run" % tj.get("source", "?").split(" ")[0]
                 except Exception:
                     traffic = None
             roofline = {"bound": "valu", "kernel": "wh::k7::score_kernel7", "achieved": round(s_tflops, 2), "peak": 157.3,
@@ -269,7 +270,7 @@ def main():
             roofline_align = {"bound": "hbm", "kernel": "wh::align_kernel", "achieved": round(a_gbs, 1), "peak": 8000.0,
                               "unit": "GB/s", "frac": round(a_gbs / 8000.0, 4), "bytes_per_cell": 52,
                               "cells_per_step": hot_path_step.aligned_cells, "stage_ms": round(align_ms, 3),
-                              "launches_per_step": kern_n[2] / args.steps, "traffic": None}
+                              "launches_per_step": kern_n[2] / args.steps, "traffic": traffic_align, "traffic_source": traffic_src}
             t_s, t_a = kern_ms[0] / args.steps, align_ms
             combined = (t_s * roofline["frac"] + t_a * roofline_align["frac"]) / (t_s + t_a) if t_s + t_a > 0 else 0.0
             # ---- the three distributions SURVEY.md 8(d) asks for with every run

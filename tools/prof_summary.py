@@ -20,39 +20,44 @@ def short(name):
 
 def main():
     d = sys.argv[1]
-    stats = glob.glob(os.path.join(d, "trace", "**", "*kernel_stats.csv"), recursive=True)
+    stats = glob.glob(os.path.join(d, "trace", "**", "*kernel_trace.csv"), recursive=True)
     if stats:
-        rows = list(csv.DictReader(open(stats[0])))
+        # per kernel: every dispatch's duration; "full-size" = within 50 % of the longest one (bench.py also
+        # scores a 256-query sample once, which rocprofv3's own kernel_stats.csv averages in)
+        dur = collections.defaultdict(list)
+        res = {}
+        for r in csv.DictReader(open(stats[0])):
+            if short(r["Kernel_Name"]):
+                dur[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+                res[r["Kernel_Name"]] = (r["VGPR_Count"], r["Accum_VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"], r["Scratch_Size"],
+                                         r["Workgroup_Size_X"])
         with open(os.path.join(d, "kernel_stats.csv"), "w") as o:
             w = csv.writer(o)
-            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage"])
-            for r in rows:
-                if short(r["Name"]):
-                    w.writerow([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]])
-    traffic = collections.defaultdict(lambda: {"launches": 0, "FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0})
+            w.writerow(["Name", "Calls", "FullSizeCalls", "FullSizeAverageNs", "MinNs", "MaxNs", "VGPR", "AGPR", "SGPR", "LDS_Block_Size",
+                        "Scratch_Size", "Workgroup_Size"])
+            for k in sorted(dur, key=lambda k: -sum(dur[k])):
+                full = [x for x in dur[k] if x >= 0.5 * max(dur[k])]
+                w.writerow([k, len(dur[k]), len(full), "%.0f" % (sum(full) / len(full)), min(dur[k]), max(dur[k])] + list(res[k]))
+    # per kernel: the LARGEST dispatch of each pass (bench.py also scores 256 queries once for the
+    # regions-per-pair sample; that small launch must not be averaged into the full-size one)
+    per = {"FETCH_SIZE": collections.defaultdict(lambda: collections.defaultdict(float)),
+           "WRITE_SIZE": collections.defaultdict(lambda: collections.defaultdict(float))}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        per_dispatch = collections.defaultdict(float)
-        names = {}
         for f in glob.glob(os.path.join(d, "pmc_" + c, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
-                if r["Counter_Name"] != c:
-                    continue
                 k = short(r["Kernel_Name"])
-                if not k:
-                    continue
-                per_dispatch[r["Dispatch_Id"]] += float(r["Counter_Value"])
-                names[r["Dispatch_Id"]] = k
-        for did, v in per_dispatch.items():
-            traffic[names[did]][c] += v
-            if c == "FETCH_SIZE":
-                traffic[names[did]]["launches"] += 1
+                if k and r["Counter_Name"] == c:
+                    per[c][k][r["Dispatch_Id"]] += float(r["Counter_Value"])
     out = {}
-    for k, t in traffic.items():
-        n = max(1, t["launches"])
-        read_b = 2.0 * t["FETCH_SIZE"] * 1024.0 / n      # gfx950: FETCH_SIZE tallies 128-B requests at 64 B
-        write_b = t["WRITE_SIZE"] * 1024.0 / n
-        out[k] = {"launches": t["launches"], "read_bytes_per_launch": read_b, "write_bytes_per_launch": write_b,
-                  "hbm_bytes_per_launch": read_b + write_b}
+    for k in sorted(set(per["FETCH_SIZE"]) | set(per["WRITE_SIZE"])):
+        fetch = max(per["FETCH_SIZE"][k].values(), default=0.0)
+        write = max(per["WRITE_SIZE"][k].values(), default=0.0)
+        read_b = 2.0 * fetch * 1024.0                    # gfx950: FETCH_SIZE tallies 128-B requests at 64 B
+        write_b = write * 1024.0
+        out[k] = {"dispatches_seen": len(per["FETCH_SIZE"][k]), "FETCH_SIZE_raw_KB": fetch, "WRITE_SIZE_raw_KB": write,
+                  "read_bytes_per_launch": read_b, "write_bytes_per_launch": write_b,
+                  "hbm_bytes_per_launch": read_b + write_b,
+                  "note": "largest dispatch of the kernel in each pass; FETCH_SIZE doubled (gfx950 correction, MI355X_MICROARCH.md)"}
     json.dump(out, open(os.path.join(d, "traffic.json"), "w"), indent=1)
     print(open(os.path.join(d, "kernel_stats.csv")).read() if stats else "no kernel stats")
     print(json.dumps(out, indent=1))

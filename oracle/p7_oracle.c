@@ -1300,3 +1300,43 @@ int orc_align_batch(orc_hmm *const *hmms, const uint8_t *residues, const int64_t
 }
 
 int orc_result_size(void) { return (int) sizeof(orc_result); }
+
+/* Design aid (tools/band_stats.py): for the FIRST envelope of a pair, the range of model nodes whose
+ * lane block (Q nodes per block) holds a cell with posterior >= 2^log2eps on some envelope row -
+ * out[0..1] from the multihit Forward/Backward of the whole sequence (what the scoring kernel knows
+ * after its first two sweeps), out[2..3] from the unihit Forward/Backward of the envelope itself
+ * (what the envelope sweeps need), out[4..5] = the envelope.  Block maxima over M, I, D. */
+int orc_band_stats(const orc_hmm *h, const uint8_t *dsq, int L, int Q, double log2eps, int *out)
+{
+  int M = h->M, i, k, which;
+  orc_result r;
+  orc_len cm = len_config(L, 1), cu = len_config(L, 0);
+  const double eps = exp2(log2eps);
+  orc_score_pair(h, dsq, L, &r);
+  if (r.nenv < 1) return 0;
+  out[4] = r.env_i[0]; out[5] = r.env_j[0];
+  for (which = 0; which < 2; which++) {
+    const int i0 = which ? 1 : r.env_i[0], i1 = which ? r.env_j[0] - r.env_i[0] + 1 : r.env_j[0];
+    const int Lx = which ? r.env_j[0] - r.env_i[0] + 1 : L;
+    const uint8_t *x = which ? dsq + (r.env_i[0] - 1) : dsq;
+    orc_mx *fx = mx_new(Lx, M), *bx = mx_new(Lx, M);
+    double fwd = forward(h, x, Lx, which ? cu : cm, fx);
+    int lo = M + 1, hi = 0;
+    backward(h, x, Lx, which ? cu : cm, bx);
+    for (i = i0; i <= i1; i++) {
+      const double sc = exp(fx->lscale[i] + bx->lscale[i] - fwd);
+      int b;
+      for (b = 0; b * Q < M; b++) {
+        double fm = 0.0, bm = 0.0;
+        for (k = b * Q + 1; k <= (b + 1) * Q && k <= M; k++) {
+          int st;
+          for (st = 0; st < 3; st++) { if (MX(fx, i, k, st) > fm) fm = MX(fx, i, k, st); if (MX(bx, i, k, st) > bm) bm = MX(bx, i, k, st); }
+        }
+        if (fm * bm * sc >= eps) { if (b * Q + 1 < lo) lo = b * Q + 1; if ((b + 1) * Q > hi) hi = (b + 1) * Q; }
+      }
+    }
+    out[2 * which] = lo; out[2 * which + 1] = hi;
+    mx_free(fx); mx_free(bx);
+  }
+  return 1;
+}

@@ -9,7 +9,7 @@ from oracle import oracle as orc
 import witch_amd._lib as _L
 if os.environ.get('WITCH_LIB'):
     _L.LIB_PATH = os.environ['WITCH_LIB']
-    _L.SYMBOLS.pop('wh_set_option', None) if 'old' in _L.LIB_PATH else None
+    _L.SYMBOLS.pop('wh_set_option', None) if 'old_lib' in _L.LIB_PATH else None
 from tests.conftest import load_case
 from witch_amd.ehmm import EHMM, pack_queries
 case = load_case(case_name)

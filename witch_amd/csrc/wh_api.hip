@@ -467,11 +467,16 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       r.Lcap = Lc; r.Mmax = e->max_M;
       r.mx_stride = (size_t)(Lc + 2) * ((size_t)3 * Qmax * kWave + 8);
       r.seg_cap = resolve_seg_cap();
-      r.seg_stride = (size_t)6 * r.seg_cap;
+      r.seg_stride = resolve_seg_ints(Lc, e->max_M);
       r.decibits = d_decibits; r.flags = d_flags; r.detail = d_detail;
       r.H = (int)e->hmms.size(); r.K = e->K; r.Kp = e->Kp;
       memcpy(r.degen, e->degen, sizeof r.degen);
       r.dbg = e->knobs.rdbg;
+      if (e->knobs.stats) {
+        if (e->d_recs.ensure(128)) return WH_ENOMEM;
+        HIPCHK(hipMemsetAsync(e->d_recs.p, 0, 128, s));
+        r.stats = (unsigned long long *)e->d_recs.p;
+      }
       const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, kLdsBudget / rlds));
       int blocks = std::min(n_multi, e->cu_count * per_cu);
       blocks = clamp_blocks(blocks, r.mx_stride * sizeof(double) + r.seg_stride * sizeof(int32_t), e->d_rmx);
@@ -483,6 +488,14 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       if (err != hipSuccess) { set_error("resolve kernel launch failed: %s", hipGetErrorString(err)); return WH_EHIP; }
       rlaunches++;
       e->last_resolved = n_multi;
+      if (r.stats) {
+        unsigned long long st[8];
+        HIPCHK(hipMemcpyAsync(st, r.stats, sizeof st, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        const double tot = (double)(st[0] + st[1] + st[2] + st[3] + st[4]);
+        fprintf(stderr, "[wh] resolver wave cycles: region Forward %.1f%%  traces %.1f%%  clustering %.1f%%  cluster statistics %.1f%%  envelope Forward %.1f%%  (%.3g cycles per pair)\n",
+                100.0 * st[0] / tot, 100.0 * st[1] / tot, 100.0 * st[2] / tot, 100.0 * st[3] / tot, 100.0 * st[4] / tot, tot / n_multi);
+      }
     }
   }
   if (timer_end(e, 4, s, rlaunches)) return WH_EHIP;

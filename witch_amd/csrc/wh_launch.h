@@ -79,11 +79,13 @@ struct ResolveArgs {
   wh_pair_detail *detail;
   int H, K, Kp;
   uint32_t degen[32];
-  int dbg;                     // WH_DBG > 0: print the first <dbg> sampled segments and the cluster statistics of every region
+  unsigned long long *stats;   // WH_STATS: wave cycles per phase [0] region Forward [1] traces [2] clustering [3] cluster statistics [4] envelope Forward
+  int dbg;                     // WH_RDBG > 0: print the first <dbg> sampled segments and the cluster statistics of every region
 };
 hipError_t launch_resolve(const ResolveArgs &a, int blocks, size_t lds, hipStream_t s);
 size_t resolve_lds_bytes(int Lcap, int Mmax);
 int resolve_seg_cap();
+size_t resolve_seg_ints(int Lcap, int Mmax);
 
 struct TopkArgs {
   const int32_t *decibits;

@@ -19,6 +19,8 @@
 // wave-uniform (one random number per choice, strictly serial by construction of the generator),
 // the E-state choice and the per-trace null2 / segment bookkeeping use the 64 lanes, the
 // clustering reproduces Easel's vertex order exactly (parallel link tests, serial stack updates).
+// -DWH_RESOLVE_DEBUG compiles the device printf dumps in (option WH_RDBG; tests/dbg/dbg_resolve.py):
+// off by default, device printf alone costs the kernel half of its register budget.
 #include <hip/hip_runtime.h>
 
 #include "wh_launch.h"
@@ -45,6 +47,11 @@ __device__ __forceinline__ double shfl_up_d(double v, int d) {
 __device__ __forceinline__ double shfl_d(double v, int l) {
   const long long u = __double_as_longlong(v);
   const int lo = __shfl((int)(u & 0xFFFFFFFFll), l), hi = __shfl((int)(u >> 32), l);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double readlane_d(double v, int l) {      // l must be wave-uniform
+  const long long u = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(u & 0xFFFFFFFFll), l), hi = __builtin_amdgcn_readlane((int)(u >> 32), l);
   return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
 __device__ __forceinline__ double wave_sum_d(double x) {
@@ -226,30 +233,38 @@ __device__ __forceinline__ bool seg_linked(int i1, int j1, int k1, int m1, int i
 }  // namespace
 
 // LDS per wave (ints unless noted): see resolve_lds_bytes()
+// LDS per wave (4-byte units): residues, n2sc and accumulators (float per residue), the domains of the
+// current trace and their null2 vectors, the emitting state per residue (int16), Easel's two vertex
+// stacks (uint16).  The end-point histograms of the cluster statistics live in the wave's HBM slab.
 __host__ __device__ inline size_t resolve_lds_ints(int Lcap, int Mmax) {
-  const int Lp = (Lcap + 4) & ~1, W = (Lcap > Mmax ? Lcap : Mmax) + 4;
-  return (size_t)(Lcap + 8) / 4 + 2 /*seq*/ + Lp /*n2sc*/ + Lp /*acc*/ + Lp /*stk*/ + W /*epc*/ + kDomMax * (4 + 32) + 2 * kSegCap + 64;
+  (void)Mmax;
+  const int Lp = (Lcap + 4) & ~1;
+  return (size_t)(Lcap + 8) / 4 + 2 /*seq*/ + Lp /*n2sc*/ + Lp /*acc*/ + kDomMax * (4 + 32) + Lp / 2 + 2 /*stk*/ + kSegCap /*two uint16 stacks*/ + 7 * kEnvMax + 16;
 }
 size_t resolve_lds_bytes(int Lcap, int Mmax) { return resolve_lds_ints(Lcap, Mmax) * 4 + 16; }
+size_t resolve_seg_ints(int Lcap, int Mmax) { return (size_t)6 * kSegCap + (size_t)(Lcap > Mmax ? Lcap : Mmax) + 8; }
 int resolve_seg_cap() { return kSegCap; }
 
-__global__ __launch_bounds__(64) void resolve_kernel(ResolveArgs a) {
+#define RTICK(slot) do { if (a.stats) { const long long t_now = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(a.stats + (slot), (unsigned long long)(t_now - tk0)); tk0 = t_now; } } while (0)
+
+__global__ __launch_bounds__(64, 2) void resolve_kernel(ResolveArgs a) {
   extern __shared__ __attribute__((aligned(16))) int lds_raw[];
   const int lane = threadIdx.x;
-  const int Lp = (a.Lcap + 4) & ~1, W = (a.Lcap > a.Mmax ? a.Lcap : a.Mmax) + 4;
+  const int Lp = (a.Lcap + 4) & ~1;
   uint8_t *seq = reinterpret_cast<uint8_t *>(lds_raw);
   float *n2sc = reinterpret_cast<float *>(lds_raw + (a.Lcap + 8) / 4 + 2);
   float *acc = n2sc + Lp;
-  int *stk = reinterpret_cast<int *>(acc + Lp);
-  int *epc = stk + Lp;
-  int *dom = epc + W;                                  // kDomMax x (sqfrom, sqto, hmmfrom, hmmto)
+  int *dom = reinterpret_cast<int *>(acc + Lp);        // kDomMax x (sqfrom, sqto, hmmfrom, hmmto)
   float *dnull = reinterpret_cast<float *>(dom + 4 * kDomMax);   // kDomMax x 32
+  short *stk = reinterpret_cast<short *>(dnull + 32 * kDomMax);  // emitting state of each residue: +k match, -k insert
   const int SEGCAP = a.seg_cap;
-  int *s_a = reinterpret_cast<int *>(dnull + 32 * kDomMax);      // Easel's vertex stacks of the clustering (LDS)
-  int *s_b = s_a + SEGCAP;
-  int32_t *sg = a.segs + (size_t)blockIdx.x * a.seg_stride;      // per wave in HBM: 6 arrays of SEGCAP ints
+  unsigned short *s_a = reinterpret_cast<unsigned short *>(stk + Lp + 4);   // Easel's vertex stacks of the clustering
+  unsigned short *s_b = s_a + SEGCAP;
+  int *misc = reinterpret_cast<int *>(s_b + SEGCAP);             // 7 x kEnvMax ints: envelope and cluster lists of the pair
+  int32_t *sg = a.segs + (size_t)blockIdx.x * a.seg_stride;      // per wave in HBM: 6 arrays of SEGCAP ints + the histogram
   int32_t *s_idx = sg, *s_i = sg + SEGCAP, *s_j = sg + 2 * SEGCAP, *s_k = sg + 3 * SEGCAP, *s_m = sg + 4 * SEGCAP;
   int32_t *s_as = sg + 5 * SEGCAP;
+  int32_t *epc = sg + 6 * SEGCAP;                                // end-point histogram of one cluster
   const double LOG2 = 0.69314718055994529;
   const int n_items = *a.count < a.rec_cap ? *a.count : a.rec_cap;
 
@@ -258,6 +273,9 @@ __global__ __launch_bounds__(64) void resolve_kernel(ResolveArgs a) {
     if (lane == 0) item = atomicAdd(a.counter, 1);
     item = __shfl(item, 0);
     if (item >= n_items) break;
+    // By value: with a reference into the queue AND the LDS lists below, this toolchain produced a kernel that
+    // read a garbage record (out-of-slab writes); either alone was fine.  Record fields are range-checked below
+    // and the sampling loop is bounded, so a bad record can no longer run the wave out of its slab.
     const ResolveRec rec = a.recs[item];
     const DevHMM hm = a.hmms[rec.h];
     GModel m;
@@ -275,11 +293,15 @@ __global__ __launch_bounds__(64) void resolve_kernel(ResolveArgs a) {
     int flags = rec.flags | WH_FLAG_MULTI;
     // envelope list of the pair
     int nenv = 0;
-    int env_i[kEnvMax], env_j[kEnvMax];
-    float env_sc[kEnvMax], env_dc[kEnvMax];
+    // small per-pair lists live in LDS (every lane writes the same value): as arrays in registers they pushed the
+    // kernel to one wave per SIMD
+    int *env_i = misc, *env_j = misc + kEnvMax;
+    float *env_sc = reinterpret_cast<float *>(misc + 2 * kEnvMax), *env_dc = reinterpret_cast<float *>(misc + 3 * kEnvMax);
     float seqbias_sum = 0.f;
-    for (int e = 0; e < rec.nenv; e++) {
+    const int nrec = rec.nenv < 0 ? 0 : rec.nenv > WH_MAX_ENVELOPES ? WH_MAX_ENVELOPES : rec.nenv;
+    for (int e = 0; e < nrec; e++) {
       const int ireg = rec.ri[e], jreg = rec.rj[e], Lr = jreg - ireg + 1;
+      if (ireg < 1 || jreg > L || Lr < 1 || L > a.Lcap) { flags |= WH_FLAG_TRUNC; continue; }     // never true for a well-formed record
       if (!((rec.multi_mask >> e) & 1)) {
         // single-domain region: envelope = region, scored by the scoring kernel (A.5)
         seqbias_sum += rec.domcorr[e];
@@ -289,8 +311,12 @@ __global__ __launch_bounds__(64) void resolve_kernel(ResolveArgs a) {
       }
       // ---------------- A.4b
       const uint8_t *rs = seq + (ireg - 1);       // rs[pos-1] = residue at region position pos
+      long long tk0 = a.stats ? __builtin_readcyclecounter() : 0;
       const double regfwd = gforward<true>(m, rs, Lr, cm, mx, lane);
+      RTICK(0);
+#ifdef WH_RESOLVE_DEBUG
       if (a.dbg && lane == 0) printf("[resolve] region forward %.12f\n", regfwd);
+#endif
       for (int t = lane; t <= Lr + 1; t += 64) acc[t] = 0.f;
       int nseg = 0;
       Rng rng;
@@ -299,42 +325,70 @@ __global__ __launch_bounds__(64) void resolve_kernel(ResolveArgs a) {
       const int Qs = ((m.M - 1) / 4 + 1) > 2 ? ((m.M - 1) / 4 + 1) : 2;     // HMMER's striping: vectors of 4 floats
       for (int t = 0; t < kSamples; t++) {
         int i = Lr, k = 0, s0 = stC, ndom = 0, sqto = 0, hmmto = 0, sqfrom = 0, hmmfrom = 0;
-        while (s0 != stS) {
+        int run_state = 0, run_j = 0;            // decision cache of the current run (see below)
+        double run_r1 = 0.0, run_r2 = 0.0, run_r3 = 0.0;
+        int guard = 4 * (Lr + m.M) + 64;         // a sampled path has at most Lr + M + a few states
+        while (s0 != stS && --guard > 0 && i >= 0 && k >= 0 && k <= m.M) {
           double path[4] = {0.0, 0.0, 0.0, 0.0};
           int s1;
-          switch (s0) {
-            case stM: {
-              path[0] = mx.spec(i - 1, xB) * m.t(gE, k);
-              path[1] = mx.cell(i - 1, k - 1, 0) * m.t(gA, k);
-              path[2] = mx.cell(i - 1, k - 1, 1) * m.t(gB, k);
-              path[3] = mx.cell(i - 1, k - 1, 2) * m.t(gC, k);
-              const int c4 = rng_choose(rng, path, 4);
+          if (s0 == stN) { i = 0; s0 = stS; continue; }     // N(i) <- N(i-1) ... <- S: no random number is drawn on the way
+          if (s0 == stM || s0 == stD || s0 == stC || s0 == stJ) {
+            // A sampled path mostly RUNS: M along a diagonal, D along a row, C / J along a flank.  One random
+            // number per decision keeps the walk serial, but the inputs of the next 64 decisions of a run are
+            // independent of the outcomes: lane t fetches those of the run's t-th state in one round of loads
+            // (instead of one memory round trip per step) and turns them into esl_rnd_FChoose's thresholds.
+            if (run_state != s0 || run_j >= 64) {
+              const int it = (s0 == stD) ? i : i - lane, kt = (s0 == stM || s0 == stD) ? k - lane : 0;
+              double pd[4] = {0.0, 0.0, 0.0, 0.0};
+              if (s0 == stM) {
+                if (it >= 1 && kt >= 1) {
+                  pd[0] = mx.spec(it - 1, xB) * m.t(gE, kt);
+                  pd[1] = mx.cell(it - 1, kt - 1, 0) * m.t(gA, kt);
+                  pd[2] = mx.cell(it - 1, kt - 1, 1) * m.t(gB, kt);
+                  pd[3] = mx.cell(it - 1, kt - 1, 2) * m.t(gC, kt);
+                }
+              } else if (s0 == stD) {
+                if (kt >= 1) {
+                  pd[0] = mx.cell(it, kt - 1, 0) * m.t(gD1, kt);
+                  pd[1] = mx.cell(it, kt - 1, 2) * m.t(gD2, kt);
+                }
+              } else if (it >= 1) {
+                pd[0] = mx.spec(it - 1, s0 == stC ? xC : xJ) * cm.loop;
+                pd[1] = mx.spec(it, xE) * (s0 == stC ? cm.EC : cm.EJ) * exp(mx.spec(it, xLS));
+              }
+              const int nch = s0 == stM ? 4 : 2;
+              double tot = 0.0;
+              for (int u = 0; u < nch; u++) tot += pd[u];
+              float pf[4] = {0.f, 0.f, 0.f, 0.f};
+              for (int u = 0; u < nch; u++) pf[u] = tot > 0.0 ? (float)(pd[u] / tot) : 1.0f / (float)nch;
+              double norm = 0.0;
+              for (int u = 0; u < nch; u++) norm += (double)pf[u];
+              const double c1 = (double)pf[0], c2 = c1 + (double)pf[1], c3 = c2 + (double)pf[2];
+              run_r1 = c1 / norm; run_r2 = c2 / norm; run_r3 = c3 / norm;
+              run_state = s0; run_j = 0;
+            }
+            const int jl = __builtin_amdgcn_readfirstlane(run_j);
+            const double roll = rng_next(rng);
+            const double a1 = readlane_d(run_r1, jl), a2 = readlane_d(run_r2, jl), a3 = readlane_d(run_r3, jl);
+            run_j++;
+            if (s0 == stM) {
+              const int c4 = a1 > roll ? 0 : a2 > roll ? 1 : a3 > roll ? 2 : 3;
               s1 = c4 == 0 ? stB : c4 == 1 ? stM : c4 == 2 ? stI : stD;
               k--; i--;
-              break;
-            }
-            case stD:
-              path[0] = mx.cell(i, k - 1, 0) * m.t(gD1, k);
-              path[1] = mx.cell(i, k - 1, 2) * m.t(gD2, k);
-              s1 = rng_choose(rng, path, 2) == 0 ? stM : stD;
+            } else if (s0 == stD) {
+              s1 = a1 > roll ? stM : stD;
               k--;
-              break;
+            } else {
+              s1 = a1 > roll ? s0 : stE;
+            }
+            if (s1 != s0) run_state = 0;
+          } else
+          switch (s0) {
             case stI:
               path[0] = mx.cell(i - 1, k, 0) * m.t(gMI, k);
               path[1] = mx.cell(i - 1, k, 1) * m.t(gII, k);
               s1 = rng_choose(rng, path, 2) == 0 ? stM : stI;
               i--;
-              break;
-            case stN: s1 = (i == 0) ? stS : stN; break;
-            case stC:
-              path[0] = mx.spec(i - 1, xC) * cm.loop;
-              path[1] = mx.spec(i, xE) * cm.EC * exp(mx.spec(i, xLS));
-              s1 = rng_choose(rng, path, 2) == 0 ? stC : stE;
-              break;
-            case stJ:
-              path[0] = mx.spec(i - 1, xJ) * cm.loop;
-              path[1] = mx.spec(i, xE) * cm.EJ * exp(mx.spec(i, xLS));
-              s1 = rng_choose(rng, path, 2) == 0 ? stJ : stE;
               break;
             case stE: {
               // FChoose over M(i,*) and D(i,*) in HMMER's striped order: position p = q*8 + state*4 + r
@@ -374,15 +428,17 @@ __global__ __launch_bounds__(64) void resolve_kernel(ResolveArgs a) {
               break;
             default: s1 = stS; break;
           }
+#ifdef WH_RESOLVE_DEBUG
           if (a.dbg >= 1000 && t == a.dbg - 1000 && lane == 0)
             printf("   [trace %d] s0 %d -> s1 %d at i %d k %d  path %.9g %.9g %.9g %.9g rng %u\n", t, s0, s1, i, k, path[0], path[1], path[2], path[3], rng.x);
+#endif
           // the state just chosen sits at (k, i)
           if (s1 == stE) { sqto = 0; hmmto = 0; }
           else if (s1 == stM) {
             if (sqto == 0) { sqto = i; hmmto = k; }
             sqfrom = i; hmmfrom = k;
-            if (lane == 0) stk[i] = k;
-          } else if (s1 == stI) { if (lane == 0) stk[i] = -k; }
+            if (lane == 0) stk[i] = (short)k;
+          } else if (s1 == stI) { if (lane == 0) stk[i] = (short)-k; }
           else if (s1 == stB) {
             if (ndom < kDomMax) {
               if (lane == 0) { dom[4 * ndom] = sqfrom; dom[4 * ndom + 1] = sqto; dom[4 * ndom + 2] = hmmfrom; dom[4 * ndom + 3] = hmmto; }
@@ -437,12 +493,13 @@ __global__ __launch_bounds__(64) void resolve_kernel(ResolveArgs a) {
         nseg = min(SEGCAP, nseg + ndom);
         __builtin_amdgcn_wave_barrier();
       }
+      RTICK(1);
       for (int pos = 1 + lane; pos <= Lr; pos += 64) n2sc[ireg + pos - 1] = logf(acc[pos] / (float)kSamples);
       wave_mem_sync();
       // ---------------- single-linkage clustering in Easel's vertex order (esl_cluster_SingleLinkage)
       int nc = 0;
       {
-        for (int v = lane; v < nseg; v += 64) s_a[v] = nseg - v - 1;
+        for (int v = lane; v < nseg; v += 64) s_a[v] = (unsigned short)(nseg - v - 1);
         __builtin_amdgcn_wave_barrier();
         int na = nseg;
         while (na > 0) {
@@ -450,7 +507,7 @@ __global__ __launch_bounds__(64) void resolve_kernel(ResolveArgs a) {
           na--;
           int nb = 1;
           __builtin_amdgcn_wave_barrier();
-          if (lane == 0) s_b[0] = v;
+          if (lane == 0) s_b[0] = (unsigned short)v;
           __builtin_amdgcn_wave_barrier();
           while (nb > 0) {
             v = s_b[nb - 1];
@@ -479,7 +536,7 @@ __global__ __launch_bounds__(64) void resolve_kernel(ResolveArgs a) {
                 __builtin_amdgcn_wave_barrier();
                 if (lane == 0) {
                   s_a[tp] = s_a[na - 1];
-                  s_b[nb] = wv;
+                  s_b[nb] = (unsigned short)wv;
                 }
                 na--; nb++;
                 __builtin_amdgcn_wave_barrier();
@@ -490,14 +547,17 @@ __global__ __launch_bounds__(64) void resolve_kernel(ResolveArgs a) {
         }
       }
       wave_mem_sync();
+#ifdef WH_RESOLVE_DEBUG
       if (a.dbg && lane == 0) {
         printf("[resolve q=%lld h=%d region %d..%d] nseg %d nc %d rng %u\n", (long long)rec.q, rec.h, ireg, jreg, nseg, nc, rng.x);
         for (int z = 0; z < nseg && z < a.dbg; z++) printf("   seg %d: t %d i %d j %d k %d m %d cluster %d\n", z, s_idx[z], s_i[z], s_j[z], s_k[z], s_m[z], s_as[z]);
       }
+#endif
+      RTICK(2);
       // ---------------- clusters -> envelopes (p7_spensemble_Cluster)
       int nsig = 0;
-      int g_i[kEnvMax], g_j[kEnvMax];
-      float g_p[kEnvMax];
+      int *g_i = misc + 4 * kEnvMax, *g_j = misc + 5 * kEnvMax;
+      float *g_p = reinterpret_cast<float *>(misc + 6 * kEnvMax);
       for (int c = 0; c < nc; c++) {
         // posterior of the cluster: traces that contribute (segments are in trace order)
         int ninc = 0;
@@ -535,35 +595,39 @@ __global__ __launch_bounds__(64) void resolve_kernel(ResolveArgs a) {
           const int32_t *src = which == 0 ? s_i : which == 1 ? s_k : which == 2 ? s_j : s_m;
           const int n = hi - lo + 1;
           for (int t = lane; t < n; t += 64) epc[t] = 0;
-          __builtin_amdgcn_wave_barrier();
+          wave_mem_sync();
           for (int h = lane; h < nseg; h += 64)
             if (__builtin_nontemporal_load(s_as + h) == c) atomicAdd(&epc[__builtin_nontemporal_load(src + h) - lo], 1);
-          __builtin_amdgcn_wave_barrier();
+          wave_mem_sync();
           int b = -1;
           if (which < 2) {          // leftmost position with enough end points, else the (first) most frequent one
             int cand = 1 << 30;
-            for (int t = lane; t < n; t += 64) if (epc[t] >= thr) cand = min(cand, t);
+            for (int t = lane; t < n; t += 64) if (__builtin_nontemporal_load(epc + t) >= thr) cand = min(cand, t);
             cand = wave_min_i(cand);
             if (cand < (1 << 30)) b = cand;
           } else {
             int cand = -1;
-            for (int t = lane; t < n; t += 64) if (epc[t] >= thr) cand = max(cand, t);
+            for (int t = lane; t < n; t += 64) if (__builtin_nontemporal_load(epc + t) >= thr) cand = max(cand, t);
             cand = wave_max_i(cand);
             if (cand >= 0) b = cand;
           }
           if (b < 0) {              // esl_vec_IArgMax: first maximum
-            int bv = -1, bt = 0;
-            for (int t = 0; t < n; t++) { const int e2 = epc[t]; if (e2 > bv) { bv = e2; bt = t; } }
-            b = bt;
+            int bv = -1, bt = 1 << 30;
+            for (int t = lane; t < n; t += 64) { const int e2 = __builtin_nontemporal_load(epc + t); if (e2 > bv) { bv = e2; bt = t; } }
+            const int gmax = wave_max_i(bv);
+            b = wave_min_i(bv == gmax ? bt : (1 << 30));
           }
           best[which] = lo + b;
           __builtin_amdgcn_wave_barrier();
         }
+#ifdef WH_RESOLVE_DEBUG
         if (a.dbg && lane == 0) printf("[resolve q=%lld h=%d region %d..%d] cluster %d: ninc %d thr %d i %d..%d j %d..%d k %d..%d m %d..%d best %d %d %d %d\n", (long long)rec.q, rec.h, ireg, jreg, c, ninc, thr, imin, imax, jmin, jmax, kmin, kmax, mmin, mmax, best[0], best[2], best[1], best[3]);
+#endif
         if (best[0] > best[2] || best[1] > best[3]) continue;
         if (nsig < kEnvMax) { g_i[nsig] = best[0]; g_j[nsig] = best[2]; g_p[nsig] = (float)ninc / (float)kSamples; nsig++; }
         else flags |= WH_FLAG_TRUNC;
       }
+      RTICK(3);
       // order by start (stable), drop dominated clusters (region_trace_ensemble)
       for (int d = 1; d < nsig; d++) {
         const int ti = g_i[d], tj = g_j[d]; const float tp = g_p[d];
@@ -584,7 +648,9 @@ __global__ __launch_bounds__(64) void resolve_kernel(ResolveArgs a) {
       float regsum = 0.f;
       for (int pos = ireg; pos <= jreg; pos++) regsum += n2sc[pos];
       seqbias_sum += regsum;
+#ifdef WH_RESOLVE_DEBUG
       if (a.dbg && lane == 0) { printf("[resolve] region n2sc sum %.6f; n2sc:", regsum); for (int pos = ireg; pos <= jreg; pos++) printf(" %.3f", n2sc[pos]); printf("\n"); }
+#endif
       for (int d = 0; d < nsig; d++) {
         if (dominated & (1u << d)) continue;
         const int i2 = g_i[d], j2 = g_j[d], Ld = j2 - i2 + 1;
@@ -594,6 +660,7 @@ __global__ __launch_bounds__(64) void resolve_kernel(ResolveArgs a) {
         if (nenv < kEnvMax) { env_i[nenv] = i2; env_j[nenv] = j2; env_sc[nenv] = (float)envsc; env_dc[nenv] = dc; nenv++; }
         else flags |= WH_FLAG_TRUNC;
       }
+      RTICK(4);
     }
     // ---------------- A.6 score assembly (float32 where HMMER is float32), as in the scoring kernels
     int decibits = 0;

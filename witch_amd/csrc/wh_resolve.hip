@@ -139,17 +139,31 @@ __device__ double gforward(const GModel &m, const uint8_t *seq, int L, GLen c, c
       pd1 = __builtin_nontemporal_load(pr + 2 * SQ + (size_t)(Q - 1) * 64 + lane - 1);
     }
     double mprev = 0.0, dloc = 0.0, P = 1.0, esum = 0.0;
-    for (int q = 0; q < Q; q++) {
-      const size_t o = (size_t)q * 64 + lane;
-      const double pM = __builtin_nontemporal_load(pr + o), pI = __builtin_nontemporal_load(pr + SQ + o), pD = __builtin_nontemporal_load(pr + 2 * SQ + o);
-      const double mm = od[o] * (pm1 * m.tf[gA * SQ + o] + pi1 * m.tf[gB * SQ + o] + pd1 * m.tf[gC * SQ + o] + pB * m.tf[gE * SQ + o]);
-      const double ins = pM * m.tf[gMI * SQ + o] + pI * m.tf[gII * SQ + o];
-      // D chain inside the lane with nothing entering from the left (the entering value is added below)
-      dloc = q > 0 ? mprev * m.tf[gD1 * SQ + o] + dloc * m.tf[gD2 * SQ + o] : 0.0;
-      if (q > 0) P *= m.tf[gD2 * SQ + o];
-      cr[o] = mm; cr[SQ + o] = ins; cr[2 * SQ + o] = dloc;
-      esum += mm;
-      pm1 = pM; pi1 = pI; pd1 = pD; mprev = mm;
+    // four nodes per step (Q is a multiple of 4): all loads of the step are issued before any of them is
+    // used, so a step costs one memory round trip instead of one per node
+    for (int q0 = 0; q0 < Q; q0 += 4) {
+      double pM[4], pI[4], pD[4], tA[4], tB[4], tC[4], tE[4], tMI[4], tII[4], tD1[4], tD2[4], em[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const size_t o = (size_t)(q0 + u) * 64 + lane;
+        pM[u] = __builtin_nontemporal_load(pr + o); pI[u] = __builtin_nontemporal_load(pr + SQ + o); pD[u] = __builtin_nontemporal_load(pr + 2 * SQ + o);
+        tA[u] = m.tf[gA * SQ + o]; tB[u] = m.tf[gB * SQ + o]; tC[u] = m.tf[gC * SQ + o]; tE[u] = m.tf[gE * SQ + o];
+        tMI[u] = m.tf[gMI * SQ + o]; tII[u] = m.tf[gII * SQ + o]; tD1[u] = m.tf[gD1 * SQ + o]; tD2[u] = m.tf[gD2 * SQ + o];
+        em[u] = od[o];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int q = q0 + u;
+        const size_t o = (size_t)q * 64 + lane;
+        const double mm = em[u] * (pm1 * tA[u] + pi1 * tB[u] + pd1 * tC[u] + pB * tE[u]);
+        const double ins = pM[u] * tMI[u] + pI[u] * tII[u];
+        // D chain inside the lane with nothing entering from the left (the entering value is added below)
+        dloc = q > 0 ? mprev * tD1[u] + dloc * tD2[u] : 0.0;
+        if (q > 0) P *= tD2[u];
+        cr[o] = mm; cr[SQ + o] = ins; cr[2 * SQ + o] = dloc;
+        esum += mm;
+        pm1 = pM[u]; pi1 = pI[u]; pd1 = pD[u]; mprev = mm;
+      }
     }
     // cross-lane: Dlast(r) = [dloc_last + P * D1_0 * Mlast(r-1)] + [P * D2_0] * Dlast(r-1)
     // (shuffles stay outside conditionals: a lane that skips a ds_bpermute does not lend its value)
@@ -165,12 +179,22 @@ __device__ double gforward(const GModel &m, const uint8_t *seq, int L, GLen c, c
     const double dleft = lane > 0 ? dup : 0.0;                   // true D of lane-1's last node
     const double c0 = lane > 0 ? d10 * mleft + d20 * dleft : 0.0;  // true D of my first node
     double Pq = 1.0;
-    for (int q = 0; q < Q; q++) {
-      const size_t o = (size_t)q * 64 + lane;
-      if (q > 0) Pq *= m.tf[gD2 * SQ + o];
-      const double dv = __builtin_nontemporal_load(cr + 2 * SQ + o) + Pq * c0;
-      cr[2 * SQ + o] = dv;
-      esum += dv;
+    for (int q0 = 0; q0 < Q; q0 += 4) {
+      double dl[4], t2[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const size_t o = (size_t)(q0 + u) * 64 + lane;
+        dl[u] = __builtin_nontemporal_load(cr + 2 * SQ + o);
+        t2[u] = m.tf[gD2 * SQ + o];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const size_t o = (size_t)(q0 + u) * 64 + lane;
+        if (q0 + u > 0) Pq *= t2[u];
+        const double dv = dl[u] + Pq * c0;
+        cr[2 * SQ + o] = dv;
+        esum += dv;
+      }
     }
     double xe = wave_sum_d(esum);
     double xn = pN * c.loop, xc = pC * c.loop + xe * c.EC, xj = pJ * c.loop + xe * c.EJ, lsd = 0.0;
@@ -401,21 +425,33 @@ __global__ __launch_bounds__(64, 2) void resolve_kernel(ResolveArgs a) {
                 return kk <= m.M ? (double)(float)(mx.cell(i, kk, st ? 2 : 0) * norm) : 0.0;
               };
               double mine = 0.0;
-              for (int p = p0; p < p1; p++) mine += term(p);
+              for (int pb = p0; pb < p1; pb += 8) {          // eight loads in flight per step
+                double tv[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) tv[u] = pb + u < p1 ? term(pb + u) : 0.0;
+#pragma unroll
+                for (int u = 0; u < 8; u++) mine += tv[u];
+              }
               double incl = mine;
               for (int d = 1; d < 64; d <<= 1) { const double o = shfl_up_d(incl, d); if (lane >= d) incl += o; }
               const double excl = incl - mine;
               const unsigned long long hit = __ballot(roll < incl);
               int found_p = -1;
               if (hit) {
+                // the chunk that holds the crossing is re-walked by the whole wave: lane u takes its u-th term
                 const int src = __ffsll((long long)hit) - 1;
-                int fp = -1;
-                if (lane == src) {
-                  double sum = excl;
-                  for (int p = p0; p < p1; p++) { sum += term(p); if (roll < sum) { fp = p; break; } }
-                  if (fp < 0) fp = p1 - 1;
+                const int c0p = __shfl(p0, src), c1p = __shfl(p1, src);
+                double base = shfl_d(excl, src);
+                for (int pb = c0p; pb < c1p && found_p < 0; pb += 64) {
+                  const int p = pb + lane;
+                  const double tv = p < c1p ? term(p) : 0.0;
+                  double run = tv;
+                  for (int d = 1; d < 64; d <<= 1) { const double o = shfl_up_d(run, d); if (lane >= d) run += o; }
+                  const unsigned long long h2 = __ballot(p < c1p && roll < base + run);
+                  if (h2) found_p = pb + __ffsll((long long)h2) - 1;
+                  base += shfl_d(run, 63);
                 }
-                found_p = __shfl(fp, src);
+                if (found_p < 0) found_p = c1p - 1;
               }
               if (found_p < 0) { k = 1; s1 = stM; }        // rounding left the sum below the roll: HMMER rescans, first non-zero cell wins
               else { k = (found_p & 3) * Qs + (found_p >> 3) + 1; s1 = ((found_p >> 2) & 1) ? stD : stM; }

@@ -161,3 +161,49 @@ def test_no_engine_installed_fails_loudly():
             gcmm.rankBitscores({}, {})
     finally:
         engine._ENGINE = old
+
+
+def test_checkpoint_file_format(tmp_path):
+    """f4: <outdir>/checkpoint_alignments.txt.gz as callback.py:19-26 appends it (one gzip member per
+    query, 'taxon\\tsequence\\n') and loader.py:95-150 reads it back (taxon = text before the LAST tab,
+    labels from the case of the characters, later lines win)."""
+    import gzip
+    from witch_amd.gcmm.merge import QueryAlignment
+    path = str(tmp_path / "checkpoint_alignments.txt.gz")
+
+    def qa(name, text):
+        q = QueryAlignment()
+        q[name] = text
+        return q
+    success, ignored, retry = [], [], []
+    gcmm.callback_queryAlignment(success, ignored, retry, 0, qa("q1", "--ACgtT-"), 0, "q1", path)
+    gcmm.callback_queryAlignment(success, ignored, retry, 0, QueryAlignment(), 1, "empty", path)      # failed -> ignored
+    gcmm.callback_queryAlignment(success, ignored, retry, 1, None, 2, "again", path)                 # retry once
+    assert (len(success), ignored, retry) == (1, ["empty"], [2])
+    n = gcmm.writeCheckpointAlignments([qa("name\twith tab", "acGT"), "skipped", QueryAlignment(), qa("q1", "AC--")], path)
+    assert n == 2
+    # the file is a concatenation of single-line gzip members: what the reference's 'ab' appends produce
+    raw = open(path, "rb").read()
+    assert raw.count(b"\x1f\x8b\x08") == 3
+    assert gzip.decompress(raw) == b"q1\t--ACgtT-\nname\twith tab\tacGT\nq1\tAC--\n"
+    back = gcmm.readCheckpointAlignments(path)
+    assert set(back) == {"q1", "name\twith tab"}
+    assert back["q1"]["q1"] == "AC--" and back["q1"]._col_labels == [0, 1, 2, 3]                  # the later line wins
+    assert back["name\twith tab"]._col_labels == [-1, -2, 0, 1]
+
+
+def test_result_files_read_back_by_the_reference_reader():
+    """tests/golden/readback.json.gz holds what the REFERENCE's readHMMSearch + ranking read from the
+    result files gcmm.search wrote (3 chunks per HMM); it must be what the engine answers."""
+    import gzip
+    import json
+    from tests.conftest import GOLDEN, load_case
+    g = json.load(gzip.open(os.path.join(GOLDEN, "readback.json.gz"), "rt"))
+    case = load_case(g["case"])
+    _engine_from_golden(case)
+    assert g["n_files"] == 3 * len(case.hmm_index)
+    index_to_hmm = {i: _Sub(p, n) for i, p, n in zip(case.hmm_index, case.hmm_paths, case.nseq)}
+    ranked = gcmm.rankBitscores(index_to_hmm, {})
+    assert set(ranked) == set(g["ranked"])
+    for t, want in g["ranked"].items():
+        assert [[i, s] for i, s in ranked[t]] == want, t

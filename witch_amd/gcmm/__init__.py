@@ -12,6 +12,7 @@ behaviour and serve their answers from that precomputed table:
     search          witch_msa/gcmm/algorithm.py:273-336 (result files: :524-537)
     alignSubQueriesNew  witch_msa/gcmm/aligner.py:350-538 (weighted consensus DP on the GPU)
     mergeAlignmentsCollapsed  witch_msa/gcmm/merger.py:40-131 (final transitive merge, closed form)
+    callback_queryAlignment / readCheckpointAlignments  witch_msa/gcmm/callback.py:9-29, loader.py:95-150 (checkpoint file)
 
 INTEGRATION.md shows the three-line change in witch_msa/gcmm/gcmm.py that installs them.
 """
@@ -22,3 +23,4 @@ from .aligner import getBackbones  # noqa: F401
 from .algorithm import search, check_query_names, divide_to_equal_chunks, num_chunks_for  # noqa: F401
 from .merge import alignSubQueriesNew, compressInsertions, trace_to_string  # noqa: F401
 from .merger import mergeAlignmentsCollapsed  # noqa: F401
+from .checkpoint import callback_queryAlignment, readCheckpointAlignments, writeCheckpointAlignments  # noqa: F401

@@ -495,6 +495,8 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
         const double tot = (double)(st[0] + st[1] + st[2] + st[3] + st[4]);
         fprintf(stderr, "[wh] resolver wave cycles: region Forward %.1f%%  traces %.1f%%  clustering %.1f%%  cluster statistics %.1f%%  envelope Forward %.1f%%  (%.3g cycles per pair)\n",
                 100.0 * st[0] / tot, 100.0 * st[1] / tot, 100.0 * st[2] / tot, 100.0 * st[3] / tot, 100.0 * st[4] / tot, tot / n_multi);
+        fprintf(stderr, "[wh]   inside the traces: decision fetches %.1f%%  E-state choice %.1f%%  null2/accumulators/segments %.1f%%  (of the trace cycles)\n",
+                100.0 * st[5] / (double)st[1], 100.0 * st[6] / (double)st[1], 100.0 * st[7] / (double)st[1]);
       }
     }
   }

@@ -303,9 +303,10 @@ __global__ __launch_bounds__(64, 2) void resolve_kernel(ResolveArgs a) {
     const ResolveRec rec = a.recs[item];
     const DevHMM hm = a.hmms[rec.h];
     GModel m;
-    m.tf = a.gtab + hm.gfw_off; m.te = a.gtab + hm.gem_off; m.Q = hm.Q; m.M = hm.M;
+    m.tf = a.gtab + hm.gfw_off; m.te = a.gtab + hm.gem_off;
+    m.Q = __builtin_amdgcn_readfirstlane(hm.Q); m.M = __builtin_amdgcn_readfirstlane(hm.M);
     GMx mx;
-    mx.Q = hm.Q; mx.rowlen = (size_t)3 * hm.Q * 64 + xNSPEC;
+    mx.Q = m.Q; mx.rowlen = (size_t)3 * m.Q * 64 + xNSPEC;
     mx.p = a.mx + (size_t)blockIdx.x * a.mx_stride;
     const int64_t off = a.offsets[rec.q];
     const int L = (int)(a.offsets[rec.q + 1] - off);
@@ -324,7 +325,8 @@ __global__ __launch_bounds__(64, 2) void resolve_kernel(ResolveArgs a) {
     float seqbias_sum = 0.f;
     const int nrec = rec.nenv < 0 ? 0 : rec.nenv > WH_MAX_ENVELOPES ? WH_MAX_ENVELOPES : rec.nenv;
     for (int e = 0; e < nrec; e++) {
-      const int ireg = rec.ri[e], jreg = rec.rj[e], Lr = jreg - ireg + 1;
+      // (values that steer the wave-uniform walk are made provably uniform: the walk then compiles to SALU code)
+      const int ireg = __builtin_amdgcn_readfirstlane(rec.ri[e]), jreg = __builtin_amdgcn_readfirstlane(rec.rj[e]), Lr = jreg - ireg + 1;
       if (ireg < 1 || jreg > L || Lr < 1 || L > a.Lcap) { flags |= WH_FLAG_TRUNC; continue; }     // never true for a well-formed record
       if (!((rec.multi_mask >> e) & 1)) {
         // single-domain region: envelope = region, scored by the scoring kernel (A.5)
@@ -347,10 +349,13 @@ __global__ __launch_bounds__(64, 2) void resolve_kernel(ResolveArgs a) {
       rng.x = mix3(42u, 87654321u, 12345678u);
       if (rng.x == 0) rng.x = 42;
       const int Qs = ((m.M - 1) / 4 + 1) > 2 ? ((m.M - 1) / 4 + 1) : 2;     // HMMER's striping: vectors of 4 floats
+      long long c_build = 0, c_e = 0, c_post = 0;
       for (int t = 0; t < kSamples; t++) {
         int i = Lr, k = 0, s0 = stC, ndom = 0, sqto = 0, hmmto = 0, sqfrom = 0, hmmfrom = 0;
         int run_state = 0, run_j = 0;            // decision cache of the current run (see below)
-        double run_r1 = 0.0, run_r2 = 0.0, run_r3 = 0.0;
+        // thresholds as integers: (sum / norm > x / 2^32) <=> x < ceil(2^32 sum / norm), exactly (both sides are exact
+        // in double); 33-bit values: a low word and an 'always true' bit (bits 0..2 of run_hi)
+        unsigned run_r1 = 0, run_r2 = 0, run_r3 = 0, run_hi = 0;
         int guard = 4 * (Lr + m.M) + 64;         // a sampled path has at most Lr + M + a few states
         while (s0 != stS && --guard > 0 && i >= 0 && k >= 0 && k <= m.M) {
           double path[4] = {0.0, 0.0, 0.0, 0.0};
@@ -362,6 +367,7 @@ __global__ __launch_bounds__(64, 2) void resolve_kernel(ResolveArgs a) {
             // independent of the outcomes: lane t fetches those of the run's t-th state in one round of loads
             // (instead of one memory round trip per step) and turns them into esl_rnd_FChoose's thresholds.
             if (run_state != s0 || run_j >= 64) {
+              const long long tb0 = a.stats ? __builtin_readcyclecounter() : 0;
               const int it = (s0 == stD) ? i : i - lane, kt = (s0 == stM || s0 == stD) ? k - lane : 0;
               double pd[4] = {0.0, 0.0, 0.0, 0.0};
               if (s0 == stM) {
@@ -388,33 +394,47 @@ __global__ __launch_bounds__(64, 2) void resolve_kernel(ResolveArgs a) {
               double norm = 0.0;
               for (int u = 0; u < nch; u++) norm += (double)pf[u];
               const double c1 = (double)pf[0], c2 = c1 + (double)pf[1], c3 = c2 + (double)pf[2];
-              run_r1 = c1 / norm; run_r2 = c2 / norm; run_r3 = c3 / norm;
+              auto as_int = [](double thr, unsigned &lo, unsigned &hi_bit) {      // x < ceil(2^32 thr)
+                const double T = ceil(thr * 4294967296.0);
+                if (!(T > 0.0)) { lo = 0; hi_bit = 0; }
+                else if (T >= 4294967296.0) { lo = 0; hi_bit = 1; }
+                else { lo = (unsigned)T; hi_bit = 0; }
+              };
+              unsigned hb;
+              run_hi = 0;
+              as_int(c1 / norm, run_r1, hb); run_hi |= hb;
+              as_int(c2 / norm, run_r2, hb); run_hi |= hb << 1;
+              as_int(c3 / norm, run_r3, hb); run_hi |= hb << 2;
               run_state = s0; run_j = 0;
+              if (a.stats) c_build += __builtin_readcyclecounter() - tb0;
             }
-            const int jl = __builtin_amdgcn_readfirstlane(run_j);
-            const double roll = rng_next(rng);
-            const double a1 = readlane_d(run_r1, jl), a2 = readlane_d(run_r2, jl), a3 = readlane_d(run_r3, jl);
-            run_j++;
+            rng.x = rng.x * 69069u + 1u;                     // one random number per decision (esl_random)
+            const unsigned x = rng.x;
+            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)run_hi, run_j);
+            const unsigned a1 = (unsigned)__builtin_amdgcn_readlane((int)run_r1, run_j);
             if (s0 == stM) {
-              const int c4 = a1 > roll ? 0 : a2 > roll ? 1 : a3 > roll ? 2 : 3;
+              const unsigned a2 = (unsigned)__builtin_amdgcn_readlane((int)run_r2, run_j), a3 = (unsigned)__builtin_amdgcn_readlane((int)run_r3, run_j);
+              const int c4 = ((hi & 1) || x < a1) ? 0 : ((hi & 2) || x < a2) ? 1 : ((hi & 4) || x < a3) ? 2 : 3;
               s1 = c4 == 0 ? stB : c4 == 1 ? stM : c4 == 2 ? stI : stD;
               k--; i--;
             } else if (s0 == stD) {
-              s1 = a1 > roll ? stM : stD;
+              s1 = ((hi & 1) || x < a1) ? stM : stD;
               k--;
             } else {
-              s1 = a1 > roll ? s0 : stE;
+              s1 = ((hi & 1) || x < a1) ? s0 : stE;
             }
+            run_j++;
             if (s1 != s0) run_state = 0;
           } else
           switch (s0) {
             case stI:
               path[0] = mx.cell(i - 1, k, 0) * m.t(gMI, k);
               path[1] = mx.cell(i - 1, k, 1) * m.t(gII, k);
-              s1 = rng_choose(rng, path, 2) == 0 ? stM : stI;
+              s1 = __builtin_amdgcn_readfirstlane(rng_choose(rng, path, 2)) == 0 ? stM : stI;
               i--;
               break;
             case stE: {
+              const long long te0 = a.stats ? __builtin_readcyclecounter() : 0;
               // FChoose over M(i,*) and D(i,*) in HMMER's striped order: position p = q*8 + state*4 + r
               // holds node r*Qs + q + 1.  Lanes take contiguous chunks, an exclusive scan finds the chunk.
               const double roll = rng_next(rng), norm = 1.0 / mx.spec(i, xE);
@@ -453,14 +473,16 @@ __global__ __launch_bounds__(64, 2) void resolve_kernel(ResolveArgs a) {
                 }
                 if (found_p < 0) found_p = c1p - 1;
               }
+              found_p = __builtin_amdgcn_readfirstlane(found_p);
               if (found_p < 0) { k = 1; s1 = stM; }        // rounding left the sum below the roll: HMMER rescans, first non-zero cell wins
               else { k = (found_p & 3) * Qs + (found_p >> 3) + 1; s1 = ((found_p >> 2) & 1) ? stD : stM; }
+              if (a.stats) c_e += __builtin_readcyclecounter() - te0;
               break;
             }
             case stB:
               path[0] = mx.spec(i, xN) * cm.move;
               path[1] = mx.spec(i, xJ) * cm.move;
-              s1 = rng_choose(rng, path, 2) == 0 ? stN : stJ;
+              s1 = __builtin_amdgcn_readfirstlane(rng_choose(rng, path, 2)) == 0 ? stN : stJ;
               break;
             default: s1 = stS; break;
           }
@@ -485,6 +507,7 @@ __global__ __launch_bounds__(64, 2) void resolve_kernel(ResolveArgs a) {
           s0 = s1;
         }
         __builtin_amdgcn_wave_barrier();
+        const long long tp0 = a.stats ? __builtin_readcyclecounter() : 0;
         // null2 by trace of every sampled domain (A.4b / p7_Null2_ByTrace): mean emission odds of the
         // M/I states that emitted the domain's residues
         for (int d = 0; d < ndom; d++) {
@@ -528,7 +551,9 @@ __global__ __launch_bounds__(64, 2) void resolve_kernel(ResolveArgs a) {
         if (nseg + ndom > SEGCAP) flags |= WH_FLAG_TRUNC;
         nseg = min(SEGCAP, nseg + ndom);
         __builtin_amdgcn_wave_barrier();
+        if (a.stats) c_post += __builtin_readcyclecounter() - tp0;
       }
+      if (a.stats && lane == 0) { atomicAdd(a.stats + 5, (unsigned long long)c_build); atomicAdd(a.stats + 6, (unsigned long long)c_e); atomicAdd(a.stats + 7, (unsigned long long)c_post); }
       RTICK(1);
       for (int pos = 1 + lane; pos <= Lr; pos += 64) n2sc[ireg + pos - 1] = logf(acc[pos] / (float)kSamples);
       wave_mem_sync();

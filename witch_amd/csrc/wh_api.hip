@@ -465,7 +465,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       r.recs = (const ResolveRec *)e->d_rrecs.p; r.count = d_rcount; r.rec_cap = (int)(nq * (int64_t)e->hmms.size());
       r.counter = d_rwork;
       r.Lcap = Lc; r.Mmax = e->max_M;
-      r.mx_stride = (size_t)(Lc + 2) * ((size_t)3 * Qmax * kWave + 8);
+      r.mx_stride = (size_t)(Lc + 2) * ((size_t)3 * Qmax * kWave + 8) + (size_t)(Lc + 2) * 65;   // matrix rows + the E-state row cache
       r.seg_cap = resolve_seg_cap();
       r.seg_stride = resolve_seg_ints(Lc, e->max_M);
       r.decibits = d_decibits; r.flags = d_flags; r.detail = d_detail;

@@ -344,6 +344,11 @@ __global__ __launch_bounds__(64, 2) void resolve_kernel(ResolveArgs a) {
       if (a.dbg && lane == 0) printf("[resolve] region forward %.12f\n", regfwd);
 #endif
       for (int t = lane; t <= Lr + 1; t += 64) acc[t] = 0.f;
+      // E-state choice: per row of the region a lazily filled line of 64 chunk prefix sums + a valid flag, at the
+      // end of the wave's slab
+      double *ecache = mx.p + a.mx_stride - (size_t)(a.Lcap + 2) * 65;
+      for (int t = lane; t <= Lr; t += 64) ecache[(size_t)t * 65 + 64] = 0.0;
+      wave_mem_sync();
       int nseg = 0;
       Rng rng;
       rng.x = mix3(42u, 87654321u, 12345678u);
@@ -444,17 +449,28 @@ __global__ __launch_bounds__(64, 2) void resolve_kernel(ResolveArgs a) {
                 const int q = p >> 3, st = (p >> 2) & 1, r = p & 3, kk = r * Qs + q + 1;
                 return kk <= m.M ? (double)(float)(mx.cell(i, kk, st ? 2 : 0) * norm) : 0.0;
               };
-              double mine = 0.0;
-              for (int pb = p0; pb < p1; pb += 8) {          // eight loads in flight per step
-                double tv[8];
+              // The chunk prefix sums of a row are the same for every trace that ends a domain there: computed once per
+              // row and kept in the slab, a hit replaces the pass over the 2M cells by one coalesced 512-byte read.
+              double incl;
+              if (__builtin_nontemporal_load(ecache + (size_t)i * 65 + 64) != 0.0) {
+                incl = __builtin_nontemporal_load(ecache + (size_t)i * 65 + lane);
+              } else {
+                double mine = 0.0;
+                for (int pb = p0; pb < p1; pb += 8) {          // eight loads in flight per step
+                  double tv[8];
 #pragma unroll
-                for (int u = 0; u < 8; u++) tv[u] = pb + u < p1 ? term(pb + u) : 0.0;
+                  for (int u = 0; u < 8; u++) tv[u] = pb + u < p1 ? term(pb + u) : 0.0;
 #pragma unroll
-                for (int u = 0; u < 8; u++) mine += tv[u];
+                  for (int u = 0; u < 8; u++) mine += tv[u];
+                }
+                incl = mine;
+                for (int d = 1; d < 64; d <<= 1) { const double o = shfl_up_d(incl, d); if (lane >= d) incl += o; }
+                ecache[(size_t)i * 65 + lane] = incl;
+                if (lane == 0) ecache[(size_t)i * 65 + 64] = 1.0;
+                wave_mem_sync();
               }
-              double incl = mine;
-              for (int d = 1; d < 64; d <<= 1) { const double o = shfl_up_d(incl, d); if (lane >= d) incl += o; }
-              const double excl = incl - mine;
+              const double up1 = shfl_up_d(incl, 1);
+              const double excl = lane > 0 ? up1 : 0.0;
               const unsigned long long hit = __ballot(roll < incl);
               int found_p = -1;
               if (hit) {

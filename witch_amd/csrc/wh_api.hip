@@ -59,6 +59,7 @@ struct Knobs {
   int max_waves = 0;         // cap on waves per workgroup (0 = planner's choice)
   bool force_specg = false;  // force the HBM special-state mode
   bool no_logspace = false;  // skip the log-space alignment pass
+  int big_waves = 4;         // waves per workgroup of the pass-synchronous long-model kernel (4 = one per SIMD, 8 = two)
   bool no_resolve = false;   // multidomain regions stay ONE envelope (round-1 behaviour) instead of HMMER's stochastic resolver
   bool stats = false, trace = false;
   int dbg = 0;
@@ -238,6 +239,7 @@ int wh_set_option(wh_ehmm *e, const char *name, const char *value) {
   else if (!strcmp(name, "WH_FORCE_SPECG")) k.force_specg = on;
   else if (!strcmp(name, "WH_NO_LOGSPACE")) k.no_logspace = on;
   else if (!strcmp(name, "WH_NO_RESOLVE")) k.no_resolve = on;
+  else if (!strcmp(name, "WH_BIG_WAVES")) k.big_waves = (*v && atoi(v) == 8) ? 8 : 4;
   else if (!strcmp(name, "WH_STATS")) k.stats = on;
   else if (!strcmp(name, "WH_TRACE")) k.trace = on;
   else if (!strcmp(name, "WH_DBG")) k.dbg = atoi(v);
@@ -247,7 +249,7 @@ int wh_set_option(wh_ehmm *e, const char *name, const char *value) {
 }
 
 static void knobs_from_env(wh_ehmm *e) {
-  for (const char *name : {"WH_SCORE_KERNEL", "WH_KEEP_LOG2", "WH_MAX_WAVES", "WH_FORCE_SPECG", "WH_NO_LOGSPACE", "WH_NO_RESOLVE", "WH_STATS", "WH_TRACE", "WH_DBG", "WH_RDBG"})
+  for (const char *name : {"WH_SCORE_KERNEL", "WH_KEEP_LOG2", "WH_MAX_WAVES", "WH_FORCE_SPECG", "WH_NO_LOGSPACE", "WH_NO_RESOLVE", "WH_BIG_WAVES", "WH_STATS", "WH_TRACE", "WH_DBG", "WH_RDBG"})
     if (const char *v = getenv(name)) (void)wh_set_option(e, name, v);
 }
 
@@ -348,6 +350,12 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       if (e->d_rrecs.ensure(sizeof(ResolveRec) * (size_t)npairs_all)) return WH_ENOMEM;
       HIPCHK(hipMemsetAsync(d_rcount, 0, 2 * sizeof(int), s));
     }
+    // pass 0 sizes the per-wave workspace of every class and allocates ONCE (growing a DevBuf class by class
+    // meant a hipFree + hipMalloc of tens of GB per class: ~25 ms per GB); pass 1 launches
+    size_t need_scratch = 0, need_spec = 0;
+    for (int pass = 0; pass < 2; pass++) {
+    list_off = 0;
+    if (pass == 1 && (e->d_scratch.ensure(need_scratch) || (need_spec && e->d_spec.ensure(need_spec)))) return WH_ENOMEM;
     for (auto &kv : e->by_q) {
       const int Q = kv.first;
       ScoreArgs a;
@@ -395,7 +403,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       }
       if (big) {
         wave_lds = 32 + kRegsInts + (Lc + 3) / 4 + 4;
-        waves = 4;
+        waves = kn.big_waves;
         a.Klds = e->K;
         size_t table = (size_t)(a.Klds + 8) * Q * kWave * sizeof(float);
         if (kLdsHeader + table + (size_t)waves * wave_lds * sizeof(float) > kLdsBudget) { a.Klds = 0; table = (size_t)8 * Q * kWave * sizeof(float); }
@@ -412,12 +420,17 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       a.spec_stride = specg ? (size_t)8 * a.SP : 0;
       int blocks = std::min(a.n_items, big ? e->cu_count : e->cu_count * std::max(1, 8 / waves));
       blocks = clamp_blocks(blocks, (size_t)waves * (a.scratch_stride + a.spec_stride) * sizeof(float), e->d_scratch);
-      if (e->d_scratch.ensure((size_t)blocks * waves * a.scratch_stride * sizeof(float))) return WH_ENOMEM;
-      a.scratch = (float *)e->d_scratch.p;
-      if (specg) {
-        if (e->d_spec.ensure((size_t)blocks * waves * a.spec_stride * sizeof(float))) return WH_ENOMEM;
-        a.spec_scratch = (float *)e->d_spec.p;
+      if (pass == 0) {
+        need_scratch = std::max(need_scratch, (size_t)blocks * waves * a.scratch_stride * sizeof(float));
+        if (specg) need_spec = std::max(need_spec, (size_t)blocks * waves * a.spec_stride * sizeof(float));
+        continue;
       }
+      // never more resident workgroups than the workspace allocated after pass 0 holds
+      blocks = (int)std::min<size_t>((size_t)blocks, e->d_scratch.cap / ((size_t)waves * a.scratch_stride * sizeof(float)));
+      if (specg) blocks = (int)std::min<size_t>((size_t)blocks, e->d_spec.cap / ((size_t)waves * a.spec_stride * sizeof(float)));
+      if (blocks < 1) { set_error("workspace planning failed (Q=%d)", Q); return WH_ENOMEM; }
+      a.scratch = (float *)e->d_scratch.p;
+      if (specg) a.spec_scratch = (float *)e->d_spec.p;
       if (kn.stats && !big) {
         if (e->d_recs.ensure(128)) return WH_ENOMEM;
         HIPCHK(hipMemsetAsync(e->d_recs.p, 0, 128, s));
@@ -440,6 +453,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
         fprintf(stderr, "[wh] Q=%d wave cycles: P1 %.1f%%  P2 %.1f%%  regions %.1f%%  P3 %.1f%%  P4 %.1f%%  null2 %.1f%%  (total %.3g ticks)\n", Q, 100.0 * st[4] / tot,
                 100.0 * st[5] / tot, 100.0 * st[6] / tot, 100.0 * st[7] / tot, 100.0 * st[8] / tot, 100.0 * st[9] / tot, tot);
       }
+    }
     }
   }
   if (timer_end(e, 0, s, launches)) return WH_EHIP;
@@ -671,11 +685,14 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
     const int n = (int)items.size() / 3 - first;
     if (n > 0) { plans.push_back({Q, first, n, waves, SP, wave_lds, Klds + (swap ? 1000 : 0)}); ldss.push_back(lds); }
   }
+  size_t need_scratch = 0, need_spec = 0;
   const size_t nit = items.size() / 3;
   std::vector<int32_t> soa(items.size());
   for (size_t t = 0; t < nit; t++) { soa[t] = items[3 * t]; soa[nit + t] = items[3 * t + 1]; soa[2 * nit + t] = items[3 * t + 2]; }
   if (e->d_items.ensure(sizeof(int32_t) * soa.size() + 16)) return WH_ENOMEM;
   HIPCHK(hipMemcpyAsync(e->d_items.p, soa.data(), sizeof(int32_t) * soa.size(), hipMemcpyHostToDevice, s));
+  for (int pass = 0; pass < 2; pass++) {        // pass 0: size the workspace of every class, allocate once; pass 1: launch
+  if (pass == 1 && (e->d_scratch.ensure(need_scratch) || (need_spec && e->d_spec.ensure(need_spec)))) return WH_ENOMEM;
   for (size_t pl = 0; pl < plans.size(); pl++) {
     const int Q = plans[pl][0], first = plans[pl][1], n = plans[pl][2], waves = plans[pl][3];
     AlignArgs a;
@@ -699,16 +716,21 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
     a.scratch_stride = (size_t)(a.Lcap + 1) * 5 * Q * kWave;
     a.spec_stride = plans[pl][5] < 0 ? (size_t)13 * a.SP : 0;
     blocks = clamp_blocks(blocks, (size_t)waves * (a.scratch_stride + a.spec_stride) * sizeof(float), e->d_scratch);
-    if (plans[pl][5] < 0) {
-      if (e->d_spec.ensure((size_t)blocks * waves * a.spec_stride * sizeof(float))) return WH_ENOMEM;
-      a.spec_scratch = (float *)e->d_spec.p;
+    if (pass == 0) {
+      need_scratch = std::max(need_scratch, (size_t)blocks * waves * a.scratch_stride * sizeof(float));
+      if (plans[pl][5] < 0) need_spec = std::max(need_spec, (size_t)blocks * waves * a.spec_stride * sizeof(float));
+      continue;
     }
-    if (e->d_scratch.ensure((size_t)blocks * waves * a.scratch_stride * sizeof(float))) return WH_ENOMEM;
+    blocks = (int)std::min<size_t>((size_t)blocks, e->d_scratch.cap / ((size_t)waves * a.scratch_stride * sizeof(float)));
+    if (plans[pl][5] < 0) blocks = (int)std::min<size_t>((size_t)blocks, e->d_spec.cap / ((size_t)waves * a.spec_stride * sizeof(float)));
+    if (blocks < 1) { set_error("workspace planning failed (Q=%d)", Q); return WH_ENOMEM; }
+    if (plans[pl][5] < 0) a.spec_scratch = (float *)e->d_spec.p;
     a.scratch = (float *)e->d_scratch.p;
     HIPCHK(hipMemsetAsync(a.counter, 0, sizeof(int), s));
     hipError_t err = launch_align(Q, a, blocks, waves * kWave, ldss[pl], s);
     if (err != hipSuccess) { set_error("align kernel launch (Q=%d) failed: %s", Q, hipGetErrorString(err)); return WH_EHIP; }
     launches++;
+  }
   }
   // the host vectors of this pass are consumed by async copies: drain before they go out of scope
   HIPCHK(hipStreamSynchronize(s));

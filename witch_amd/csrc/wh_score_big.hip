@@ -29,8 +29,8 @@ constexpr float kMassTolB = 2e-5f;
 #define BSPRI(idx) __builtin_nontemporal_load(reinterpret_cast<const int *>(spec) + (idx))
 #define BSPRU(idx) __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(spec) + (idx))
 
-template <int Q>
-__global__ __launch_bounds__(256) void score_big_kernel(ScoreArgs a) {
+template <int Q, int TH>
+__global__ __launch_bounds__(TH) void score_big_kernel(ScoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
   volatile int *s_item_p = reinterpret_cast<volatile int *>(smem_raw);
   float *smem = smem_raw + 4;
@@ -408,13 +408,21 @@ __global__ __launch_bounds__(256) void score_big_kernel(ScoreArgs a) {
   }
 }
 
-template <int Q>
-static hipError_t launch_big(const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
-  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&score_big_kernel<Q>),
+template <int Q, int TH>
+static hipError_t launch_big_th(const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&score_big_kernel<Q, TH>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (err != hipSuccess) return err;
-  hipLaunchKernelGGL((score_big_kernel<Q>), dim3(blocks), dim3(threads), lds, s, a);
+  hipLaunchKernelGGL((score_big_kernel<Q, TH>), dim3(blocks), dim3(threads), lds, s, a);
   return hipGetLastError();
+}
+
+// 256 threads: one wave per SIMD with the whole register file; 512 threads: two waves per SIMD at 256
+// registers each (the DP row of the longest models then spills to scratch)
+template <int Q>
+static hipError_t launch_big(const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
+  if (threads > 256) return launch_big_th<Q, 512>(a, blocks, threads, lds, s);
+  return launch_big_th<Q, 256>(a, blocks, threads, lds, s);
 }
 
 hipError_t launch_score_big(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {

@@ -30,6 +30,9 @@ WORKLOADS = {
     # name: (alphabet, family seed, root_len, leaves, sub_rate, indel_rate, n_hmms, n_queries, qlen, k)
     # configs[2] of BASELINE.json (headline): 100k x 150 nt DNA queries x 200-HMM eHMM, k=10
     "dna_100k_x200": ("dna", 20251205, 900, 1024, 0.03, 1e-4, 200, 100000, 150, 10),
+    # the same configuration with SURVEY.md 8(d)'s sketch of the family (root 1000 nt, 0.2 % indels per branch:
+    # models of ~1000-1100 nodes, 20 cells per lane for most of them); quoted beside the headline in DESIGN.md
+    "dna_100k_x200_m1000": ("dna", 20251205, 1000, 1024, 0.03, 2e-3, 200, 100000, 150, 10),
     # configs[1]: 1k queries x 10 HMMs, k=4 (parity-test sized)
     "dna_1k_x10": ("dna", 20251205, 1000, 256, 0.03, 2e-3, 10, 1000, 150, 4),
     # development only: longer models (24 and 12 DP cells per lane)

@@ -68,6 +68,21 @@ class EHMM:
                              (bad, "amino" if self.alphabet == 2 else "nucleic"))
         return out
 
+    def digitize_many(self, texts):
+        """Digitise a list of sequence texts in ONE library call: (residues uint8 [total], offsets int64 [n+1])."""
+        lens = np.fromiter((len(t) for t in texts), dtype=np.int64, count=len(texts))
+        offs = np.zeros(len(texts) + 1, dtype=np.int64)
+        np.cumsum(lens, out=offs[1:])
+        blob = "".join(texts).encode()
+        if len(blob) != int(offs[-1]):
+            raise ValueError("query sequences must be ASCII")
+        out = np.empty(len(blob), dtype=np.uint8)
+        bad = lib().wh_digitize(self.alphabet, blob, len(blob), out.ctypes.data) if len(blob) else 0
+        if bad != 0:
+            raise ValueError("queries contain %d characters outside the %s alphabet" %
+                             (bad, "amino" if self.alphabet == 2 else "nucleic"))
+        return out, offs
+
     def map_columns(self, h: int) -> np.ndarray:
         out = np.zeros(int(self.M[h]), dtype=np.int32)
         check(lib().wh_ehmm_map(self._h, int(h), out.ctypes.data), "wh_ehmm_map")

@@ -54,14 +54,6 @@ def readCheckpointAlignments(path, pool=None, lock=None):
         parts = line.split('\t')
         taxon, seq = '\t'.join(parts[:-1]), parts[-1]
         q = QueryAlignment()
-        q[taxon] = seq
-        insertion, regular = -1, 0
-        for ch in seq:
-            if ch.islower():
-                q._col_labels.append(insertion)
-                insertion -= 1
-            else:
-                q._col_labels.append(regular)
-                regular += 1
+        q[taxon] = seq                               # labels follow from the case of the characters, lazily
         out[taxon] = q
     return out

@@ -75,7 +75,9 @@ class QueryAlignmentEngine:
         labels = sorted(index_to_hmm.keys())
         paths = [index_to_hmm[i].hmm_model_path for i in labels]
         nseq = [int(index_to_hmm[i].num_taxa) for i in labels]
+        t_load = time.time()
         e = EHMM(paths, hmm_index=labels, nseq=nseq, device=device)
+        t_load = time.time() - t_load
         self = cls()
         self.num_hmms = int(num_hmms)
         self.hmm_index = np.asarray(labels, dtype=np.int32)
@@ -86,8 +88,9 @@ class QueryAlignmentEngine:
         self.row_lo, self.row_hi = shard_range(len(items), self.rank, self.world)
         local = items[self.row_lo:self.row_hi]
         # the reference upper-cases sequences on read (helpers/alignment_tools.py:730-731)
-        seqs = [e.digitize(s.upper()) for _, s in local]
-        res, offs = pack_queries(seqs)
+        t0 = time.time()
+        res, offs = e.digitize_many([s.upper() for _, s in local])
+        t_digit = time.time() - t0
         t0 = time.time()
         self.decibits, self.flags = e.score(res, offs)
         if multidomain_policy == "drop":
@@ -109,7 +112,7 @@ class QueryAlignmentEngine:
         self.pair_of = {(int(q) + self.row_lo, int(lab)): p for p, (q, lab) in enumerate(zip(pq.tolist(), plab.tolist()))}
         t3 = time.time()
         # same three stage names the reference logs (algorithm.py:333-335, weighting.py:165-168, aligner.py:520-525)
-        self.timings = {"search": t1 - t0, "weights": t2 - t1, "align": t3 - t2}
+        self.timings = {"load_ehmm": t_load, "digitize": t_digit, "search": t1 - t0, "weights": t2 - t1, "align": t3 - t2}
         self.query_offsets = offs
         if subset_to_retained_columns is not None:
             # the weighted consensus DP of alignSubQueriesNew (aligner.py:376-473), all local queries at once
@@ -185,12 +188,27 @@ class QueryAlignmentEngine:
                 return lo, hi
         return 0, 0
 
+    def _rank_order(self):
+        """Per local row the model positions sorted by (-score, +hmm index), reported ones first: ONE argsort
+        over the whole table (a composite integer key), computed on first use."""
+        if getattr(self, "_order", None) is None:
+            rep = (self.flags & 1) != 0
+            rank_of_label = np.argsort(np.argsort(self.hmm_index, kind="stable"), kind="stable").astype(np.int64)
+            key = (-self.decibits.astype(np.int64)) * (len(self.hmm_index) + 1) + rank_of_label[None, :]
+            key = np.where(rep, key, np.iinfo(np.int64).max)
+            self._order = np.argsort(key, axis=1, kind="stable")
+            self._nrep = rep.sum(axis=1)
+        return self._order, self._nrep
+
     def ranked(self, row: int):
         """[(idx, score)] sorted by score descending (loader.py:325-330), ties by idx."""
         r = self._local(row, "the scores")
-        rep = (self.flags[r] & 1) != 0
-        order = np.lexsort((self.hmm_index, -self.decibits[r]))
-        return [(int(self.hmm_index[j]), float(self.decibits[r, j]) / 10.0) for j in order if rep[j]]
+        order, nrep = self._rank_order()
+        js = order[r, :nrep[r]]
+        return list(zip(self.hmm_index[js].tolist(), (self.decibits[r, js] / 10.0).tolist()))
+
+    def has_hit(self, row: int) -> bool:
+        return bool(self._rank_order()[1][self._local(row, "the scores")])
 
     def weights(self, row: int):
         """((idx, np.float64 w), ...) - the value type calculateWeights returns (weighting.py:71-74)."""

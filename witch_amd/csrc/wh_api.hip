@@ -431,7 +431,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       if (blocks < 1) { set_error("workspace planning failed (Q=%d)", Q); return WH_ENOMEM; }
       a.scratch = (float *)e->d_scratch.p;
       if (specg) a.spec_scratch = (float *)e->d_spec.p;
-      if (kn.stats && !big) {
+      if (kn.stats) {
         if (e->d_recs.ensure(128)) return WH_ENOMEM;
         HIPCHK(hipMemsetAsync(e->d_recs.p, 0, 128, s));
         { unsigned long long bigv = ~0ull; HIPCHK(hipMemcpyAsync((char *)e->d_recs.p + 13 * 8, &bigv, 8, hipMemcpyHostToDevice, s)); }
@@ -440,7 +440,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       if (kn.trace) fprintf(stderr, "[wh] score Q=%d kernel=%s specg=%d waves=%d blocks=%d lds=%zu SP=%d wave_lds=%d items=%d Lcap=%d\n", Q,
                             big ? "pass-synchronous" : kn.kernel == 8 ? "phase-call(B)" : "phase-call", (int)specg, waves, blocks, lds, SP, wave_lds, a.n_items, a.Lcap);
       HIPCHK(hipMemsetAsync(a.counter, 0, sizeof(int), s));
-      hipError_t err = big ? launch_score_big(Q, a, blocks, waves * kWave, lds, s)
+      hipError_t err = big ? (waves == 8 ? launch_score_big2(Q, a, blocks, waves * kWave, lds, s) : launch_score_big(Q, a, blocks, waves * kWave, lds, s))
                        : kn.kernel == 8 ? launch_score7b(Q, a, blocks, waves * kWave, lds, s)
                                         : launch_score7(Q, a, blocks, waves * kWave, lds, s);
       if (err != hipSuccess) { set_error("score kernel launch (Q=%d) failed: %s", Q, hipGetErrorString(err)); return WH_EHIP; }
@@ -449,9 +449,9 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
         unsigned long long st[16];
         HIPCHK(hipMemcpyAsync(st, a.stats, sizeof st, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
-        const double tot = (double)(st[4] + st[5] + st[6] + st[7] + st[8] + st[9]);
-        fprintf(stderr, "[wh] Q=%d wave cycles: P1 %.1f%%  P2 %.1f%%  regions %.1f%%  P3 %.1f%%  P4 %.1f%%  null2 %.1f%%  (total %.3g ticks)\n", Q, 100.0 * st[4] / tot,
-                100.0 * st[5] / tot, 100.0 * st[6] / tot, 100.0 * st[7] / tot, 100.0 * st[8] / tot, 100.0 * st[9] / tot, tot);
+        const double tot = (double)(st[4] + st[5] + st[6] + st[7] + st[8] + st[9] + st[10] + st[11]);
+        fprintf(stderr, "[wh] Q=%d wave cycles: P1 %.1f%%  P2 %.1f%%  regions %.1f%%  P3 %.1f%%  P4 %.1f%%  null2 %.1f%%  swaps+barriers %.1f%%  other %.1f%%  (total %.3g ticks)\n", Q, 100.0 * st[4] / tot,
+                100.0 * st[5] / tot, 100.0 * st[6] / tot, 100.0 * st[7] / tot, 100.0 * st[8] / tot, 100.0 * st[9] / tot, 100.0 * st[10] / tot, 100.0 * st[11] / tot, tot);
       }
     }
     }

@@ -29,12 +29,274 @@ constexpr float kMassTolB = 2e-5f;
 #define BSPRI(idx) __builtin_nontemporal_load(reinterpret_cast<const int *>(spec) + (idx))
 #define BSPRU(idx) __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(spec) + (idx))
 
+
+// ------------------------------------------------------------------ sweeps of the long-model kernel
+// With one or two waves per SIMD nothing hides an LDS round trip, and the compiler, short of registers
+// at 28-48 cells per lane, sinks every table read down to its first use: ~100 exposed ds_read latencies
+// per DP row were most of the kernel's time.  The cell loops below are therefore software-pipelined by
+// hand: the 16-byte table pieces of 4-cell group g+1 are requested before group g is computed, and a
+// scheduling barrier on both sides of the computation keeps the compiler from undoing that, so the wait
+// in front of a group covers loads issued a whole group earlier (s_waitcnt lgkmcnt(N) with N = the next
+// group's loads).  The sweeps also keep nothing per cell beyond the DP row itself: the emission piece of
+// a group is fetched with its tables, and the Backward D row is not stored - its local chains are run
+// once for the cross-lane scan and a second time, seeded with the scanned carry, inside the M/I update
+// (the two FMAs per cell the carry fix-up would cost, one more table read per group).
+#define WH_SB() __builtin_amdgcn_sched_barrier(0)
+
+// scan_apply (wh_device.h) as ONE asm block: the six model-only multipliers are spilled around the cell
+// loops at 256 registers, and as operands of a single block they are reloaded together, not one
+// scratch round trip per step.
+__device__ __forceinline__ float scan_apply_block(const ScanC &c, float B) {
+  asm("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_fmac_f32_dpp %0, %0, %2 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_fmac_f32_dpp %0, %0, %3 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_fmac_f32_dpp %0, %0, %4 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_fmac_f32_dpp %0, %0, %5 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_fmac_f32_dpp %0, %0, %6 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(B)
+      : "v"(c.s[0]), "v"(c.s[1]), "v"(c.s[2]), "v"(c.s[3]), "v"(c.s[4]), "v"(c.s[5]));
+  return B;
+}
+
+// Software pipeline over the G 4-cell groups of a lane: ld(g, buf) requests the NT table pieces of group g,
+// body(g, buf) consumes them; the request runs DIST groups ahead (1 for the heavy M/I passes, whose ~36
+// VALU ops per group cover an LDS round trip; 2 for the light D-chain / emission passes of 8-12 ops).
+// Groups are visited in the order ord(0), ord(1), ...
+#define WH_INL __attribute__((always_inline))
+// Ties the results of a group to this point of the instruction stream: the arithmetic is pure, so without
+// it the compiler lets a group's VALU ops drift below the following groups' loads and barriers.
+__device__ __forceinline__ void pin4(float &a, float &b, float &c, float &d) {
+  asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+__device__ __forceinline__ void pin1(float &a) { asm volatile("" : "+v"(a)); }
+template <int G, int NT, int DIST, class Ord, class Ld, class Body>
+__device__ __forceinline__ void pipe_groups(Ord ord, Ld ld, Body body) {
+  float4 b0[NT], b1[NT], b2[NT];
+  ld(ord(0), b0);
+  if (DIST >= 2 && G > 1) ld(ord(1), b1);
+#pragma unroll
+  for (int s = 0; s < G; s++) {
+    if (DIST >= 2) { if (s + 2 < G) ld(ord(s + 2), b2); }
+    else { if (s + 1 < G) ld(ord(s + 1), b1); }
+    WH_SB();
+    body(ord(s), b0);
+    WH_SB();
+#pragma unroll
+    for (int t = 0; t < NT; t++) { b0[t] = b1[t]; if (DIST >= 2) b1[t] = b2[t]; }
+  }
+}
+
+template <int Q, bool STORE>
+__device__ __forceinline__ void forward_sweep_lean(const TransTab<Q, false> &T, const ScanC &sc, const float *emL,
+                                                   const float *emG, int K, const uint8_t *seq, int L, LenCfg cfg,
+                                                   float *spec, int SP, float *Fs, float keep_scale, int lane,
+                                                   float &xC_out, int &ef_out) {
+  constexpr int G = Q / 4;
+  float Mp[Q], Ip[Q], Dp[Q];
+#pragma unroll
+  for (int q = 0; q < Q; q++) { Mp[q] = 0.f; Ip[q] = 0.f; Dp[q] = 0.f; }
+  float xN = 1.0f, xB = cfg.move, xJ = 0.f, xC = 0.f, xE = 0.f;
+  int ef = 0;
+  if (lane == 0) {
+    spec[SP_N * SP] = xN; spec[SP_B * SP] = xB; spec[SP_E * SP] = 0.f; spec[SP_J * SP] = 0.f;
+    spec[SP_C * SP] = 0.f; reinterpret_cast<int *>(spec)[SP_S * SP] = 0;
+  }
+  auto up = [](int s) WH_INL { return s; };
+  auto down = [](int s) WH_INL { return G - 1 - s; };
+#pragma unroll 1
+  for (int i = 1; i <= L; i++) {
+    asm volatile("" ::: "memory");
+    const int x = __builtin_amdgcn_readfirstlane((int)seq[i - 1]);
+    const float mm1 = wave_shr1(Mp[Q - 1]), im1 = wave_shr1(Ip[Q - 1]), dm1 = wave_shr1(Dp[Q - 1]);
+    // M (without its emission factor) and I, in place: cell q reads the old q-1, so groups run downwards
+    pipe_groups<G, 6, 1>(down,
+        [&](int g, float4 (&t)[6]) WH_INL {
+          t[0] = T.ld(FW_A, g); t[1] = T.ld(FW_B, g); t[2] = T.ld(FW_C, g); t[3] = T.ld(FW_E, g);
+          t[4] = T.ld(FW_MI, g); t[5] = T.ld(FW_II, g);
+        },
+        [&](int g, const float4 (&t)[6]) WH_INL {
+#pragma unroll
+          for (int j = 3; j >= 0; j--) {
+            const int q = 4 * g + j;
+            const float pm = q > 0 ? Mp[q > 0 ? q - 1 : 0] : mm1;
+            const float pi = q > 0 ? Ip[q > 0 ? q - 1 : 0] : im1;
+            const float pd = q > 0 ? Dp[q > 0 ? q - 1 : 0] : dm1;
+            const float ni = fmaf(f4get(t[4], j), Mp[q], f4get(t[5], j) * Ip[q]);
+            float acc = xB * f4get(t[3], j);
+            acc = fmaf(f4get(t[0], j), pm, acc);
+            acc = fmaf(f4get(t[1], j), pi, acc);
+            acc = fmaf(f4get(t[2], j), pd, acc);
+            Mp[q] = acc;
+            Ip[q] = ni;
+          }
+          pin4(Mp[4 * g], Mp[4 * g + 1], Mp[4 * g + 2], Mp[4 * g + 3]);
+          pin4(Ip[4 * g], Ip[4 * g + 1], Ip[4 * g + 2], Ip[4 * g + 3]);
+        });
+    // emission factor: canonical residues from the LDS copy of the table, degenerate codes (rare) from L2;
+    // only this light pass is duplicated by the branch
+    auto emit = [&](const float4 *ep) WH_INL {
+      pipe_groups<G, 1, 2>(up, [&](int g, float4 (&t)[1]) WH_INL { t[0] = ep[g * kWave]; },
+                           [&](int g, const float4 (&t)[1]) WH_INL {
+                             Mp[4 * g] *= t[0].x; Mp[4 * g + 1] *= t[0].y; Mp[4 * g + 2] *= t[0].z; Mp[4 * g + 3] *= t[0].w;
+                             pin4(Mp[4 * g], Mp[4 * g + 1], Mp[4 * g + 2], Mp[4 * g + 3]);
+                           });
+    };
+    asm volatile("" ::: "memory");       // keeps the emission reads below the M/I pass (they would be hoisted
+                                         // to the top of the row and held in 4*G registers across it)
+    if (x < K) emit(reinterpret_cast<const float4 *>(emL + (size_t)x * Q * kWave) + lane);
+    else emit(reinterpret_cast<const float4 *>(emG + (size_t)x * Q * kWave) + lane);
+    asm volatile("" ::: "memory");
+    // D row: local chains, cross-lane scan, fix-up
+    const float mn1 = wave_shr1(Mp[Q - 1]);
+    float dprev = 0.f;
+    pipe_groups<G, 2, 2>(up, [&](int g, float4 (&t)[2]) WH_INL { t[0] = T.ld(FW_D1, g); t[1] = T.ld(FW_D2, g); },
+                         [&](int g, const float4 (&t)[2]) WH_INL {
+#pragma unroll
+                           for (int j = 0; j < 4; j++) {
+                             const int q = 4 * g + j;
+                             const float src = q > 0 ? Mp[q > 0 ? q - 1 : 0] : mn1;
+                             dprev = fmaf(f4get(t[1], j), dprev, f4get(t[0], j) * src);
+                             Dp[q] = dprev;
+                           }
+                           pin1(dprev);
+                         });
+    float carry = wave_shr1(scan_apply_block(sc, dprev));
+    float es = 0.f;
+    pipe_groups<G, 1, 2>(up, [&](int g, float4 (&t)[1]) WH_INL { t[0] = T.ld(FW_D2, g); },
+                         [&](int g, const float4 (&t)[1]) WH_INL {
+#pragma unroll
+                           for (int j = 0; j < 4; j++) {
+                             const int q = 4 * g + j;
+                             carry *= f4get(t[0], j);
+                             Dp[q] += carry;
+                             es += Mp[q] + Dp[q];
+                           }
+                           pin1(es);
+                         });
+    xE = wave_sum(es);
+    xN = xN * cfg.loop;
+    xC = fmaf(xC, cfg.loop, xE * cfg.EC);
+    xJ = fmaf(xJ, cfg.loop, xE * cfg.EJ);
+    if (xE > kRescaleHi) {
+      const int e = f32_exponent(xE);
+      const float r = pow2f_int(-e);
+#pragma unroll
+      for (int q = 0; q < Q; q++) { Mp[q] *= r; Ip[q] *= r; Dp[q] *= r; }
+      xN *= r; xC *= r; xJ *= r; xE *= r;
+      ef += e;
+    }
+    xB = (xJ + xN) * cfg.move;
+    if (lane == 0) {
+      spec[SP_N * SP + i] = xN; spec[SP_B * SP + i] = xB; spec[SP_E * SP + i] = xE;
+      spec[SP_J * SP + i] = xJ; spec[SP_C * SP + i] = xC;
+      reinterpret_cast<int *>(spec)[SP_S * SP + i] = ef;
+    }
+    if (STORE) {
+      float lmax = 0.f;
+#pragma unroll
+      for (int q = 0; q < Q; q += 2) lmax = fmaxf(lmax, fmaxf(fmaxf(Mp[q], Mp[q + 1]), fmaxf(Ip[q], Ip[q + 1])));
+      const bool keep = lmax > keep_scale * xE;
+      const unsigned long long mask = __ballot(keep);
+      if (lane == 0) {
+        reinterpret_cast<unsigned *>(spec)[SP_ML * SP + i] = (unsigned)(mask & 0xFFFFFFFFull);
+        reinterpret_cast<unsigned *>(spec)[SP_MH * SP + i] = (unsigned)(mask >> 32);
+      }
+      if (keep) {
+        float4 *row = reinterpret_cast<float4 *>(Fs) + (size_t)i * (2 * (Q / 4) * kWave) + lane;
+#pragma unroll
+        for (int q4 = 0; q4 < Q / 4; q4++) {
+          nt_store4(row + q4 * kWave, Mp[4 * q4], Mp[4 * q4 + 1], Mp[4 * q4 + 2], Mp[4 * q4 + 3]);
+          nt_store4(row + (Q / 4 + q4) * kWave, Ip[4 * q4], Ip[4 * q4 + 1], Ip[4 * q4 + 2], Ip[4 * q4 + 3]);
+        }
+      }
+    }
+  }
+  xC_out = xC;
+  ef_out = ef;
+}
+
+// G_k = o_k(x) * B_M_k in place (reversed node order) and the partial B-state sum  sum_k E_k G_k
+template <int Q>
+__device__ __forceinline__ float backward_emit_lean(const TransTab<Q, false> &T, const float *emL, const float *emG,
+                                                    int x, int K, int lane, float (&Mb)[Q]) {
+  constexpr int G = Q / 4;
+  x = __builtin_amdgcn_readfirstlane(x);
+  float part = 0.f;
+  auto up = [](int s) WH_INL { return s; };
+  auto emit = [&](const float4 *ep) WH_INL {
+    pipe_groups<G, 2, 2>(up, [&](int g, float4 (&t)[2]) WH_INL { t[0] = T.ld(BW_E, g); t[1] = ep[(G - 1 - g) * kWave]; },
+                         [&](int g, const float4 (&t)[2]) WH_INL {
+                           // forward-ordered emission piece: component 3-j is position 4*g+j
+                           Mb[4 * g + 0] *= t[1].w; part = fmaf(t[0].x, Mb[4 * g + 0], part);
+                           Mb[4 * g + 1] *= t[1].z; part = fmaf(t[0].y, Mb[4 * g + 1], part);
+                           Mb[4 * g + 2] *= t[1].y; part = fmaf(t[0].z, Mb[4 * g + 2], part);
+                           Mb[4 * g + 3] *= t[1].x; part = fmaf(t[0].w, Mb[4 * g + 3], part);
+                           pin1(part);
+                         });
+  };
+  if (x < K) emit(reinterpret_cast<const float4 *>(emL + (size_t)x * Q * kWave) + (kWave - 1 - lane));
+  else emit(reinterpret_cast<const float4 *>(emG + (size_t)x * Q * kWave) + (kWave - 1 - lane));
+  return part;
+}
+
+// One Backward row (reversed node order) without a stored D row; see backward_cells in wh_device.h for
+// the recurrences.  On entry Mb holds G (emission already applied), on exit rows i of M and I.
+template <int Q>
+__device__ __forceinline__ void backward_cells_lean(const TransTab<Q, false> &T, const ScanC &sc, float (&Mb)[Q],
+                                                    float (&Ib)[Q], float xE) {
+  constexpr int G = Q / 4;
+  auto up = [](int s) WH_INL { return s; };
+  const float gm1 = wave_shr1(Mb[Q - 1]);
+  float dprev = 0.f;
+  pipe_groups<G, 2, 2>(up, [&](int g, float4 (&t)[2]) WH_INL { t[0] = T.ld(BW_DM, g); t[1] = T.ld(BW_DD, g); },
+                       [&](int g, const float4 (&t)[2]) WH_INL {
+#pragma unroll
+                         for (int j = 0; j < 4; j++) {
+                           const int p = 4 * g + j;
+                           const float gg = p > 0 ? Mb[p > 0 ? p - 1 : 0] : gm1;
+                           dprev = fmaf(f4get(t[1], j), dprev, fmaf(f4get(t[0], j), gg, xE));
+                         }
+                         pin1(dprev);
+                       });
+  // inclusive scan value of the previous lane = its last D cell = the D this lane's chain starts from
+  float dcur = wave_shr1(scan_apply_block(sc, dprev));
+  float gprev = gm1;
+  pipe_groups<G, 7, 1>(up,
+      [&](int g, float4 (&t)[7]) WH_INL {
+        t[0] = T.ld(BW_MM, g); t[1] = T.ld(BW_IM, g); t[2] = T.ld(BW_MI, g); t[3] = T.ld(BW_II, g);
+        t[4] = T.ld(BW_MD, g); t[5] = T.ld(BW_DM, g); t[6] = T.ld(BW_DD, g);
+      },
+      [&](int g, const float4 (&t)[7]) WH_INL {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int p = 4 * g + j;
+          const float gold = Mb[p];
+          float nm = fmaf(f4get(t[0], j), gprev, xE);
+          nm = fmaf(f4get(t[2], j), Ib[p], nm);
+          nm = fmaf(f4get(t[4], j), dcur, nm);
+          const float ni = fmaf(f4get(t[1], j), gprev, f4get(t[3], j) * Ib[p]);
+          dcur = fmaf(f4get(t[6], j), dcur, fmaf(f4get(t[5], j), gprev, xE));
+          Mb[p] = nm;
+          Ib[p] = ni;
+          gprev = gold;
+        }
+        pin4(Mb[4 * g], Mb[4 * g + 1], Mb[4 * g + 2], Mb[4 * g + 3]);
+        pin4(Ib[4 * g], Ib[4 * g + 1], Ib[4 * g + 2], Ib[4 * g + 3]);
+      });
+}
+
+// per-phase wave cycles (option WH_STATS): slot 4 P1, 5 P2 + region scan, 7 P3, 8 P4 + null2, 10 table swaps and
+// the workgroup barriers around them (the lockstep cost), 11 everything else
+#define WH_TICKB(slot) do { if (a.stats) { const long long t_now = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(a.stats + (slot), (unsigned long long)(t_now - t_last)); t_last = t_now; } } while (0)
+
 template <int Q, int TH>
 __global__ __launch_bounds__(TH) void score_big_kernel(ScoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
   volatile int *s_item_p = reinterpret_cast<volatile int *>(smem_raw);
   float *smem = smem_raw + 4;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  // the wave index is uniform: saying so keeps every per-wave pointer, length and loop counter in SGPRs
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
   constexpr int TBL = Q * kWave;
   const int Klds = a.Klds;                                // emission rows staged in LDS (K, or 0: all from L2)
   float *emL = smem;
@@ -48,6 +310,7 @@ __global__ __launch_bounds__(TH) void score_big_kernel(ScoreArgs a) {
   const int SP = a.SP;
   const double LOG2 = 0.69314718055994529;
   int cur_h = -1, cur_orient = -1;
+  long long t_last = a.stats ? __builtin_readcyclecounter() : 0;
   const DevHMM *hm = nullptr;
   const float *fwG = nullptr, *bwG = nullptr, *emG = nullptr;
 
@@ -108,13 +371,15 @@ __global__ __launch_bounds__(TH) void score_big_kernel(ScoreArgs a) {
       const LenCfg cu = len_config(L > 0 ? L : 1, false);
 
       // ---------------- P1: multihit Forward (forward tables)
+      WH_TICKB(11);
       orient(0);
+      WH_TICKB(10);
       if (active) {
         TransTab<Q, false> T;
         T.load(nullptr, trL, lane);
         const ScanC sc = scan_prepare(lane_product<Q, false>(T, FW_D2));
         float xC_L;
-        forward_sweep<Q, false, false>(T, sc, emL, emG, Klds, seq, L, cm, spec, SP, nullptr, 0.f, lane, xC_L, ef_L);
+        forward_sweep_lean<Q, false>(T, sc, emL, emG, Klds, seq, L, cm, spec, SP, nullptr, 0.f, lane, xC_L, ef_L);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         const double fwd_nats = (double)ef_L * LOG2 + log((double)(xC_L * cm.move));
         fwdsc = (float)fwd_nats;
@@ -127,7 +392,9 @@ __global__ __launch_bounds__(TH) void score_big_kernel(ScoreArgs a) {
       }
 
       // ---------------- P2: multihit Backward + domain decoding + region scan (backward tables)
+      WH_TICKB(4);
       orient(1);
+      WH_TICKB(10);
       if (active && ok) {
         TransTab<Q, false> T;
         T.load(nullptr, trL, lane);
@@ -141,26 +408,14 @@ __global__ __launch_bounds__(TH) void score_big_kernel(ScoreArgs a) {
         for (int i = L; i >= 0; i--) {
           asm volatile("" ::: "memory");
           if (i < L) {
-            float od[Q];
-            load_em_rev<Q>(od, emL, emG, seq[i], Klds, lane);
-            float part = 0.f;
-#pragma unroll
-            for (int p4 = 0; p4 < Q / 4; p4++) {
-              const float4 E = T.ld(BW_E, p4);
-#pragma unroll
-              for (int j = 0; j < 4; j++) {
-                const int p = 4 * p4 + j;
-                Mb[p] *= od[p];
-                part = fmaf(f4get(E, j), Mb[p], part);
-              }
-            }
+            const float part = backward_emit_lean<Q>(T, emL, emG, seq[i], Klds, lane, Mb);
             xB = wave_sum(part);
             xJ = fmaf(xJ, cm.loop, xB * cm.move);
             xC = xC * cm.loop;
             xN = fmaf(xN, cm.loop, xB * cm.move);
           }
           float xE = fmaf(xC, cm.EC, xJ * cm.EJ);
-          if (i >= 1) backward_cells<Q, false>(T, sc, Mb, Ib, xE);
+          if (i >= 1) backward_cells_lean<Q>(T, sc, Mb, Ib, xE);
           const float big = fmaxf(xB, xN);
           if (big > kRescaleHi) {
             const int e = f32_exponent(big);
@@ -227,6 +482,7 @@ __global__ __launch_bounds__(TH) void score_big_kernel(ScoreArgs a) {
         }
         if (dp) { dp->nregions = nreg; dp->nenv = nenv; }
       }
+      WH_TICKB(5);
       // a pair with a multidomain region is finished by resolve_kernel (A.4b); its single-domain regions
       // are still scored here, their results staged in LDS for the pair's queue record
       const bool queue_pair = multi_mask != 0 && a.rrecs != nullptr;
@@ -243,19 +499,23 @@ __global__ __launch_bounds__(TH) void score_big_kernel(ScoreArgs a) {
         float xC_e = 0.f, envsc = -INFINITY, domcorr = 0.f;
         const uint8_t *eseq = seq;
         // P3: unihit Forward of the envelope (forward tables)
+        WH_TICKB(11);
         orient(0);
+        WH_TICKB(10);
         if (pending) {
           ri = regs[2 * e]; Ld = regs[2 * e + 1] - ri + 1; eseq = seq + (ri - 1);
           const float keep_scale = attempt == 0 ? kKeepScaleB : -1.0f;
           TransTab<Q, false> T;
           T.load(nullptr, trL, lane);
           const ScanC sc = scan_prepare(lane_product<Q, false>(T, FW_D2));
-          forward_sweep<Q, false, true>(T, sc, emL, emG, Klds, eseq, Ld, cu, spec, SP, Fs, keep_scale, lane, xC_e, ef_e);
+          forward_sweep_lean<Q, true>(T, sc, emL, emG, Klds, eseq, Ld, cu, spec, SP, Fs, keep_scale, lane, xC_e, ef_e);
           __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
           envsc = (float)((double)ef_e * LOG2 + log((double)(xC_e * cu.move)));
         }
         // P4: unihit Backward + posterior accumulation (backward tables)
+        WH_TICKB(7);
         orient(1);
+        WH_TICKB(10);
         if (pending) {
           bool done_env = true;
           if (xC_e > 0.f) {
@@ -269,57 +529,66 @@ __global__ __launch_bounds__(TH) void score_big_kernel(ScoreArgs a) {
             float xC = cu.move, xJ = 0.f, xN = 0.f, xB = 0.f, xfac = 0.f, fIs = 0.f;
 
             const int src = kWave - 1 - lane;
+            // Everything a row needs from HBM is requested one row ahead (the special states of row i-1 and the
+            // mask word of row i-1 during row i) or at the top of its own row (the stored Forward cells, consumed
+            // after the cell update): with one or two waves per SIMD nothing else hides these round trips, and
+            // four of them in series per row were half of the kernel's time.
+            int S_i = BSPRI(SP_S * SP + Ld), S_m = BSPRI(SP_S * SP + Ld - 1), S_prev = S_i;
+            unsigned mword = src < 32 ? BSPRU(SP_ML * SP + Ld) : BSPRU(SP_MH * SP + Ld);
+            float n_m = BSPR(SP_N * SP + Ld - 1), j_m = BSPR(SP_J * SP + Ld - 1), c_m = BSPR(SP_C * SP + Ld - 1);
 #pragma unroll 1
             for (int i = Ld; i >= 1; i--) {
               asm volatile("" ::: "memory");
-              if (i < Ld) {
-                mirror_scale<Q>(BSPRI(SP_S * SP + i + 1) - BSPRI(SP_S * SP + i), Mb, Ib, xJ, xC, xN);
-                float od[Q];
-                load_em_rev<Q>(od, emL, emG, eseq[i], Klds, lane);
-                float part = 0.f;
+              // requests for row i-1 (clamped at the envelope start; the values are not used there)
+              const int im2 = i >= 2 ? i - 2 : 0, im1 = i >= 2 ? i - 1 : 1;
+              const int S_m2 = BSPRI(SP_S * SP + im2);
+              const unsigned mword_n = src < 32 ? BSPRU(SP_ML * SP + im1) : BSPRU(SP_MH * SP + im1);
+              const float n_m2 = BSPR(SP_N * SP + im2), j_m2 = BSPR(SP_J * SP + im2), c_m2 = BSPR(SP_C * SP + im2);
+              // stored Forward cells of row i (only the lanes that own a stored block)
+              const bool have = (mword >> (src & 31)) & 1u;
+              float4 fm[Q / 4], fi[Q / 4];
+              if (have) {
+                const float4 *row = reinterpret_cast<const float4 *>(Fs) + (size_t)i * (2 * (Q / 4) * kWave) + src;
 #pragma unroll
                 for (int p4 = 0; p4 < Q / 4; p4++) {
-                  const float4 E = T.ld(BW_E, p4);
-#pragma unroll
-                  for (int j = 0; j < 4; j++) {
-                    const int p = 4 * p4 + j;
-                    Mb[p] *= od[p];
-                    part = fmaf(f4get(E, j), Mb[p], part);
-                  }
+                  fm[p4] = nt_load4(row + (Q / 4 - 1 - p4) * kWave);
+                  fi[p4] = nt_load4(row + (Q / 4 + Q / 4 - 1 - p4) * kWave);
                 }
+              }
+              asm volatile("" ::: "memory");
+              if (i < Ld) {
+                mirror_scale<Q>(S_prev - S_i, Mb, Ib, xJ, xC, xN);
+                const float part = backward_emit_lean<Q>(T, emL, emG, eseq[i], Klds, lane, Mb);
                 xB = wave_sum(part);
                 xJ = fmaf(xJ, cu.loop, xB * cu.move);
                 xC = xC * cu.loop;
                 xN = fmaf(xN, cu.loop, xB * cu.move);
               }
               float xE = fmaf(xC, cu.EC, xJ * cu.EJ);
-              backward_cells<Q, false>(T, sc, Mb, Ib, xE);
+              backward_cells_lean<Q>(T, sc, Mb, Ib, xE);
               clamp_backward<Q>(Mb, Ib, xB, xJ, xC, xN);
               // mirrored scaling (wh_device.h, "envelope Backward scaling")
               const float s_i = invZe;
-              const float s_p = ldexpf(invZe, BSPRI(SP_S * SP + i - 1) - BSPRI(SP_S * SP + i));
-              const unsigned mword = src < 32 ? BSPRU(SP_ML * SP + i) : BSPRU(SP_MH * SP + i);
-              if ((mword >> (src & 31)) & 1u) {
-                const float4 *row = reinterpret_cast<const float4 *>(Fs) + (size_t)i * (2 * (Q / 4) * kWave) + src;
+              const float s_p = ldexpf(invZe, S_m - S_i);
+              if (have) {
                 float idot = 0.f;
 #pragma unroll
                 for (int p4 = 0; p4 < Q / 4; p4++) {
                   // reversed order: component 3-j of the forward-ordered vector is position 4*p4+j
-                  const float4 fm = nt_load4(row + (Q / 4 - 1 - p4) * kWave);
-                  const float4 fi = nt_load4(row + (Q / 4 + Q / 4 - 1 - p4) * kWave);
-                  fM[4 * p4 + 0] = fmaf(fm.w * Mb[4 * p4 + 0], s_i, fM[4 * p4 + 0]);
-                  fM[4 * p4 + 1] = fmaf(fm.z * Mb[4 * p4 + 1], s_i, fM[4 * p4 + 1]);
-                  fM[4 * p4 + 2] = fmaf(fm.y * Mb[4 * p4 + 2], s_i, fM[4 * p4 + 2]);
-                  fM[4 * p4 + 3] = fmaf(fm.x * Mb[4 * p4 + 3], s_i, fM[4 * p4 + 3]);
-                  idot = fmaf(fi.w, Ib[4 * p4 + 0], idot); idot = fmaf(fi.z, Ib[4 * p4 + 1], idot);
-                  idot = fmaf(fi.y, Ib[4 * p4 + 2], idot); idot = fmaf(fi.x, Ib[4 * p4 + 3], idot);
+                  fM[4 * p4 + 0] = fmaf(fm[p4].w * Mb[4 * p4 + 0], s_i, fM[4 * p4 + 0]);
+                  fM[4 * p4 + 1] = fmaf(fm[p4].z * Mb[4 * p4 + 1], s_i, fM[4 * p4 + 1]);
+                  fM[4 * p4 + 2] = fmaf(fm[p4].y * Mb[4 * p4 + 2], s_i, fM[4 * p4 + 2]);
+                  fM[4 * p4 + 3] = fmaf(fm[p4].x * Mb[4 * p4 + 3], s_i, fM[4 * p4 + 3]);
+                  idot = fmaf(fi[p4].w, Ib[4 * p4 + 0], idot); idot = fmaf(fi[p4].z, Ib[4 * p4 + 1], idot);
+                  idot = fmaf(fi[p4].y, Ib[4 * p4 + 2], idot); idot = fmaf(fi[p4].x, Ib[4 * p4 + 3], idot);
                 }
                 fIs = fmaf(idot, s_i, fIs);
               }
-              float nj = BSPR(SP_N * SP + i - 1) * xN;
-              nj = fmaf(BSPR(SP_J * SP + i - 1), xJ, nj);
-              nj = fmaf(BSPR(SP_C * SP + i - 1), xC, nj);
+              float nj = n_m * xN;
+              nj = fmaf(j_m, xJ, nj);
+              nj = fmaf(c_m, xC, nj);
               xfac = fmaf(nj * cu.loop, s_p, xfac);
+              S_prev = S_i; S_i = S_m; S_m = S_m2; mword = mword_n; n_m = n_m2; j_m = j_m2; c_m = c_m2;
             }
             const float norm = 1.0f / (float)Ld;
             float sm = 0.f;
@@ -373,6 +642,7 @@ __global__ __launch_bounds__(TH) void score_big_kernel(ScoreArgs a) {
         }
       }
 
+      WH_TICKB(8);
       // ---------------- A.6 score assembly
       if (queue_pair) {
         __builtin_amdgcn_wave_barrier();
@@ -417,24 +687,29 @@ static hipError_t launch_big_th(const ScoreArgs &a, int blocks, int threads, siz
   return hipGetLastError();
 }
 
-// 256 threads: one wave per SIMD with the whole register file; 512 threads: two waves per SIMD at 256
-// registers each (the DP row of the longest models then spills to scratch)
-template <int Q>
-static hipError_t launch_big(const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
-  if (threads > 256) return launch_big_th<Q, 512>(a, blocks, threads, lds, s);
-  return launch_big_th<Q, 256>(a, blocks, threads, lds, s);
-}
+// This file is compiled twice (Makefile): as wh_score_big.o for 256 threads - one wave per SIMD with the
+// whole register file, default flags (a wave alone on its SIMD is issue-bound, where the SLP vectoriser's
+// packed fp32 ops save issue slots) - and with -DWH_BIG_LEAN -fno-slp-vectorize as wh_score_big2.o for 512
+// threads: two waves per SIMD at 256 registers each, the register-lean sweeps above.
+#ifdef WH_BIG_LEAN
+#define WH_BIG_LAUNCH launch_score_big2
+#define WH_BIG_TH 512
+#else
+#define WH_BIG_LAUNCH launch_score_big
+#define WH_BIG_TH 256
+#endif
 
-hipError_t launch_score_big(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
+hipError_t WH_BIG_LAUNCH(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
+  if (threads != WH_BIG_TH) return hipErrorInvalidValue;
   switch (Q) {
-    case 20: return launch_big<20>(a, blocks, threads, lds, s);
-    case 24: return launch_big<24>(a, blocks, threads, lds, s);
-    case 28: return launch_big<28>(a, blocks, threads, lds, s);
-    case 32: return launch_big<32>(a, blocks, threads, lds, s);
-    case 36: return launch_big<36>(a, blocks, threads, lds, s);
-    case 40: return launch_big<40>(a, blocks, threads, lds, s);
-    case 44: return launch_big<44>(a, blocks, threads, lds, s);
-    case 48: return launch_big<48>(a, blocks, threads, lds, s);
+    case 20: return launch_big_th<20, WH_BIG_TH>(a, blocks, threads, lds, s);
+    case 24: return launch_big_th<24, WH_BIG_TH>(a, blocks, threads, lds, s);
+    case 28: return launch_big_th<28, WH_BIG_TH>(a, blocks, threads, lds, s);
+    case 32: return launch_big_th<32, WH_BIG_TH>(a, blocks, threads, lds, s);
+    case 36: return launch_big_th<36, WH_BIG_TH>(a, blocks, threads, lds, s);
+    case 40: return launch_big_th<40, WH_BIG_TH>(a, blocks, threads, lds, s);
+    case 44: return launch_big_th<44, WH_BIG_TH>(a, blocks, threads, lds, s);
+    case 48: return launch_big_th<48, WH_BIG_TH>(a, blocks, threads, lds, s);
     default: return hipErrorInvalidValue;
   }
 }

@@ -59,7 +59,6 @@ struct Knobs {
   int max_waves = 0;         // cap on waves per workgroup (0 = planner's choice)
   bool force_specg = false;  // force the HBM special-state mode
   bool no_logspace = false;  // skip the log-space alignment pass
-  int big_waves = 4;         // waves per workgroup of the pass-synchronous long-model kernel (4 = one per SIMD, 8 = two)
   bool no_resolve = false;   // multidomain regions stay ONE envelope (round-1 behaviour) instead of HMMER's stochastic resolver
   bool stats = false, trace = false;
   int dbg = 0;
@@ -239,7 +238,6 @@ int wh_set_option(wh_ehmm *e, const char *name, const char *value) {
   else if (!strcmp(name, "WH_FORCE_SPECG")) k.force_specg = on;
   else if (!strcmp(name, "WH_NO_LOGSPACE")) k.no_logspace = on;
   else if (!strcmp(name, "WH_NO_RESOLVE")) k.no_resolve = on;
-  else if (!strcmp(name, "WH_BIG_WAVES")) k.big_waves = (*v && atoi(v) == 8) ? 8 : 4;
   else if (!strcmp(name, "WH_STATS")) k.stats = on;
   else if (!strcmp(name, "WH_TRACE")) k.trace = on;
   else if (!strcmp(name, "WH_DBG")) k.dbg = atoi(v);
@@ -249,7 +247,7 @@ int wh_set_option(wh_ehmm *e, const char *name, const char *value) {
 }
 
 static void knobs_from_env(wh_ehmm *e) {
-  for (const char *name : {"WH_SCORE_KERNEL", "WH_KEEP_LOG2", "WH_MAX_WAVES", "WH_FORCE_SPECG", "WH_NO_LOGSPACE", "WH_NO_RESOLVE", "WH_BIG_WAVES", "WH_STATS", "WH_TRACE", "WH_DBG", "WH_RDBG"})
+  for (const char *name : {"WH_SCORE_KERNEL", "WH_KEEP_LOG2", "WH_MAX_WAVES", "WH_FORCE_SPECG", "WH_NO_LOGSPACE", "WH_NO_RESOLVE", "WH_STATS", "WH_TRACE", "WH_DBG", "WH_RDBG"})
     if (const char *v = getenv(name)) (void)wh_set_option(e, name, v);
 }
 
@@ -403,7 +401,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       }
       if (big) {
         wave_lds = 32 + kRegsInts + (Lc + 3) / 4 + 4;
-        waves = kn.big_waves;
+        waves = 4;            // one per SIMD: the long-model kernel uses the whole register file
         a.Klds = e->K;
         size_t table = (size_t)(a.Klds + 8) * Q * kWave * sizeof(float);
         if (kLdsHeader + table + (size_t)waves * wave_lds * sizeof(float) > kLdsBudget) { a.Klds = 0; table = (size_t)8 * Q * kWave * sizeof(float); }
@@ -413,7 +411,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
         specg = true;
       }
       a.SP = SP; a.wave_lds = wave_lds;
-      a.QB = waves * 4;
+      a.QB = big ? waves * 2 : waves * 4;   // long models: a pair is milliseconds, smaller items shorten the tail of the launch
       a.n_qblocks = (int)((nq + a.QB - 1) / a.QB);
       a.n_items = a.n_list * a.n_qblocks;
       a.scratch_stride = (size_t)(a.Lcap + 1) * 2 * Q * kWave;   // Forward slab per wave
@@ -440,7 +438,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       if (kn.trace) fprintf(stderr, "[wh] score Q=%d kernel=%s specg=%d waves=%d blocks=%d lds=%zu SP=%d wave_lds=%d items=%d Lcap=%d\n", Q,
                             big ? "pass-synchronous" : kn.kernel == 8 ? "phase-call(B)" : "phase-call", (int)specg, waves, blocks, lds, SP, wave_lds, a.n_items, a.Lcap);
       HIPCHK(hipMemsetAsync(a.counter, 0, sizeof(int), s));
-      hipError_t err = big ? (waves == 8 ? launch_score_big2(Q, a, blocks, waves * kWave, lds, s) : launch_score_big(Q, a, blocks, waves * kWave, lds, s))
+      hipError_t err = big ? launch_score_big(Q, a, blocks, waves * kWave, lds, s)
                        : kn.kernel == 8 ? launch_score7b(Q, a, blocks, waves * kWave, lds, s)
                                         : launch_score7(Q, a, blocks, waves * kWave, lds, s);
       if (err != hipSuccess) { set_error("score kernel launch (Q=%d) failed: %s", Q, hipGetErrorString(err)); return WH_EHIP; }

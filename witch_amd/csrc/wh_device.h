@@ -211,6 +211,51 @@ enum { SP_N = 0, SP_B, SP_E, SP_J, SP_C, SP_S, SP_ML, SP_MH, SP_NARR };   // SP_
 
 constexpr float kRescaleHi = 1048576.0f;   // 2^20
 
+// ------------------------------------------------------------------ region scan over special states in HBM
+// A.4's scan over rows 1..L (thresholds rt1/rt2) when the per-row arrays live in global memory: 64 rows are
+// fetched with one coalesced load per array and walked with v_readlane, instead of three dependent L2/HBM
+// round trips per row; the running sums are formed in the same order, so the result is bit-identical to the
+// row-by-row loop.  Writes the cumulative sums into SP_J / SP_C (coalesced) and the regions into regs[].
+__device__ __forceinline__ void region_scan_global(float *spec, int SP, int L, int *regs, int lane, int &nenv,
+                                                   int &nreg, int &flags) {
+  const float rt1 = 0.25f, rt2 = 0.10f;
+  float btot = 0.f, etot = 0.f;
+  int i0 = -1;
+  bool trig = false;
+  if (lane == 0) { spec[SP_J * SP] = 0.f; spec[SP_C * SP] = 0.f; }
+  for (int j0 = 1; j0 <= L; j0 += kWave) {
+    const int jj = j0 + lane;
+    const bool valid = jj <= L;
+    const float nv = valid ? __builtin_nontemporal_load(spec + SP_N * SP + jj) : 0.f;
+    const float bv = valid ? __builtin_nontemporal_load(spec + SP_B * SP + jj - 1) : 0.f;
+    const float ev = valid ? __builtin_nontemporal_load(spec + SP_E * SP + jj) : 0.f;
+    float jout = 0.f, cout = 0.f;
+    const int cnt = L - j0 + 1 < kWave ? L - j0 + 1 : kWave;
+    for (int t = 0; t < cnt; t++) {
+      const int j = j0 + t;
+      const float mocc = 1.0f - readlane_f(nv, t);
+      const float bold = btot, eold = etot;
+      btot += readlane_f(bv, t);
+      etot += readlane_f(ev, t);
+      if (lane == t) { jout = btot; cout = etot; }
+      if (!trig) {
+        if (mocc - (btot - bold) < rt2) i0 = j;
+        else if (i0 == -1) i0 = j;
+        if (mocc >= rt1) trig = true;
+      } else if (mocc - (etot - eold) < rt2) {
+        if (nenv < WH_MAX_ENVELOPES) {
+          if (lane == 0) { regs[2 * nenv] = i0; regs[2 * nenv + 1] = j; }
+          nenv++;
+        } else flags |= WH_FLAG_TRUNC;
+        nreg++;
+        i0 = -1;
+        trig = false;
+      }
+    }
+    if (valid) { spec[SP_J * SP + jj] = jout; spec[SP_C * SP + jj] = cout; }
+  }
+}
+
 // ------------------------------------------------------------------ Forward sweep
 // Fills spec[SP_*][0..L]; with STORE also writes the M and I rows (1..L) to <Fs>:
 // [row][2][Q/4][64 lanes][4] floats (forward node order; a wavefront's store instruction covers

@@ -300,25 +300,29 @@ __device__ __noinline__ RegOut region_scan(lds_f *spec3, glb_f *specg, int SP, i
   float btot = 0.f, etot = 0.f;
   int i0 = -1;
   bool trig = false;
-  if (lane == 0) { spec[SP_J * SP] = 0.f; spec[SP_C * SP] = 0.f; }
-  for (int j = 1; j <= L; j++) {
-    const float mocc = 1.0f - ldf(SP_N * SP + j);
-    const float bold = btot, eold = etot;
-    btot += ldf(SP_B * SP + j - 1);
-    etot += ldf(SP_E * SP + j);
-    if (lane == 0) { spec[SP_J * SP + j] = btot; spec[SP_C * SP + j] = etot; }
-    if (!trig) {
-      if (mocc - (btot - bold) < rt2) i0 = j;
-      else if (i0 == -1) i0 = j;
-      if (mocc >= rt1) trig = true;
-    } else if (mocc - (etot - eold) < rt2) {
-      if (nenv < WH_MAX_ENVELOPES) {
-        if (lane == 0) { regs[2 * nenv] = i0; regs[2 * nenv + 1] = j; }
-        nenv++;
-      } else flags |= WH_FLAG_TRUNC;
-      nreg++;
-      i0 = -1;
-      trig = false;
+  if constexpr (SG) {
+    region_scan_global(spec, SP, L, regs, lane, nenv, nreg, flags);   // 64 rows per fetch (wh_device.h)
+  } else {
+    if (lane == 0) { spec[SP_J * SP] = 0.f; spec[SP_C * SP] = 0.f; }
+    for (int j = 1; j <= L; j++) {
+      const float mocc = 1.0f - ldf(SP_N * SP + j);
+      const float bold = btot, eold = etot;
+      btot += ldf(SP_B * SP + j - 1);
+      etot += ldf(SP_E * SP + j);
+      if (lane == 0) { spec[SP_J * SP + j] = btot; spec[SP_C * SP + j] = etot; }
+      if (!trig) {
+        if (mocc - (btot - bold) < rt2) i0 = j;
+        else if (i0 == -1) i0 = j;
+        if (mocc >= rt1) trig = true;
+      } else if (mocc - (etot - eold) < rt2) {
+        if (nenv < WH_MAX_ENVELOPES) {
+          if (lane == 0) { regs[2 * nenv] = i0; regs[2 * nenv + 1] = j; }
+          nenv++;
+        } else flags |= WH_FLAG_TRUNC;
+        nreg++;
+        i0 = -1;
+        trig = false;
+      }
     }
   }
   __builtin_amdgcn_wave_barrier();

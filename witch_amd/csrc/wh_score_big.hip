@@ -404,8 +404,17 @@ __global__ __launch_bounds__(TH) void score_big_kernel(ScoreArgs a) {
         for (int p = 0; p < Q; p++) { Mb[p] = 0.f; Ib[p] = 0.f; }
         float xC = cm.move, xJ = 0.f, xN = 0.f, xB = 0.f;
         int eb = 0;
+        // the special states of a row are requested one row ahead (see the envelope Backward sweep below)
+        int S_i = BSPRI(SP_S * SP + L), S_m = BSPRI(SP_S * SP + L - 1);
+        float E_i = BSPR(SP_E * SP + L), B_i = BSPR(SP_B * SP + L);
+        float n_m = BSPR(SP_N * SP + L - 1), j_m = BSPR(SP_J * SP + L - 1), c_m = BSPR(SP_C * SP + L - 1);
 #pragma unroll 1
         for (int i = L; i >= 0; i--) {
+          asm volatile("" ::: "memory");
+          const int ip1 = i >= 1 ? i - 1 : 0, ip2 = i >= 2 ? i - 2 : 0;
+          const float E_n = BSPR(SP_E * SP + ip1), B_n = BSPR(SP_B * SP + ip1);
+          const int S_m2 = BSPRI(SP_S * SP + ip2);
+          const float n_m2 = BSPR(SP_N * SP + ip2), j_m2 = BSPR(SP_J * SP + ip2), c_m2 = BSPR(SP_C * SP + ip2);
           asm volatile("" ::: "memory");
           if (i < L) {
             const float part = backward_emit_lean<Q>(T, emL, emG, seq[i], Klds, lane, Mb);
@@ -425,48 +434,26 @@ __global__ __launch_bounds__(TH) void score_big_kernel(ScoreArgs a) {
             xB *= r; xJ *= r; xC *= r; xN *= r; xE *= r;
             eb += e;
           }
-          const float s_i = ldexpf(invZ, BSPRI(SP_S * SP + i) + eb - ef_L);
-          const float pe = BSPR(SP_E * SP + i) * xE * s_i;
-          const float pb = BSPR(SP_B * SP + i) * xB * s_i;
+          const float s_i = ldexpf(invZ, S_i + eb - ef_L);
+          const float pe = E_i * xE * s_i;
+          const float pb = B_i * xB * s_i;
           float njc = 0.f;
           if (i >= 1) {
-            const float s_p = ldexpf(invZ, BSPRI(SP_S * SP + i - 1) + eb - ef_L);
-            njc = BSPR(SP_N * SP + i - 1) * xN;
-            njc = fmaf(BSPR(SP_J * SP + i - 1), xJ, njc);
-            njc = fmaf(BSPR(SP_C * SP + i - 1), xC, njc);
+            const float s_p = ldexpf(invZ, S_m + eb - ef_L);
+            njc = n_m * xN;
+            njc = fmaf(j_m, xJ, njc);
+            njc = fmaf(c_m, xC, njc);
             njc = njc * cm.loop * s_p;
           }
           __builtin_amdgcn_wave_barrier();
           if (lane == 0) { spec[SP_E * SP + i] = pe; spec[SP_B * SP + i] = pb; spec[SP_N * SP + i] = njc; }
           __builtin_amdgcn_wave_barrier();
+          S_i = S_m; S_m = S_m2; E_i = E_n; B_i = B_n; n_m = n_m2; j_m = j_m2; c_m = c_m2;
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        // region scan (A.4)
-        const float rt1 = 0.25f, rt2 = 0.10f, rt3 = 0.20f;
-        float btot = 0.f, etot = 0.f;
-        int i0 = -1;
-        bool trig = false;
-        if (lane == 0) { spec[SP_J * SP] = 0.f; spec[SP_C * SP] = 0.f; }
-        for (int j = 1; j <= L; j++) {
-          const float mocc = 1.0f - BSPR(SP_N * SP + j);
-          const float bold = btot, eold = etot;
-          btot += BSPR(SP_B * SP + j - 1);
-          etot += BSPR(SP_E * SP + j);
-          if (lane == 0) { spec[SP_J * SP + j] = btot; spec[SP_C * SP + j] = etot; }
-          if (!trig) {
-            if (mocc - (btot - bold) < rt2) i0 = j;
-            else if (i0 == -1) i0 = j;
-            if (mocc >= rt1) trig = true;
-          } else if (mocc - (etot - eold) < rt2) {
-            if (nenv < WH_MAX_ENVELOPES) {
-              if (lane == 0) { regs[2 * nenv] = i0; regs[2 * nenv + 1] = j; }
-              nenv++;
-            } else flags |= WH_FLAG_TRUNC;
-            nreg++;
-            i0 = -1;
-            trig = false;
-          }
-        }
+        // region scan (A.4), 64 rows per fetch
+        const float rt3 = 0.20f;
+        region_scan_global(spec, SP, L, regs, lane, nenv, nreg, flags);
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         for (int e = 0; e < nenv; e++) {
@@ -687,17 +674,10 @@ static hipError_t launch_big_th(const ScoreArgs &a, int blocks, int threads, siz
   return hipGetLastError();
 }
 
-// This file is compiled twice (Makefile): as wh_score_big.o for 256 threads - one wave per SIMD with the
-// whole register file, default flags (a wave alone on its SIMD is issue-bound, where the SLP vectoriser's
-// packed fp32 ops save issue slots) - and with -DWH_BIG_LEAN -fno-slp-vectorize as wh_score_big2.o for 512
-// threads: two waves per SIMD at 256 registers each, the register-lean sweeps above.
-#ifdef WH_BIG_LEAN
-#define WH_BIG_LAUNCH launch_score_big2
-#define WH_BIG_TH 512
-#else
+// 256 threads: one wave per SIMD with the whole register file (a DP row of 3 x 48 cells, the double-buffered
+// table pieces and the landing registers of the row prefetch)
 #define WH_BIG_LAUNCH launch_score_big
 #define WH_BIG_TH 256
-#endif
 
 hipError_t WH_BIG_LAUNCH(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
   if (threads != WH_BIG_TH) return hipErrorInvalidValue;

@@ -35,6 +35,7 @@ def main():
         maxlen = int(np.max(np.diff(offs)))
         res_t = torch.from_numpy(res).cuda()
         off_t = torch.from_numpy(offs).cuda()
+        cells = float(np.diff(offs).sum()) * float(e.M.astype(np.int64).sum())
         knobs = set()
         for v in variants:
             for kv in filter(None, v.split(",")):
@@ -61,8 +62,8 @@ def main():
                 nd = int((d != ref[0]).sum())
                 nf = int(((f & 7) != (ref[1] & 7)).sum())
                 mx = int(np.abs(d.astype(np.int64) - ref[0]).max())
-                print("rep %d  %-44s kernel %9.3f ms (wall %9.3f)  decibit diffs vs first: %d (max %d)  flag diffs: %d  dense redos: %d"
-                      % (rep, v or "(default)", ms, dt, nd, mx, nf, int(((f & 16) != 0).sum())), flush=True)
+                print("rep %d  %-44s kernel %9.3f ms (wall %9.3f)  %.3g cells/s  decibit diffs vs first: %d (max %d)  flag diffs: %d  dense redos: %d"
+                      % (rep, v or "(default)", ms, dt, cells / (ms * 1e-3), nd, mx, nf, int(((f & 16) != 0).sum())), flush=True)
     finally:
         shutil.rmtree(wd, ignore_errors=True)
 

@@ -79,7 +79,7 @@ struct wh_ehmm {
   int last_resolved = 0;                    // pairs the resolver finished in the last wh_score call
   // staging for the host-pointer entry points
   DevBuf s_res, s_off, s_deci, s_flags, s_fwd, s_det, s_idx, s_w, s_nk, s_nu, s_pq, s_ph, s_co, s_cols, s_pos;
-  DevBuf d_order, d_items, d_recs, d_spec, d_back, d_cwj, d_cwv, d_cwn, c_buf[10];
+  DevBuf d_qorder, d_order, d_items, d_recs, d_spec, d_back, d_cwj, d_cwv, d_cwn, c_buf[10];
   uint32_t degen[32];
   bool timing = false;
   KernelTimer timers[5];
@@ -129,7 +129,7 @@ void wh_ehmm_free(wh_ehmm *e) {
   if (!e) return;
   for (DevBuf *b : {&e->d_gtab, &e->d_rrecs, &e->d_rmx, &e->d_rsegs, &e->d_hmms, &e->d_tables, &e->d_nseq, &e->d_index, &e->d_lists, &e->d_counter, &e->d_scratch,
                     &e->s_res, &e->s_off, &e->s_deci, &e->s_flags, &e->s_fwd, &e->s_det, &e->s_idx, &e->s_w,
-                    &e->s_nk, &e->s_nu, &e->s_pq, &e->s_ph, &e->s_co, &e->s_cols, &e->s_pos, &e->d_order, &e->d_items, &e->d_recs, &e->d_spec, &e->d_back, &e->d_cwj, &e->d_cwv, &e->d_cwn,
+                    &e->s_nk, &e->s_nu, &e->s_pq, &e->s_ph, &e->s_co, &e->s_cols, &e->s_pos, &e->d_qorder, &e->d_order, &e->d_items, &e->d_recs, &e->d_spec, &e->d_back, &e->d_cwj, &e->d_cwv, &e->d_cwn,
                     &e->c_buf[0], &e->c_buf[1], &e->c_buf[2], &e->c_buf[3], &e->c_buf[4], &e->c_buf[5], &e->c_buf[6],
                     &e->c_buf[7], &e->c_buf[8], &e->c_buf[9]})
     b->release();
@@ -348,6 +348,24 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       if (e->d_rrecs.ensure(sizeof(ResolveRec) * (size_t)npairs_all)) return WH_ENOMEM;
       HIPCHK(hipMemsetAsync(d_rcount, 0, 2 * sizeof(int), s));
     }
+    // Long models run four waves in lockstep per workgroup (wh_score_big.hip): hand them the queries in
+    // descending length order, so that the waves of a workgroup finish their sweeps together and the longest
+    // pairs start first.  (One D2H copy of the offsets and a host sort; only when such a class exists.)
+    bool any_long = false;
+    for (auto &kv : e->by_q) any_long = any_long || kv.first >= 20;
+    const int32_t *d_qorder = nullptr;
+    if (any_long && nq > 4 && nq < 0x7FFFFFFF) {
+      std::vector<int64_t> offs((size_t)nq + 1);
+      HIPCHK(hipMemcpyAsync(offs.data(), d_offsets, sizeof(int64_t) * offs.size(), hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
+      std::vector<int32_t> ord((size_t)nq);
+      for (int64_t q = 0; q < nq; q++) ord[(size_t)q] = (int32_t)q;
+      std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) { return offs[x + 1] - offs[x] > offs[y + 1] - offs[y]; });
+      if (e->d_qorder.ensure(sizeof(int32_t) * ord.size())) return WH_ENOMEM;
+      HIPCHK(hipMemcpyAsync(e->d_qorder.p, ord.data(), sizeof(int32_t) * ord.size(), hipMemcpyHostToDevice, s));
+      HIPCHK(hipStreamSynchronize(s));   // ord is a local
+      d_qorder = (const int32_t *)e->d_qorder.p;
+    }
     // pass 0 sizes the per-wave workspace of every class and allocates ONCE (growing a DevBuf class by class
     // meant a hipFree + hipMalloc of tens of GB per class: ~25 ms per GB); pass 1 launches
     size_t need_scratch = 0, need_spec = 0;
@@ -411,6 +429,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
         specg = true;
       }
       a.SP = SP; a.wave_lds = wave_lds;
+      a.qorder = big ? d_qorder : nullptr;
       a.QB = big ? waves * 2 : waves * 4;   // long models: a pair is milliseconds, smaller items shorten the tail of the launch
       a.n_qblocks = (int)((nq + a.QB - 1) / a.QB);
       a.n_items = a.n_list * a.n_qblocks;

@@ -52,7 +52,8 @@ struct ScoreArgs {
   ResolveRec *rrecs;           // queue of pairs with a multidomain region (NULL: such regions become one envelope)
   int *rcount;                 // queue length (device counter)
   int rcap;
-  unsigned long long *stats;   // WH_STATS: [4..9] wave cycles per phase (or NULL)
+  unsigned long long *stats;   // WH_STATS: [4..11] wave cycles per phase (or NULL)
+  const int32_t *qorder;       // long-model kernel: queries in descending length order (or NULL: input order)
 };
 
 hipError_t launch_score_big(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);

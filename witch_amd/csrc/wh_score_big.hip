@@ -348,12 +348,15 @@ __global__ __launch_bounds__(TH) void score_big_kernel(ScoreArgs a) {
     }
     const int nround = (int)((q_hi - q_lo + nwaves - 1) / nwaves);
     for (int round = 0; round < nround; round++) {
-      const int64_t qi = q_lo + (int64_t)round * nwaves + wave;
+      // the waves of a workgroup sweep in lockstep: neighbours in LENGTH order keep them busy for the same time
+      const int64_t qpos = q_lo + (int64_t)round * nwaves + wave;
+      const bool in_range = qpos < q_hi;
+      const int64_t qi = in_range ? (a.qorder ? (int64_t)a.qorder[qpos] : qpos) : 0;
       int L = 0;
       int64_t off = 0;
-      if (qi < q_hi) { off = a.offsets[qi]; L = (int)(a.offsets[qi + 1] - off); if (L > a.Lcap) L = 0; }
-      const bool active = qi < q_hi && L > 0;
-      const size_t out = (size_t)(qi < q_hi ? qi : q_lo) * a.H + h;
+      if (in_range) { off = a.offsets[qi]; L = (int)(a.offsets[qi + 1] - off); if (L > a.Lcap) L = 0; }
+      const bool active = in_range && L > 0;
+      const size_t out = (size_t)qi * a.H + h;
       int flags = 0, decibits = 0, nreg = 0, nenv = 0, ef_L = 0, multi_mask = 0;
       float fwd_bits_out = -INFINITY, fwdsc = 0.f, nullsc = 0.f, invZ = 0.f;
       bool ok = false;
@@ -656,7 +659,7 @@ __global__ __launch_bounds__(TH) void score_big_kernel(ScoreArgs a) {
         flags |= WH_FLAG_REPORTED;
         if (dp) { dp->seq_score = seq_score; dp->pre_score = pre_score; dp->seqbias_nats = seqbias; }
       }
-      if (qi < q_hi && lane == 0) {
+      if (in_range && lane == 0) {
         a.decibits[out] = decibits;
         a.flags[out] = (uint8_t)flags;
         if (a.fwd_bits) a.fwd_bits[out] = fwd_bits_out;

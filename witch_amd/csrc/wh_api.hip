@@ -508,7 +508,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
         HIPCHK(hipMemsetAsync(e->d_recs.p, 0, 128, s));
         r.stats = (unsigned long long *)e->d_recs.p;
       }
-      const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, kLdsBudget / rlds));
+      const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)resolve_waves_per_cu(), kLdsBudget / rlds));
       int blocks = std::min(n_multi, e->cu_count * per_cu);
       blocks = clamp_blocks(blocks, r.mx_stride * sizeof(double) + r.seg_stride * sizeof(int32_t), e->d_rmx);
       if (e->d_rmx.ensure((size_t)blocks * r.mx_stride * sizeof(double)) || e->d_rsegs.ensure((size_t)blocks * r.seg_stride * sizeof(int32_t)))

@@ -86,6 +86,7 @@ struct ResolveArgs {
 hipError_t launch_resolve(const ResolveArgs &a, int blocks, size_t lds, hipStream_t s);
 size_t resolve_lds_bytes(int Lcap, int Mmax);
 int resolve_seg_cap();
+int resolve_waves_per_cu();
 size_t resolve_seg_ints(int Lcap, int Mmax);
 
 struct TopkArgs {

@@ -108,6 +108,12 @@ struct GMx {
     return k <= 0 ? 0.0 : __builtin_nontemporal_load(p + (size_t)i * rowlen + ((size_t)s * Q + (k - 1) % Q) * 64 + (k - 1) / Q);
   }
   __device__ __forceinline__ double spec(int i, int s) const { return __builtin_nontemporal_load(p + (size_t)i * rowlen + (size_t)3 * Q * 64 + s); }
+  // cached reads for the sampling walk: the matrix is complete and the vector L1 was invalidated after the fill
+  // (wave_mem_sync); 200 traces revisit the same band of cells, which then stay in L1 / L2
+  __device__ __forceinline__ double cellc(int i, int k, int s) const {
+    return k <= 0 ? 0.0 : p[(size_t)i * rowlen + ((size_t)s * Q + (k - 1) % Q) * 64 + (k - 1) / Q];
+  }
+  __device__ __forceinline__ double specc(int i, int s) const { return p[(size_t)i * rowlen + (size_t)3 * Q * 64 + s]; }
 };
 
 // Forward sweep (A.2), float64.  STORE keeps every row (row i at slab row i), otherwise rows
@@ -265,13 +271,18 @@ __host__ __device__ inline size_t resolve_lds_ints(int Lcap, int Mmax) {
   const int Lp = (Lcap + 4) & ~1;
   return (size_t)(Lcap + 8) / 4 + 2 /*seq*/ + Lp /*n2sc*/ + Lp /*acc*/ + kDomMax * (4 + 32) + Lp / 2 + 2 /*stk*/ + kSegCap /*two uint16 stacks*/ + 7 * kEnvMax + 16;
 }
+// waves per SIMD the kernel is compiled for (registers per lane = 512 / WH_RES_OCC)
+#ifndef WH_RES_OCC
+#define WH_RES_OCC 2
+#endif
 size_t resolve_lds_bytes(int Lcap, int Mmax) { return resolve_lds_ints(Lcap, Mmax) * 4 + 16; }
 size_t resolve_seg_ints(int Lcap, int Mmax) { return (size_t)6 * kSegCap + (size_t)(Lcap > Mmax ? Lcap : Mmax) + 8; }
 int resolve_seg_cap() { return kSegCap; }
+int resolve_waves_per_cu() { return 4 * WH_RES_OCC; }
 
 #define RTICK(slot) do { if (a.stats) { const long long t_now = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(a.stats + (slot), (unsigned long long)(t_now - tk0)); tk0 = t_now; } } while (0)
 
-__global__ __launch_bounds__(64, 2) void resolve_kernel(ResolveArgs a) {
+__global__ __launch_bounds__(64, WH_RES_OCC) void resolve_kernel(ResolveArgs a) {
   extern __shared__ __attribute__((aligned(16))) int lds_raw[];
   const int lane = threadIdx.x;
   const int Lp = (a.Lcap + 4) & ~1;
@@ -355,12 +366,21 @@ __global__ __launch_bounds__(64, 2) void resolve_kernel(ResolveArgs a) {
       if (rng.x == 0) rng.x = 42;
       const int Qs = ((m.M - 1) / 4 + 1) > 2 ? ((m.M - 1) / 4 + 1) : 2;     // HMMER's striping: vectors of 4 floats
       long long c_build = 0, c_e = 0, c_post = 0;
+      // lane t's jump of esl_random's LCG by t+1 steps: x_{n+t+1} = lcgA * x_n + lcgC (mod 2^32)
+      unsigned lcgA = 1u, lcgC = 0u;
+      for (int u = 0; u < 64; u++) if (u <= lane) { lcgA *= 69069u; lcgC = lcgC * 69069u + 1u; }
       for (int t = 0; t < kSamples; t++) {
         int i = Lr, k = 0, s0 = stC, ndom = 0, sqto = 0, hmmto = 0, sqfrom = 0, hmmfrom = 0;
         int run_state = 0, run_j = 0;            // decision cache of the current run (see below)
         // thresholds as integers: (sum / norm > x / 2^32) <=> x < ceil(2^32 sum / norm), exactly (both sides are exact
         // in double); 33-bit values: a low word and an 'always true' bit (bits 0..2 of run_hi)
         unsigned run_r1 = 0, run_r2 = 0, run_r3 = 0, run_hi = 0;
+        // ... and, since the random numbers of those decisions are known too (one LCG step each), their OUTCOMES:
+        // lane t holds the number (run_x) and the choice (run_c) of the run's t-th decision, run_cont has bit t set
+        // where that choice continues the run.  A run is then consumed in one step up to its first exit.
+        unsigned run_x = 0;
+        int run_c = 0;
+        unsigned long long run_cont = 0;
         int guard = 4 * (Lr + m.M) + 64;         // a sampled path has at most Lr + M + a few states
         while (s0 != stS && --guard > 0 && i >= 0 && k >= 0 && k <= m.M) {
           double path[4] = {0.0, 0.0, 0.0, 0.0};
@@ -377,19 +397,19 @@ __global__ __launch_bounds__(64, 2) void resolve_kernel(ResolveArgs a) {
               double pd[4] = {0.0, 0.0, 0.0, 0.0};
               if (s0 == stM) {
                 if (it >= 1 && kt >= 1) {
-                  pd[0] = mx.spec(it - 1, xB) * m.t(gE, kt);
-                  pd[1] = mx.cell(it - 1, kt - 1, 0) * m.t(gA, kt);
-                  pd[2] = mx.cell(it - 1, kt - 1, 1) * m.t(gB, kt);
-                  pd[3] = mx.cell(it - 1, kt - 1, 2) * m.t(gC, kt);
+                  pd[0] = mx.specc(it - 1, xB) * m.t(gE, kt);
+                  pd[1] = mx.cellc(it - 1, kt - 1, 0) * m.t(gA, kt);
+                  pd[2] = mx.cellc(it - 1, kt - 1, 1) * m.t(gB, kt);
+                  pd[3] = mx.cellc(it - 1, kt - 1, 2) * m.t(gC, kt);
                 }
               } else if (s0 == stD) {
                 if (kt >= 1) {
-                  pd[0] = mx.cell(it, kt - 1, 0) * m.t(gD1, kt);
-                  pd[1] = mx.cell(it, kt - 1, 2) * m.t(gD2, kt);
+                  pd[0] = mx.cellc(it, kt - 1, 0) * m.t(gD1, kt);
+                  pd[1] = mx.cellc(it, kt - 1, 2) * m.t(gD2, kt);
                 }
               } else if (it >= 1) {
-                pd[0] = mx.spec(it - 1, s0 == stC ? xC : xJ) * cm.loop;
-                pd[1] = mx.spec(it, xE) * (s0 == stC ? cm.EC : cm.EJ) * exp(mx.spec(it, xLS));
+                pd[0] = mx.specc(it - 1, s0 == stC ? xC : xJ) * cm.loop;
+                pd[1] = mx.specc(it, xE) * (s0 == stC ? cm.EC : cm.EJ) * exp(mx.specc(it, xLS));
               }
               const int nch = s0 == stM ? 4 : 2;
               double tot = 0.0;
@@ -411,30 +431,60 @@ __global__ __launch_bounds__(64, 2) void resolve_kernel(ResolveArgs a) {
               as_int(c2 / norm, run_r2, hb); run_hi |= hb << 1;
               as_int(c3 / norm, run_r3, hb); run_hi |= hb << 2;
               run_state = s0; run_j = 0;
+              run_x = lcgA * rng.x + lcgC;
+              bool cont;
+              if (s0 == stM) {
+                run_c = ((run_hi & 1) || run_x < run_r1) ? 0 : ((run_hi & 2) || run_x < run_r2) ? 1 : ((run_hi & 4) || run_x < run_r3) ? 2 : 3;
+                cont = run_c == 1 && it >= 1 && kt >= 1;
+              } else {
+                run_c = ((run_hi & 1) || run_x < run_r1) ? 0 : 1;
+                cont = s0 == stD ? (run_c == 1 && kt >= 1) : (run_c == 0 && it >= 1);
+              }
+              run_cont = __ballot(cont);
               if (a.stats) c_build += __builtin_readcyclecounter() - tb0;
             }
-            rng.x = rng.x * 69069u + 1u;                     // one random number per decision (esl_random)
-            const unsigned x = rng.x;
-            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)run_hi, run_j);
-            const unsigned a1 = (unsigned)__builtin_amdgcn_readlane((int)run_r1, run_j);
+            {
+              // the leading decisions of the run that stay in its state, all at once
+              const unsigned long long rest = ~(run_cont >> run_j);
+              int n = rest ? __builtin_ctzll(rest) : 64;
+              if (n > 64 - run_j) n = 64 - run_j;
+              if (n > guard - 1) n = guard - 1 > 0 ? guard - 1 : 0;
+              if (n > 0) {
+                rng.x = (unsigned)__builtin_amdgcn_readlane((int)run_x, run_j + n - 1);
+                if (s0 == stM) {
+                  if (sqto == 0) { sqto = i - 1; hmmto = k - 1; }
+                  if (lane < n) stk[i - 1 - lane] = (short)(k - 1 - lane);
+                  i -= n; k -= n;
+                  sqfrom = i; hmmfrom = k;
+                } else if (s0 == stD) {
+                  k -= n;
+                } else {
+                  i -= n;
+                }
+                run_j += n;
+                guard -= n;
+                continue;
+              }
+            }
+            // the run's next decision, one random number (esl_random): its outcome was formed with the cache
+            rng.x = (unsigned)__builtin_amdgcn_readlane((int)run_x, run_j);
+            const int c4 = __builtin_amdgcn_readlane(run_c, run_j);
             if (s0 == stM) {
-              const unsigned a2 = (unsigned)__builtin_amdgcn_readlane((int)run_r2, run_j), a3 = (unsigned)__builtin_amdgcn_readlane((int)run_r3, run_j);
-              const int c4 = ((hi & 1) || x < a1) ? 0 : ((hi & 2) || x < a2) ? 1 : ((hi & 4) || x < a3) ? 2 : 3;
               s1 = c4 == 0 ? stB : c4 == 1 ? stM : c4 == 2 ? stI : stD;
               k--; i--;
             } else if (s0 == stD) {
-              s1 = ((hi & 1) || x < a1) ? stM : stD;
+              s1 = c4 == 0 ? stM : stD;
               k--;
             } else {
-              s1 = ((hi & 1) || x < a1) ? s0 : stE;
+              s1 = c4 == 0 ? s0 : stE;
             }
             run_j++;
             if (s1 != s0) run_state = 0;
           } else
           switch (s0) {
             case stI:
-              path[0] = mx.cell(i - 1, k, 0) * m.t(gMI, k);
-              path[1] = mx.cell(i - 1, k, 1) * m.t(gII, k);
+              path[0] = mx.cellc(i - 1, k, 0) * m.t(gMI, k);
+              path[1] = mx.cellc(i - 1, k, 1) * m.t(gII, k);
               s1 = __builtin_amdgcn_readfirstlane(rng_choose(rng, path, 2)) == 0 ? stM : stI;
               i--;
               break;
@@ -442,12 +492,12 @@ __global__ __launch_bounds__(64, 2) void resolve_kernel(ResolveArgs a) {
               const long long te0 = a.stats ? __builtin_readcyclecounter() : 0;
               // FChoose over M(i,*) and D(i,*) in HMMER's striped order: position p = q*8 + state*4 + r
               // holds node r*Qs + q + 1.  Lanes take contiguous chunks, an exclusive scan finds the chunk.
-              const double roll = rng_next(rng), norm = 1.0 / mx.spec(i, xE);
+              const double roll = rng_next(rng), norm = 1.0 / mx.specc(i, xE);
               const int total = 8 * Qs, chunk = (total + 63) / 64;
               const int p0 = lane * chunk, p1 = min(total, p0 + chunk);
               auto term = [&](int p) -> double {
                 const int q = p >> 3, st = (p >> 2) & 1, r = p & 3, kk = r * Qs + q + 1;
-                return kk <= m.M ? (double)(float)(mx.cell(i, kk, st ? 2 : 0) * norm) : 0.0;
+                return kk <= m.M ? (double)(float)(mx.cellc(i, kk, st ? 2 : 0) * norm) : 0.0;
               };
               // The chunk prefix sums of a row are the same for every trace that ends a domain there: computed once per
               // row and kept in the slab, a hit replaces the pass over the 2M cells by one coalesced 512-byte read.
@@ -496,8 +546,8 @@ __global__ __launch_bounds__(64, 2) void resolve_kernel(ResolveArgs a) {
               break;
             }
             case stB:
-              path[0] = mx.spec(i, xN) * cm.move;
-              path[1] = mx.spec(i, xJ) * cm.move;
+              path[0] = mx.specc(i, xN) * cm.move;
+              path[1] = mx.specc(i, xJ) * cm.move;
               s1 = __builtin_amdgcn_readfirstlane(rng_choose(rng, path, 2)) == 0 ? stN : stJ;
               break;
             default: s1 = stS; break;

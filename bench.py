@@ -259,7 +259,7 @@ def main():
                         traffic_src = "profiles/traffic.json <- %s; counters of an earlier run of this command, NOT measured in this run" % tj.get("source", "?").split(" ")[0]
                 except Exception:
                     traffic = None
-            roofline = {"bound": "valu", "kernel": "wh::k7::score_kernel7", "achieved": round(s_tflops, 2), "peak": 157.3,
+            roofline = {"bound": "valu", "kernel": "wh::score_big_kernel" if int(np.max(e.M)) > 1536 else "wh::k7::score_kernel7", "achieved": round(s_tflops, 2), "peak": 157.3,
                         "unit": "TFLOP/s", "frac": round(s_tflops / 157.3, 4), "traffic": traffic, "traffic_source": traffic_src,
                         "flop_per_cell": 77, "cells_per_launch": cells_launch,
                         "kernel_ms_avg": round(score_ms, 3), "launches": score_launches,

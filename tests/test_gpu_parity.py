@@ -321,7 +321,7 @@ def test_consensus_merge_against_oracle_and_reference(golden_case):
     assert n_orc > 0 and n_ref > 0
 
 
-@pytest.mark.parametrize("root_len", [1700, 2950])
+@pytest.mark.parametrize("root_len", [1700, 2574, 2950])
 def test_long_models_use_the_pass_synchronous_kernels(root_len, orc, tmp_path):
     """Models beyond 1536 nodes (the reference's example backbone has up to 2574 match
     columns) run with one transition orientation resident in LDS; parity with the oracle."""

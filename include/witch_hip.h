@@ -155,6 +155,19 @@ int wh_set_timing(wh_ehmm *e, int enabled);
  * changes a knob on a live handle (A/B harness tools/ab_score.py).  Production needs none of them. */
 int wh_set_option(wh_ehmm *e, const char *name, const char *value);
 
+/* ---- eHMM construction (host code, no GPU needed) -------------------------------
+ * Replaces the reference's per-subset call
+ *     hmmbuild --cpu 1 --<molecule> --ere 0.59 --symfrac 0.0 --informat afa -o /dev/null MODEL SUBSET.fasta
+ * (witch_msa/gcmm/algorithm.py:463-470).  rows: nseq aligned sequences of alen characters each (aligned
+ * FASTA text, '-' '.' '_' gaps; no terminator needed), molecule "dna" | "rna" | "amino".  Writes the model as
+ * HMMER3/f text (same probability fields, MAP / CONS annotation, COMPO, NSEQ / EFFN / CKSUM as hmmbuild
+ * 3.1b2; no STATS / MAXL lines) into a malloc'ed buffer the caller releases with wh_free_text.  out_M /
+ * out_neff (optional): model length and effective sequence number. */
+int  wh_hmmbuild(const char *molecule, int32_t nseq, int64_t alen, const char *const *rows, const char *name,
+                 double ere, double symfrac, double fragthresh, char **out_text, int64_t *out_len,
+                 int32_t *out_M, double *out_neff);
+void wh_free_text(char *text);
+
 #ifdef __cplusplus
 }
 #endif

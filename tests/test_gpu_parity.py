@@ -1005,3 +1005,46 @@ def test_end_to_end_example_against_the_reference_pipeline(tmp_path):
         assert got_rows.keys() == want_rows.keys()
         bad = {n for n in got_rows if got_rows[n] != want_rows[n]}
         assert bad <= {qn for qn, _ in differing}, sorted(bad - {qn for qn, _ in differing})[:5]
+
+
+@pytest.mark.gpu
+def test_ehmm_built_without_hmmbuild_scores_identically(tmp_path):
+    """the eHMM of the end-to-end example built by wh_hmmbuild (no STATS / MAXL lines, from the
+    reduced subset alignments as the reference builds them) loads and scores exactly like the files HMMER's
+    hmmbuild wrote: same deci-bits, flags, top-k and aligned columns for all 500 fragments."""
+    _need_gpu()
+    import gzip
+    from witch_amd import synth
+    from witch_amd.ehmm import EHMM, pack_queries
+    from witch_amd.gcmm.hmmbuild import build_ehmm
+    from tests.conftest import load_case
+    case = load_case("example_e2e")
+    names, rows = [], []
+    with gzip.open(os.path.join(case.dir, "backbone.fasta.gz"), "rt") as fh:
+        for line in fh:
+            line = line.strip()
+            if line.startswith(">"):
+                names.append(line[1:].split()[0]); rows.append("")
+            elif line:
+                rows[-1] += line
+    subs = synth.bfs_subsets(len(rows), 15)
+    built = build_ehmm(names, rows, [("A_0_%d" % i, list(range(lo, hi))) for i, (lo, hi) in enumerate(subs)], "dna", str(tmp_path))
+    e1 = EHMM(case.hmm_paths, hmm_index=case.hmm_index, nseq=case.nseq)
+    e2 = EHMM([b[0] for b in built], hmm_index=case.hmm_index, nseq=case.nseq)
+    assert np.array_equal(e1.M, e2.M)
+    seqs = [e1.digitize(s) for s in case.qseqs]
+    res, offs = pack_queries(seqs)
+    d1, f1 = e1.score(res, offs)
+    d2, f2 = e2.score(res, offs)
+    assert np.array_equal(d1, d2) and np.array_equal(f1, f2)
+    i1, w1, _, nu1 = e1.topk(d1, f1, case.k)
+    i2, w2, _, nu2 = e2.topk(d2, f2, case.k)
+    assert np.array_equal(i1, i2) and np.array_equal(w1, w2) and np.array_equal(nu1, nu2)
+    pq = [q for q in range(0, len(seqs), 10) for _ in range(int(nu1[q]))]
+    ph = [e1.pos_of_index[int(i1[q, j])] for q in range(0, len(seqs), 10) for j in range(int(nu1[q]))]
+    c1, o1 = e1.align(res, offs, pq, ph)
+    c2, o2 = e2.align(res, offs, pq, ph)
+    assert np.array_equal(o1, o2)
+    # aligned columns are MODEL columns (0-based node index); the MAP numbers differ (reduced vs full alignment)
+    assert np.array_equal(c1, c2)
+    e1.close(); e2.close()

@@ -1,0 +1,151 @@
+"""The hmmbuild equivalent (witch_amd/csrc/wh_build.cpp) against HMMER 3.1b2.
+
+The expected files were written by the reference's bundled hmmbuild with the reference's command line
+(witch_msa/gcmm/algorithm.py:463-470): the golden models of the scoring tests (tests/golden/make_golden*.py)
+and hand-shaped edge cases (tests/golden/make_golden_hmmbuild.py).  The bar is TEXT identity of every line
+except NAME, DATE, and the two things this build does not compute: the STATS lines (E-value calibration by
+simulation) and MAXL.  No GPU is needed: the builder is host code behind the C ABI.
+"""
+import gzip
+import json
+import os
+
+import numpy as np
+import pytest
+
+from witch_amd import synth
+from witch_amd.gcmm.hmmbuild import hmmbuild_text, subset_alignment_and_hmmbuild, build_ehmm
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SKIP = ("NAME", "DATE", "STATS", "MAXL")
+
+
+def body(text):
+    return [l for l in text.splitlines() if not l.startswith(SKIP)]
+
+
+def read(path):
+    return (gzip.open(path, "rt") if path.endswith(".gz") else open(path)).read()
+
+
+def backbone_rows():
+    names, rows = [], []
+    with gzip.open(os.path.join(GOLD, "example_e2e", "backbone.fasta.gz"), "rt") as fh:
+        for line in fh:
+            line = line.strip()
+            if line.startswith(">"):
+                names.append(line[1:].split()[0])
+                rows.append("")
+            elif line:
+                rows[-1] += line
+    return names, rows
+
+
+def family_rows(alphabet, seed, root_len, n_leaves, n_sub, sub_rate, indel_rate):
+    """The alignments tests/golden/make_golden.py::family_case handed to hmmbuild (seeded, reproducible)."""
+    fam = synth.make_family(seed, root_len, n_leaves, alphabet, sub_rate, indel_rate)
+    sym = synth.symbols(alphabet) + "-"
+    rows = []
+    for i in range(n_leaves):
+        r = fam.msa[i].astype(np.int64).copy()
+        r[r < 0] = len(sym) - 1
+        rows.append("".join(sym[int(x)] for x in r))
+    return rows, synth.bfs_subsets(n_leaves, n_sub)
+
+
+def assert_same(text, gold_text, what):
+    a, b = body(text), body(gold_text)
+    assert len(a) == len(b), (what, len(a), len(b))
+    bad = [(x, y) for x, y in zip(a, b) if x != y]
+    assert not bad, (what, len(bad), bad[:3])
+
+
+CASES = sorted(f[:-4] for f in os.listdir(os.path.join(GOLD, "hmmbuild_cases")) if f.endswith(".afa"))
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_edge_cases_against_hmmbuild(case):
+    """Fragments (span below / at / above half the alignment, at both ends), degenerate residues, lower case,
+    '.' gaps, U in DNA, RNA, amino with B/Z/X, one sequence, identical sequences, all-gap columns, entropy
+    weighting far below nseq."""
+    d = os.path.join(GOLD, "hmmbuild_cases")
+    rows = [l.strip() for l in open(os.path.join(d, case + ".afa")) if not l.startswith(">")]
+    gold = read(os.path.join(d, case + ".hmm"))
+    mol = {"DNA": "dna", "RNA": "rna", "amino": "amino"}[[l.split()[1] for l in gold.splitlines() if l.startswith("ALPH")][0]]
+    text, M, neff = hmmbuild_text(rows, mol, case)
+    assert_same(text, gold, case)
+    assert "EFFN  %f" % neff in text and "LENG  %d" % M in text
+
+
+@pytest.mark.parametrize("case,args,mol", [
+    ("dna_hmmbuild", ("dna", 11, 120, 32, 8, 0.04, 0.004), "dna"),          # entropy weighting active: Neff 1.9 .. 3.8
+    ("amino_hmmbuild", ("amino", 13, 90, 16, 4, 0.08, 0.004), "amino"),      # nine-component mixture prior, Neff ~1
+])
+def test_golden_family_models(case, args, mol):
+    rows, subs = family_rows(*args)
+    for idx, (lo, hi) in enumerate(subs):
+        text, _, _ = hmmbuild_text(rows[lo:hi], mol, "sub")
+        assert_same(text, read(os.path.join(GOLD, case, "hmms", "A_0_%d.hmm" % idx)), (case, idx))
+
+
+def test_example_backbone_models_and_column_tuples(tmp_path):
+    """The 15 models of the end-to-end golden (the reference's example backbone, 62..500 sequences, 1278..2574
+    nodes): text identity, and the reference's retained-column / non-gap tuples (algorithm.py:423-429)."""
+    names, rows = backbone_rows()
+    subs = synth.bfs_subsets(len(rows), 15)
+    gold = json.load(gzip.open(os.path.join(GOLD, "example_e2e", "golden.json.gz"), "rt"))
+    for idx, (lo, hi) in enumerate(subs):
+        text, M, _ = hmmbuild_text([r.upper() for r in rows[lo:hi]], "dna", "sub")
+        assert_same(text, read(os.path.join(GOLD, "example_e2e", "hmms", "A_0_%d.hmm.gz" % idx)), idx)
+    out = build_ehmm(names, rows, [("A_0_%d" % i, list(range(lo, hi))) for i, (lo, hi) in enumerate(subs)], "dna",
+                     str(tmp_path), threads=4)
+    for idx, (path, label, retained, nongaps) in enumerate(out):
+        assert label == "A_0_%d" % idx and os.path.exists(path)
+        assert list(retained) == gold["retained"][str(idx)]
+        assert list(nongaps) == gold["nongaps"][str(idx)]
+        # built from the reduced alignment (as the reference does), the model has the same probabilities; only the
+        # MAP column numbers are those of the reduced alignment
+        mine = [l for l in body(open(path).read()) if not l.startswith("CKSUM")]
+        ref = [l for l in body(read(os.path.join(GOLD, "example_e2e", "hmms", "A_0_%d.hmm.gz" % idx))) if not l.startswith("CKSUM")]
+        assert len(mine) == len(ref)
+        k = 0
+        for x, y in zip(mine, ref):
+            fx, fy = x.split(), y.split()
+            if len(fx) == 4 + 6 and fx[0].isdigit():          # match line: node, 4 emissions, MAP, cons, rf, mm, cs
+                k += 1
+                assert int(fx[0]) == k and int(fx[5]) == k and int(fy[5]) == retained[k - 1] + 1
+                assert fx[:5] + fx[6:] == fy[:5] + fy[6:]
+            else:
+                assert x == y
+        assert k == len(retained)
+
+
+def test_numpy_restatement_agrees():
+    """oracle/hmmbuild_np.py (written first, independently) and the C++ agree on probabilities and Neff."""
+    from oracle import hmmbuild_np as hb
+    d = os.path.join(GOLD, "hmmbuild_cases")
+    for case in ("dna_fragments", "dna_degenerate", "dna_conserved", "dna_fragment_edges"):
+        rows = [l.strip() for l in open(os.path.join(d, case + ".afa")) if not l.startswith(">")]
+        m = hb.build(rows, "dna")
+        text, M, neff = hmmbuild_text(rows, "dna", case)
+        assert M == m["M"] and abs(neff - m["neff"]) < 1e-9
+        lines = text.splitlines()
+        start = next(i for i, l in enumerate(lines) if l.startswith("  COMPO")) + 3
+        for k in range(1, M + 1):
+            f = lines[start + 3 * (k - 1)].split()
+            got = np.array([float(x) for x in f[1:5]])
+            with np.errstate(divide="ignore"):
+                want = -np.log(m["mat"][k].astype(np.float64))
+            assert np.max(np.abs(got - want)) < 2e-5, (case, k)
+
+
+def test_bad_input_is_refused():
+    from witch_amd._lib import WitchHipError
+    with pytest.raises(ValueError):
+        hmmbuild_text(["ACGT", "ACG"], "dna")
+    with pytest.raises(WitchHipError):
+        hmmbuild_text(["AC#T", "ACGT"], "dna")
+    with pytest.raises(WitchHipError):
+        hmmbuild_text(["----", "----"], "dna")          # no consensus column
+    with pytest.raises(ValueError):
+        hmmbuild_text(["ACGT"], "protein")

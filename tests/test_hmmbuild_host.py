@@ -149,3 +149,26 @@ def test_bad_input_is_refused():
         hmmbuild_text(["----", "----"], "dna")          # no consensus column
     with pytest.raises(ValueError):
         hmmbuild_text(["ACGT"], "protein")
+
+
+def test_level0_hmmbuild_executable(tmp_path):
+    """WITCH's `hmmbuildpath` key pointed at witch_amd/shim/bin/hmmbuild: the reference's command line
+    (algorithm.py:463-470) produces hmmbuild's model; the name is the alignment file's basename (HMMER's rule);
+    options that would change the model are refused."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "witch_amd", "shim", "bin", "hmmbuild")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(root, "witch_amd", "shim"), "bin/hmmbuild"], check=True, stdout=subprocess.DEVNULL)
+    for case, mol in (("dna_fragments", "dna"), ("amino_mixed", "amino"), ("rna_small", "rna")):
+        out = tmp_path / ("hmmbuild.model.%s" % case)
+        afa = os.path.join(GOLD, "hmmbuild_cases", case + ".afa")
+        cmd = [exe, "--cpu", "1", "--" + mol, "--ere", "0.59", "--symfrac", "0.0", "--informat", "afa", "-o", "/dev/null", str(out), afa]
+        subprocess.run(cmd, check=True)
+        text = out.read_text()
+        assert_same(text, read(os.path.join(GOLD, "hmmbuild_cases", case + ".hmm")), case)
+        assert "NAME  %s\n" % case in text
+    r = subprocess.run([exe, "--dna", "--wblosum", "x", "y"], capture_output=True, text=True)
+    assert r.returncode != 0 and "not supported" in r.stderr
+    r = subprocess.run([exe, "--ere", "0.59", str(tmp_path / "o"), os.path.join(GOLD, "hmmbuild_cases", "dna_single.afa")], capture_output=True, text=True)
+    assert r.returncode != 0 and "required" in r.stderr

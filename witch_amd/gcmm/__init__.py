@@ -13,6 +13,7 @@ behaviour and serve their answers from that precomputed table:
     alignSubQueriesNew  witch_msa/gcmm/aligner.py:350-538 (weighted consensus DP on the GPU)
     mergeAlignmentsCollapsed  witch_msa/gcmm/merger.py:40-131 (final transitive merge, closed form)
     callback_queryAlignment / readCheckpointAlignments  witch_msa/gcmm/callback.py:9-29, loader.py:95-150 (checkpoint file)
+    subset_alignment_and_hmmbuild / build_ehmm  witch_msa/gcmm/algorithm.py:394-477 (the model of a subset, without hmmbuild)
 
 INTEGRATION.md shows the three-line change in witch_msa/gcmm/gcmm.py that installs them.
 """
@@ -24,3 +25,4 @@ from .algorithm import search, check_query_names, divide_to_equal_chunks, num_ch
 from .merge import alignSubQueriesNew, compressInsertions, trace_to_string  # noqa: F401
 from .merger import mergeAlignmentsCollapsed  # noqa: F401
 from .checkpoint import callback_queryAlignment, readCheckpointAlignments, writeCheckpointAlignments  # noqa: F401
+from .hmmbuild import subset_alignment_and_hmmbuild, build_ehmm, hmmbuild_text  # noqa: F401

@@ -174,6 +174,16 @@ wh_ehmm *wh_ehmm_load(const char *const *hmm_paths, const int32_t *hmm_index, co
     d.bw_off = (int64_t)tables.size(); tables.insert(tables.end(), bw.begin(), bw.end());
     d.em_off = (int64_t)tables.size(); tables.insert(tables.end(), em.begin(), em.end());
     {
+      // node-major float32 odds of the canonical residues: the resolver's null2-by-trace reads the K values of ONE
+      // node together (one lane per sampled position), not K lane-blocked arrays
+      tables.resize((tables.size() + 3) / 4 * 4, 0.f);          // 16-byte aligned: the rows are read as float4
+      d.emn_off = (int64_t)tables.size();
+      tables.resize(tables.size() + (size_t)(h.M + 1) * h.K, 0.f);
+      float *emn = tables.data() + d.emn_off;
+      for (int k = 1; k <= h.M; k++)
+        for (int x = 0; x < h.K; x++) emn[(size_t)k * h.K + x] = (float)h.odds[(size_t)x * (h.M + 1) + k];
+    }
+    {
       std::vector<double> gfw, gem;
       build_tables_f64(h, Q, gfw, gem);
       d.gfw_off = (int64_t)gtab.size(); gtab.insert(gtab.end(), gfw.begin(), gfw.end());
@@ -491,7 +501,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       for (auto &kv : e->by_q) Qmax = std::max(Qmax, kv.first);
       ResolveArgs r;
       memset(&r, 0, sizeof r);
-      r.hmms = (const DevHMM *)e->d_hmms.p; r.gtab = (const double *)e->d_gtab.p;
+      r.hmms = (const DevHMM *)e->d_hmms.p; r.gtab = (const double *)e->d_gtab.p; r.ftab = (const float *)e->d_tables.p;
       r.residues = d_residues; r.offsets = d_offsets;
       r.recs = (const ResolveRec *)e->d_rrecs.p; r.count = d_rcount; r.rec_cap = (int)(nq * (int64_t)e->hmms.size());
       r.counter = d_rwork;
@@ -520,7 +530,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       rlaunches++;
       e->last_resolved = n_multi;
       if (r.stats) {
-        unsigned long long st[8];
+        unsigned long long st[12];
         HIPCHK(hipMemcpyAsync(st, r.stats, sizeof st, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         const double tot = (double)(st[0] + st[1] + st[2] + st[3] + st[4]);
@@ -528,6 +538,9 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
                 100.0 * st[0] / tot, 100.0 * st[1] / tot, 100.0 * st[2] / tot, 100.0 * st[3] / tot, 100.0 * st[4] / tot, tot / n_multi);
         fprintf(stderr, "[wh]   inside the traces: decision fetches %.1f%%  E-state choice %.1f%%  null2/accumulators/segments %.1f%%  (of the trace cycles)\n",
                 100.0 * st[5] / (double)st[1], 100.0 * st[6] / (double)st[1], 100.0 * st[7] / (double)st[1]);
+        fprintf(stderr, "[wh]   per multidomain region and trace: %.1f fetches of M runs, %.1f of D runs, %.1f of flank (C/J) runs, %.1f single I steps; %.0f cycles per fetch\n",
+                st[8] / (200.0 * n_multi), st[9] / (200.0 * n_multi), st[10] / (200.0 * n_multi), st[11] / (200.0 * n_multi),
+                (double)st[5] / (double)std::max<unsigned long long>(1, st[8] + st[9] + st[10]));
       }
     }
   }

@@ -49,6 +49,7 @@ struct DevHMM {
   int32_t M, Q, Mpad, K, Kp, nseq, index, qclass;
   int64_t fw_off, bw_off, em_off;    // offsets (in floats) into the table buffer
   int64_t gfw_off, gem_off;          // offsets (in doubles) into the float64 table buffer of the resolver
+  int64_t emn_off;                   // node-major float32 emission odds [M+1][K] in the float table buffer (resolver: null2 by trace)
 };
 
 enum { FW_A = 0, FW_B, FW_C, FW_E, FW_MI, FW_II, FW_D1, FW_D2, FW_NARR, FW_P = FW_NARR };

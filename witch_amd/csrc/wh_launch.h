@@ -63,6 +63,7 @@ hipError_t launch_score7b(int Q, const ScoreArgs &a, int blocks, int threads, si
 struct ResolveArgs {
   const DevHMM *hmms;
   const double *gtab;          // float64 tables of every model (DevHMM::gfw_off / gem_off)
+  const float *ftab;           // float32 table buffer (DevHMM::emn_off: node-major emission odds)
   const uint8_t *residues;
   const int64_t *offsets;
   const ResolveRec *recs;

@@ -315,6 +315,7 @@ __global__ __launch_bounds__(64, WH_RES_OCC) void resolve_kernel(ResolveArgs a) 
     const DevHMM hm = a.hmms[rec.h];
     GModel m;
     m.tf = a.gtab + hm.gfw_off; m.te = a.gtab + hm.gem_off;
+    const float *emn = a.ftab + hm.emn_off;
     m.Q = __builtin_amdgcn_readfirstlane(hm.Q); m.M = __builtin_amdgcn_readfirstlane(hm.M);
     GMx mx;
     mx.Q = m.Q; mx.rowlen = (size_t)3 * m.Q * 64 + xNSPEC;
@@ -366,6 +367,7 @@ __global__ __launch_bounds__(64, WH_RES_OCC) void resolve_kernel(ResolveArgs a) 
       if (rng.x == 0) rng.x = 42;
       const int Qs = ((m.M - 1) / 4 + 1) > 2 ? ((m.M - 1) / 4 + 1) : 2;     // HMMER's striping: vectors of 4 floats
       long long c_build = 0, c_e = 0, c_post = 0;
+      unsigned n_bm = 0, n_bd = 0, n_bf = 0, n_i = 0;     // WH_STATS: fetches of M / D / flank (C, J) runs, scalar I steps
       // lane t's jump of esl_random's LCG by t+1 steps: x_{n+t+1} = lcgA * x_n + lcgC (mod 2^32)
       unsigned lcgA = 1u, lcgC = 0u;
       for (int u = 0; u < 64; u++) if (u <= lane) { lcgA *= 69069u; lcgC = lcgC * 69069u + 1u; }
@@ -441,7 +443,7 @@ __global__ __launch_bounds__(64, WH_RES_OCC) void resolve_kernel(ResolveArgs a) 
                 cont = s0 == stD ? (run_c == 1 && kt >= 1) : (run_c == 0 && it >= 1);
               }
               run_cont = __ballot(cont);
-              if (a.stats) c_build += __builtin_readcyclecounter() - tb0;
+              if (a.stats) { c_build += __builtin_readcyclecounter() - tb0; if (s0 == stM) n_bm++; else if (s0 == stD) n_bd++; else n_bf++; }
             }
             {
               // the leading decisions of the run that stay in its state, all at once
@@ -483,6 +485,7 @@ __global__ __launch_bounds__(64, WH_RES_OCC) void resolve_kernel(ResolveArgs a) 
           } else
           switch (s0) {
             case stI:
+              n_i++;
               path[0] = mx.cellc(i - 1, k, 0) * m.t(gMI, k);
               path[1] = mx.cellc(i - 1, k, 1) * m.t(gII, k);
               s1 = __builtin_amdgcn_readfirstlane(rng_choose(rng, path, 2)) == 0 ? stM : stI;
@@ -579,14 +582,36 @@ __global__ __launch_bounds__(64, WH_RES_OCC) void resolve_kernel(ResolveArgs a) 
         for (int d = 0; d < ndom; d++) {
           const int df = dom[4 * d], dt = dom[4 * d + 1], Ld = dt - df + 1;
           float mine = 1.0f;
-          for (int x = 0; x < a.K; x++) {
-            float s = 0.f;
-            for (int pos = df + lane; pos <= dt; pos += 64) {
-              const int kk = stk[pos];
-              s += kk > 0 ? (float)m.te[((size_t)x * m.Q + (kk - 1) % m.Q) * 64 + (kk - 1) / m.Q] : 1.0f;
+          // one lane per sampled position: the K odds of its emitting node are contiguous (node-major float
+          // copy, DevHMM::emn_off), summed per residue in registers, then K wave sums
+          float part[20];
+#pragma unroll
+          for (int x = 0; x < 20; x++) part[x] = 0.f;
+          for (int pos = df + lane; pos <= dt; pos += 64) {
+            const int kk = stk[pos];
+            if (kk > 0) {
+              const float *en = emn + (size_t)kk * a.K;
+              if (a.K == 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(en);
+                part[0] += v.x; part[1] += v.y; part[2] += v.z; part[3] += v.w;
+              } else {
+#pragma unroll
+                for (int x4 = 0; x4 < 5; x4++) {
+                  const float4 v = *reinterpret_cast<const float4 *>(en + 4 * x4);
+                  part[4 * x4] += v.x; part[4 * x4 + 1] += v.y; part[4 * x4 + 2] += v.z; part[4 * x4 + 3] += v.w;
+                }
+              }
+            } else {
+#pragma unroll
+              for (int x = 0; x < 20; x++) part[x] += 1.0f;
             }
-            s = wave_sum_f(s);
-            if (lane == x) mine = s / (float)Ld;
+          }
+#pragma unroll
+          for (int x = 0; x < 20; x++) {
+            if (x < a.K) {
+              const float s = wave_sum_f(part[x]);
+              if (lane == x) mine = s / (float)Ld;
+            }
           }
           __builtin_amdgcn_wave_barrier();
           if (lane < a.K) dnull[32 * d + lane] = mine;
@@ -619,7 +644,10 @@ __global__ __launch_bounds__(64, WH_RES_OCC) void resolve_kernel(ResolveArgs a) 
         __builtin_amdgcn_wave_barrier();
         if (a.stats) c_post += __builtin_readcyclecounter() - tp0;
       }
-      if (a.stats && lane == 0) { atomicAdd(a.stats + 5, (unsigned long long)c_build); atomicAdd(a.stats + 6, (unsigned long long)c_e); atomicAdd(a.stats + 7, (unsigned long long)c_post); }
+      if (a.stats && lane == 0) {
+        atomicAdd(a.stats + 5, (unsigned long long)c_build); atomicAdd(a.stats + 6, (unsigned long long)c_e); atomicAdd(a.stats + 7, (unsigned long long)c_post);
+        atomicAdd(a.stats + 8, (unsigned long long)n_bm); atomicAdd(a.stats + 9, (unsigned long long)n_bd); atomicAdd(a.stats + 10, (unsigned long long)n_bf); atomicAdd(a.stats + 11, (unsigned long long)n_i);
+      }
       RTICK(1);
       for (int pos = 1 + lane; pos <= Lr; pos += 64) n2sc[ireg + pos - 1] = logf(acc[pos] / (float)kSamples);
       wave_mem_sync();

@@ -371,10 +371,15 @@ extern "C" int wh_hmmbuild(const char *molecule, int32_t nseq, int64_t alen, con
   // ---- 5. effective sequence number
   const Prior pri = prior_for(K);
   const double etarget = std::max(ere, (45.0 - std::log2(2.0 / ((double)M * (double)(M + 1)))) / (double)M);
+  // (only the match emissions enter the relative entropy: the transition and insert estimates of HMMER's
+  // target function are not needed to evaluate it)
+  Model h2;
+  h2.M = M; h2.K = K;
   auto target_f = [&](double neff) {
-    Model h2 = cnt;
-    scale_model(h2, neff / (double)nseq);
-    parameter_estimation(h2, pri);
+    const float sc = (float)(neff / (double)nseq);
+    h2.mat = cnt.mat;
+    for (float &v : h2.mat) v *= sc;
+    for (int k = 1; k <= M; k++) mp_parameters(&h2.mat[(size_t)k * K], K, pri.em, &h2.mat[(size_t)k * K]);
     return mean_match_relent(h2, abc.bg) - etarget;
   };
   double neff = (double)nseq;

@@ -79,7 +79,7 @@ struct wh_ehmm {
   int last_resolved = 0;                    // pairs the resolver finished in the last wh_score call
   // staging for the host-pointer entry points
   DevBuf s_res, s_off, s_deci, s_flags, s_fwd, s_det, s_idx, s_w, s_nk, s_nu, s_pq, s_ph, s_co, s_cols, s_pos;
-  DevBuf d_qorder, d_order, d_items, d_recs, d_spec, d_back, d_cwj, d_cwv, d_cwn, c_buf[10];
+  DevBuf d_rkeys, d_rorder, d_qorder, d_order, d_items, d_recs, d_spec, d_back, d_cwj, d_cwv, d_cwn, c_buf[10];
   uint32_t degen[32];
   bool timing = false;
   KernelTimer timers[5];
@@ -129,7 +129,7 @@ void wh_ehmm_free(wh_ehmm *e) {
   if (!e) return;
   for (DevBuf *b : {&e->d_gtab, &e->d_rrecs, &e->d_rmx, &e->d_rsegs, &e->d_hmms, &e->d_tables, &e->d_nseq, &e->d_index, &e->d_lists, &e->d_counter, &e->d_scratch,
                     &e->s_res, &e->s_off, &e->s_deci, &e->s_flags, &e->s_fwd, &e->s_det, &e->s_idx, &e->s_w,
-                    &e->s_nk, &e->s_nu, &e->s_pq, &e->s_ph, &e->s_co, &e->s_cols, &e->s_pos, &e->d_qorder, &e->d_order, &e->d_items, &e->d_recs, &e->d_spec, &e->d_back, &e->d_cwj, &e->d_cwv, &e->d_cwn,
+                    &e->s_nk, &e->s_nu, &e->s_pq, &e->s_ph, &e->s_co, &e->s_cols, &e->s_pos, &e->d_rkeys, &e->d_rorder, &e->d_qorder, &e->d_order, &e->d_items, &e->d_recs, &e->d_spec, &e->d_back, &e->d_cwj, &e->d_cwv, &e->d_cwn,
                     &e->c_buf[0], &e->c_buf[1], &e->c_buf[2], &e->c_buf[3], &e->c_buf[4], &e->c_buf[5], &e->c_buf[6],
                     &e->c_buf[7], &e->c_buf[8], &e->c_buf[9]})
     b->release();
@@ -507,6 +507,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       r.counter = d_rwork;
       r.Lcap = Lc; r.Mmax = e->max_M;
       r.mx_stride = (size_t)(Lc + 2) * ((size_t)3 * Qmax * kWave + 8) + (size_t)(Lc + 2) * 65;   // matrix rows + the E-state row cache
+      r.mx_stride = (r.mx_stride + 1) & ~(size_t)1;      // every wave's slab 16-byte aligned: the Forward sweep moves node pairs
       r.seg_cap = resolve_seg_cap();
       r.seg_stride = resolve_seg_ints(Lc, e->max_M);
       r.decibits = d_decibits; r.flags = d_flags; r.detail = d_detail;
@@ -517,6 +518,23 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
         if (e->d_recs.ensure(128)) return WH_ENOMEM;
         HIPCHK(hipMemsetAsync(e->d_recs.p, 0, 128, s));
         r.stats = (unsigned long long *)e->d_recs.p;
+      }
+      // Longest pairs first: a wave gets only a handful of pairs (8 412 pairs over 2 048 waves on the reference's
+      // example data) and their costs differ several-fold, so the order of the queue decides the tail of the launch.
+      r.order = nullptr;
+      if (n_multi > 1 && n_multi < 32 * e->cu_count * resolve_waves_per_cu()) {      // (with 32+ pairs per wave the order no longer matters)
+        if (e->d_rkeys.ensure(sizeof(float) * (size_t)n_multi) || e->d_rorder.ensure(sizeof(int32_t) * (size_t)n_multi)) return WH_ENOMEM;
+        hipError_t kerr = launch_resolve_keys(r.recs, n_multi, r.hmms, (float *)e->d_rkeys.p, s);
+        if (kerr != hipSuccess) { set_error("resolve key kernel launch failed: %s", hipGetErrorString(kerr)); return WH_EHIP; }
+        std::vector<float> keys((size_t)n_multi);
+        HIPCHK(hipMemcpyAsync(keys.data(), e->d_rkeys.p, sizeof(float) * keys.size(), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        std::vector<int32_t> ord((size_t)n_multi);
+        for (int t = 0; t < n_multi; t++) ord[(size_t)t] = t;
+        std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) { return keys[(size_t)x] > keys[(size_t)y]; });
+        HIPCHK(hipMemcpyAsync(e->d_rorder.p, ord.data(), sizeof(int32_t) * ord.size(), hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));     // ord is a local
+        r.order = (const int32_t *)e->d_rorder.p;
       }
       const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)resolve_waves_per_cu(), kLdsBudget / rlds));
       int blocks = std::min(n_multi, e->cu_count * per_cu);

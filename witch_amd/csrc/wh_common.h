@@ -63,7 +63,7 @@ int  choose_Q(int M);     // cells per lane for a model of M nodes, or -1 if uns
 void build_tables(const HostHMM &h, int Q, std::vector<float> &fw, std::vector<float> &bw,
                   std::vector<float> &em);
 // float64 tables of the multidomain resolver: 8 forward arrays and Kp emission rows, value of node
-// k = lane*Q + q + 1 at [(arr*Q + q)*64 + lane]
+// k = lane*Q + q + 1 at arr*Q*64 + ((q/2)*64 + lane)*2 + q%2 (the two nodes of a pair adjacent: 16-byte accesses)
 void build_tables_f64(const HostHMM &h, int Q, std::vector<double> &fw, std::vector<double> &em);
 
 }  // namespace wh

@@ -243,7 +243,8 @@ void build_tables(const HostHMM &h, int Q, std::vector<float> &fw, std::vector<f
 void build_tables_f64(const HostHMM &h, int Q, std::vector<double> &fw, std::vector<double> &em) {
   enum { tMM = 0, tMI, tMD, tIM, tII, tDM, tDD };
   const int M = h.M, Mpad = Q * kWave;
-  auto at = [&](int arr, int k) -> size_t { return ((size_t)arr * Q + (k - 1) % Q) * kWave + (k - 1) / Q; };
+  // nodes 2j, 2j+1 of a lane adjacent inside every array (wh_resolve.hip ofs2: one 16-byte access per pair)
+  auto at = [&](int arr, int k) -> size_t { const int q = (k - 1) % Q, ln = (k - 1) / Q; return (size_t)arr * Q * kWave + ((((size_t)(q >> 1) * kWave + ln) << 1) + (q & 1)); };
   fw.assign((size_t)8 * Mpad, 0.0);
   em.assign((size_t)h.Kp * Mpad, 0.0);
   for (int k = 1; k <= M; k++) {

@@ -67,6 +67,7 @@ struct ResolveArgs {
   const uint8_t *residues;
   const int64_t *offsets;
   const ResolveRec *recs;
+  const int32_t *order;        // queue positions in descending cost order (longest pairs first), or NULL
   const int *count;            // number of queued pairs (device)
   int rec_cap;
   int *counter;                // work-queue head
@@ -85,6 +86,8 @@ struct ResolveArgs {
   int dbg;                     // WH_RDBG > 0: print the first <dbg> sampled segments and the cluster statistics of every region
 };
 hipError_t launch_resolve(const ResolveArgs &a, int blocks, size_t lds, hipStream_t s);
+// cost estimate of every queued pair (cells of its multidomain regions) for the longest-first order
+hipError_t launch_resolve_keys(const ResolveRec *recs, int n, const DevHMM *hmms, float *keys, hipStream_t s);
 size_t resolve_lds_bytes(int Lcap, int Mmax);
 int resolve_seg_cap();
 int resolve_waves_per_cu();

@@ -94,30 +94,44 @@ __device__ __forceinline__ GLen glen_config(int Lcfg, bool multihit) {
 struct GModel {
   const double *tf, *te;
   int Q, M;
-  __device__ __forceinline__ size_t at(int arr, int k) const { return ((size_t)arr * Q + (k - 1) % Q) * 64 + (k - 1) / Q; }
+  // node k = lane*Q + q + 1; inside an array the nodes 2j, 2j+1 of a lane are adjacent (ofs2 below)
+  __device__ __forceinline__ size_t at(int arr, int k) const { const int q = (k - 1) % Q, ln = (k - 1) / Q; return (size_t)arr * Q * 64 + ((((size_t)(q >> 1) * 64 + ln) << 1) + (q & 1)); }
   __device__ __forceinline__ double t(int arr, int k) const { return tf[at(arr, k)]; }
 };
 
-// The per-wave matrix slab: row i = [3 states][Q][64 lanes] doubles + xNSPEC specials.
+// The per-wave matrix slab: row i = [3 states][Q/2][64 lanes][2] doubles + xNSPEC specials.
 struct GMx {
   double *p;
   size_t rowlen;
   int Q;
   __device__ __forceinline__ double *row(int i) const { return p + (size_t)i * rowlen; }
   __device__ __forceinline__ double cell(int i, int k, int s) const {   // k = 0 reads as 0
-    return k <= 0 ? 0.0 : __builtin_nontemporal_load(p + (size_t)i * rowlen + ((size_t)s * Q + (k - 1) % Q) * 64 + (k - 1) / Q);
+    if (k <= 0) return 0.0;
+    const int q = (k - 1) % Q, ln = (k - 1) / Q;
+    return __builtin_nontemporal_load(p + (size_t)i * rowlen + (size_t)s * Q * 64 + ((((size_t)(q >> 1) * 64 + ln) << 1) + (q & 1)));
   }
   __device__ __forceinline__ double spec(int i, int s) const { return __builtin_nontemporal_load(p + (size_t)i * rowlen + (size_t)3 * Q * 64 + s); }
   // cached reads for the sampling walk: the matrix is complete and the vector L1 was invalidated after the fill
   // (wave_mem_sync); 200 traces revisit the same band of cells, which then stay in L1 / L2
   __device__ __forceinline__ double cellc(int i, int k, int s) const {
-    return k <= 0 ? 0.0 : p[(size_t)i * rowlen + ((size_t)s * Q + (k - 1) % Q) * 64 + (k - 1) / Q];
+    if (k <= 0) return 0.0;
+    const int q = (k - 1) % Q, ln = (k - 1) / Q;
+    return p[(size_t)i * rowlen + (size_t)s * Q * 64 + ((((size_t)(q >> 1) * 64 + ln) << 1) + (q & 1))];
   }
   __device__ __forceinline__ double specc(int i, int s) const { return p[(size_t)i * rowlen + (size_t)3 * Q * 64 + s]; }
 };
 
 // Forward sweep (A.2), float64.  STORE keeps every row (row i at slab row i), otherwise rows
 // alternate between slab rows 0 and 1.  Returns ln P in nats (Forward score).
+// Within one array of Q x 64 values, node (q, lane) sits at ofs2(q, lane): the two nodes 2j and 2j+1 of a lane are
+// adjacent, so the Forward sweep moves them with ONE 16-byte access (it is bound by the number of memory
+// instructions: 60 -> 30 per 4-node step).
+__device__ __forceinline__ size_t ofs2(int q, int lane) { return (((size_t)(q >> 1) * 64 + lane) << 1) + (q & 1); }
+typedef double d2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ d2_t nt_load_d2(const double *p) { return __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(p)); }
+__device__ __forceinline__ d2_t ld_d2(const double *p) { return *reinterpret_cast<const d2_t *>(p); }
+__device__ __forceinline__ void st_d2(double *p, double a, double b) { d2_t v = {a, b}; *reinterpret_cast<d2_t *>(p) = v; }
+
 template <bool STORE>
 __device__ double gforward(const GModel &m, const uint8_t *seq, int L, GLen c, const GMx &mx, int lane) {
   const int Q = m.Q;
@@ -131,7 +145,7 @@ __device__ double gforward(const GModel &m, const uint8_t *seq, int L, GLen c, c
   double pN = 1.0, pB = c.move, pJ = 0.0, pC = 0.0;
   // model-only part of the cross-lane D scan: A_r = (prod_{q>=1} D2_q) * D2_0 = product of the lane's D2
   double Alane = 1.0;
-  for (int q = 0; q < Q; q++) Alane *= m.tf[((size_t)gD2 * Q + q) * 64 + lane];
+  for (int q = 0; q < Q; q++) Alane *= m.tf[(size_t)gD2 * SQ + ofs2(q, lane)];
   for (int i = 1; i <= L; i++) {
     wave_mem_sync();    // row i-1 was written by other lanes of this wave
     const double *pr = mx.row(STORE ? i - 1 : (i - 1) & 1);
@@ -140,9 +154,10 @@ __device__ double gforward(const GModel &m, const uint8_t *seq, int L, GLen c, c
     // previous row at node k-1 for my first node: lane-1's last node
     double pm1 = 0.0, pi1 = 0.0, pd1 = 0.0;
     if (lane > 0) {
-      pm1 = __builtin_nontemporal_load(pr + (size_t)(Q - 1) * 64 + lane - 1);
-      pi1 = __builtin_nontemporal_load(pr + SQ + (size_t)(Q - 1) * 64 + lane - 1);
-      pd1 = __builtin_nontemporal_load(pr + 2 * SQ + (size_t)(Q - 1) * 64 + lane - 1);
+      const size_t ol = ofs2(Q - 1, lane - 1);
+      pm1 = __builtin_nontemporal_load(pr + ol);
+      pi1 = __builtin_nontemporal_load(pr + SQ + ol);
+      pd1 = __builtin_nontemporal_load(pr + 2 * SQ + ol);
     }
     double mprev = 0.0, dloc = 0.0, P = 1.0, esum = 0.0;
     // four nodes per step (Q is a multiple of 4): all loads of the step are issued before any of them is
@@ -150,32 +165,42 @@ __device__ double gforward(const GModel &m, const uint8_t *seq, int L, GLen c, c
     for (int q0 = 0; q0 < Q; q0 += 4) {
       double pM[4], pI[4], pD[4], tA[4], tB[4], tC[4], tE[4], tMI[4], tII[4], tD1[4], tD2[4], em[4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const size_t o = (size_t)(q0 + u) * 64 + lane;
-        pM[u] = __builtin_nontemporal_load(pr + o); pI[u] = __builtin_nontemporal_load(pr + SQ + o); pD[u] = __builtin_nontemporal_load(pr + 2 * SQ + o);
-        tA[u] = m.tf[gA * SQ + o]; tB[u] = m.tf[gB * SQ + o]; tC[u] = m.tf[gC * SQ + o]; tE[u] = m.tf[gE * SQ + o];
-        tMI[u] = m.tf[gMI * SQ + o]; tII[u] = m.tf[gII * SQ + o]; tD1[u] = m.tf[gD1 * SQ + o]; tD2[u] = m.tf[gD2 * SQ + o];
-        em[u] = od[o];
+      for (int u2 = 0; u2 < 2; u2++) {
+        const size_t o = ofs2(q0 + 2 * u2, lane);
+        const d2_t vM = nt_load_d2(pr + o), vI = nt_load_d2(pr + SQ + o), vD = nt_load_d2(pr + 2 * SQ + o);
+        const d2_t vA = ld_d2(m.tf + gA * SQ + o), vB = ld_d2(m.tf + gB * SQ + o), vC = ld_d2(m.tf + gC * SQ + o), vE = ld_d2(m.tf + gE * SQ + o);
+        const d2_t vMI = ld_d2(m.tf + gMI * SQ + o), vII = ld_d2(m.tf + gII * SQ + o), vD1 = ld_d2(m.tf + gD1 * SQ + o), vD2 = ld_d2(m.tf + gD2 * SQ + o);
+        const d2_t vem = ld_d2(od + o);
+        pM[2 * u2] = vM.x; pM[2 * u2 + 1] = vM.y; pI[2 * u2] = vI.x; pI[2 * u2 + 1] = vI.y; pD[2 * u2] = vD.x; pD[2 * u2 + 1] = vD.y;
+        tA[2 * u2] = vA.x; tA[2 * u2 + 1] = vA.y; tB[2 * u2] = vB.x; tB[2 * u2 + 1] = vB.y; tC[2 * u2] = vC.x; tC[2 * u2 + 1] = vC.y;
+        tE[2 * u2] = vE.x; tE[2 * u2 + 1] = vE.y; tMI[2 * u2] = vMI.x; tMI[2 * u2 + 1] = vMI.y; tII[2 * u2] = vII.x; tII[2 * u2 + 1] = vII.y;
+        tD1[2 * u2] = vD1.x; tD1[2 * u2 + 1] = vD1.y; tD2[2 * u2] = vD2.x; tD2[2 * u2 + 1] = vD2.y;
+        em[2 * u2] = vem.x; em[2 * u2 + 1] = vem.y;
       }
+      double oM[4], oI[4], oD[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const int q = q0 + u;
-        const size_t o = (size_t)q * 64 + lane;
         const double mm = em[u] * (pm1 * tA[u] + pi1 * tB[u] + pd1 * tC[u] + pB * tE[u]);
         const double ins = pM[u] * tMI[u] + pI[u] * tII[u];
         // D chain inside the lane with nothing entering from the left (the entering value is added below)
         dloc = q > 0 ? mprev * tD1[u] + dloc * tD2[u] : 0.0;
         if (q > 0) P *= tD2[u];
-        cr[o] = mm; cr[SQ + o] = ins; cr[2 * SQ + o] = dloc;
+        oM[u] = mm; oI[u] = ins; oD[u] = dloc;
         esum += mm;
         pm1 = pM[u]; pi1 = pI[u]; pd1 = pD[u]; mprev = mm;
+      }
+#pragma unroll
+      for (int u2 = 0; u2 < 2; u2++) {
+        const size_t o = ofs2(q0 + 2 * u2, lane);
+        st_d2(cr + o, oM[2 * u2], oM[2 * u2 + 1]); st_d2(cr + SQ + o, oI[2 * u2], oI[2 * u2 + 1]); st_d2(cr + 2 * SQ + o, oD[2 * u2], oD[2 * u2 + 1]);
       }
     }
     // cross-lane: Dlast(r) = [dloc_last + P * D1_0 * Mlast(r-1)] + [P * D2_0] * Dlast(r-1)
     // (shuffles stay outside conditionals: a lane that skips a ds_bpermute does not lend its value)
     const double mup = shfl_up_d(mprev, 1);
     const double mleft = lane > 0 ? mup : 0.0;
-    const double d10 = m.tf[gD1 * SQ + lane], d20 = m.tf[gD2 * SQ + lane];
+    const double d10 = m.tf[gD1 * SQ + ofs2(0, lane)], d20 = m.tf[gD2 * SQ + ofs2(0, lane)];
     double Bv = dloc + P * d10 * (lane > 0 ? mleft : 0.0), Av = Alane;
     for (int d = 1; d < 64; d <<= 1) {
       const double Bo = shfl_up_d(Bv, d), Ao = shfl_up_d(Av, d);
@@ -188,26 +213,27 @@ __device__ double gforward(const GModel &m, const uint8_t *seq, int L, GLen c, c
     for (int q0 = 0; q0 < Q; q0 += 4) {
       double dl[4], t2[4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const size_t o = (size_t)(q0 + u) * 64 + lane;
-        dl[u] = __builtin_nontemporal_load(cr + 2 * SQ + o);
-        t2[u] = m.tf[gD2 * SQ + o];
+      for (int u2 = 0; u2 < 2; u2++) {
+        const size_t o = ofs2(q0 + 2 * u2, lane);
+        const d2_t vd = nt_load_d2(cr + 2 * SQ + o), vt = ld_d2(m.tf + gD2 * SQ + o);
+        dl[2 * u2] = vd.x; dl[2 * u2 + 1] = vd.y; t2[2 * u2] = vt.x; t2[2 * u2 + 1] = vt.y;
       }
+      double dv[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        const size_t o = (size_t)(q0 + u) * 64 + lane;
         if (q0 + u > 0) Pq *= t2[u];
-        const double dv = dl[u] + Pq * c0;
-        cr[2 * SQ + o] = dv;
-        esum += dv;
+        dv[u] = dl[u] + Pq * c0;
+        esum += dv[u];
       }
+#pragma unroll
+      for (int u2 = 0; u2 < 2; u2++) st_d2(cr + 2 * SQ + ofs2(q0 + 2 * u2, lane), dv[2 * u2], dv[2 * u2 + 1]);
     }
     double xe = wave_sum_d(esum);
     double xn = pN * c.loop, xc = pC * c.loop + xe * c.EC, xj = pJ * c.loop + xe * c.EJ, lsd = 0.0;
     if (xe > kRescaleHi) {
       const double r = 1.0 / xe;
       for (int q = 0; q < Q; q++) {
-        const size_t o = (size_t)q * 64 + lane;
+        const size_t o = (size_t)q * 64 + lane;      // every entry of the row once, in any order
         cr[o] = __builtin_nontemporal_load(cr + o) * r; cr[SQ + o] = __builtin_nontemporal_load(cr + SQ + o) * r; cr[2 * SQ + o] = __builtin_nontemporal_load(cr + 2 * SQ + o) * r;
       }
       xn *= r; xc *= r; xj *= r; lsd = log(xe); ls += lsd; xe = 1.0;
@@ -311,7 +337,7 @@ __global__ __launch_bounds__(64, WH_RES_OCC) void resolve_kernel(ResolveArgs a) 
     // By value: with a reference into the queue AND the LDS lists below, this toolchain produced a kernel that
     // read a garbage record (out-of-slab writes); either alone was fine.  Record fields are range-checked below
     // and the sampling loop is bounded, so a bad record can no longer run the wave out of its slab.
-    const ResolveRec rec = a.recs[item];
+    const ResolveRec rec = a.recs[a.order ? a.order[item] : item];
     const DevHMM hm = a.hmms[rec.h];
     GModel m;
     m.tf = a.gtab + hm.gfw_off; m.te = a.gtab + hm.gem_off;
@@ -854,6 +880,24 @@ __global__ __launch_bounds__(64, WH_RES_OCC) void resolve_kernel(ResolveArgs a) 
     }
     if (lane == 0) { a.decibits[out] = decibits; a.flags[out] = (uint8_t)flags; }
   }
+}
+
+// One thread per queued pair: the cells of its multidomain regions (region length x model length), the
+// quantity the Forward fill, the walk and the envelope rescoring all scale with.
+__global__ void resolve_keys_kernel(const ResolveRec *recs, int n, const DevHMM *hmms, float *keys) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const ResolveRec &r = recs[t];
+  const int ne = r.nenv < 0 ? 0 : r.nenv > WH_MAX_ENVELOPES ? WH_MAX_ENVELOPES : r.nenv;
+  float cost = 0.f;
+  for (int e = 0; e < ne; e++)
+    if ((r.multi_mask >> e) & 1) cost += (float)(r.rj[e] - r.ri[e] + 1);
+  keys[t] = cost * (float)hmms[r.h].M;
+}
+
+hipError_t launch_resolve_keys(const ResolveRec *recs, int n, const DevHMM *hmms, float *keys, hipStream_t s) {
+  hipLaunchKernelGGL(resolve_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, s, recs, n, hmms, keys);
+  return hipGetLastError();
 }
 
 hipError_t launch_resolve(const ResolveArgs &a, int blocks, size_t lds, hipStream_t s) {

@@ -90,6 +90,27 @@ def main():
     rows[3] = ["-"] * 2 + rows[3][2:20] + ["-"] * 30      # fragment starting at column 3
     rows[4] = ["-"] * 35 + rows[4][35:50]                 # fragment at the right end
     cases["dna_fragment_edges"] = ("dna", rows)
+    # 8. randomised alignments: random gap runs, fragments, degenerate codes and case, all three alphabets
+    deg = {"dna": "RYMKSWHBVDN", "rna": "RYMKSWHBVDN", "amino": "BJZOUX"}
+    alpha = {"dna": "ACGT", "rna": "ACGU", "amino": aa}
+    for t in range(12):
+        mol = ("dna", "rna", "amino")[t % 3]
+        n, L = int(rng.integers(2, 24)), int(rng.integers(12, 70))
+        rows = family(rng, alpha[mol], n, L, float(rng.uniform(0.02, 0.4)))
+        for r in rows:
+            for _ in range(int(rng.integers(0, 4))):                    # interior gap runs
+                a = int(rng.integers(0, L)); b = min(L, a + int(rng.integers(1, 6)))
+                r[a:b] = ["-"] * (b - a)
+            if rng.random() < 0.35:                                      # fragment: keep a random window
+                a = int(rng.integers(0, L - 3)); b = min(L, a + int(rng.integers(3, L)))
+                r[:a] = ["-"] * a; r[b:] = ["-"] * (L - b)
+            for _ in range(int(rng.integers(0, 3))):
+                r[int(rng.integers(0, L))] = deg[mol][int(rng.integers(len(deg[mol])))]
+            if rng.random() < 0.3:
+                r[:] = [c.lower() for c in r]
+        if all(c == "-" for r in rows for c in r[:1]):
+            rows[0][0] = alpha[mol][0]
+        cases["random_%02d_%s" % (t, mol)] = (mol, rows)
     for name, (mol, rows) in cases.items():
         afa = os.path.join(OUT, name + ".afa")
         with open(afa, "w") as f:

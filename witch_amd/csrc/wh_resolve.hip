@@ -530,17 +530,16 @@ __global__ __launch_bounds__(64, WH_RES_OCC) void resolve_kernel(ResolveArgs a) 
               };
               // The chunk prefix sums of a row are the same for every trace that ends a domain there: computed once per
               // row and kept in the slab, a hit replaces the pass over the 2M cells by one coalesced 512-byte read.
-              double incl;
-              if (__builtin_nontemporal_load(ecache + (size_t)i * 65 + 64) != 0.0) {
-                incl = __builtin_nontemporal_load(ecache + (size_t)i * 65 + lane);
-              } else {
+              // (the line is requested together with its valid flag: one round trip on a hit, a harmless read on a miss)
+              double incl = __builtin_nontemporal_load(ecache + (size_t)i * 65 + lane);
+              if (__builtin_nontemporal_load(ecache + (size_t)i * 65 + 64) == 0.0) {
                 double mine = 0.0;
-                for (int pb = p0; pb < p1; pb += 8) {          // eight loads in flight per step
-                  double tv[8];
+                for (int pb = p0; pb < p1; pb += 16) {         // sixteen loads in flight per step
+                  double tv[16];
 #pragma unroll
-                  for (int u = 0; u < 8; u++) tv[u] = pb + u < p1 ? term(pb + u) : 0.0;
+                  for (int u = 0; u < 16; u++) tv[u] = pb + u < p1 ? term(pb + u) : 0.0;
 #pragma unroll
-                  for (int u = 0; u < 8; u++) mine += tv[u];
+                  for (int u = 0; u < 16; u++) mine += tv[u];
                 }
                 incl = mine;
                 for (int d = 1; d < 64; d <<= 1) { const double o = shfl_up_d(incl, d); if (lane >= d) incl += o; }
@@ -557,9 +556,12 @@ __global__ __launch_bounds__(64, WH_RES_OCC) void resolve_kernel(ResolveArgs a) 
                 const int src = __ffsll((long long)hit) - 1;
                 const int c0p = __shfl(p0, src), c1p = __shfl(p1, src);
                 double base = shfl_d(excl, src);
+                // (a chunk holds at most 2 x 64 terms for models of up to 4096 nodes: both halves are requested at once)
+                const double tvA = c0p + lane < c1p ? term(c0p + lane) : 0.0;
+                const double tvB = c0p + 64 + lane < c1p ? term(c0p + 64 + lane) : 0.0;
                 for (int pb = c0p; pb < c1p && found_p < 0; pb += 64) {
                   const int p = pb + lane;
-                  const double tv = p < c1p ? term(p) : 0.0;
+                  const double tv = pb == c0p ? tvA : pb == c0p + 64 ? tvB : (p < c1p ? term(p) : 0.0);
                   double run = tv;
                   for (int d = 1; d < 64; d <<= 1) { const double o = shfl_up_d(run, d); if (lane >= d) run += o; }
                   const unsigned long long h2 = __ballot(p < c1p && roll < base + run);

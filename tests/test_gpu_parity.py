@@ -905,7 +905,8 @@ def test_single_pair_launches_match_the_batch(orc):
     e.close()
 
 
-def test_end_to_end_example_against_the_reference_pipeline(tmp_path):
+@pytest.mark.parametrize("ehmm_source", ["hmmbuild_files", "wh_hmmbuild"])
+def test_end_to_end_example_against_the_reference_pipeline(tmp_path, ehmm_source):
     """north_star: "identical final merged alignment".  The reference's example data (500-row backbone of
     2574 columns, 500 fragments) against a 15-HMM eHMM of the backbone: the GPU chain
     score -> top-k -> align -> consensus -> transitive merge writes the two FASTA files the reference's own
@@ -929,6 +930,23 @@ def test_end_to_end_example_against_the_reference_pipeline(tmp_path):
     bpath = str(tmp_path / "backbone.fasta")
     with gzip.open(os.path.join(case.dir, "backbone.fasta.gz"), "rt") as f, open(bpath, "w") as o:
         o.write(f.read())
+    if ehmm_source == "wh_hmmbuild":
+        # NO HMMER anywhere: the eHMM itself comes from wh_hmmbuild, built from the reduced subset
+        # alignments as the reference builds them, with the tuples it returns
+        from witch_amd import synth
+        names, rows = [], []
+        for line in open(bpath):
+            line = line.strip()
+            if line.startswith(">"):
+                names.append(line[1:].split()[0]); rows.append("")
+            elif line:
+                rows[-1] += line
+        subs = synth.bfs_subsets(len(rows), len(case.hmm_index))
+        built = gcmm.build_ehmm(names, rows, [("A_0_%d" % i, list(range(lo, hi))) for i, (lo, hi) in enumerate(subs)],
+                                "dna", str(tmp_path / "tree_decomp"))
+        index_to_hmm = {i: _Sub(b[0], n) for i, b, n in zip(case.hmm_index, built, case.nseq)}
+        retained = {i: list(b[2]) for i, b in zip(case.hmm_index, built)}
+        nongaps = {i: list(b[3]) for i, b in zip(case.hmm_index, built)}
     eng = gcmm.install(gcmm.QueryAlignmentEngine.run(
         index_to_hmm, list(zip(case.qnames, case.qseqs)), case.k,
         subset_to_retained_columns=retained, subset_to_nongaps_per_column=nongaps, backbone_length=B))

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <array>
 #include <cstdio>
 #include <cstdlib>
@@ -151,44 +153,63 @@ wh_ehmm *wh_ehmm_load(const char *const *hmm_paths, const int32_t *hmm_index, co
   std::vector<float> tables;
   std::vector<double> gtab;
   e->dev.resize((size_t)n);
+  // Parsing the text files and laying out the tables is host work per model (a few ms per 1 500-node model):
+  // done on a small thread pool, then concatenated in model order so that the buffers do not depend on timing.
+  struct Built { int rc = WH_OK; std::string err; int Q = -1; std::vector<float> fw, bw, em, emn; std::vector<double> gfw, gem; };
+  std::vector<Built> built((size_t)n);
+  {
+    std::atomic<int> next{0};
+    auto work = [&]() {
+      for (;;) {
+        const int i = next.fetch_add(1);
+        if (i >= n) break;
+        HostHMM &h = e->hmms[(size_t)i];
+        Built &b = built[(size_t)i];
+        if (parse_hmm_file(hmm_paths[i], h) != WH_OK) { b.rc = WH_EIO; b.err = last_error(); continue; }
+        h.index = hmm_index ? hmm_index[i] : i;
+        if (nseq) h.nseq = nseq[i];
+        b.Q = choose_Q(h.M);
+        if (b.Q < 0) continue;
+        build_tables(h, b.Q, b.fw, b.bw, b.em);
+        // node-major float32 odds of the canonical residues: the resolver's null2-by-trace reads the K values of ONE
+        // node together (one lane per sampled position), not K lane-blocked arrays
+        b.emn.assign((size_t)(h.M + 1) * h.K, 0.f);
+        for (int k = 1; k <= h.M; k++)
+          for (int x = 0; x < h.K; x++) b.emn[(size_t)k * h.K + x] = (float)h.odds[(size_t)x * (h.M + 1) + k];
+        build_tables_f64(h, b.Q, b.gfw, b.gem);
+      }
+    };
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int nthreads = std::max(1, std::min<int>(n, (int)std::min<unsigned>(16u, hw ? hw : 4u)));
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nthreads; t++) pool.emplace_back(work);
+    work();
+    for (auto &t : pool) t.join();
+  }
   for (int i = 0; i < n; i++) {
     HostHMM &h = e->hmms[(size_t)i];
-    if (parse_hmm_file(hmm_paths[i], h) != WH_OK) return nullptr;
-    h.index = hmm_index ? hmm_index[i] : i;
-    if (nseq) h.nseq = nseq[i];
+    Built &b = built[(size_t)i];
+    if (b.rc != WH_OK) { set_error("%s", b.err.c_str()); return nullptr; }
     if (i == 0) { e->alphabet = h.alphabet; e->K = h.K; e->Kp = h.Kp; }
     else if ((h.alphabet == WH_ALPH_AMINO) != (e->alphabet == WH_ALPH_AMINO)) {
       set_error("%s: alphabet differs from the first model", hmm_paths[i]);
       return nullptr;
     }
-    const int Q = choose_Q(h.M);
+    const int Q = b.Q;
     if (Q < 0) {
       set_error("%s: model length %d exceeds this build's limit of %d nodes", hmm_paths[i], h.M, kMaxQ * kWave);
       return nullptr;
     }
-    std::vector<float> fw, bw, em;
-    build_tables(h, Q, fw, bw, em);
     DevHMM &d = e->dev[(size_t)i];
     d.M = h.M; d.Q = Q; d.Mpad = Q * kWave; d.K = h.K; d.Kp = h.Kp; d.nseq = h.nseq; d.index = h.index; d.qclass = Q;
-    d.fw_off = (int64_t)tables.size(); tables.insert(tables.end(), fw.begin(), fw.end());
-    d.bw_off = (int64_t)tables.size(); tables.insert(tables.end(), bw.begin(), bw.end());
-    d.em_off = (int64_t)tables.size(); tables.insert(tables.end(), em.begin(), em.end());
-    {
-      // node-major float32 odds of the canonical residues: the resolver's null2-by-trace reads the K values of ONE
-      // node together (one lane per sampled position), not K lane-blocked arrays
-      tables.resize((tables.size() + 3) / 4 * 4, 0.f);          // 16-byte aligned: the rows are read as float4
-      d.emn_off = (int64_t)tables.size();
-      tables.resize(tables.size() + (size_t)(h.M + 1) * h.K, 0.f);
-      float *emn = tables.data() + d.emn_off;
-      for (int k = 1; k <= h.M; k++)
-        for (int x = 0; x < h.K; x++) emn[(size_t)k * h.K + x] = (float)h.odds[(size_t)x * (h.M + 1) + k];
-    }
-    {
-      std::vector<double> gfw, gem;
-      build_tables_f64(h, Q, gfw, gem);
-      d.gfw_off = (int64_t)gtab.size(); gtab.insert(gtab.end(), gfw.begin(), gfw.end());
-      d.gem_off = (int64_t)gtab.size(); gtab.insert(gtab.end(), gem.begin(), gem.end());
-    }
+    d.fw_off = (int64_t)tables.size(); tables.insert(tables.end(), b.fw.begin(), b.fw.end());
+    d.bw_off = (int64_t)tables.size(); tables.insert(tables.end(), b.bw.begin(), b.bw.end());
+    d.em_off = (int64_t)tables.size(); tables.insert(tables.end(), b.em.begin(), b.em.end());
+    tables.resize((tables.size() + 3) / 4 * 4, 0.f);          // 16-byte aligned: the node-major rows are read as float4
+    d.emn_off = (int64_t)tables.size(); tables.insert(tables.end(), b.emn.begin(), b.emn.end());
+    d.gfw_off = (int64_t)gtab.size(); gtab.insert(gtab.end(), b.gfw.begin(), b.gfw.end());
+    d.gem_off = (int64_t)gtab.size(); gtab.insert(gtab.end(), b.gem.begin(), b.gem.end());
+    b = Built();                                              // release the per-model copies as we go
     e->by_q[Q].push_back(i);
     e->max_M = std::max(e->max_M, h.M);
   }

@@ -155,6 +155,20 @@ int wh_set_timing(wh_ehmm *e, int enabled);
  * changes a knob on a live handle (A/B harness tools/ab_score.py).  Production needs none of them. */
 int wh_set_option(wh_ehmm *e, const char *name, const char *value);
 
+/* ---- final transitive merge ---------------------------------------------------
+ * Replaces mergeAlignmentsCollapsed -> ExtendedAlignment.merge_in per query (witch_msa/gcmm/merger.py:40-131,
+ * helpers/alignment_tools.py:1183-1316) and the masked writer (alignment_tools.py:1140-1156, merger.py:100-103),
+ * fed directly with wh_consensus' per-residue codes (code >= 0 backbone column; -1 - g insertion in front of
+ * column g).  q_text: the queries' characters as given (case is normalised as the reference does: aligned
+ * residues upper, insertions lower); q_row[q]: >= 0 the query gets a row (rows follow the backbone rows in query
+ * order), -1 its insertions widen the gaps but it gets no row (its name exists already), -2 no alignment.
+ * backbone: nb rows of B characters (already upper-cased).  Returns two malloc'ed row-major byte matrices
+ * (release with wh_free_text): the full alignment rows x width and the masked one rows x B.  Needs no model
+ * handle: device = the HIP device to run on. */
+int wh_merge(int device, const uint8_t *q_text, const int64_t *q_off, int64_t nq, const int32_t *codes, const int32_t *q_row,
+             const uint8_t *backbone, int32_t nb, int32_t B, uint8_t **out_full, uint8_t **out_masked, int64_t *out_rows,
+             int64_t *out_width);
+
 /* ---- eHMM construction (host code, no GPU needed) -------------------------------
  * Replaces the reference's per-subset call
  *     hmmbuild --cpu 1 --<molecule> --ere 0.59 --symfrac 0.0 --informat afa -o /dev/null MODEL SUBSET.fasta

@@ -1066,3 +1066,48 @@ def test_ehmm_built_without_hmmbuild_scores_identically(tmp_path):
     # aligned columns are MODEL columns (0-based node index); the MAP numbers differ (reduced vs full alignment)
     assert np.array_equal(c1, c2)
     e1.close(); e2.close()
+
+
+@pytest.mark.gpu
+def test_device_merge_writes_the_host_mergers_bytes(tmp_path):
+    """SURVEY 8f #2 on the device: wh_merge (codes of the consensus kernel -> the two final matrices) against the
+    host closed form fed with the per-query strings, on the end-to-end example (500 fragments into a 500-row
+    backbone; insertion runs at hundreds of gaps, leading / trailing insertions, a renamed taxon) - and against the
+    reference pipeline's own two files (sha256 of the golden)."""
+    _need_gpu()
+    import gzip
+    import hashlib
+    from tests.conftest import load_case
+    from witch_amd import gcmm
+    case = load_case("example_e2e")
+    g = case.g
+
+    class _Sub:
+        def __init__(self, path, n):
+            self.hmm_model_path, self.num_taxa = path, n
+    index_to_hmm = {i: _Sub(p, n) for i, p, n in zip(case.hmm_index, case.hmm_paths, case.nseq)}
+    retained = {int(k): v for k, v in g["retained"].items()}
+    nongaps = {int(k): v for k, v in g["nongaps"].items()}
+    B = g["backbone_length"]
+    bpath = str(tmp_path / "backbone.fasta")
+    with gzip.open(os.path.join(case.dir, "backbone.fasta.gz"), "rt") as f, open(bpath, "w") as o:
+        o.write(f.read())
+    eng = gcmm.install(gcmm.QueryAlignmentEngine.run(
+        index_to_hmm, list(zip(case.qnames, case.qseqs)), case.k,
+        subset_to_retained_columns=retained, subset_to_nongaps_per_column=nongaps, backbone_length=B))
+    weights = gcmm.writeWeights(index_to_hmm, gcmm.rankBitscores(index_to_hmm, {}))
+    taxa = [qn for qn in case.qnames if qn in weights]
+    queries = [gcmm.alignSubQueriesNew(bpath, B, index_to_hmm, None, 120, qn, qs, weights[qn], q)[0]
+               for q, (qn, qs) in enumerate(zip(case.qnames, case.qseqs)) if qn in weights]
+    rename = {taxa[3]: taxa[3] + "_renamed_original"}          # merger.py:84-93: renamed taxa move to the end
+    for tag, ren in (("plain", {}), ("renamed", rename)):
+        h_full, h_masked = gcmm.mergeAlignmentsCollapsed(bpath, queries, ren, None, output_path=str(tmp_path / ("host_%s.fasta" % tag)))
+        d_full, d_masked = gcmm.mergeAlignmentsDevice(bpath, ren, output_path=str(tmp_path / ("dev_%s.fasta" % tag)), taxa=taxa)
+        assert open(h_full, "rb").read() == open(d_full, "rb").read(), tag
+        assert open(h_masked, "rb").read() == open(d_masked, "rb").read(), tag
+        if tag == "plain":
+            assert hashlib.sha256(open(d_full, "rb").read()).hexdigest() == g["final_sha256"]["full"]
+            assert hashlib.sha256(open(d_masked, "rb").read()).hexdigest() == g["final_sha256"]["masked"]
+    # default taxa = every query with a reported HMM, batch order
+    d2, _ = gcmm.mergeAlignmentsDevice(bpath, {}, output_path=str(tmp_path / "dev_default.fasta"))
+    assert open(d2, "rb").read() == open(str(tmp_path / "dev_plain.fasta"), "rb").read()

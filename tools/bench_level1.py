@@ -52,7 +52,15 @@ T["alignSubQueriesNew x %d" % len(queries)] = time.time() - t0
 t0 = time.time()
 gcmm.mergeAlignmentsCollapsed(bpath, queries, {}, None, output_path=os.path.join(wd, "out.fasta"))
 T["mergeAlignmentsCollapsed"] = time.time() - t0
+t0 = time.time()
+gcmm.mergeAlignmentsDevice(bpath, {}, output_path=os.path.join(wd, "out_dev.fasta"), taxa=[t for t in names if t in weights])
+t_dev = time.time() - t0
+same = open(os.path.join(wd, "out.fasta"), "rb").read() == open(os.path.join(wd, "out_dev.fasta"), "rb").read()
 tot = sum(v for kk, v in T.items() if not kk.startswith("  "))
 for kk, v in T.items():
     print("%-44s %8.2f s" % (kk, v))
 print("%-44s %8.2f s  -> %.0f queries/s end to end (level 1, one GPU)" % ("total", tot, nq / tot))
+host = T["alignSubQueriesNew x %d" % len(queries)] + T["mergeAlignmentsCollapsed"]
+print("%-44s %8.2f s  (wh_merge from the consensus codes, instead of the %.2f s of per-query strings + host merge; same bytes: %s)"
+      % ("mergeAlignmentsDevice", t_dev, host, same))
+print("%-44s %8.2f s  -> %.0f queries/s end to end with the device merge" % ("total", tot - host + t_dev, nq / (tot - host + t_dev)))

@@ -587,6 +587,62 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
   return WH_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- final merge
+int wh_merge(int device, const uint8_t *q_text, const int64_t *q_off, int64_t nq, const int32_t *codes, const int32_t *q_row,
+             const uint8_t *backbone, int32_t nb, int32_t B, uint8_t **out_full, uint8_t **out_masked, int64_t *out_rows,
+             int64_t *out_width) {
+  if (!q_off || !q_row || !backbone || !out_full || !out_masked || !out_rows || !out_width || nq < 0 || nb < 1 || B < 1 ||
+      (nq > 0 && (!q_text || !codes))) {
+    set_error("wh_merge: bad argument");
+    return WH_EINVAL;
+  }
+  if (g_device < 0 && wh_init(device) != WH_OK) return WH_EHIP;
+  HIPCHK(hipSetDevice(device));
+  // the merge needs no model: its device buffers live for this call only
+  struct Bufs { DevBuf b[12]; ~Bufs() { for (DevBuf &x : b) x.release(); } } bufs;
+  DevBuf *m_buf = bufs.b;
+  const int64_t total = nq > 0 ? q_off[nq] : 0;
+  std::vector<int64_t> row_q;
+  for (int64_t q = 0; q < nq; q++) {
+    if (q_row[q] < -2) { set_error("wh_merge: q_row[%lld] = %d", (long long)q, q_row[q]); return WH_EINVAL; }
+    if (q_row[q] >= 0) row_q.push_back(q);
+  }
+  for (int64_t r = 0; r < total; r++)
+    if (codes[r] >= B || codes[r] < -1 - B) { set_error("wh_merge: code %d of residue %lld outside the backbone (%d columns)", codes[r], (long long)r, B); return WH_EINVAL; }
+  const int64_t nrows = (int64_t)nb + (int64_t)row_q.size();
+  enum { mTEXT = 0, mOFF, mCODES, mQROW, mROWQ, mBB, mW, mGAP, mK, mLAY, mFULL, mMASK };
+  const size_t by[10] = {(size_t)total, sizeof(int64_t) * (size_t)(nq + 1), sizeof(int32_t) * (size_t)total, sizeof(int32_t) * (size_t)nq,
+                         sizeof(int64_t) * row_q.size(), (size_t)nb * (size_t)B, sizeof(int32_t) * (size_t)(B + 1), sizeof(int32_t) * (size_t)total,
+                         sizeof(int32_t) * (size_t)total, sizeof(long long) * (size_t)(2 * B + 2)};
+  for (int t = 0; t < 10; t++) if (m_buf[t].ensure(by[t] + 16)) return WH_ENOMEM;
+  const void *src[6] = {q_text, q_off, codes, q_row, row_q.data(), backbone};
+  for (int t = 0; t < 6; t++) if (by[t]) HIPCHK(hipMemcpy(m_buf[t].p, src[t], by[t], hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(m_buf[mW].p, 0, by[mW]));
+  MergeArgs a;
+  memset(&a, 0, sizeof a);
+  a.q_text = (const uint8_t *)m_buf[mTEXT].p; a.q_off = (const int64_t *)m_buf[mOFF].p; a.codes = (const int32_t *)m_buf[mCODES].p;
+  a.q_row = (const int32_t *)m_buf[mQROW].p; a.row_q = (const int64_t *)m_buf[mROWQ].p; a.nq = nq;
+  a.bb = (const uint8_t *)m_buf[mBB].p; a.nb = nb; a.B = B;
+  a.W = (int32_t *)m_buf[mW].p; a.res_gap = (int32_t *)m_buf[mGAP].p; a.res_k = (int32_t *)m_buf[mK].p;
+  a.gap_start = (long long *)m_buf[mLAY].p; a.col_pos = a.gap_start + (B + 1); a.width = a.col_pos + B;
+  hipError_t err = launch_merge_runs(a, nullptr);
+  if (err != hipSuccess) { set_error("merge kernels failed to launch: %s", hipGetErrorString(err)); return WH_EHIP; }
+  long long width = 0;
+  HIPCHK(hipMemcpy(&width, a.width, sizeof width, hipMemcpyDeviceToHost));
+  if (width < B || (double)width * (double)nrows > 6.0e10) { set_error("wh_merge: %lld rows x %lld columns is not a plausible alignment", (long long)nrows, width); return WH_ERANGE; }
+  if (m_buf[mFULL].ensure((size_t)nrows * (size_t)width + 16) || m_buf[mMASK].ensure((size_t)nrows * (size_t)B + 16)) return WH_ENOMEM;
+  a.out_full = (uint8_t *)m_buf[mFULL].p; a.out_masked = (uint8_t *)m_buf[mMASK].p;
+  err = launch_merge_render(a, nrows, nullptr);
+  if (err != hipSuccess) { set_error("merge render kernel failed to launch: %s", hipGetErrorString(err)); return WH_EHIP; }
+  uint8_t *hf = (uint8_t *)malloc((size_t)nrows * (size_t)width + 1), *hm = (uint8_t *)malloc((size_t)nrows * (size_t)B + 1);
+  if (!hf || !hm) { free(hf); free(hm); set_error("wh_merge: out of host memory"); return WH_ENOMEM; }
+  hipError_t c1 = hipMemcpy(hf, a.out_full, (size_t)nrows * (size_t)width, hipMemcpyDeviceToHost);
+  hipError_t c2 = hipMemcpy(hm, a.out_masked, (size_t)nrows * (size_t)B, hipMemcpyDeviceToHost);
+  if (c1 != hipSuccess || c2 != hipSuccess) { free(hf); free(hm); set_error("wh_merge: copying the alignment back failed: %s", hipGetErrorString(c1 != hipSuccess ? c1 : c2)); return WH_EHIP; }
+  *out_full = hf; *out_masked = hm; *out_rows = nrows; *out_width = width;
+  return WH_OK;
+}
+
 static int max_query_len(const int64_t *offsets, int64_t nq) {
   int64_t m = 0;
   for (int64_t i = 0; i < nq; i++) m = std::max(m, offsets[i + 1] - offsets[i]);

@@ -93,6 +93,24 @@ int resolve_seg_cap();
 int resolve_waves_per_cu();
 size_t resolve_seg_ints(int Lcap, int Mmax);
 
+// final transitive merge (wh_merge.hip)
+struct MergeArgs {
+  const uint8_t *q_text;       // query characters as given (ASCII), concatenated
+  const int64_t *q_off;        // [nq+1]
+  const int32_t *codes;        // consensus kernel output per residue
+  const int32_t *q_row;        // per query: >= 0 the query gets a row; -1 widens the gaps only; -2 no alignment
+  const int64_t *row_q;        // per query row (in output order after the backbone rows): its query
+  int64_t nq;
+  const uint8_t *bb;           // backbone rows [nb][B], upper case
+  int32_t nb, B;
+  int32_t *W;                  // [B+1] widest insertion run per gap (zeroed before merge_runs)
+  int32_t *res_gap, *res_k;    // per residue: gap of an insertion (or -1) and position inside its run
+  long long *gap_start, *col_pos, *width;   // [B+1], [B], [1]
+  uint8_t *out_full, *out_masked;
+};
+hipError_t launch_merge_runs(const MergeArgs &a, hipStream_t s);
+hipError_t launch_merge_render(const MergeArgs &a, int64_t nrows, hipStream_t s);
+
 struct TopkArgs {
   const int32_t *decibits;
   const uint8_t *flags;

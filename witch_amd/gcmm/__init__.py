@@ -23,6 +23,6 @@ from .weighting import writeWeights, calculateWeights, writeWeightsToLocal, read
 from .aligner import getBackbones  # noqa: F401
 from .algorithm import search, check_query_names, divide_to_equal_chunks, num_chunks_for  # noqa: F401
 from .merge import alignSubQueriesNew, compressInsertions, trace_to_string  # noqa: F401
-from .merger import mergeAlignmentsCollapsed  # noqa: F401
+from .merger import mergeAlignmentsCollapsed, mergeAlignmentsDevice  # noqa: F401
 from .checkpoint import callback_queryAlignment, readCheckpointAlignments, writeCheckpointAlignments  # noqa: F401
 from .hmmbuild import subset_alignment_and_hmmbuild, build_ehmm, hmmbuild_text  # noqa: F401

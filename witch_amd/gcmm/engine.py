@@ -46,6 +46,8 @@ class QueryAlignmentEngine:
         self.merged = None            # int32 CSR by query: consensus codes (gcmm/merge.py)
         self.query_offsets = None     # int64 [nq+1]
         self.merged_minmax = None
+        self.query_text = None        # uint8: the local queries' characters (upper-cased on read), concatenated like query_offsets
+        self.device = 0
         # multi-GPU (one process per GPU): this rank scored, aligned and merged the
         # contiguous block [row_lo, row_hi) of the batch; the top-k tables cover EVERY query once gathered
         self.world, self.rank = 1, 0
@@ -89,7 +91,10 @@ class QueryAlignmentEngine:
         local = items[self.row_lo:self.row_hi]
         # the reference upper-cases sequences on read (helpers/alignment_tools.py:730-731)
         t0 = time.time()
-        res, offs = e.digitize_many([s.upper() for _, s in local])
+        upper = [s.upper() for _, s in local]
+        res, offs = e.digitize_many(upper)
+        self.query_text = np.frombuffer("".join(upper).encode("ascii"), dtype=np.uint8)
+        self.device = int(device)
         t_digit = time.time() - t0
         t0 = time.time()
         self.decibits, self.flags = e.score(res, offs)

@@ -153,3 +153,80 @@ def mergeAlignmentsCollapsed(backbone_alignment_path, queries, renamed_taxa, poo
     if log is not None:
         log('Time to merge all outputs (s): {}'.format(time.time() - start))
     return output_path, mpath
+
+
+def mergeAlignmentsDevice(backbone_alignment_path, renamed_taxa=None, output_path=None, engine=None, taxa=None, log=None):
+    """The final merge straight from the consensus kernel's codes (wh_merge, witch_amd/csrc/wh_merge.hip): what
+    `[alignSubQueriesNew(...) for every query]` + `mergeAlignmentsCollapsed(...)` write, without building the
+    per-query strings on the host.  `taxa`: the queries to merge, in the order the reference would append them
+    (default: every local query of the engine that has weights, in batch order); the others are left out like the
+    reference's 'ignored' ones.  Returns the two paths (merger.py:95-103)."""
+    import ctypes as C
+    from .._lib import lib, check
+    from .engine import current_engine
+    eng = engine or current_engine()
+    if eng.merged is None:
+        raise RuntimeError("the engine ran without the consensus step (subset_to_retained_columns not given)")
+    s1 = time.time()
+    backbone = read_fasta_upper(backbone_alignment_path)
+    names = list(backbone.keys())
+    B = len(backbone[names[0]])
+    bb = np.frombuffer("".join(backbone[n] for n in names).encode("ascii"), dtype=np.uint8)
+    if bb.size != len(names) * B:
+        raise ValueError("backbone rows differ in length")
+    nloc = eng.row_hi - eng.row_lo
+    if taxa is None:
+        taxa = [t for r, t in enumerate(eng.taxa[eng.row_lo:eng.row_hi]) if eng.has_hit(r + eng.row_lo)]
+    q_row = np.full(nloc, -2, dtype=np.int32)
+    seen = set(names)
+    order_rows = []                                   # local query rows in append order
+    for t in taxa:
+        r = eng._local(eng.taxon_row[t], "the consensus alignment")
+        if t in seen:
+            q_row[r] = -1                             # widens the gaps, no new row (alignment_tools.py:1226-1230)
+        else:
+            q_row[r] = len(order_rows)
+            order_rows.append(r)
+            seen.add(t)
+    # wh_merge appends the rows in QUERY order; taxa given in another order are permuted back below
+    codes = np.ascontiguousarray(eng.merged, dtype=np.int32)
+    offs = np.ascontiguousarray(eng.query_offsets, dtype=np.int64)
+    text = np.ascontiguousarray(eng.query_text, dtype=np.uint8)
+    pf, pm, nr, wd = C.c_void_p(), C.c_void_p(), C.c_int64(0), C.c_int64(0)
+    check(lib().wh_merge(int(eng.device), text.ctypes.data, offs.ctypes.data, nloc, codes.ctypes.data, q_row.ctypes.data,
+                         bb.ctypes.data, len(names), B, C.byref(pf), C.byref(pm), C.byref(nr), C.byref(wd)), "wh_merge")
+    try:
+        nrows, width = int(nr.value), int(wd.value)
+        full = np.ctypeslib.as_array(C.cast(pf, C.POINTER(C.c_uint8)), shape=(nrows * width,)).reshape(nrows, width).copy()
+        masked = np.ctypeslib.as_array(C.cast(pm, C.POINTER(C.c_uint8)), shape=(nrows * B,)).reshape(nrows, B).copy()
+    finally:
+        lib().wh_free_text(pf)
+        lib().wh_free_text(pm)
+    in_query_order = sorted(order_rows)
+    row_of = {r: len(names) + i for i, r in enumerate(in_query_order)}
+    perm = list(range(len(names))) + [row_of[r] for r in order_rows]
+    all_names = names + [eng.taxa[r + eng.row_lo] for r in order_rows]
+    if renamed_taxa:                                   # merger.py:84-93
+        name_map = {v: k for k, v in renamed_taxa.items()}
+        pos = {n: i for i, n in enumerate(all_names)}
+        order = list(range(len(all_names)))
+        for name, ori in name_map.items():
+            if name in pos:
+                i = pos.pop(name)
+                order.remove(i)
+                if ori in pos:
+                    order[order.index(pos[ori])] = i
+                else:
+                    order.append(i)
+                pos[ori] = i
+                all_names[i] = ori
+        perm = [perm[i] for i in order]
+        all_names = [all_names[i] for i in order]
+    if output_path is None:
+        raise ValueError("output_path is required")
+    write_fasta_matrix(output_path, all_names, full[perm])
+    mpath = masked_path(output_path)
+    write_fasta_matrix(mpath, all_names, masked[perm])
+    if log:
+        log("Finished merging all GCM subproblems on the device, runtime (s): %s" % (time.time() - s1))
+    return output_path, mpath

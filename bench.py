@@ -110,10 +110,39 @@ def consensus_stage(e, synth_ehmm, fam, off_t, maxlen, k):
     ro_t = torch.from_numpy(ro).to(dev)
     ret_t = torch.from_numpy(np.concatenate(ret)).to(dev)
     ng_t = torch.from_numpy(np.concatenate(ng)).to(dev)
-    e.consensus_t(off_t, maxlen, qpo, d["ph"], d["pw"], d["co"], d["cols"], ro_t, ret_t, ng_t, fam.msa.shape[1], k)
+    codes, _ = e.consensus_t(off_t, maxlen, qpo, d["ph"], d["pw"], d["co"], d["cols"], ro_t, ret_t, ng_t, fam.msa.shape[1], k)
     torch.cuda.synchronize()
     ms, _ = e.last_kernel_ms(3)
+    consensus_stage.codes = codes
     return ms
+
+
+def merge_stage(fam, seqs_local, off_t, nu_t, alphabet):
+    """Next row #2 (merger.py:40-131) on the codes of consensus_stage: wall time of wh_merge (host buffers in,
+    the two final matrices out: upload + three kernels + download) for this rank's queries merged into the 64 first
+    backbone rows.  Reported as an extra stage, not part of <value>."""
+    import ctypes as C
+    from witch_amd import synth
+    from witch_amd._lib import lib, check
+    codes = consensus_stage.codes.cpu().numpy().astype(np.int32)
+    offs = off_t.cpu().numpy().astype(np.int64)
+    nq = len(offs) - 1
+    sym = np.frombuffer((synth.symbols(alphabet) + "N").encode(), dtype=np.uint8)
+    text = sym[np.minimum(np.concatenate([np.asarray(s, dtype=np.int64) for s in seqs_local]), len(sym) - 1)]
+    q_row = np.where(nu_t.cpu().numpy() > 0, 0, -2).astype(np.int32)
+    nb, B = 64, fam.msa.shape[1]
+    bbm = fam.msa[:nb].astype(np.int64).copy()
+    bbm[bbm < 0] = len(sym)
+    bb = np.concatenate([sym, np.frombuffer(b"-", dtype=np.uint8)])[bbm].astype(np.uint8)
+    pf, pm, nr, wd = C.c_void_p(), C.c_void_p(), C.c_int64(0), C.c_int64(0)
+    t0 = time.perf_counter()
+    check(lib().wh_merge(int(off_t.device.index or 0), text.ctypes.data, offs.ctypes.data, nq, codes.ctypes.data, q_row.ctypes.data,
+                         np.ascontiguousarray(bb).ctypes.data, nb, B, C.byref(pf), C.byref(pm), C.byref(nr), C.byref(wd)), "wh_merge")
+    ms = (time.perf_counter() - t0) * 1e3
+    rows, width = int(nr.value), int(wd.value)
+    lib().wh_free_text(pf)
+    lib().wh_free_text(pm)
+    return ms, rows, width
 
 
 def crc_of(*arrays):
@@ -228,6 +257,12 @@ def main():
             dt = float(tmax.item())
         # ---- outside the timed region: the next stage (weighted consensus) and the value distributions
         cons_ms = consensus_stage(e, synth_ehmm, fam, off_t, maxlen, k) if hi > lo else 0.0
+        merge_info = None
+        try:
+            if hi > lo and rank == 0:
+                merge_info = merge_stage(fam, seqs[lo:hi], off_t, hot_path_step.dev["nu"], WORKLOADS[args.workload][0])
+        except Exception as ex:           # an extra stage must never take the bench line down
+            merge_info = ("failed: %s" % ex, 0, 0)
         e.set_timing(False)
 
         if rank == 0:
@@ -304,7 +339,9 @@ def main():
                                       "score_parts": {"scoring_kernels": round(kern_ms[0] / args.steps, 3),
                                                       "multidomain_resolver": round(kern_ms[4] / args.steps, 3)}},
                 "extra_stage_ms": {"consensus_rank0": round(cons_ms, 3),
-                                   "note": "weighted consensus DP (next row #1) over this rank's queries, outside the timed region"},
+                                   "merge_rank0_wall": (round(merge_info[0], 3) if merge_info and not isinstance(merge_info[0], str) else (merge_info[0] if merge_info else None)),
+                                   "merge_rows_x_width": ([merge_info[1], merge_info[2]] if merge_info else None),
+                                   "note": "weighted consensus DP (next row #1, HIP-event time) and final merge (next row #2, wh_merge wall time incl. upload of the codes and download of the two matrices) over this rank's queries, outside the timed region"},
                 "roofline": roofline, "roofline_align": roofline_align,
                 "roofline_time_weighted_frac": round(combined, 4),
                 "distributions": dist3,

@@ -1111,3 +1111,44 @@ def test_device_merge_writes_the_host_mergers_bytes(tmp_path):
     # default taxa = every query with a reported HMM, batch order
     d2, _ = gcmm.mergeAlignmentsDevice(bpath, {}, output_path=str(tmp_path / "dev_default.fasta"))
     assert open(d2, "rb").read() == open(str(tmp_path / "dev_plain.fasta"), "rb").read()
+
+
+@pytest.mark.gpu
+def test_device_merge_on_every_golden_case(golden_case, tmp_path):
+    """wh_merge == the host closed-form merger on every golden case that has consensus data (short DNA, protein,
+    degenerate residues, chimeric and very short queries -> leading / trailing / interior insertion runs), with a
+    stand-in backbone (the merge never looks at the backbone's characters) that already contains one query's name
+    (that query widens the gaps but gets no row, alignment_tools.py:1226-1230)."""
+    _need_gpu()
+    from witch_amd import gcmm
+    case = golden_case
+    g = case.g
+    if not g.get("merged"):
+        pytest.skip("case has no backbone alignment")
+
+    class _Sub:
+        def __init__(self, path, n):
+            self.hmm_model_path, self.num_taxa = path, n
+    index_to_hmm = {i: _Sub(p, n) for i, p, n in zip(case.hmm_index, case.hmm_paths, case.nseq)}
+    retained = {int(k): v for k, v in g["retained"].items()}
+    nongaps = {int(k): v for k, v in g["nongaps"].items()}
+    B = g["backbone_length"]
+    gcmm.install(gcmm.QueryAlignmentEngine.run(
+        index_to_hmm, list(zip(case.qnames, case.qseqs)), case.k,
+        subset_to_retained_columns=retained, subset_to_nongaps_per_column=nongaps, backbone_length=B))
+    weights = gcmm.writeWeights(index_to_hmm, gcmm.rankBitscores(index_to_hmm, {}))
+    taxa = [qn for qn in case.qnames if qn in weights]
+    assert len(taxa) >= 2
+    queries = [gcmm.alignSubQueriesNew("bb", B, index_to_hmm, None, 120, qn, qs, weights[qn], q)[0]
+               for q, (qn, qs) in enumerate(zip(case.qnames, case.qseqs)) if qn in weights]
+    sym = "ACDEFGHIKLMNPQRSTVWY" if case.alphabet == "amino" else "ACGT"
+    rng = np.random.default_rng(5)
+    bpath = str(tmp_path / "bb.fasta")
+    with open(bpath, "w") as f:
+        for r, name in enumerate(["bb0", "bb1", taxa[1], "bb3"]):
+            row = "".join(sym[int(x)] if rng.random() > 0.2 else "-" for x in rng.integers(0, len(sym), size=B))
+            f.write(">%s\n%s\n" % (name, row))
+    h_full, h_masked = gcmm.mergeAlignmentsCollapsed(bpath, queries, {}, None, output_path=str(tmp_path / "host.fasta"))
+    d_full, d_masked = gcmm.mergeAlignmentsDevice(bpath, {}, output_path=str(tmp_path / "dev.fasta"), taxa=taxa)
+    assert open(h_full, "rb").read() == open(d_full, "rb").read(), case.name
+    assert open(h_masked, "rb").read() == open(d_masked, "rb").read(), case.name

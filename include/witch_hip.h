@@ -168,6 +168,14 @@ int wh_set_option(wh_ehmm *e, const char *name, const char *value);
 int wh_merge(int device, const uint8_t *q_text, const int64_t *q_off, int64_t nq, const int32_t *codes, const int32_t *q_row,
              const uint8_t *backbone, int32_t nb, int32_t B, uint8_t **out_full, uint8_t **out_masked, int64_t *out_rows,
              int64_t *out_width);
+/* One process per GPU (queries sharded): the width of a gap is the MAX over all ranks' queries - the merge's one
+ * exchange step.  Call once with widths_local != NULL and out_full == NULL (fills widths_local[B+1] from this
+ * rank's queries, renders nothing; backbone may be NULL), all-reduce MAX over the ranks (RCCL), call again with
+ * widths_global: this rank's rows (nb backbone rows first; pass nb = 0 on the ranks that do not write them) are
+ * rendered in the global layout. */
+int wh_merge_sharded(int device, const uint8_t *q_text, const int64_t *q_off, int64_t nq, const int32_t *codes, const int32_t *q_row,
+                     const uint8_t *backbone, int32_t nb, int32_t B, int32_t *widths_local, const int32_t *widths_global,
+                     uint8_t **out_full, uint8_t **out_masked, int64_t *out_rows, int64_t *out_width);
 
 /* ---- eHMM construction (host code, no GPU needed) -------------------------------
  * Replaces the reference's per-subset call

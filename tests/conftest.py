@@ -53,9 +53,10 @@ class GoldenCase:
         os.makedirs(d, exist_ok=True)
         out = os.path.join(d, os.path.basename(hf))
         if not os.path.exists(out):
-            with gzip.open(path + ".gz", "rb") as fi, open(out + ".tmp", "wb") as fo:
+            tmp = "%s.tmp.%d" % (out, os.getpid())          # several ranks may unpack at once
+            with gzip.open(path + ".gz", "rb") as fi, open(tmp, "wb") as fo:
                 fo.write(fi.read())
-            os.replace(out + ".tmp", out)
+            os.replace(tmp, out)
         return out
 
 

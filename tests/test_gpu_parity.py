@@ -1152,3 +1152,34 @@ def test_device_merge_on_every_golden_case(golden_case, tmp_path):
     d_full, d_masked = gcmm.mergeAlignmentsDevice(bpath, {}, output_path=str(tmp_path / "dev.fasta"), taxa=taxa)
     assert open(h_full, "rb").read() == open(d_full, "rb").read(), case.name
     assert open(h_masked, "rb").read() == open(d_masked, "rb").read(), case.name
+
+
+@pytest.mark.gpu
+def test_two_rank_level1_writes_the_reference_files(tmp_path):
+    """SURVEY 8e through the PRODUCT path, rehearsed with two ranks on one GPU (gloo):
+    sharded engine -> gathered top-k -> mergeAlignmentsDevice with the all-reduced gap widths -> rank 0 writes.
+    The two files must be the reference pipeline's (sha256 of the end-to-end golden), like the one-rank run."""
+    _need_gpu()
+    import json
+    import socket
+    import subprocess
+    import sys
+    from tests.conftest import ROOT, load_case
+    g = load_case("example_e2e").g
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", WITCH_LEVEL1_REHEARSAL="1")
+    script = os.path.join(ROOT, "tools", "level1_ranks.py")
+    r1 = subprocess.run([sys.executable, script, str(tmp_path / "one.fasta")], capture_output=True, text=True, timeout=600, env=env)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                         "--master-addr", "127.0.0.1", "--master-port", str(port), script, str(tmp_path / "two.fasta")],
+                        capture_output=True, text=True, timeout=600, env=env)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    j1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][0])
+    j2 = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][0])
+    assert j2["world"] == 2 and j2["rows_local"] == [0, 250]
+    for j in (j1, j2):
+        assert j["full"] == g["final_sha256"]["full"] and j["masked"] == g["final_sha256"]["masked"]

@@ -591,8 +591,15 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
 int wh_merge(int device, const uint8_t *q_text, const int64_t *q_off, int64_t nq, const int32_t *codes, const int32_t *q_row,
              const uint8_t *backbone, int32_t nb, int32_t B, uint8_t **out_full, uint8_t **out_masked, int64_t *out_rows,
              int64_t *out_width) {
-  if (!q_off || !q_row || !backbone || !out_full || !out_masked || !out_rows || !out_width || nq < 0 || nb < 1 || B < 1 ||
-      (nq > 0 && (!q_text || !codes))) {
+  return wh_merge_sharded(device, q_text, q_off, nq, codes, q_row, backbone, nb, B, nullptr, nullptr, out_full, out_masked, out_rows, out_width);
+}
+
+int wh_merge_sharded(int device, const uint8_t *q_text, const int64_t *q_off, int64_t nq, const int32_t *codes, const int32_t *q_row,
+                     const uint8_t *backbone, int32_t nb, int32_t B, int32_t *widths_local, const int32_t *widths_global,
+                     uint8_t **out_full, uint8_t **out_masked, int64_t *out_rows, int64_t *out_width) {
+  const bool widths_only = widths_local != nullptr && out_full == nullptr;
+  if (!q_off || !q_row || nq < 0 || nb < 0 || B < 1 || (nq > 0 && !codes) ||
+      (!widths_only && (!backbone && nb > 0)) || (!widths_only && (!out_full || !out_masked || !out_rows || !out_width || (nq > 0 && !q_text)))) {
     set_error("wh_merge: bad argument");
     return WH_EINVAL;
   }
@@ -616,7 +623,7 @@ int wh_merge(int device, const uint8_t *q_text, const int64_t *q_off, int64_t nq
                          sizeof(int32_t) * (size_t)total, sizeof(long long) * (size_t)(2 * B + 2)};
   for (int t = 0; t < 10; t++) if (m_buf[t].ensure(by[t] + 16)) return WH_ENOMEM;
   const void *src[6] = {q_text, q_off, codes, q_row, row_q.data(), backbone};
-  for (int t = 0; t < 6; t++) if (by[t]) HIPCHK(hipMemcpy(m_buf[t].p, src[t], by[t], hipMemcpyHostToDevice));
+  for (int t = 0; t < 6; t++) if (by[t] && src[t]) HIPCHK(hipMemcpy(m_buf[t].p, src[t], by[t], hipMemcpyHostToDevice));
   HIPCHK(hipMemset(m_buf[mW].p, 0, by[mW]));
   MergeArgs a;
   memset(&a, 0, sizeof a);
@@ -627,6 +634,16 @@ int wh_merge(int device, const uint8_t *q_text, const int64_t *q_off, int64_t nq
   a.gap_start = (long long *)m_buf[mLAY].p; a.col_pos = a.gap_start + (B + 1); a.width = a.col_pos + B;
   hipError_t err = launch_merge_runs(a, nullptr);
   if (err != hipSuccess) { set_error("merge kernels failed to launch: %s", hipGetErrorString(err)); return WH_EHIP; }
+  // sharded use (one process per GPU): the widest run per gap is a MAX over all ranks - the caller all-reduces
+  // widths_local and hands the result back as widths_global; the layout is then the same on every rank
+  if (widths_local) HIPCHK(hipMemcpy(widths_local, a.W, by[mW], hipMemcpyDeviceToHost));
+  if (widths_only) return WH_OK;
+  if (widths_global) {
+    for (int g = 0; g <= B; g++) if (widths_global[g] < 0) { set_error("wh_merge: negative width at gap %d", g); return WH_EINVAL; }
+    HIPCHK(hipMemcpy(a.W, widths_global, by[mW], hipMemcpyHostToDevice));
+    err = launch_merge_layout(a, nullptr);
+    if (err != hipSuccess) { set_error("merge layout kernel failed to launch: %s", hipGetErrorString(err)); return WH_EHIP; }
+  }
   long long width = 0;
   HIPCHK(hipMemcpy(&width, a.width, sizeof width, hipMemcpyDeviceToHost));
   if (width < B || (double)width * (double)nrows > 6.0e10) { set_error("wh_merge: %lld rows x %lld columns is not a plausible alignment", (long long)nrows, width); return WH_ERANGE; }

@@ -109,6 +109,7 @@ struct MergeArgs {
   uint8_t *out_full, *out_masked;
 };
 hipError_t launch_merge_runs(const MergeArgs &a, hipStream_t s);
+hipError_t launch_merge_layout(const MergeArgs &a, hipStream_t s);
 hipError_t launch_merge_render(const MergeArgs &a, int64_t nrows, hipStream_t s);
 
 struct TopkArgs {

@@ -102,6 +102,11 @@ hipError_t launch_merge_runs(const MergeArgs &a, hipStream_t s) {
   return hipGetLastError();
 }
 
+hipError_t launch_merge_layout(const MergeArgs &a, hipStream_t s) {
+  hipLaunchKernelGGL(merge_layout_kernel, dim3(1), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_merge_render(const MergeArgs &a, int64_t nrows, hipStream_t s) {
   if (nrows > 0) hipLaunchKernelGGL(merge_render_kernel, dim3((unsigned)nrows), dim3(256), 0, s, a);
   return hipGetLastError();

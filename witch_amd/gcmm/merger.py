@@ -155,18 +155,30 @@ def mergeAlignmentsCollapsed(backbone_alignment_path, queries, renamed_taxa, poo
     return output_path, mpath
 
 
-def mergeAlignmentsDevice(backbone_alignment_path, renamed_taxa=None, output_path=None, engine=None, taxa=None, log=None):
+def world_of(eng):
+    return int(getattr(eng, "world", 1))
+
+
+def mergeAlignmentsDevice(backbone_alignment_path, renamed_taxa=None, output_path=None, engine=None, taxa=None, log=None,
+                          group=None):
     """The final merge straight from the consensus kernel's codes (wh_merge, witch_amd/csrc/wh_merge.hip): what
     `[alignSubQueriesNew(...) for every query]` + `mergeAlignmentsCollapsed(...)` write, without building the
     per-query strings on the host.  `taxa`: the queries to merge, in the order the reference would append them
-    (default: every local query of the engine that has weights, in batch order); the others are left out like the
-    reference's 'ignored' ones.  Returns the two paths (merger.py:95-103)."""
+    (default: every query that has weights, in batch order); the others are left out like the reference's 'ignored'
+    ones.  Returns the two paths (merger.py:95-103).
+
+    One process per GPU (engine.world > 1, torch.distributed initialised): every rank calls this with the same
+    arguments.  The width of a gap is the maximum over ALL queries, so the ranks all-reduce (MAX) their local gap
+    widths - the merge's one exchange step - render their own rows in the common layout, and rank 0 gathers the
+    rows and writes the two files (the other ranks return the paths without writing)."""
     import ctypes as C
     from .._lib import lib, check
     from .engine import current_engine
     eng = engine or current_engine()
     if eng.merged is None:
         raise RuntimeError("the engine ran without the consensus step (subset_to_retained_columns not given)")
+    if output_path is None:
+        raise ValueError("output_path is required")
     s1 = time.time()
     backbone = read_fasta_upper(backbone_alignment_path)
     names = list(backbone.keys())
@@ -174,42 +186,79 @@ def mergeAlignmentsDevice(backbone_alignment_path, renamed_taxa=None, output_pat
     bb = np.frombuffer("".join(backbone[n] for n in names).encode("ascii"), dtype=np.uint8)
     if bb.size != len(names) * B:
         raise ValueError("backbone rows differ in length")
-    nloc = eng.row_hi - eng.row_lo
+    lo, hi = eng.row_lo, eng.row_hi
+    nloc = hi - lo
     if taxa is None:
-        taxa = [t for r, t in enumerate(eng.taxa[eng.row_lo:eng.row_hi]) if eng.has_hit(r + eng.row_lo)]
+        # a query has weights iff at least one HMM reported it: n_kept of the (gathered) top-k table
+        t_lo, t_hi = eng.topk_rows
+        if world_of(eng) > 1 and (t_lo, t_hi) != (0, len(eng.taxa)):
+            raise RuntimeError("call engine.gather() first: the merge needs every rank's top-k records")
+        taxa = [eng.taxa[r] for r in range(t_lo, t_hi) if eng.n_kept[r - t_lo] > 0]
+    # rows in append order, decided over ALL given taxa (every rank computes the same list); a name that exists
+    # already widens the gaps but gets no row (alignment_tools.py:1226-1230)
     q_row = np.full(nloc, -2, dtype=np.int32)
     seen = set(names)
-    order_rows = []                                   # local query rows in append order
+    appended = []                                     # (global query row, name) in append order
     for t in taxa:
-        r = eng._local(eng.taxon_row[t], "the consensus alignment")
-        if t in seen:
-            q_row[r] = -1                             # widens the gaps, no new row (alignment_tools.py:1226-1230)
-        else:
-            q_row[r] = len(order_rows)
-            order_rows.append(r)
-            seen.add(t)
-    # wh_merge appends the rows in QUERY order; taxa given in another order are permuted back below
+        g = eng.taxon_row[t]
+        new = t not in seen
+        seen.add(t)
+        if new:
+            appended.append((g, t))
+        if lo <= g < hi:
+            q_row[g - lo] = 0 if new else -1
     codes = np.ascontiguousarray(eng.merged, dtype=np.int32)
     offs = np.ascontiguousarray(eng.query_offsets, dtype=np.int64)
     text = np.ascontiguousarray(eng.query_text, dtype=np.uint8)
+    world = world_of(eng)
+    W = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        Wl = np.zeros(B + 1, dtype=np.int32)
+        check(lib().wh_merge_sharded(int(eng.device), None, offs.ctypes.data, nloc, codes.ctypes.data, q_row.ctypes.data,
+                                     None, 0, B, Wl.ctypes.data, None, None, None, None, None), "wh_merge_sharded (widths)")
+        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+        wt = torch.from_numpy(Wl).to(dev)
+        dist.all_reduce(wt, op=dist.ReduceOp.MAX, group=group)
+        W = np.ascontiguousarray(wt.cpu().numpy(), dtype=np.int32)
+    write_bb = world == 1 or eng.rank == 0
+    nb = len(names) if write_bb else 0
     pf, pm, nr, wd = C.c_void_p(), C.c_void_p(), C.c_int64(0), C.c_int64(0)
-    check(lib().wh_merge(int(eng.device), text.ctypes.data, offs.ctypes.data, nloc, codes.ctypes.data, q_row.ctypes.data,
-                         bb.ctypes.data, len(names), B, C.byref(pf), C.byref(pm), C.byref(nr), C.byref(wd)), "wh_merge")
+    check(lib().wh_merge_sharded(int(eng.device), text.ctypes.data, offs.ctypes.data, nloc, codes.ctypes.data, q_row.ctypes.data,
+                                 bb.ctypes.data if nb else None, nb, B, None, W.ctypes.data if W is not None else None,
+                                 C.byref(pf), C.byref(pm), C.byref(nr), C.byref(wd)), "wh_merge")
     try:
         nrows, width = int(nr.value), int(wd.value)
-        full = np.ctypeslib.as_array(C.cast(pf, C.POINTER(C.c_uint8)), shape=(nrows * width,)).reshape(nrows, width).copy()
-        masked = np.ctypeslib.as_array(C.cast(pm, C.POINTER(C.c_uint8)), shape=(nrows * B,)).reshape(nrows, B).copy()
+        full = np.ctypeslib.as_array(C.cast(pf, C.POINTER(C.c_uint8)), shape=(max(nrows * width, 1),))[:nrows * width].reshape(nrows, width).copy()
+        masked = np.ctypeslib.as_array(C.cast(pm, C.POINTER(C.c_uint8)), shape=(max(nrows * B, 1),))[:nrows * B].reshape(nrows, B).copy()
     finally:
         lib().wh_free_text(pf)
         lib().wh_free_text(pm)
-    in_query_order = sorted(order_rows)
-    row_of = {r: len(names) + i for i, r in enumerate(in_query_order)}
-    perm = list(range(len(names))) + [row_of[r] for r in order_rows]
-    all_names = names + [eng.taxa[r + eng.row_lo] for r in order_rows]
+    # this rank's query rows come out in QUERY order
+    mine = sorted(g for g, _ in appended if lo <= g < hi)
+    local_row = {g: nb + i for i, g in enumerate(mine)}
+    mpath = masked_path(output_path)
+    if world > 1:
+        import torch.distributed as dist
+        part = {g: (full[local_row[g]].tobytes(), masked[local_row[g]].tobytes()) for g in mine}
+        parts = [None] * world
+        dist.all_gather_object(parts, part, group=group)          # rows x width bytes: small next to the DP
+        if eng.rank != 0:
+            return output_path, mpath
+        rows = {}
+        for p_ in parts:
+            rows.update(p_)
+        full_rows = [full[i].tobytes() for i in range(nb)] + [rows[g][0] for g, _ in appended]
+        masked_rows = [masked[i].tobytes() for i in range(nb)] + [rows[g][1] for g, _ in appended]
+    else:
+        full_rows = [full[i].tobytes() for i in range(nb)] + [full[local_row[g]].tobytes() for g, _ in appended]
+        masked_rows = [masked[i].tobytes() for i in range(nb)] + [masked[local_row[g]].tobytes() for g, _ in appended]
+    all_names = names + [t for _, t in appended]
+    order = list(range(len(all_names)))
     if renamed_taxa:                                   # merger.py:84-93
         name_map = {v: k for k, v in renamed_taxa.items()}
         pos = {n: i for i, n in enumerate(all_names)}
-        order = list(range(len(all_names)))
         for name, ori in name_map.items():
             if name in pos:
                 i = pos.pop(name)
@@ -220,13 +269,10 @@ def mergeAlignmentsDevice(backbone_alignment_path, renamed_taxa=None, output_pat
                     order.append(i)
                 pos[ori] = i
                 all_names[i] = ori
-        perm = [perm[i] for i in order]
-        all_names = [all_names[i] for i in order]
-    if output_path is None:
-        raise ValueError("output_path is required")
-    write_fasta_matrix(output_path, all_names, full[perm])
-    mpath = masked_path(output_path)
-    write_fasta_matrix(mpath, all_names, masked[perm])
+    for path, rows_ in ((output_path, full_rows), (mpath, masked_rows)):
+        with open(path, "wb") as f:
+            for i in order:
+                f.write(b">" + all_names[i].encode() + b"\n" + rows_[i] + b"\n")
     if log:
         log("Finished merging all GCM subproblems on the device, runtime (s): %s" % (time.time() - s1))
     return output_path, mpath

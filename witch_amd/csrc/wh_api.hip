@@ -527,7 +527,9 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       r.recs = (const ResolveRec *)e->d_rrecs.p; r.count = d_rcount; r.rec_cap = (int)(nq * (int64_t)e->hmms.size());
       r.counter = d_rwork;
       r.Lcap = Lc; r.Mmax = e->max_M;
-      r.mx_stride = (size_t)(Lc + 2) * ((size_t)3 * Qmax * kWave + 8) + (size_t)(Lc + 2) * 65;   // matrix rows + the E-state row cache
+      // a wave's slab: matrix rows | threshold-line cache of the walk | E-state row cache (at the end)
+      r.dc_off = ((size_t)(Lc + 2) * ((size_t)3 * Qmax * kWave + 8) + 1) & ~(size_t)1;
+      r.mx_stride = r.dc_off + resolve_dcache_doubles() + (size_t)(Lc + 2) * 65;
       r.mx_stride = (r.mx_stride + 1) & ~(size_t)1;      // every wave's slab 16-byte aligned: the Forward sweep moves node pairs
       r.seg_cap = resolve_seg_cap();
       r.seg_stride = resolve_seg_ints(Lc, e->max_M);
@@ -569,7 +571,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       rlaunches++;
       e->last_resolved = n_multi;
       if (r.stats) {
-        unsigned long long st[12];
+        unsigned long long st[13];
         HIPCHK(hipMemcpyAsync(st, r.stats, sizeof st, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         const double tot = (double)(st[0] + st[1] + st[2] + st[3] + st[4]);
@@ -580,6 +582,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
         fprintf(stderr, "[wh]   per multidomain region and trace: %.1f fetches of M runs, %.1f of D runs, %.1f of flank (C/J) runs, %.1f single I steps; %.0f cycles per fetch\n",
                 st[8] / (200.0 * n_multi), st[9] / (200.0 * n_multi), st[10] / (200.0 * n_multi), st[11] / (200.0 * n_multi),
                 (double)st[5] / (double)std::max<unsigned long long>(1, st[8] + st[9] + st[10]));
+        fprintf(stderr, "[wh]   threshold-line cache: %.1f%% of the fetches hit\n", 100.0 * st[12] / (double)std::max<unsigned long long>(1, st[8] + st[9] + st[10]));
       }
     }
   }

@@ -74,6 +74,7 @@ struct ResolveArgs {
   int Lcap, Mmax;
   double *mx;                  // per-wave matrix slabs
   size_t mx_stride;            // doubles per wave
+  size_t dc_off;               // offset (doubles, even) of the walk's threshold-line cache inside a wave's slab
   int32_t *segs;               // per-wave segment arrays
   size_t seg_stride;           // ints per wave
   int seg_cap;
@@ -92,6 +93,7 @@ size_t resolve_lds_bytes(int Lcap, int Mmax);
 int resolve_seg_cap();
 int resolve_waves_per_cu();
 size_t resolve_seg_ints(int Lcap, int Mmax);
+size_t resolve_dcache_doubles();
 
 // final transitive merge (wh_merge.hip)
 struct MergeArgs {

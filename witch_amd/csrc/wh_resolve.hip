@@ -132,6 +132,17 @@ __device__ __forceinline__ d2_t nt_load_d2(const double *p) { return __builtin_n
 __device__ __forceinline__ d2_t ld_d2(const double *p) { return *reinterpret_cast<const d2_t *>(p); }
 __device__ __forceinline__ void st_d2(double *p, double a, double b) { d2_t v = {a, b}; *reinterpret_cast<d2_t *>(p) = v; }
 
+// global-address-space views for code that is CALLED (see gforward_reg)
+typedef __attribute__((address_space(1))) double gdbl;
+typedef __attribute__((address_space(1))) d2_t gd2_t;
+__device__ __forceinline__ gdbl *as_global(const double *p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (gdbl *)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ d2_t ldg_d2(const gdbl *p) { return *reinterpret_cast<const gd2_t *>(p); }
+__device__ __forceinline__ void stg_d2(gdbl *p, double a, double b) { d2_t v = {a, b}; *reinterpret_cast<gd2_t *>(p) = v; }
+
 template <bool STORE>
 __device__ double gforward(const GModel &m, const uint8_t *seq, int L, GLen c, const GMx &mx, int lane) {
   const int Q = m.Q;
@@ -246,6 +257,124 @@ __device__ double gforward(const GModel &m, const uint8_t *seq, int L, GLen c, c
   return ls + log(pC * c.move);
 }
 
+// The same sweep for models of up to 64 * QC nodes with the DP row in REGISTERS (3 x QC doubles per lane + the
+// running D2 products for the D fix-up): the version above reads row i-1 back from the slab - eight dependent
+// memory round trips per row, ~29 000 cycles per row on the protein workload with 2 048 waves in flight - here
+// the only loads are the model's tables (independent of the recurrence), rows are written out and never read
+// back, and the neighbour lane's last node arrives by shuffle.  Same operations in the same order as gforward.
+template <int QC>
+__device__ __attribute__((noinline)) double gforward_reg(const double *tf_, const double *te_, int Q_, const uint8_t *seq, int L_, GLen c,
+                                                         double *slab_, size_t rowlen, int lane, bool store_) {
+  // (a called function receives its arguments in vector registers: what is wave-uniform is said again, and the
+  // table / slab pointers are given their address space back, or every access becomes a flat_ instruction with a
+  // per-lane address and every guard a divergent branch.  Inlined at its eight call sites the function cost the
+  // kernel 491 spilled registers and ran 15 % slower than called.)
+  const int Q = __builtin_amdgcn_readfirstlane(Q_), L = __builtin_amdgcn_readfirstlane(L_);
+  const bool store = __builtin_amdgcn_readfirstlane((int)store_) != 0;
+  const gdbl *tf = as_global(tf_), *te = as_global(te_);
+  gdbl *slab = as_global(slab_);
+  const size_t SQ = (size_t)Q * 64;
+  double M[QC], I[QC], D[QC], PQ[QC];
+#pragma unroll
+  for (int q = 0; q < QC; q++) { M[q] = 0.0; I[q] = 0.0; D[q] = 0.0; PQ[q] = 1.0; }
+  double ls = 0.0;
+  if (store) {
+    gdbl *r0 = slab;
+    for (int q = 0; q < Q; q++) { r0[(size_t)q * 64 + lane] = 0.0; r0[SQ + (size_t)q * 64 + lane] = 0.0; r0[2 * SQ + (size_t)q * 64 + lane] = 0.0; }
+    if (lane == 0) { gdbl *s = r0 + 3 * SQ; s[xN] = 1.0; s[xB] = c.move; s[xE] = 0.0; s[xJ] = 0.0; s[xC] = 0.0; s[xLS] = 0.0; }
+  }
+  double pN = 1.0, pB = c.move, pJ = 0.0, pC = 0.0;
+  double Alane = 1.0;
+  for (int q = 0; q < Q; q++) Alane *= tf[(size_t)gD2 * SQ + ofs2(q, lane)];
+  double lastM = 0.0, lastI = 0.0, lastD = 0.0;     // node Q of this lane in the previous row
+  for (int i = 1; i <= L; i++) {
+    gdbl *cr = slab + (size_t)i * rowlen;
+    const gdbl *od = te + (size_t)seq[i - 1] * SQ;
+    const double um = shfl_up_d(lastM, 1), ui = shfl_up_d(lastI, 1), ud = shfl_up_d(lastD, 1);
+    double pm1 = lane > 0 ? um : 0.0, pi1 = lane > 0 ? ui : 0.0, pd1 = lane > 0 ? ud : 0.0;
+    double mprev = 0.0, dloc = 0.0, P = 1.0, esum = 0.0, d10 = 0.0, d20 = 0.0;
+#pragma unroll
+    for (int q0 = 0; q0 < QC; q0 += 4) {
+      if (q0 < Q) {
+        double tA[4], tB[4], tC[4], tE[4], tMI[4], tII[4], tD1[4], tD2[4], em[4];
+#pragma unroll
+        for (int u2 = 0; u2 < 2; u2++) {
+          const size_t o = ofs2(q0 + 2 * u2, lane);
+          const d2_t vA = ldg_d2(tf + gA * SQ + o), vB = ldg_d2(tf + gB * SQ + o), vC = ldg_d2(tf + gC * SQ + o), vE = ldg_d2(tf + gE * SQ + o);
+          const d2_t vMI = ldg_d2(tf + gMI * SQ + o), vII = ldg_d2(tf + gII * SQ + o), vD1 = ldg_d2(tf + gD1 * SQ + o), vD2 = ldg_d2(tf + gD2 * SQ + o);
+          const d2_t vem = ldg_d2(od + o);
+          tA[2 * u2] = vA.x; tA[2 * u2 + 1] = vA.y; tB[2 * u2] = vB.x; tB[2 * u2 + 1] = vB.y; tC[2 * u2] = vC.x; tC[2 * u2 + 1] = vC.y;
+          tE[2 * u2] = vE.x; tE[2 * u2 + 1] = vE.y; tMI[2 * u2] = vMI.x; tMI[2 * u2 + 1] = vMI.y; tII[2 * u2] = vII.x; tII[2 * u2 + 1] = vII.y;
+          tD1[2 * u2] = vD1.x; tD1[2 * u2 + 1] = vD1.y; tD2[2 * u2] = vD2.x; tD2[2 * u2 + 1] = vD2.y;
+          em[2 * u2] = vem.x; em[2 * u2 + 1] = vem.y;
+        }
+        if (q0 == 0) { d10 = tD1[0]; d20 = tD2[0]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int q = q0 + u;
+          const double oM = M[q], oI = I[q], oD = D[q];
+          const double mm = em[u] * (pm1 * tA[u] + pi1 * tB[u] + pd1 * tC[u] + pB * tE[u]);
+          const double ins = oM * tMI[u] + oI * tII[u];
+          dloc = q > 0 ? mprev * tD1[u] + dloc * tD2[u] : 0.0;
+          if (q > 0) P *= tD2[u];
+          PQ[q] = P;
+          M[q] = mm; I[q] = ins; D[q] = dloc;
+          esum += mm;
+          pm1 = oM; pi1 = oI; pd1 = oD; mprev = mm;
+        }
+      }
+    }
+    const double mup = shfl_up_d(mprev, 1);
+    const double mleft = lane > 0 ? mup : 0.0;
+    double Bv = dloc + P * d10 * (lane > 0 ? mleft : 0.0), Av = Alane;
+    for (int d = 1; d < 64; d <<= 1) {
+      const double Bo = shfl_up_d(Bv, d), Ao = shfl_up_d(Av, d);
+      if (lane >= d) { Bv = Bv + Av * Bo; Av = Av * Ao; }
+    }
+    const double dup = shfl_up_d(Bv, 1);
+    const double dleft = lane > 0 ? dup : 0.0;
+    const double c0 = lane > 0 ? d10 * mleft + d20 * dleft : 0.0;
+#pragma unroll
+    for (int q = 0; q < QC; q++)
+      if (q < Q) { D[q] = D[q] + PQ[q] * c0; esum += D[q]; }
+    double xe = wave_sum_d(esum);
+    double xn = pN * c.loop, xc = pC * c.loop + xe * c.EC, xj = pJ * c.loop + xe * c.EJ, lsd = 0.0;
+    if (xe > kRescaleHi) {
+      const double r = 1.0 / xe;
+#pragma unroll
+      for (int q = 0; q < QC; q++) { M[q] *= r; I[q] *= r; D[q] *= r; }
+      xn *= r; xc *= r; xj *= r; lsd = log(xe); ls += lsd; xe = 1.0;
+    }
+    const double xb = xj * c.move + xn * c.move;
+#pragma unroll
+    for (int q = 0; q < QC; q++)
+      if (q == Q - 1) { lastM = M[q]; lastI = I[q]; lastD = D[q]; }
+    if (store) {
+#pragma unroll
+      for (int q = 0; q < QC; q += 2)
+        if (q < Q) {
+          const size_t o = ofs2(q, lane);
+          stg_d2(cr + o, M[q], M[q + 1]); stg_d2(cr + SQ + o, I[q], I[q + 1]); stg_d2(cr + 2 * SQ + o, D[q], D[q + 1]);
+        }
+      if (lane == 0) { gdbl *s = cr + 3 * SQ; s[xN] = xn; s[xB] = xb; s[xE] = xe; s[xJ] = xj; s[xC] = xc; s[xLS] = lsd; }
+    }
+    pN = xn; pB = xb; pJ = xj; pC = xc;
+  }
+  wave_mem_sync();
+  return ls + log(pC * c.move);
+}
+
+template <bool STORE>
+__device__ __forceinline__ double gforward_any(const GModel &m, const uint8_t *seq, int L, GLen c, const GMx &mx, int lane) {
+  switch (m.Q) {
+    case 4: return gforward_reg<4>(m.tf, m.te, m.Q, seq, L, c, mx.p, mx.rowlen, lane, STORE);
+    case 8: return gforward_reg<8>(m.tf, m.te, m.Q, seq, L, c, mx.p, mx.rowlen, lane, STORE);
+    case 12: return gforward_reg<12>(m.tf, m.te, m.Q, seq, L, c, mx.p, mx.rowlen, lane, STORE);
+    case 16: return gforward_reg<16>(m.tf, m.te, m.Q, seq, L, c, mx.p, mx.rowlen, lane, STORE);
+    default: return gforward<STORE>(m, seq, L, c, mx, lane);
+  }
+}
+
 struct Rng { uint32_t x; };
 __device__ __forceinline__ uint32_t mix3(uint32_t a, uint32_t b, uint32_t c) {
   a -= b; a -= c; a ^= (c >> 13);
@@ -289,21 +418,28 @@ __device__ __forceinline__ bool seg_linked(int i1, int j1, int k1, int m1, int i
 }  // namespace
 
 // LDS per wave (ints unless noted): see resolve_lds_bytes()
-// LDS per wave (4-byte units): residues, n2sc and accumulators (float per residue), the domains of the
+// LDS per wave (4-byte units): residues, the domains of the
 // current trace and their null2 vectors, the emitting state per residue (int16), Easel's two vertex
 // stacks (uint16).  The end-point histograms of the cluster statistics live in the wave's HBM slab.
 __host__ __device__ inline size_t resolve_lds_ints(int Lcap, int Mmax) {
   (void)Mmax;
   const int Lp = (Lcap + 4) & ~1;
-  return (size_t)(Lcap + 8) / 4 + 2 /*seq*/ + Lp /*n2sc*/ + Lp /*acc*/ + kDomMax * (4 + 32) + Lp / 2 + 2 /*stk*/ + kSegCap /*two uint16 stacks*/ + 7 * kEnvMax + 16;
+  return (size_t)(Lcap + 8) / 4 + 2 /*seq*/ + kDomMax * (4 + 32) + Lp / 2 + 2 /*stk*/ + kSegCap /*two uint16 stacks*/ + 7 * kEnvMax + 16;
 }
 // waves per SIMD the kernel is compiled for (registers per lane = 512 / WH_RES_OCC)
 #ifndef WH_RES_OCC
 #define WH_RES_OCC 2
 #endif
 size_t resolve_lds_bytes(int Lcap, int Mmax) { return resolve_lds_ints(Lcap, Mmax) * 4 + 16; }
-size_t resolve_seg_ints(int Lcap, int Mmax) { return (size_t)6 * kSegCap + (size_t)(Lcap > Mmax ? Lcap : Mmax) + 8; }
+// per wave in HBM: the segment arrays, the end-point histogram, and the two per-residue float arrays (null2 scores of
+// the pair, accumulators of the region): in LDS they cost 8 bytes per residue of the LONGEST query of the batch and
+// halved the resident waves for 2 000-residue proteins
+size_t resolve_seg_ints(int Lcap, int Mmax) { return (size_t)6 * kSegCap + (size_t)(Lcap > Mmax ? Lcap : Mmax) + 8 + 2 * ((size_t)Lcap + 8); }
 int resolve_seg_cap() { return kSegCap; }
+// the walk's cache of threshold lines: 2^kDcBits lines of 64 x 16 bytes + their 8-byte tags, in doubles
+constexpr int kDcBits = 11;
+size_t resolve_dcache_doubles() { return (size_t)129 * (1 << kDcBits); }
+typedef unsigned u4_t __attribute__((ext_vector_type(4)));
 int resolve_waves_per_cu() { return 4 * WH_RES_OCC; }
 
 #define RTICK(slot) do { if (a.stats) { const long long t_now = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(a.stats + (slot), (unsigned long long)(t_now - tk0)); tk0 = t_now; } } while (0)
@@ -313,9 +449,7 @@ __global__ __launch_bounds__(64, WH_RES_OCC) void resolve_kernel(ResolveArgs a) 
   const int lane = threadIdx.x;
   const int Lp = (a.Lcap + 4) & ~1;
   uint8_t *seq = reinterpret_cast<uint8_t *>(lds_raw);
-  float *n2sc = reinterpret_cast<float *>(lds_raw + (a.Lcap + 8) / 4 + 2);
-  float *acc = n2sc + Lp;
-  int *dom = reinterpret_cast<int *>(acc + Lp);        // kDomMax x (sqfrom, sqto, hmmfrom, hmmto)
+  int *dom = lds_raw + (a.Lcap + 8) / 4 + 2;           // kDomMax x (sqfrom, sqto, hmmfrom, hmmto)
   float *dnull = reinterpret_cast<float *>(dom + 4 * kDomMax);   // kDomMax x 32
   short *stk = reinterpret_cast<short *>(dnull + 32 * kDomMax);  // emitting state of each residue: +k match, -k insert
   const int SEGCAP = a.seg_cap;
@@ -326,6 +460,19 @@ __global__ __launch_bounds__(64, WH_RES_OCC) void resolve_kernel(ResolveArgs a) 
   int32_t *s_idx = sg, *s_i = sg + SEGCAP, *s_j = sg + 2 * SEGCAP, *s_k = sg + 3 * SEGCAP, *s_m = sg + 4 * SEGCAP;
   int32_t *s_as = sg + 5 * SEGCAP;
   int32_t *epc = sg + 6 * SEGCAP;                                // end-point histogram of one cluster
+  float *n2sc = reinterpret_cast<float *>(epc + (a.Lcap > a.Mmax ? a.Lcap : a.Mmax) + 8);   // per residue, HBM (read with L1 bypass)
+  float *acc = n2sc + a.Lcap + 8;
+  // sum of n2sc[lo..hi] in position order (float32, as HMMER adds them): 64 values per fetch, walked with v_readlane
+  auto n2sum = [&](int lo, int hi) -> float {
+    float sum = 0.f;
+    for (int p0 = lo; p0 <= hi; p0 += 64) {
+      const int pp = p0 + lane;
+      const float v = pp <= hi ? __builtin_nontemporal_load(n2sc + pp) : 0.f;
+      const int cnt = hi - p0 + 1 < 64 ? hi - p0 + 1 : 64;
+      for (int t = 0; t < cnt; t++) sum += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), t));
+    }
+    return sum;
+  };
   const double LOG2 = 0.69314718055994529;
   const int n_items = *a.count < a.rec_cap ? *a.count : a.rec_cap;
 
@@ -376,7 +523,7 @@ __global__ __launch_bounds__(64, WH_RES_OCC) void resolve_kernel(ResolveArgs a) 
       // ---------------- A.4b
       const uint8_t *rs = seq + (ireg - 1);       // rs[pos-1] = residue at region position pos
       long long tk0 = a.stats ? __builtin_readcyclecounter() : 0;
-      const double regfwd = gforward<true>(m, rs, Lr, cm, mx, lane);
+      const double regfwd = gforward_any<true>(m, rs, Lr, cm, mx, lane);
       RTICK(0);
 #ifdef WH_RESOLVE_DEBUG
       if (a.dbg && lane == 0) printf("[resolve] region forward %.12f\n", regfwd);
@@ -385,7 +532,10 @@ __global__ __launch_bounds__(64, WH_RES_OCC) void resolve_kernel(ResolveArgs a) 
       // E-state choice: per row of the region a lazily filled line of 64 chunk prefix sums + a valid flag, at the
       // end of the wave's slab
       double *ecache = mx.p + a.mx_stride - (size_t)(a.Lcap + 2) * 65;
+      u4_t *dlines = reinterpret_cast<u4_t *>(mx.p + a.dc_off);
+      unsigned long long *dtags = reinterpret_cast<unsigned long long *>(mx.p + a.dc_off + (size_t)128 * (1 << kDcBits));
       for (int t = lane; t <= Lr; t += 64) ecache[(size_t)t * 65 + 64] = 0.0;
+      for (int t = lane; t < (1 << kDcBits); t += 64) dtags[t] = 0ull;        // the threshold-line cache of the walk, per region
       wave_mem_sync();
       int nseg = 0;
       Rng rng;
@@ -393,7 +543,7 @@ __global__ __launch_bounds__(64, WH_RES_OCC) void resolve_kernel(ResolveArgs a) 
       if (rng.x == 0) rng.x = 42;
       const int Qs = ((m.M - 1) / 4 + 1) > 2 ? ((m.M - 1) / 4 + 1) : 2;     // HMMER's striping: vectors of 4 floats
       long long c_build = 0, c_e = 0, c_post = 0;
-      unsigned n_bm = 0, n_bd = 0, n_bf = 0, n_i = 0;     // WH_STATS: fetches of M / D / flank (C, J) runs, scalar I steps
+      unsigned n_bm = 0, n_bd = 0, n_bf = 0, n_i = 0, n_hit = 0;     // WH_STATS: fetches of M / D / flank (C, J) runs, scalar I steps
       // lane t's jump of esl_random's LCG by t+1 steps: x_{n+t+1} = lcgA * x_n + lcgC (mod 2^32)
       unsigned lcgA = 1u, lcgC = 0u;
       for (int u = 0; u < 64; u++) if (u <= lane) { lcgA *= 69069u; lcgC = lcgC * 69069u + 1u; }
@@ -422,6 +572,22 @@ __global__ __launch_bounds__(64, WH_RES_OCC) void resolve_kernel(ResolveArgs a) 
             if (run_state != s0 || run_j >= 64) {
               const long long tb0 = a.stats ? __builtin_readcyclecounter() : 0;
               const int it = (s0 == stD) ? i : i - lane, kt = (s0 == stM || s0 == stD) ? k - lane : 0;
+              // The thresholds depend on the run's first cell only, and the 200 paths of a region mostly re-enter the
+              // same cells (they leave and rejoin the diagonals at the same insertions): a direct-mapped cache of
+              // threshold lines in the wave's slab, keyed by (state, i, k).  A hit is ONE coalesced 1 KB read instead
+              // of three scattered matrix reads per lane (192 cache lines; at 2 048 waves the walk was bound by HBM
+              // line traffic).  The line and its tag are requested together.
+              const int sidx = s0 == stM ? 0 : s0 == stD ? 1 : s0 == stC ? 2 : 3;
+              const unsigned kkey = (s0 == stM || s0 == stD) ? (unsigned)k : 0u;
+              const unsigned long long key = (1ull << 63) | ((unsigned long long)sidx << 60) | ((unsigned long long)(unsigned)i << 30) | kkey;
+              const unsigned slot = (((unsigned)i * 0x9E3779B1u) ^ (kkey * 0x85EBCA77u) ^ ((unsigned)sidx * 0xC2B2AE3Du)) >> (32 - kDcBits);
+              u4_t *dline = dlines + (size_t)slot * 64 + lane;
+              const u4_t ent = __builtin_nontemporal_load(dline);
+              const unsigned long long tg = __builtin_nontemporal_load(dtags + slot);
+              if (tg == key) {
+                run_r1 = ent.x; run_r2 = ent.y; run_r3 = ent.z; run_hi = ent.w;
+                if (a.stats) n_hit++;
+              } else {
               double pd[4] = {0.0, 0.0, 0.0, 0.0};
               if (s0 == stM) {
                 if (it >= 1 && kt >= 1) {
@@ -458,6 +624,11 @@ __global__ __launch_bounds__(64, WH_RES_OCC) void resolve_kernel(ResolveArgs a) 
               as_int(c1 / norm, run_r1, hb); run_hi |= hb;
               as_int(c2 / norm, run_r2, hb); run_hi |= hb << 1;
               as_int(c3 / norm, run_r3, hb); run_hi |= hb << 2;
+              u4_t wr; wr.x = run_r1; wr.y = run_r2; wr.z = run_r3; wr.w = run_hi;
+              *dline = wr;
+              if (lane == 0) dtags[slot] = key;
+              wave_mem_sync();
+              }
               run_state = s0; run_j = 0;
               run_x = lcgA * rng.x + lcgC;
               bool cont;
@@ -658,7 +829,7 @@ __global__ __launch_bounds__(64, WH_RES_OCC) void resolve_kernel(ResolveArgs a) 
           float add = 1.0f;
           for (int d = 0; d < ndom; d++)
             if (pos > dom[4 * d] && pos <= dom[4 * d + 1]) add = dnull[32 * d + rs[pos - 1]];
-          acc[pos] += add;
+          acc[pos] = __builtin_nontemporal_load(acc + pos) + add;
         }
         // the ensemble takes the domains left to right (they were found right to left)
         if (lane == 0)
@@ -674,10 +845,10 @@ __global__ __launch_bounds__(64, WH_RES_OCC) void resolve_kernel(ResolveArgs a) 
       }
       if (a.stats && lane == 0) {
         atomicAdd(a.stats + 5, (unsigned long long)c_build); atomicAdd(a.stats + 6, (unsigned long long)c_e); atomicAdd(a.stats + 7, (unsigned long long)c_post);
-        atomicAdd(a.stats + 8, (unsigned long long)n_bm); atomicAdd(a.stats + 9, (unsigned long long)n_bd); atomicAdd(a.stats + 10, (unsigned long long)n_bf); atomicAdd(a.stats + 11, (unsigned long long)n_i);
+        atomicAdd(a.stats + 8, (unsigned long long)n_bm); atomicAdd(a.stats + 9, (unsigned long long)n_bd); atomicAdd(a.stats + 10, (unsigned long long)n_bf); atomicAdd(a.stats + 11, (unsigned long long)n_i); atomicAdd(a.stats + 12, (unsigned long long)n_hit);
       }
       RTICK(1);
-      for (int pos = 1 + lane; pos <= Lr; pos += 64) n2sc[ireg + pos - 1] = logf(acc[pos] / (float)kSamples);
+      for (int pos = 1 + lane; pos <= Lr; pos += 64) n2sc[ireg + pos - 1] = logf(__builtin_nontemporal_load(acc + pos) / (float)kSamples);
       wave_mem_sync();
       // ---------------- single-linkage clustering in Easel's vertex order (esl_cluster_SingleLinkage)
       int nc = 0;
@@ -828,18 +999,16 @@ __global__ __launch_bounds__(64, WH_RES_OCC) void resolve_kernel(ResolveArgs a) 
         }
       // ---------------- every surviving cluster is an envelope: unihit Forward score, trace-derived null2
       // HMMER sums n2sc over the whole sequence in position order; per region here (float32 either way)
-      float regsum = 0.f;
-      for (int pos = ireg; pos <= jreg; pos++) regsum += n2sc[pos];
+      const float regsum = n2sum(ireg, jreg);
       seqbias_sum += regsum;
 #ifdef WH_RESOLVE_DEBUG
-      if (a.dbg && lane == 0) { printf("[resolve] region n2sc sum %.6f; n2sc:", regsum); for (int pos = ireg; pos <= jreg; pos++) printf(" %.3f", n2sc[pos]); printf("\n"); }
+      if (a.dbg && lane == 0) { printf("[resolve] region n2sc sum %.6f; n2sc:", regsum); for (int pos = ireg; pos <= jreg; pos++) printf(" %.3f", __builtin_nontemporal_load(n2sc + pos)); printf("\n"); }
 #endif
       for (int d = 0; d < nsig; d++) {
         if (dominated & (1u << d)) continue;
         const int i2 = g_i[d], j2 = g_j[d], Ld = j2 - i2 + 1;
-        const double envsc = gforward<false>(m, seq + (i2 - 1), Ld, cu, mx, lane);
-        float dc = 0.f;
-        for (int pos = i2; pos <= j2; pos++) dc += n2sc[pos];
+        const double envsc = gforward_any<false>(m, seq + (i2 - 1), Ld, cu, mx, lane);
+        const float dc = n2sum(i2, j2);
         if (nenv < kEnvMax) { env_i[nenv] = i2; env_j[nenv] = j2; env_sc[nenv] = (float)envsc; env_dc[nenv] = dc; nenv++; }
         else flags |= WH_FLAG_TRUNC;
       }

@@ -348,7 +348,11 @@ def main():
             }
             if not args.no_cpu_baseline:
                 threads = min(os.cpu_count() or 1, 64)
-                n_sample = 384 if H >= 100 else 2048      # about 15 s of CPU work on 64 host threads
+                # about 15 s of CPU work on 64 host threads: 384 queries of the headline (150 nt x 200 models of ~900
+                # nodes = 1.0e10 cells); other workloads get the same number of cells
+                mean_len = float(np.mean([len(x) for x in seqs[:2048]]))
+                cells_per_query = mean_len * float(M.sum())
+                n_sample = int(max(16, min(2048, 1.05e10 / max(cells_per_query, 1.0))))
                 v, cdt = cpu_baseline(synth_ehmm.paths, synth_ehmm.nseq, seqs, k, min(n_sample, nq_total), threads)
                 line["cpu_baseline"] = {"value": round(v, 3), "unit": "queries/s", "cores": threads, "kind": "port",
                                         "sample": "first %d queries x %d HMMs through the float64 oracle "

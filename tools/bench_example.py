@@ -32,8 +32,9 @@ for it in range(2):
 idx, w, nk, nu = e.topk(deci, flags, case.k)
 pq = [q for q in range(len(seqs)) for _ in range(int(nu[q]))]
 ph = [e.pos_of_index[int(idx[q, j])] for q in range(len(seqs)) for j in range(int(nu[q]))]
-t0 = time.time()
-cols, co = e.align(res, offs, pq, ph)
-ms2, _ = e.last_kernel_ms(2)
-print("align: %d pairs, %.1f ms kernel, wall %.2f s" % (len(pq), ms2, time.time() - t0))
+for it in range(2):      # (the first call allocates the workspace)
+    t0 = time.time()
+    cols, co = e.align(res, offs, pq, ph)
+    ms2, _ = e.last_kernel_ms(2)
+    print("align %d: %d pairs, %.1f ms kernel, wall %.2f s" % (it, len(pq), ms2, time.time() - t0))
 e.close()

@@ -542,19 +542,30 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
         HIPCHK(hipMemsetAsync(e->d_recs.p, 0, 128, s));
         r.stats = (unsigned long long *)e->d_recs.p;
       }
-      // Longest pairs first: a wave gets only a handful of pairs (8 412 pairs over 2 048 waves on the reference's
-      // example data) and their costs differ several-fold, so the order of the queue decides the tail of the launch.
+      // The order of the queue.  Few pairs per wave (8 412 pairs over 2 048 waves on the reference's example data,
+      // costs several-fold apart): longest first, the order decides the tail of the launch.  Many pairs per wave:
+      // model by model (longest first inside a model) - the float64 tables of a model are 9 doubles per node and
+      // every wave streams its model's tables once per ROW of its Forward sweeps; with the pairs in arrival order
+      // hundreds of models were in flight and those reads missed L2.
       r.order = nullptr;
-      if (n_multi > 1 && n_multi < 32 * e->cu_count * resolve_waves_per_cu()) {      // (with 32+ pairs per wave the order no longer matters)
-        if (e->d_rkeys.ensure(sizeof(float) * (size_t)n_multi) || e->d_rorder.ensure(sizeof(int32_t) * (size_t)n_multi)) return WH_ENOMEM;
-        hipError_t kerr = launch_resolve_keys(r.recs, n_multi, r.hmms, (float *)e->d_rkeys.p, s);
+      if (n_multi > 1) {
+        if (e->d_rkeys.ensure(2 * sizeof(float) * (size_t)n_multi) || e->d_rorder.ensure(sizeof(int32_t) * (size_t)n_multi)) return WH_ENOMEM;
+        int32_t *d_models = (int32_t *)e->d_rkeys.p + n_multi;
+        hipError_t kerr = launch_resolve_keys(r.recs, n_multi, r.hmms, (float *)e->d_rkeys.p, d_models, s);
         if (kerr != hipSuccess) { set_error("resolve key kernel launch failed: %s", hipGetErrorString(kerr)); return WH_EHIP; }
         std::vector<float> keys((size_t)n_multi);
+        std::vector<int32_t> models((size_t)n_multi);
         HIPCHK(hipMemcpyAsync(keys.data(), e->d_rkeys.p, sizeof(float) * keys.size(), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(models.data(), d_models, sizeof(int32_t) * models.size(), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         std::vector<int32_t> ord((size_t)n_multi);
         for (int t = 0; t < n_multi; t++) ord[(size_t)t] = t;
-        std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) { return keys[(size_t)x] > keys[(size_t)y]; });
+        if (n_multi < 32 * e->cu_count * resolve_waves_per_cu())
+          std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) { return keys[(size_t)x] > keys[(size_t)y]; });
+        else
+          std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) {
+            return models[(size_t)x] != models[(size_t)y] ? models[(size_t)x] < models[(size_t)y] : keys[(size_t)x] > keys[(size_t)y];
+          });
         HIPCHK(hipMemcpyAsync(e->d_rorder.p, ord.data(), sizeof(int32_t) * ord.size(), hipMemcpyHostToDevice, s));
         HIPCHK(hipStreamSynchronize(s));     // ord is a local
         r.order = (const int32_t *)e->d_rorder.p;

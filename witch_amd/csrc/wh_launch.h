@@ -67,7 +67,7 @@ struct ResolveArgs {
   const uint8_t *residues;
   const int64_t *offsets;
   const ResolveRec *recs;
-  const int32_t *order;        // queue positions in descending cost order (longest pairs first), or NULL
+  const int32_t *order;        // queue positions in processing order (longest pairs first / model by model), or NULL
   const int *count;            // number of queued pairs (device)
   int rec_cap;
   int *counter;                // work-queue head
@@ -88,7 +88,7 @@ struct ResolveArgs {
 };
 hipError_t launch_resolve(const ResolveArgs &a, int blocks, size_t lds, hipStream_t s);
 // cost estimate of every queued pair (cells of its multidomain regions) for the longest-first order
-hipError_t launch_resolve_keys(const ResolveRec *recs, int n, const DevHMM *hmms, float *keys, hipStream_t s);
+hipError_t launch_resolve_keys(const ResolveRec *recs, int n, const DevHMM *hmms, float *keys, int32_t *models, hipStream_t s);
 size_t resolve_lds_bytes(int Lcap, int Mmax);
 int resolve_seg_cap();
 int resolve_waves_per_cu();

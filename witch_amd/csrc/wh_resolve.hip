@@ -786,23 +786,26 @@ __global__ __launch_bounds__(64, WH_RES_OCC) void resolve_kernel(ResolveArgs a) 
           float part[20];
 #pragma unroll
           for (int x = 0; x < 20; x++) part[x] = 0.f;
-          for (int pos = df + lane; pos <= dt; pos += 64) {
-            const int kk = stk[pos];
-            if (kk > 0) {
-              const float *en = emn + (size_t)kk * a.K;
-              if (a.K == 4) {
-                const float4 v = *reinterpret_cast<const float4 *>(en);
-                part[0] += v.x; part[1] += v.y; part[2] += v.z; part[3] += v.w;
-              } else {
+          // (two positions per lane and step: the reads of both are requested before either is used; a lane's
+          // positions are still added in ascending order)
+          for (int pos = df + lane; pos <= dt; pos += 128) {
+            const int kk0 = stk[pos], kk1 = pos + 64 <= dt ? stk[pos + 64] : 0;
+            const bool has1 = pos + 64 <= dt;
+            float4 v0[5], v1[5];
+            const int nq4 = a.K == 4 ? 1 : 5;
 #pragma unroll
-                for (int x4 = 0; x4 < 5; x4++) {
-                  const float4 v = *reinterpret_cast<const float4 *>(en + 4 * x4);
-                  part[4 * x4] += v.x; part[4 * x4 + 1] += v.y; part[4 * x4 + 2] += v.z; part[4 * x4 + 3] += v.w;
-                }
+            for (int x4 = 0; x4 < 5; x4++) {
+              v0[x4] = make_float4(1.f, 1.f, 1.f, 1.f); v1[x4] = make_float4(1.f, 1.f, 1.f, 1.f);
+              if (x4 < nq4) {
+                if (kk0 > 0) v0[x4] = *reinterpret_cast<const float4 *>(emn + (size_t)kk0 * a.K + 4 * x4);
+                if (kk1 > 0) v1[x4] = *reinterpret_cast<const float4 *>(emn + (size_t)kk1 * a.K + 4 * x4);
               }
-            } else {
+            }
 #pragma unroll
-              for (int x = 0; x < 20; x++) part[x] += 1.0f;
+            for (int x4 = 0; x4 < 5; x4++) { part[4 * x4] += v0[x4].x; part[4 * x4 + 1] += v0[x4].y; part[4 * x4 + 2] += v0[x4].z; part[4 * x4 + 3] += v0[x4].w; }
+            if (has1) {
+#pragma unroll
+              for (int x4 = 0; x4 < 5; x4++) { part[4 * x4] += v1[x4].x; part[4 * x4 + 1] += v1[x4].y; part[4 * x4 + 2] += v1[x4].z; part[4 * x4 + 3] += v1[x4].w; }
             }
           }
 #pragma unroll
@@ -825,11 +828,21 @@ __global__ __launch_bounds__(64, WH_RES_OCC) void resolve_kernel(ResolveArgs a) 
         }
         // per-residue accumulators: +1 outside sampled domains AND at a domain's first residue (sic),
         // + null2[x] at the domain's other residues
-        for (int pos = 1 + lane; pos <= Lr; pos += 64) {
-          float add = 1.0f;
-          for (int d = 0; d < ndom; d++)
-            if (pos > dom[4 * d] && pos <= dom[4 * d + 1]) add = dnull[32 * d + rs[pos - 1]];
-          acc[pos] = __builtin_nontemporal_load(acc + pos) + add;
+        // (the accumulators live in the wave's HBM slab: eight positions per lane are requested at once)
+        for (int p0 = 1 + lane; p0 <= Lr; p0 += 512) {
+          float old[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) old[u] = p0 + 64 * u <= Lr ? __builtin_nontemporal_load(acc + p0 + 64 * u) : 0.f;
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const int pos = p0 + 64 * u;
+            if (pos <= Lr) {
+              float add = 1.0f;
+              for (int d = 0; d < ndom; d++)
+                if (pos > dom[4 * d] && pos <= dom[4 * d + 1]) add = dnull[32 * d + rs[pos - 1]];
+              acc[pos] = old[u] + add;
+            }
+          }
         }
         // the ensemble takes the domains left to right (they were found right to left)
         if (lane == 0)
@@ -1054,8 +1067,8 @@ __global__ __launch_bounds__(64, WH_RES_OCC) void resolve_kernel(ResolveArgs a) 
 }
 
 // One thread per queued pair: the cells of its multidomain regions (region length x model length), the
-// quantity the Forward fill, the walk and the envelope rescoring all scale with.
-__global__ void resolve_keys_kernel(const ResolveRec *recs, int n, const DevHMM *hmms, float *keys) {
+// quantity the Forward fill, the walk and the envelope rescoring all scale with; and its model.
+__global__ void resolve_keys_kernel(const ResolveRec *recs, int n, const DevHMM *hmms, float *keys, int32_t *models) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   const ResolveRec &r = recs[t];
@@ -1064,10 +1077,11 @@ __global__ void resolve_keys_kernel(const ResolveRec *recs, int n, const DevHMM 
   for (int e = 0; e < ne; e++)
     if ((r.multi_mask >> e) & 1) cost += (float)(r.rj[e] - r.ri[e] + 1);
   keys[t] = cost * (float)hmms[r.h].M;
+  models[t] = r.h;
 }
 
-hipError_t launch_resolve_keys(const ResolveRec *recs, int n, const DevHMM *hmms, float *keys, hipStream_t s) {
-  hipLaunchKernelGGL(resolve_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, s, recs, n, hmms, keys);
+hipError_t launch_resolve_keys(const ResolveRec *recs, int n, const DevHMM *hmms, float *keys, int32_t *models, hipStream_t s) {
+  hipLaunchKernelGGL(resolve_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, s, recs, n, hmms, keys, models);
   return hipGetLastError();
 }
 

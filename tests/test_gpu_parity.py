@@ -506,6 +506,31 @@ def test_every_kernel_instantiation_against_the_oracle(root_len, orc, tmp_path):
     e.close()
 
 
+@pytest.mark.parametrize("root_len", [200, 450, 700, 950, 1300])
+def test_resolver_on_every_forward_class(root_len, orc, tmp_path):
+    """Queries that hold two or three copies of the family (multidomain regions: HMMER's stochastic
+    resolver) on models of 4/8/12/16 nodes per lane - the resolver's register-resident
+    Forward (wh_resolve.hip gforward_reg<4..16>) - and of 24 (its slab version): the resolved scores
+    against the oracle's, which runs the same 200 seeded tracebacks in float64."""
+    _need_gpu()
+    from witch_amd import synth
+    from witch_amd.ehmm import EHMM, pack_queries
+    fam = synth.make_family(7100 + root_len, root_len, 16, "dna", 0.03, 1e-4)
+    eh = synth.make_ehmm(fam, 2, str(tmp_path), witch_layout=False)
+    names, seqs = synth.make_queries(fam, 23 + root_len, 8, (2 * root_len, 3 * root_len), flank_frac=0.3)
+    seqs = [s_.astype(np.uint8) for s_ in seqs]
+    e = EHMM(eh.paths, hmm_index=eh.index, nseq=eh.nseq)
+    res, offs = pack_queries(seqs)
+    deci, flags, fwd = e.score(res, offs, want_fwd=True)
+    ohm = [orc.OracleHMM(p) for p in eh.paths]
+    od, of, ofwd, osc = orc.score_batch(ohm, res, offs)
+    assert int(((flags & 2) != 0).sum()) >= 3, "the case is meant to have multidomain pairs"
+    assert np.array_equal(flags & 3, of & 3), root_len
+    assert np.max(np.abs(fwd - ofwd)) <= 2e-4 * max(1.0, root_len / 500.0), root_len
+    _check_decibits(deci, od, osc, (of & 1) == 1, root_len, LONG_EPS)
+    e.close()
+
+
 def test_multihit_queries_on_a_long_model_align_like_hmmalign(orc, tmp_path):
     """1900-node models (pass-synchronous kernels) with queries that hold two or three copies of
     the family: the pairs leave float32 range and go through the log-space pass."""

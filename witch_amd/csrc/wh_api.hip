@@ -76,6 +76,7 @@ struct wh_ehmm {
   std::vector<HostHMM> hmms;
   std::vector<DevHMM> dev;          // host copy of the descriptors
   std::map<int, std::vector<int32_t>> by_q;   // Q class -> model positions
+  std::vector<int32_t> generic;               // models beyond the register-resident classes (wh_generic.hip)
   DevBuf d_hmms, d_tables, d_nseq, d_index, d_lists, d_counter, d_scratch;
   DevBuf d_gtab, d_rrecs, d_rmx, d_rsegs;   // multidomain resolver: float64 tables, pair queue, matrix slabs, segment arrays
   int last_resolved = 0;                    // pairs the resolver finished in the last wh_score call
@@ -86,6 +87,7 @@ struct wh_ehmm {
   bool timing = false;
   KernelTimer timers[5];
   int max_M = 0;
+  int max_Q = 4;                              // largest cells-per-lane of any model (sizes the float64 slabs)
   int last_align_redo = 0;          // pairs of the last wh_align call that went through the log-space pass
 };
 
@@ -170,7 +172,7 @@ wh_ehmm *wh_ehmm_load(const char *const *hmm_paths, const int32_t *hmm_index, co
         if (nseq) h.nseq = nseq[i];
         b.Q = choose_Q(h.M);
         if (b.Q < 0) continue;
-        build_tables(h, b.Q, b.fw, b.bw, b.em);
+        if (b.Q <= kMaxQ) build_tables(h, b.Q, b.fw, b.bw, b.em);     // (the any-size kernels read the float64 tables only)
         // node-major float32 odds of the canonical residues: the resolver's null2-by-trace reads the K values of ONE
         // node together (one lane per sampled position), not K lane-blocked arrays
         b.emn.assign((size_t)(h.M + 1) * h.K, 0.f);
@@ -197,7 +199,7 @@ wh_ehmm *wh_ehmm_load(const char *const *hmm_paths, const int32_t *hmm_index, co
     }
     const int Q = b.Q;
     if (Q < 0) {
-      set_error("%s: model length %d exceeds this build's limit of %d nodes", hmm_paths[i], h.M, kMaxQ * kWave);
+      set_error("%s: model length %d exceeds this build's limit of %d nodes", hmm_paths[i], h.M, kMaxQGen * kWave);
       return nullptr;
     }
     DevHMM &d = e->dev[(size_t)i];
@@ -210,7 +212,8 @@ wh_ehmm *wh_ehmm_load(const char *const *hmm_paths, const int32_t *hmm_index, co
     d.gfw_off = (int64_t)gtab.size(); gtab.insert(gtab.end(), b.gfw.begin(), b.gfw.end());
     d.gem_off = (int64_t)gtab.size(); gtab.insert(gtab.end(), b.gem.begin(), b.gem.end());
     b = Built();                                              // release the per-model copies as we go
-    e->by_q[Q].push_back(i);
+    if (Q <= kMaxQ) e->by_q[Q].push_back(i); else e->generic.push_back(i);
+    e->max_Q = std::max(e->max_Q, Q);
     e->max_M = std::max(e->max_M, h.M);
   }
   degen_masks(e->alphabet, e->degen);
@@ -226,6 +229,7 @@ wh_ehmm *wh_ehmm_load(const char *const *hmm_paths, const int32_t *hmm_index, co
   auto up = [&](void *dst, const void *src, size_t bytes) { return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess; };
   std::vector<int32_t> lists;
   for (auto &kv : e->by_q) lists.insert(lists.end(), kv.second.begin(), kv.second.end());
+  lists.insert(lists.end(), e->generic.begin(), e->generic.end());      // after the size classes
   if (!up(e->d_hmms.p, e->dev.data(), sizeof(DevHMM) * (size_t)n) || !up(e->d_tables.p, tables.data(), sizeof(float) * tables.size()) ||
       !up(e->d_nseq.p, ns.data(), sizeof(int32_t) * (size_t)n) || !up(e->d_index.p, ix.data(), sizeof(int32_t) * (size_t)n) ||
       !up(e->d_lists.p, lists.data(), sizeof(int32_t) * (size_t)n) || !up(e->d_gtab.p, gtab.data(), sizeof(double) * gtab.size())) {
@@ -504,6 +508,43 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
     }
     }
   }
+  if (nq > 0 && !e->generic.empty()) {
+    // ---- models of more than 3072 nodes: the any-size float64 front end (wh_generic.hip), one wavefront per pair;
+    // every pair with a region goes through the resolver's queue, which also assembles its score
+    const int Lc = std::max(max_len, 1);
+    const int64_t npairs_all = nq * (int64_t)e->hmms.size();
+    if (e->knobs.no_resolve || resolve_lds_bytes(Lc, e->max_M) > kLdsBudget || npairs_all >= 0x7FFFFFFF || nq * (int64_t)e->generic.size() >= 0x7FFFFFFF) {
+      set_error("models of more than %d nodes need the resolver stage (query length %d, %lld pairs)", kMaxQ * kWave, max_len, (long long)npairs_all);
+      return WH_ERANGE;
+    }
+    GenericArgs g;
+    memset(&g, 0, sizeof g);
+    g.hmms = (const DevHMM *)e->d_hmms.p; g.gtab = (const double *)e->d_gtab.p;
+    size_t goff = 0;
+    for (auto &kv : e->by_q) goff += kv.second.size();
+    g.hmm_list = (const int32_t *)e->d_lists.p + goff; g.n_list = (int)e->generic.size();
+    g.residues = d_residues; g.offsets = d_offsets; g.nq = nq;
+    g.counter = (int *)e->d_counter.p + 66;
+    g.Lcap = Lc; g.Qmax = e->max_Q;
+    g.slab_stride = (generic_front_doubles(Lc, e->max_Q) + 1) & ~(size_t)1;
+    g.decibits = d_decibits; g.flags = d_flags; g.fwd_bits = d_fwd_bits; g.detail = d_detail;
+    g.H = (int)e->hmms.size(); g.K = e->K; g.Kp = e->Kp;
+    memcpy(g.degen, e->degen, sizeof g.degen);
+    g.rrecs = (ResolveRec *)e->d_rrecs.p; g.rcount = (int *)e->d_counter.p + 64; g.rcap = (int)npairs_all;
+    const size_t glds = generic_lds_bytes(Lc);
+    if (glds > kLdsBudget) { set_error("query length %d does not fit the any-size kernel's LDS", max_len); return WH_ERANGE; }
+    const int64_t n_items = nq * (int64_t)e->generic.size();
+    int blocks = (int)std::min<int64_t>(n_items, (int64_t)e->cu_count * std::min<size_t>(8, kLdsBudget / glds));
+    blocks = clamp_blocks(blocks, g.slab_stride * sizeof(double), e->d_rmx);
+    if (e->d_rmx.ensure((size_t)blocks * g.slab_stride * sizeof(double))) return WH_ENOMEM;
+    g.slab = (double *)e->d_rmx.p;
+    HIPCHK(hipMemsetAsync(g.counter, 0, sizeof(int), s));
+    if (e->knobs.trace) fprintf(stderr, "[wh] any-size front end: %lld pairs on %zu models (up to %d nodes), %d wavefronts, slab %zu MB per wave\n",
+                                (long long)n_items, e->generic.size(), e->max_M, blocks, g.slab_stride * 8 >> 20);
+    hipError_t gerr = launch_generic_front(g, blocks, glds, s);
+    if (gerr != hipSuccess) { set_error("any-size front kernel launch failed: %s", hipGetErrorString(gerr)); return WH_EHIP; }
+    launches++;
+  }
   if (timer_end(e, 0, s, launches)) return WH_EHIP;
   if (timer_begin(e, 4, s)) return WH_EHIP;
   int rlaunches = 0;
@@ -518,8 +559,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       HIPCHK(hipStreamSynchronize(s));
     }
     if (n_multi > 0) {
-      int Qmax = 4;
-      for (auto &kv : e->by_q) Qmax = std::max(Qmax, kv.first);
+      const int Qmax = e->max_Q;
       ResolveArgs r;
       memset(&r, 0, sizeof r);
       r.hmms = (const DevHMM *)e->d_hmms.p; r.gtab = (const double *)e->d_gtab.p; r.ftab = (const float *)e->d_tables.p;
@@ -914,6 +954,36 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
     if (rc != WH_OK) return rc;
   }
   e->last_align_redo = n_redo;
+  if (!e->generic.empty()) {
+    // pairs on models of more than 3072 nodes: the any-size float64 alignment kernel, one wavefront per pair
+    std::vector<int32_t> gitems;
+    for (int64_t p = 0; p < npairs; p++) if (e->dev[(size_t)ph[(size_t)p]].Q > kMaxQ) gitems.push_back((int32_t)p);
+    if (!gitems.empty()) {
+      const int Lc = std::max(max_len, 1);
+      GenericAlignArgs g;
+      memset(&g, 0, sizeof g);
+      g.hmms = (const DevHMM *)e->d_hmms.p; g.gtab = (const double *)e->d_gtab.p;
+      g.residues = d_residues; g.offsets = d_offsets;
+      HIPCHK(hipMemcpyAsync(e->d_order.p, gitems.data(), sizeof(int32_t) * gitems.size(), hipMemcpyHostToDevice, s));
+      g.items = (const int32_t *)e->d_order.p; g.n_items = (int)gitems.size();
+      g.pair_q = d_pair_q; g.pair_h = d_pair_h; g.col_off = d_col_offsets; g.cols = d_cols; g.status = nullptr;
+      g.counter = (int *)e->d_counter.p + 67;
+      g.Lcap = Lc; g.Qmax = e->max_Q; g.Kp = e->Kp;
+      g.slab_stride = (generic_align_doubles(Lc, e->max_Q) + 1) & ~(size_t)1;
+      const size_t glds = (size_t)Lc + 64;
+      if (glds > kLdsBudget) { set_error("query length %d does not fit the any-size kernel's LDS", max_len); return WH_ERANGE; }
+      int blocks = (int)std::min<size_t>(gitems.size(), (size_t)e->cu_count * std::min<size_t>(8, kLdsBudget / glds));
+      blocks = clamp_blocks(blocks, g.slab_stride * sizeof(double), e->d_rmx);
+      if (e->d_rmx.ensure((size_t)blocks * g.slab_stride * sizeof(double))) return WH_ENOMEM;
+      g.slab = (double *)e->d_rmx.p;
+      HIPCHK(hipMemsetAsync(g.counter, 0, sizeof(int), s));
+      if (e->knobs.trace) fprintf(stderr, "[wh] any-size alignment: %zu pairs, %d wavefronts, slab %zu MB per wave\n", gitems.size(), blocks, g.slab_stride * 8 >> 20);
+      hipError_t gerr = launch_generic_align(g, blocks, glds, s);
+      if (gerr != hipSuccess) { set_error("any-size alignment kernel launch failed: %s", hipGetErrorString(gerr)); return WH_EHIP; }
+      launches++;
+      HIPCHK(hipStreamSynchronize(s));     // gitems is a local
+    }
+  }
   if (timer_end(e, 2, s, launches)) return WH_EHIP;
   return WH_OK;
 }

@@ -10,7 +10,8 @@
 namespace wh {
 
 constexpr int kWave = 64;          // CDNA wavefront width
-constexpr int kMaxQ = 48;          // cells per lane supported by this build -> M <= 64*kMaxQ = 3072
+constexpr int kMaxQ = 48;          // cells per lane of the register-resident kernels -> M <= 64*kMaxQ = 3072
+constexpr int kMaxQGen = 256;      // ... of the any-size float64 kernels (wh_generic.hip) -> M <= 16384
 constexpr int kMaxQFast = 24;      // up to here both transition orientations stay resident in LDS
 constexpr int kQRegMax = 16;       // up to this Q the transition tables live in VGPRs
 // per-wave LDS block of the scoring kernels: region list (i, j) x WH_MAX_ENVELOPES, 8 spare ints, and the

@@ -1,0 +1,592 @@
+// Models of ANY size: scoring front end and alignment for the models the register-resident kernels cannot take
+// (more than 3072 nodes: `--symfrac 0.0` makes every populated backbone column a node, so the root subsets of
+// large backbones - 16S alignments of 5-12 k columns - get there; witch_msa/gcmm/algorithm.py:463-470).
+//
+// ONE wavefront per (query, model) pair, float64, lane r owns nodes r*Q+1 .. r*Q+Q for any Q, the DP rows in a
+// per-wave HBM slab (wh_f64.h).  Slow beside the register kernels (every row goes through memory) and meant
+// as the tail of an ensemble, not its body:
+//  * generic_front_kernel: what the scoring kernels do up to the envelopes - multihit
+//    Forward and Backward keeping only the special states, domain decoding, the region scan and the multidomain
+//    test; single-domain regions are rescored here (unihit Forward with the rows kept, Backward with the
+//    posterior expectations accumulated per node, null2 by expectation).  EVERY pair with a region is then
+//    queued for resolve_kernel (wh_resolve.hip), which resolves the multidomain regions - it is generic in the
+//    model size already - and assembles the score of the pair (A.6) from the queue record.
+//  * generic_align_kernel: hmmalign's unihit Forward / Backward / posterior decoding / optimal-accuracy fill and
+//    traceback (A.7; witch_msa/gcmm/aligner.py:96-142) in place in one slab: Forward rows -> posteriors ->
+//    OA rows.
+#include <hip/hip_runtime.h>
+
+#include "wh_launch.h"
+#include "wh_f64.h"
+
+namespace wh {
+
+namespace {
+
+__device__ __forceinline__ double shfl_down_d(double v, int d) {
+  const long long u = __double_as_longlong(v);
+  const int lo = __shfl_down((int)(u & 0xFFFFFFFFll), d), hi = __shfl_down((int)(u >> 32), d);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double wave_max_d(double x) {
+  for (int m = 32; m >= 1; m >>= 1) {
+    const long long u = __double_as_longlong(x);
+    const int lo = __shfl_xor((int)(u & 0xFFFFFFFFll), m), hi = __shfl_xor((int)(u >> 32), m);
+    const double o = __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+    x = o > x ? o : x;
+  }
+  return x;
+}
+__device__ __forceinline__ float wave_max_f(float x) { for (int m = 32; m >= 1; m >>= 1) { const float o = __shfl_xor(x, m); x = o > x ? o : x; } return x; }
+
+// value of array <arr> at node (lane, q+1): the lane's next node, or the first node of lane+1; 0 beyond the table
+__device__ __forceinline__ double next_node(const double *base, int Q, int q, int lane) {
+  if (q + 1 < Q) return __builtin_nontemporal_load(base + ofs2(q + 1, lane));
+  if (lane < 63) return __builtin_nontemporal_load(base + ofs2(0, lane + 1));
+  return 0.0;
+}
+
+// Backward sweep (A.2), float64, over seq[0..L-1] with length model c.  Two alternating rows (brow[0], brow[1]:
+// 3 x Q x 64 doubles each; row i in brow[i & 1]).
+//   MODE 0: the special states of every row go to xs ((L+1) x xNSPEC doubles: N B E J C, xCLS = cumulated scale).
+//   MODE 1: posterior expectations against the stored Forward rows <fmx> (rows 0..L, specials in the row tails):
+//           accM/accI[node] += F x B x scale per row (arrays of Q x 64 doubles, zeroed by the caller); returns the
+//           unnormalised flank factor sum_i P(N, J, C emit residue i).
+//   MODE 2: posteriors in place: row i of <fmx> gets (float)ppM / (float)ppI in its state slots 0 / 1, xs gets
+//           ppN, ppJ, ppC per row in slots 0..2.
+template <int MODE>
+__device__ double gbackward(const GModel &m, const uint8_t *seq, int L, GLen c, const GMx &fmx, double *brow0, double *brow1,
+                            double *xs, double fwdsc, double *accM, double *accI, int lane) {
+  const int Q = m.Q, M = m.M;
+  const size_t SQ = (size_t)Q * 64;
+  const double *tf = m.tf;
+  double ls = 0.0, xfactor = 0.0;
+  // row L+1 does not exist: specials of "row L" start the recursion
+  double nN = 0.0, nJ = 0.0, nC = c.move;          // specials of the row below the one being formed
+  double xbsum_prev = 0.0;                         // sum_k M(i+1,k) od_{x_{i+1}}[k] entry[k], formed while row i+1 was written
+  for (int i = L; i >= 0; i--) {
+    double xBv, xJv, xCv, xNv, xEv;
+    if (i == L) { xCv = c.move; xJv = 0.0; xNv = 0.0; xBv = 0.0; }
+    else {
+      xBv = wave_sum_d(xbsum_prev);
+      xJv = nJ * c.loop + xBv * c.move;
+      xCv = nC * c.loop;
+      xNv = nN * c.loop + xBv * c.move;
+    }
+    xEv = xCv * c.EC + xJv * c.EJ;
+    // the rescale of this row depends on its special states only: it is applied while the cells are formed
+    double rs = 1.0;
+    if (xBv > kRescaleHi || xNv > kRescaleHi) {
+      const double big = xBv > xNv ? xBv : xNv;
+      rs = 1.0 / big;
+      xBv *= rs; xJv *= rs; xCv *= rs; xNv *= rs; xEv *= rs; ls += log(big);
+    }
+    if (i >= 1) {
+      wave_mem_sync();     // row i+1 was written by other lanes of this wave
+      const bool have_next = i < L;
+      const double *nr = (i + 1) & 1 ? brow1 : brow0;
+      double *cr = i & 1 ? brow1 : brow0;
+      const double *odn = have_next ? m.te + (size_t)seq[i] * SQ : nullptr;     // residue x_{i+1}
+      const double *odc = m.te + (size_t)seq[i - 1] * SQ;                       // residue x_i
+      // pass 1, nodes of the lane from the last to the first: I, the M terms that do not need D, the D chain with
+      // nothing entering from the right
+      double dloc = 0.0, P = 1.0;
+      for (int q = Q - 1; q >= 0; q--) {
+        const int k = lane * Q + q + 1;
+        const size_t o = ofs2(q, lane);
+        double mnext = 0.0, in = 0.0;
+        if (have_next) {
+          mnext = next_node(nr, Q, q, lane) * next_node(odn, Q, q, lane) * rs;
+          in = __builtin_nontemporal_load(nr + SQ + o) * rs;
+        }
+        const double tMMn = next_node(tf + gA * SQ, Q, q, lane), tIMn = next_node(tf + gB * SQ, Q, q, lane);
+        const double tDMn = next_node(tf + gC * SQ, Q, q, lane), tDDn = next_node(tf + gD2 * SQ, Q, q, lane);
+        double iv = mnext * tIMn + in * tf[gII * SQ + o];
+        double mpart = mnext * tMMn + in * tf[gMI * SQ + o] + xEv;
+        double av = mnext * tDMn + xEv;
+        if (k >= M) { iv = 0.0; if (k == M) { mpart = xEv; av = xEv; } else { mpart = 0.0; av = 0.0; } }
+        dloc = k > M ? 0.0 : av + tDDn * dloc;
+        P = k > M ? 0.0 : P * tDDn;
+        cr[o] = mpart; cr[SQ + o] = iv; cr[2 * SQ + o] = dloc;
+      }
+      // cross-lane: D(first node of lane r) = dloc + P * D(first node of lane r+1), from the last lane down
+      double Bv = dloc, Av = P;
+      for (int d = 1; d < 64; d <<= 1) {
+        const double Bo = shfl_down_d(Bv, d), Ao = shfl_down_d(Av, d);
+        if (lane + d < 64) { Bv = Bv + Av * Bo; Av = Av * Ao; }
+      }
+      const double dn = shfl_down_d(Bv, 1);
+      const double din = lane < 63 ? dn : 0.0;          // true D of the first node of lane+1
+      // pass 2: true D, the M term through D(k+1), and what the row above needs from this one
+      double Pq = 1.0, dnext = din, xbsum = 0.0;
+      const double *fr = MODE != 0 ? fmx.row(i) : nullptr;
+      double sc = 0.0;
+      if (MODE != 0) sc = exp(__builtin_nontemporal_load(fr + 3 * SQ + xCLS) + ls - fwdsc);
+      for (int q = Q - 1; q >= 0; q--) {
+        const int k = lane * Q + q + 1;
+        const size_t o = ofs2(q, lane);
+        const double tDDn = next_node(tf + gD2 * SQ, Q, q, lane), tMDn = next_node(tf + gD1 * SQ, Q, q, lane);
+        Pq = k > M ? 0.0 : Pq * tDDn;
+        double dv = __builtin_nontemporal_load(cr + 2 * SQ + o) + Pq * din;
+        double mv = __builtin_nontemporal_load(cr + o) + (k < M ? dnext * tMDn : 0.0);
+        if (k > M) { dv = 0.0; mv = 0.0; }
+        cr[o] = mv; cr[2 * SQ + o] = dv;
+        dnext = dv;
+        xbsum += mv * odc[o] * tf[gE * SQ + o];
+        if (MODE == 1) {
+          const double iv = __builtin_nontemporal_load(cr + SQ + o);
+          accM[o] = __builtin_nontemporal_load(accM + o) + __builtin_nontemporal_load(fr + o) * mv * sc;
+          accI[o] = __builtin_nontemporal_load(accI + o) + __builtin_nontemporal_load(fr + SQ + o) * iv * sc;
+        }
+        if (MODE == 2) {
+          const double iv = __builtin_nontemporal_load(cr + SQ + o);
+          double *fw = const_cast<double *>(fr);
+          const float pm = (float)(__builtin_nontemporal_load(fr + o) * mv * sc), pi = (float)(__builtin_nontemporal_load(fr + SQ + o) * iv * sc);
+          fw[o] = (double)pm; fw[SQ + o] = (double)pi;
+        }
+      }
+      xbsum_prev = xbsum;
+      if (MODE != 0) {
+        // flank posteriors of residue i: F(i-1) x loop x B(i)
+        const double *fp = fmx.row(i - 1) + 3 * SQ;
+        const double sc2 = exp(__builtin_nontemporal_load(fp + xCLS) + ls - fwdsc);
+        const double pn = __builtin_nontemporal_load(fp + xN) * xNv * c.loop * sc2;
+        const double pj = __builtin_nontemporal_load(fp + xJ) * xJv * c.loop * sc2;
+        const double pc = __builtin_nontemporal_load(fp + xC) * xCv * c.loop * sc2;
+        if (MODE == 1) { xfactor += pn; xfactor += pj; xfactor += pc; }
+        if (MODE == 2 && lane == 0) { double *t = xs + (size_t)i * xNSPEC; t[0] = (double)(float)pn; t[1] = (double)(float)pj; t[2] = (double)(float)pc; }
+      }
+    }
+    if (MODE == 0 && lane == 0) { double *t = xs + (size_t)i * xNSPEC; t[xN] = xNv; t[xB] = xBv; t[xE] = xEv; t[xJ] = xJv; t[xC] = xCv; t[xCLS] = ls; }
+    nN = xNv; nJ = xJv; nC = xCv;
+  }
+  wave_mem_sync();
+  return xfactor;
+}
+
+// per-wave slab of the front kernel (doubles): rows 0..Lcap+3 | xsF | xsB | pb pe mocc btot etot | accM accI
+__host__ __device__ inline size_t generic_rowlen(int Q) { return (size_t)3 * Q * 64 + xNSPEC; }
+
+constexpr double kRt1 = 0.25, kRt2 = 0.10, kRt3 = 0.20;
+
+}  // namespace
+
+size_t generic_front_doubles(int Lcap, int Qmax) {
+  return (size_t)(Lcap + 4) * generic_rowlen(Qmax) + 2 * (size_t)(Lcap + 2) * xNSPEC + 5 * (size_t)(Lcap + 2) + 2 * (size_t)Qmax * 64 + 8;
+}
+size_t generic_align_doubles(int Lcap, int Qmax) {
+  return (size_t)(Lcap + 4) * generic_rowlen(Qmax) + 2 * (size_t)(Lcap + 2) * xNSPEC + 8;
+}
+size_t generic_lds_bytes(int Lcap) { return (size_t)(Lcap + 16) + 64 * 4 + 4 * WH_MAX_ENVELOPES * 4 + 64; }
+
+__global__ __launch_bounds__(64, 2) void generic_front_kernel(GenericArgs a) {
+  extern __shared__ __attribute__((aligned(16))) int lds_raw[];
+  const int lane = threadIdx.x;
+  float *null2 = reinterpret_cast<float *>(lds_raw);                 // 32 floats (+ 32 spare)
+  int *regs = lds_raw + 64;                                          // 2 x WH_MAX_ENVELOPES region bounds
+  float *envres = reinterpret_cast<float *>(regs + 2 * WH_MAX_ENVELOPES);   // envsc, domcorr per region
+  uint8_t *seq = reinterpret_cast<uint8_t *>(envres + 2 * WH_MAX_ENVELOPES);
+  const double LOG2 = 0.69314718055994529;
+  double *slab = a.slab + (size_t)blockIdx.x * a.slab_stride;
+  for (;;) {
+    int item = 0;
+    if (lane == 0) item = atomicAdd(a.counter, 1);
+    item = __builtin_amdgcn_readfirstlane(__shfl(item, 0));
+    if ((int64_t)item >= a.nq * a.n_list) break;
+    const int h = a.hmm_list[item / a.nq];
+    const int64_t qi = item % a.nq;
+    const DevHMM hm = a.hmms[h];
+    GModel m;
+    m.tf = a.gtab + hm.gfw_off; m.te = a.gtab + hm.gem_off;
+    m.Q = __builtin_amdgcn_readfirstlane(hm.Q); m.M = __builtin_amdgcn_readfirstlane(hm.M);
+    const size_t SQ = (size_t)m.Q * 64;
+    GMx mx;
+    mx.Q = m.Q; mx.rowlen = generic_rowlen(m.Q); mx.p = slab;
+    double *xsF = slab + (size_t)(a.Lcap + 4) * generic_rowlen(a.Qmax);
+    double *xsB = xsF + (size_t)(a.Lcap + 2) * xNSPEC;
+    double *pbv = xsB + (size_t)(a.Lcap + 2) * xNSPEC, *pev = pbv + (a.Lcap + 2), *moccv = pev + (a.Lcap + 2);
+    double *btotv = moccv + (a.Lcap + 2), *etotv = btotv + (a.Lcap + 2);
+    double *accM = etotv + (a.Lcap + 2), *accI = accM + (size_t)a.Qmax * 64;
+    const int64_t off = a.offsets[qi];
+    const int L = (int)(a.offsets[qi + 1] - off);
+    const size_t out = (size_t)qi * a.H + h;
+    int flags = 0;
+    float fwd_bits_out = -INFINITY;
+    wh_pair_detail *dp = (a.detail && lane == 0) ? a.detail + out : nullptr;
+    if (dp) { dp->fwd_bits = -INFINITY; dp->seq_score = 0.f; dp->pre_score = 0.f; dp->seqbias_nats = 0.f; dp->nregions = 0; dp->nenv = 0; }
+    bool queued = false;
+    if (L > 0 && L <= a.Lcap) {
+      for (int t = lane; t < L; t += 64) { const int r = a.residues[off + t]; seq[t] = (uint8_t)(r < a.Kp ? r : a.Kp - 1); }
+      __builtin_amdgcn_wave_barrier();
+      // ---------------- A.2 multihit Forward and Backward of the whole sequence, special states only
+      const GLen cm = glen_config(L, true), cu = glen_config(L, false);
+      const double fwd = gforward<false>(m, seq, L, cm, mx, lane, xsF);
+      const float fwdsc = (float)fwd;
+      const float p1 = (float)L / (float)(L + 1);
+      const float nullsc = (float)((double)(float)L * log((double)p1) + log(1.0 - (double)p1));
+      fwd_bits_out = (float)((fwd - (double)nullsc) / LOG2);
+      if (dp) dp->fwd_bits = fwd_bits_out;
+      if (isfinite(fwd)) {
+        (void)gbackward<0>(m, seq, L, cm, mx, mx.row(0), mx.row(1), xsB, fwd, nullptr, nullptr, lane);
+        // ---------------- A.4 domain decoding (lanes over rows), then the serial region scan 64 rows per fetch
+        for (int i = 1 + lane; i <= L; i += 64) {
+          const double *f0 = xsF + (size_t)(i - 1) * xNSPEC, *f1 = xsF + (size_t)i * xNSPEC;
+          const double *b0 = xsB + (size_t)(i - 1) * xNSPEC, *b1 = xsB + (size_t)i * xNSPEC;
+          const double pb = f0[xB] * b0[xB] * exp(f0[xCLS] + b0[xCLS] - fwd);
+          const double pe = f1[xE] * b1[xE] * exp(f1[xCLS] + b1[xCLS] - fwd);
+          const double sc = exp(f0[xCLS] + b1[xCLS] - fwd);
+          const double njcp = (f0[xN] * b1[xN] + f0[xJ] * b1[xJ] + f0[xC] * b1[xC]) * cm.loop * sc;
+          pbv[i] = pb; pev[i] = pe; moccv[i] = 1.0 - njcp;
+        }
+        if (lane == 0) { btotv[0] = 0.0; etotv[0] = 0.0; }
+        wave_mem_sync();
+        int nenv = 0, nreg = 0, i0 = -1;
+        bool trig = false;
+        double btot = 0.0, etot = 0.0;
+        for (int j0 = 1; j0 <= L; j0 += 64) {
+          const int jj = j0 + lane;
+          const bool valid = jj <= L;
+          const double pbl = valid ? __builtin_nontemporal_load(pbv + jj) : 0.0, pel = valid ? __builtin_nontemporal_load(pev + jj) : 0.0;
+          const double mol = valid ? __builtin_nontemporal_load(moccv + jj) : 0.0;
+          double bout = 0.0, eout = 0.0;
+          const int cnt = L - j0 + 1 < 64 ? L - j0 + 1 : 64;
+          for (int t = 0; t < cnt; t++) {
+            const int j = j0 + t;
+            const double mocc = readlane_d(mol, t);
+            const double bold = btot, eold = etot;
+            btot = btot + readlane_d(pbl, t);
+            etot = etot + readlane_d(pel, t);
+            if (lane == t) { bout = btot; eout = etot; }
+            if (!trig) {
+              if (mocc - (btot - bold) < kRt2) i0 = j;
+              else if (i0 == -1) i0 = j;
+              if (mocc >= kRt1) trig = true;
+            } else if (mocc - (etot - eold) < kRt2) {
+              if (nenv < WH_MAX_ENVELOPES) { if (lane == 0) { regs[2 * nenv] = i0; regs[2 * nenv + 1] = j; } nenv++; }
+              else flags |= WH_FLAG_TRUNC;
+              nreg++;
+              i0 = -1; trig = false;
+            }
+          }
+          if (valid) { btotv[jj] = bout; etotv[jj] = eout; }
+        }
+        wave_mem_sync();
+        __builtin_amdgcn_wave_barrier();
+        // multidomain test: max_z min(etot[z]-etot[i-1], btot[j]-btot[z-1]) >= rt3
+        int multi_mask = 0;
+        for (int e = 0; e < nenv; e++) {
+          const int ri = regs[2 * e], rj = regs[2 * e + 1];
+          const double e0 = __builtin_nontemporal_load(etotv + ri - 1), bj = __builtin_nontemporal_load(btotv + rj);
+          double mxv = -1.0;
+          for (int z = ri + lane; z <= rj; z += 64) {
+            const double u = __builtin_nontemporal_load(etotv + z) - e0, v = bj - __builtin_nontemporal_load(btotv + z - 1);
+            const double w = u < v ? u : v;
+            mxv = w > mxv ? w : mxv;
+          }
+          mxv = wave_max_d(mxv);
+          if (mxv >= kRt3) { flags |= WH_FLAG_MULTI; multi_mask |= 1 << e; }
+        }
+        if (dp) { dp->nregions = nreg; dp->nenv = nenv; }
+        if (nenv > 0) {
+          // ---------------- A.5 single-domain regions: the envelope is the region
+          for (int e = 0; e < nenv; e++) {
+            if ((multi_mask >> e) & 1) { if (lane == 0) { envres[e] = 0.f; envres[WH_MAX_ENVELOPES + e] = 0.f; } continue; }
+            const int ri = regs[2 * e], rj = regs[2 * e + 1], Ld = rj - ri + 1;
+            const uint8_t *eseq = seq + (ri - 1);
+            const double envsc = gforward<true>(m, eseq, Ld, cu, mx, lane);
+            float domcorr = 0.f;
+            if (isfinite(envsc)) {
+              for (int q = 0; q < m.Q; q++) { accM[ofs2(q, lane)] = 0.0; accI[ofs2(q, lane)] = 0.0; }
+              double xfactor = gbackward<1>(m, eseq, Ld, cu, mx, mx.row(a.Lcap + 2), mx.row(a.Lcap + 3), nullptr, envsc, accM, accI, lane);
+              const double norm = 1.0 / (double)Ld;
+              xfactor *= norm;
+              // null2 by expectation: canonical residues, then the degenerate codes as unweighted means
+              double si = 0.0;
+              for (int q = 0; q < m.Q; q++) si += __builtin_nontemporal_load(accI + ofs2(q, lane)) * norm;
+              for (int x = 0; x < a.K; x++) {
+                const double *od = m.te + (size_t)x * SQ;
+                double sm = 0.0;
+                for (int q = 0; q < m.Q; q++) sm += __builtin_nontemporal_load(accM + ofs2(q, lane)) * norm * od[ofs2(q, lane)];
+                const double tot = wave_sum_d(sm + si);
+                if (lane == 0) null2[x] = (float)(tot + xfactor);
+              }
+              __builtin_amdgcn_wave_barrier();
+              if (lane >= a.K && lane < a.Kp) {
+                const uint32_t msk = a.degen[lane];
+                float s = 0.f; int n = 0;
+                for (int x = 0; x < a.K; x++) if (msk & (1u << x)) { s += null2[x]; n++; }
+                null2[lane] = n > 0 ? s / (float)n : 1.0f;
+              }
+              __builtin_amdgcn_wave_barrier();
+              float dc = 0.f;
+              for (int t = lane; t < Ld; t += 64) dc += logf(null2[eseq[t]]);
+              domcorr = wave_sum_f(dc);
+              __builtin_amdgcn_wave_barrier();
+            }
+            if (lane == 0) { envres[e] = (float)envsc; envres[WH_MAX_ENVELOPES + e] = domcorr; }
+            if (dp) { dp->env_i[e] = ri; dp->env_j[e] = rj; dp->envsc[e] = (float)envsc; dp->domcorr[e] = domcorr; }
+          }
+          __builtin_amdgcn_wave_barrier();
+          // every pair with a region is finished by resolve_kernel: multidomain regions and the score assembly
+          int slot = 0;
+          if (lane == 0) slot = atomicAdd(a.rcount, 1);
+          slot = __shfl(slot, 0);
+          if (slot < a.rcap) {
+            queued = true;
+            if (lane == 0) {
+              ResolveRec *rr = a.rrecs + slot;
+              rr->q = qi; rr->h = h; rr->fwdsc = fwdsc; rr->fwd_bits = fwd_bits_out; rr->nreg = nreg; rr->nenv = nenv;
+              rr->multi_mask = multi_mask; rr->flags = flags;
+              for (int e = 0; e < nenv; e++) { rr->ri[e] = regs[2 * e]; rr->rj[e] = regs[2 * e + 1]; rr->envsc[e] = envres[e]; rr->domcorr[e] = envres[WH_MAX_ENVELOPES + e]; }
+            }
+          } else flags |= WH_FLAG_TRUNC;
+        }
+      }
+    }
+    if (lane == 0) {
+      if (!queued) { a.decibits[out] = 0; a.flags[out] = (uint8_t)flags; }
+      if (a.fwd_bits) a.fwd_bits[out] = fwd_bits_out;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- alignment (A.7)
+namespace {
+__device__ __forceinline__ float gatef(double t, float v) { return t > 0.0 ? v : 0.0f; }
+__device__ __forceinline__ float ldf(const double *p) { return (float)__builtin_nontemporal_load(p); }
+}  // namespace
+
+__global__ __launch_bounds__(64, 2) void generic_align_kernel(GenericAlignArgs a) {
+  extern __shared__ __attribute__((aligned(16))) int lds_raw[];
+  const int lane = threadIdx.x;
+  uint8_t *seq = reinterpret_cast<uint8_t *>(lds_raw);
+  double *slab = a.slab + (size_t)blockIdx.x * a.slab_stride;
+  enum { oN = 0, oB, oE, oJ, oC };
+  for (;;) {
+    int item = 0;
+    if (lane == 0) item = atomicAdd(a.counter, 1);
+    item = __builtin_amdgcn_readfirstlane(__shfl(item, 0));
+    if (item >= a.n_items) break;
+    const int p = a.items[item];
+    const int h = a.pair_h[p];
+    const int64_t qi = a.pair_q[p];
+    const DevHMM hm = a.hmms[h];
+    GModel m;
+    m.tf = a.gtab + hm.gfw_off; m.te = a.gtab + hm.gem_off;
+    m.Q = __builtin_amdgcn_readfirstlane(hm.Q); m.M = __builtin_amdgcn_readfirstlane(hm.M);
+    const int Q = m.Q, M = m.M;
+    const size_t SQ = (size_t)Q * 64;
+    const double *tf = m.tf;
+    GMx mx;
+    mx.Q = Q; mx.rowlen = generic_rowlen(Q); mx.p = slab;
+    double *pps = slab + (size_t)(a.Lcap + 4) * generic_rowlen(a.Qmax);      // ppN ppJ ppC per row
+    double *oxs = pps + (size_t)(a.Lcap + 2) * xNSPEC;                        // OA special states per row
+    const int64_t off = a.offsets[qi];
+    const int L = (int)(a.offsets[qi + 1] - off);
+    int32_t *cols = a.cols + a.col_off[p];
+    for (int t = lane; t < L; t += 64) cols[t] = -1;
+    if (L <= 0 || L > a.Lcap) continue;
+    for (int t = lane; t < L; t += 64) { const int r = a.residues[off + t]; seq[t] = (uint8_t)(r < a.Kp ? r : a.Kp - 1); }
+    __builtin_amdgcn_wave_barrier();
+    const GLen c = glen_config(L, false);
+    const double fwd = gforward<true>(m, seq, L, c, mx, lane);
+    if (!isfinite(fwd)) { if (lane == 0 && a.status) a.status[p] = 1; continue; }
+    (void)gbackward<2>(m, seq, L, c, mx, mx.row(a.Lcap + 2), mx.row(a.Lcap + 3), pps, fwd, nullptr, nullptr, lane);
+    // ---------------- optimal-accuracy fill, in place: row i holds ppM / ppI on entry, oM / oI / oD on exit
+    const float tNl = c.loop > 0.0 ? 1.0f : 0.0f, tNm = c.move > 0.0 ? 1.0f : 0.0f;
+    const float tEJ = c.EJ > 0.0 ? 1.0f : 0.0f, tEC = c.EC > 0.0 ? 1.0f : 0.0f;
+    {
+      double *r0 = mx.row(0);
+      for (int q = 0; q < Q; q++) { const size_t o = ofs2(q, lane); r0[o] = -INFINITY; r0[SQ + o] = -INFINITY; r0[2 * SQ + o] = -INFINITY; }
+      if (lane == 0) { oxs[oN] = 0.0; oxs[oB] = 0.0; oxs[oE] = -INFINITY; oxs[oJ] = -INFINITY; oxs[oC] = -INFINITY; }
+    }
+    float pxN = 0.f, pxB = 0.f, pxJ = -INFINITY, pxC = -INFINITY;
+    for (int i = 1; i <= L; i++) {
+      wave_mem_sync();
+      const double *pr = mx.row(i - 1);
+      double *cr = mx.row(i);
+      // node k-1 of my first node: lane-1's last node of the previous row
+      float pm1 = -INFINITY, pi1 = -INFINITY, pd1 = -INFINITY;
+      if (lane > 0) { const size_t ol = ofs2(Q - 1, lane - 1); pm1 = ldf(pr + ol); pi1 = ldf(pr + SQ + ol); pd1 = ldf(pr + 2 * SQ + ol); }
+      float mprev = -INFINITY, dloc = -INFINITY, xE = -INFINITY;
+      bool pass = true;          // every D->D gate of the lane's nodes 2..Q is open: an entering D reaches the last node
+      for (int q = 0; q < Q; q++) {
+        const int k = lane * Q + q + 1;
+        const size_t o = ofs2(q, lane);
+        const float oM1 = ldf(pr + o), oI1 = ldf(pr + SQ + o), oD1 = ldf(pr + 2 * SQ + o);
+        const float ppm = ldf(cr + o), ppi = ldf(cr + SQ + o);
+        float sv = gatef(tf[gE * SQ + o], pxB), t;
+        // (node 1: its predecessors are node 0, whose transitions are zero: every gate closed, value 0)
+        t = gatef(tf[gA * SQ + o], pm1); if (t > sv) sv = t;
+        t = gatef(tf[gB * SQ + o], pi1); if (t > sv) sv = t;
+        t = gatef(tf[gC * SQ + o], pd1); if (t > sv) sv = t;
+        sv += ppm;
+        const float av = gatef(tf[gMI * SQ + o], oM1), bv = gatef(tf[gII * SQ + o], oI1);
+        float iv = (av > bv ? av : bv) + ppi;
+        if (k > M) { sv = -INFINITY; iv = -INFINITY; }
+        cr[o] = (double)sv; cr[SQ + o] = (double)iv;
+        if (k <= M && sv > xE) xE = sv;
+        // D chain inside the lane with -inf in its first node (the true first node comes from lane-1, below)
+        if (q > 0) {
+          const bool gd = tf[gD2 * SQ + o] > 0.0;
+          const float a1 = gatef(tf[gD1 * SQ + o], mprev), b1 = gd ? dloc : 0.0f;
+          dloc = a1 > b1 ? a1 : b1;
+          pass = pass && gd;
+        }
+        pm1 = oM1; pi1 = oI1; pd1 = oD1; mprev = sv;
+      }
+      // cross-lane: D(first node of lane r) = max(gate(tMD, M_last(r-1)), tDD open ? D_last(r-1) : 0), and
+      // D_last(r) = max(dloc, pass ? D_first(r) : -inf).  Serial over the lanes: this is the slow path.
+      const float mlast_up = __shfl_up(mprev, 1);
+      const float mleft = lane > 0 ? mlast_up : -INFINITY;
+      const double t1 = tf[gD1 * SQ + ofs2(0, lane)], t2 = tf[gD2 * SQ + ofs2(0, lane)];
+      float dfirst = -INFINITY, dlast_prev = -INFINITY;
+      for (int r = 0; r < 64; r++) {
+        const float a1 = gatef(t1, mleft), b1 = t2 > 0.0 ? dlast_prev : 0.0f;
+        const float f = a1 > b1 ? a1 : b1;
+        const float mine_last = pass ? (dloc > f ? dloc : f) : dloc;
+        if (lane == r) dfirst = f;
+        dlast_prev = __shfl(mine_last, r);
+      }
+      // pass 2: the lane's true D values
+      {
+        float dprev = -INFINITY, mp = -INFINITY;
+        for (int q = 0; q < Q; q++) {
+          const int k = lane * Q + q + 1;
+          const size_t o = ofs2(q, lane);
+          float dv;
+          if (q == 0) dv = dfirst;
+          else {
+            const float a1 = gatef(tf[gD1 * SQ + o], mp), b1 = tf[gD2 * SQ + o] > 0.0 ? dprev : 0.0f;
+            dv = a1 > b1 ? a1 : b1;
+          }
+          if (k > M) dv = -INFINITY;
+          cr[2 * SQ + o] = (double)dv;
+          if (k <= M && dv > xE) xE = dv;
+          dprev = dv; mp = ldf(cr + o);
+        }
+      }
+      xE = wave_max_f(xE);
+      const float ppN = ldf(pps + (size_t)i * xNSPEC + 0), ppJ = ldf(pps + (size_t)i * xNSPEC + 1), ppC = ldf(pps + (size_t)i * xNSPEC + 2);
+      float av = tNl * (pxJ + ppJ), bv = tEJ * xE;
+      const float xJ = av > bv ? av : bv;
+      av = tNl * (pxC + ppC); bv = tEC * xE;
+      const float xC = av > bv ? av : bv;
+      const float xN = tNl * (pxN + ppN);
+      av = tNm * xN; bv = tNm * xJ;
+      const float xBn = av > bv ? av : bv;
+      if (lane == 0) { double *t = oxs + (size_t)i * xNSPEC; t[oN] = xN; t[oB] = xBn; t[oE] = xE; t[oJ] = xJ; t[oC] = xC; }
+      pxN = xN; pxB = xBn; pxJ = xJ; pxC = xC;
+    }
+    wave_mem_sync();
+    // ---------------- traceback (first maximum wins, candidate order as in A.7), wave-uniform
+    {
+      enum { tS, tN, tB, tM, tI, tD, tE, tJ, tC };
+      auto cell = [&](int i, int k, int s) -> float {
+        if (k <= 0) return -INFINITY;
+        const int q = (k - 1) % Q, ln = (k - 1) / Q;
+        return ldf(mx.row(i) + (size_t)s * SQ + ofs2(q, ln));
+      };
+      auto ox = [&](int i, int s) -> float { return ldf(oxs + (size_t)i * xNSPEC + s); };
+      auto pp = [&](int i, int s) -> float { return ldf(pps + (size_t)i * xNSPEC + s); };
+      int s0 = tC, s1, i = L, k = 0, guard = 4 * (L + M) + 16;
+      while (s0 != tS && guard-- > 0) {
+        switch (s0) {
+          case tC: {
+            const float av = tNl * (ox(i - 1 < 0 ? 0 : i - 1, oC) + pp(i, 2)), bv = tEC * ox(i, oE);
+            s1 = i == 0 ? tE : (bv > av ? tE : tC);
+            break;
+          }
+          case tJ: {
+            const float av = tNl * (ox(i - 1 < 0 ? 0 : i - 1, oJ) + pp(i, 1)), bv = tEJ * ox(i, oE);
+            s1 = i == 0 ? tE : (bv > av ? tE : tJ);
+            break;
+          }
+          case tE: {
+            // argmax over M (">=": later wins) and D (">") in HMMER's striped scan order k = r*Qs + qs + 1: the winner
+            // is the LAST M cell at the maximum if any M cell reaches it, else the FIRST D cell at the maximum
+            const int Qs = ((M - 1) / 4 + 1) > 2 ? ((M - 1) / 4 + 1) : 2;
+            float mxv = -INFINITY;
+            const double *row = mx.row(i);
+            for (int q = 0; q < Q; q++) {
+              const int kk = lane * Q + q + 1;
+              if (kk <= M) { const float vm = ldf(row + ofs2(q, lane)), vd = ldf(row + 2 * SQ + ofs2(q, lane)); mxv = vm > mxv ? vm : mxv; mxv = vd > mxv ? vd : mxv; }
+            }
+            mxv = wave_max_f(mxv);
+            int bestM = -1, bestD = 0x7FFFFFFF;
+            for (int q = 0; q < Q; q++) {
+              const int kk = lane * Q + q + 1;
+              if (kk <= M) {
+                const int pos = ((kk - 1) % Qs) * 8 + (kk - 1) / Qs;
+                if (ldf(row + ofs2(q, lane)) == mxv && pos > bestM) bestM = pos;
+                if (ldf(row + 2 * SQ + ofs2(q, lane)) == mxv && pos + 4 < bestD) bestD = pos + 4;
+              }
+            }
+            bestM = wave_max_i(bestM); bestD = wave_min_i(bestD);
+            if (mxv == -INFINITY || (bestM < 0 && bestD == 0x7FFFFFFF)) { guard = 0; s1 = tS; if (lane == 0 && a.status) a.status[p] = 2; break; }
+            if (bestM >= 0) { k = (bestM & 3) * Qs + (bestM >> 3) + 1; s1 = tM; }
+            else { const int pd = bestD - 4; k = (pd & 3) * Qs + (pd >> 3) + 1; s1 = tD; }
+            break;
+          }
+          case tM: {
+            const size_t o = m.at(0, k);     // offset of node k inside an array
+            float path[4];
+            path[0] = gatef(tf[gE * SQ + o], ox(i - 1, oB));
+            path[1] = gatef(tf[gA * SQ + o], cell(i - 1, k - 1, 0));
+            path[2] = gatef(tf[gB * SQ + o], cell(i - 1, k - 1, 1));
+            path[3] = gatef(tf[gC * SQ + o], cell(i - 1, k - 1, 2));
+            int best = 0;
+            for (int u = 1; u < 4; u++) if (path[u] > path[best]) best = u;
+            s1 = best == 0 ? tB : best == 1 ? tM : best == 2 ? tI : tD;
+            if (lane == 0) cols[i - 1] = k - 1;
+            k--; i--;
+            break;
+          }
+          case tD: {
+            const size_t o = m.at(0, k);
+            const float av = gatef(tf[gD1 * SQ + o], cell(i, k - 1, 0)), bv = gatef(tf[gD2 * SQ + o], cell(i, k - 1, 2));
+            s1 = bv > av ? tD : tM;
+            k--;
+            break;
+          }
+          case tI: {
+            const size_t o = m.at(0, k);
+            const float av = gatef(tf[gMI * SQ + o], cell(i - 1, k, 0)), bv = gatef(tf[gII * SQ + o], cell(i - 1, k, 1));
+            s1 = bv > av ? tI : tM;
+            i--;
+            break;
+          }
+          case tB: {
+            const float av = tNm * ox(i, oN), bv = tNm * ox(i, oJ);
+            s1 = bv > av ? tJ : tN;
+            break;
+          }
+          case tN: s1 = i == 0 ? tS : tN; break;
+          default: s1 = tS; break;
+        }
+        s1 = __builtin_amdgcn_readfirstlane(s1);
+        if ((s1 == tN || s1 == tJ || s1 == tC) && s1 == s0) i--;
+        s0 = s1;
+        if (i < 0 || k < 0 || k > M) break;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+hipError_t launch_generic_front(const GenericArgs &a, int blocks, size_t lds, hipStream_t s) {
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&generic_front_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (err != hipSuccess) return err;
+  hipLaunchKernelGGL(generic_front_kernel, dim3(blocks), dim3(64), lds, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_generic_align(const GenericAlignArgs &a, int blocks, size_t lds, hipStream_t s) {
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&generic_align_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (err != hipSuccess) return err;
+  hipLaunchKernelGGL(generic_align_kernel, dim3(blocks), dim3(64), lds, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace wh

@@ -188,8 +188,9 @@ int choose_Q(int M) {
   int q = (M + kWave - 1) / kWave;
   q = (q + 3) / 4 * 4;
   if (q < 4) q = 4;
-  // instantiated classes: 4..24 (both orientations resident in LDS), 28..48 (pass-synchronous swap)
-  if (q > kMaxQ) return -1;
+  // instantiated classes: 4..24 (both orientations resident in LDS), 28..48 (pass-synchronous swap); beyond:
+  // the any-size float64 kernels (wh_generic.hip), which take Q as a run-time value
+  if (q > kMaxQGen) return -1;
   return q;
 }
 

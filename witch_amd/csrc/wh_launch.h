@@ -95,6 +95,52 @@ int resolve_waves_per_cu();
 size_t resolve_seg_ints(int Lcap, int Mmax);
 size_t resolve_dcache_doubles();
 
+// models of any size (wh_generic.hip)
+struct GenericArgs {
+  const DevHMM *hmms;
+  const double *gtab;
+  const int32_t *hmm_list;     // model positions served by the generic kernels
+  int n_list;
+  const uint8_t *residues;
+  const int64_t *offsets;
+  int64_t nq;
+  int *counter;                // work-queue head
+  int Lcap, Qmax;
+  double *slab;                // per-wave workspace
+  size_t slab_stride;          // doubles per wave
+  int32_t *decibits;
+  uint8_t *flags;
+  float *fwd_bits;
+  wh_pair_detail *detail;
+  int H, K, Kp;
+  uint32_t degen[32];
+  ResolveRec *rrecs;           // EVERY pair with a region is finished by resolve_kernel
+  int *rcount;
+  int rcap;
+};
+struct GenericAlignArgs {
+  const DevHMM *hmms;
+  const double *gtab;
+  const uint8_t *residues;
+  const int64_t *offsets;
+  const int32_t *items;        // pair indices served by this launch
+  int n_items;
+  const int64_t *pair_q;
+  const int32_t *pair_h;
+  const int64_t *col_off;
+  int32_t *cols;
+  int32_t *status;             // per pair: 0 ok, 1 no path has probability, 2 traceback found no cell (or NULL)
+  int *counter;
+  int Lcap, Qmax, Kp;
+  double *slab;
+  size_t slab_stride;
+};
+hipError_t launch_generic_front(const GenericArgs &a, int blocks, size_t lds, hipStream_t s);
+hipError_t launch_generic_align(const GenericAlignArgs &a, int blocks, size_t lds, hipStream_t s);
+size_t generic_front_doubles(int Lcap, int Qmax);
+size_t generic_align_doubles(int Lcap, int Qmax);
+size_t generic_lds_bytes(int Lcap);
+
 // final transitive merge (wh_merge.hip)
 struct MergeArgs {
   const uint8_t *q_text;       // query characters as given (ASCII), concatenated

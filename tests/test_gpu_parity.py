@@ -577,7 +577,67 @@ def test_models_beyond_3072_nodes_take_the_any_size_kernels(root_len, orc, tmp_p
             continue
         want = ohm[ph[p]].align(seqs[pq[p]])
         assert np.array_equal(cols[co[p]:co[p + 1]], want), (pq[p], ph[p])
+    # the two-copy queries: aligned like the oracle, or reported and returned unaligned - never a wrong alignment
+    big = [h for h in range(e.H) if int(e.M[h]) > 3072]
+    double_ = [q for q in range(len(seqs)) if len(seqs[q]) > root_len]
+    pq = [q for q in double_ for _ in big]
+    ph = [h for q in double_ for h in big]
+    cols, co = e.align(res, offs, pq, ph)
+    for p in range(len(pq)):
+        got = cols[co[p]:co[p + 1]]
+        assert np.all(got == -1) or np.array_equal(got, ohm[ph[p]].align(seqs[pq[p]])), (pq[p], ph[p])
     e.close()
+
+
+def test_level1_chain_with_a_backbone_of_more_than_3072_columns(tmp_path):
+    """The reference-shaped functions end to end on a family whose models have ~3 300 nodes: engine (scores, top-k,
+    alignment, consensus), the per-query strings and both mergers.  Every query row of the merged alignment spells its
+    query, and the device merge writes the host merger's bytes."""
+    _need_gpu()
+    from witch_amd import gcmm, synth
+    fam = synth.make_family(4711, 3300, 16, "dna", 0.03, 1e-4)
+    se = synth.make_ehmm(fam, 3, str(tmp_path), witch_layout=True)
+    assert min(h.M for h in se.hmms) > 3072
+    names, seqs = synth.make_queries(fam, 31, 24, (150, 500))
+
+    class _Sub:
+        def __init__(self, path, n):
+            self.hmm_model_path, self.num_taxa = path, n
+
+    index_to_hmm = {i: _Sub(p, n) for i, p, n in zip(se.index, se.paths, se.nseq)}
+    retained = {i: (h.map_cols[1:] - 1).tolist() for i, h in zip(se.index, se.hmms)}
+    nongaps = {i: h.nongaps.tolist() for i, h in zip(se.index, se.hmms)}
+    B = fam.msa.shape[1]
+    texts = [synth.to_text(s_, "dna") for s_ in seqs]
+    bpath = str(tmp_path / "backbone.fasta")
+    synth.write_msa_fasta(bpath, fam, 0, 16)
+    eng = gcmm.install(gcmm.QueryAlignmentEngine.run(index_to_hmm, list(zip(names, texts)), 3, subset_to_retained_columns=retained,
+                                                     subset_to_nongaps_per_column=nongaps, backbone_length=B))
+    ranked = gcmm.rankBitscores(index_to_hmm, {})
+    weights = gcmm.writeWeights(index_to_hmm, ranked)
+    assert len(weights) == len(names)
+    queries = [gcmm.alignSubQueriesNew(bpath, B, index_to_hmm, None, 0, t, s_, weights[t], i)[0]
+               for i, (t, s_) in enumerate(zip(names, texts))]
+    out_host, out_dev = str(tmp_path / "out.fasta"), str(tmp_path / "out_dev.fasta")
+    gcmm.mergeAlignmentsCollapsed(bpath, queries, {}, None, output_path=out_host)
+    gcmm.mergeAlignmentsDevice(bpath, {}, output_path=out_dev, taxa=list(names))
+    assert open(out_host, "rb").read() == open(out_dev, "rb").read()
+    rows = {}
+    name = None
+    for line in open(out_host):
+        line = line.strip()
+        if line.startswith(">"):
+            name = line[1:]
+            rows[name] = []
+        elif name is not None:
+            rows[name].append(line)
+    width = {len("".join(v)) for v in rows.values()}
+    assert len(width) == 1
+    for t, s_ in zip(names, texts):
+        row = "".join(rows[t])
+        assert row.replace("-", "").upper() == s_.upper(), t
+        assert sum(1 for ch in row if ch.isupper()) > 0.8 * len(s_), t      # a family member: mostly match columns
+    assert eng is not None
 
 
 def test_multihit_queries_on_a_long_model_align_like_hmmalign(orc, tmp_path):

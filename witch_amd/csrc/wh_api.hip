@@ -89,6 +89,7 @@ struct wh_ehmm {
   int max_M = 0;
   int max_Q = 4;                              // largest cells-per-lane of any model (sizes the float64 slabs)
   int last_align_redo = 0;          // pairs of the last wh_align call that went through the log-space pass
+  int last_align_unaligned = 0;     // ... that the any-size kernel could not align (float64 range)
 };
 
 static int g_device = -1;
@@ -954,6 +955,7 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
     if (rc != WH_OK) return rc;
   }
   e->last_align_redo = n_redo;
+  e->last_align_unaligned = 0;
   if (!e->generic.empty()) {
     // pairs on models of more than 3072 nodes: the any-size float64 alignment kernel, one wavefront per pair
     std::vector<int32_t> gitems;
@@ -966,7 +968,10 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       g.residues = d_residues; g.offsets = d_offsets;
       HIPCHK(hipMemcpyAsync(e->d_order.p, gitems.data(), sizeof(int32_t) * gitems.size(), hipMemcpyHostToDevice, s));
       g.items = (const int32_t *)e->d_order.p; g.n_items = (int)gitems.size();
-      g.pair_q = d_pair_q; g.pair_h = d_pair_h; g.col_off = d_col_offsets; g.cols = d_cols; g.status = nullptr;
+      g.pair_q = d_pair_q; g.pair_h = d_pair_h; g.col_off = d_col_offsets; g.cols = d_cols;
+      if (e->d_recs.ensure(sizeof(int32_t) * ((size_t)npairs + 4))) return WH_ENOMEM;
+      HIPCHK(hipMemsetAsync(e->d_recs.p, 0, sizeof(int32_t) * (size_t)npairs, s));
+      g.status = (int32_t *)e->d_recs.p;
       g.counter = (int *)e->d_counter.p + 67;
       g.Lcap = Lc; g.Qmax = e->max_Q; g.Kp = e->Kp;
       g.slab_stride = (generic_align_doubles(Lc, e->max_Q) + 1) & ~(size_t)1;
@@ -981,7 +986,15 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       hipError_t gerr = launch_generic_align(g, blocks, glds, s);
       if (gerr != hipSuccess) { set_error("any-size alignment kernel launch failed: %s", hipGetErrorString(gerr)); return WH_EHIP; }
       launches++;
+      std::vector<int32_t> st((size_t)npairs);
+      HIPCHK(hipMemcpyAsync(st.data(), e->d_recs.p, sizeof(int32_t) * st.size(), hipMemcpyDeviceToHost, s));
       HIPCHK(hipStreamSynchronize(s));     // gitems is a local
+      int n_range = 0;
+      for (int32_t v : st) n_range += v == 3;
+      e->last_align_unaligned = n_range;
+      if (n_range > 0)
+        fprintf(stderr, "[wh] warning: %d pair(s) on models of more than %d nodes hold hits beyond float64 range in one alignment; "
+                        "they are returned unaligned (all residues -1)\n", n_range, kMaxQ * kWave);
     }
   }
   if (timer_end(e, 2, s, launches)) return WH_EHIP;

@@ -56,7 +56,7 @@ __device__ __forceinline__ double next_node(const double *base, int Q, int q, in
 //           ppN, ppJ, ppC per row in slots 0..2.
 template <int MODE>
 __device__ double gbackward(const GModel &m, const uint8_t *seq, int L, GLen c, const GMx &fmx, double *brow0, double *brow1,
-                            double *xs, double fwdsc, double *accM, double *accI, int lane) {
+                            double *xs, double fwdsc, double *accM, double *accI, int lane, double *bwd_out = nullptr) {
   const int Q = m.Q, M = m.M;
   const size_t SQ = (size_t)Q * 64;
   const double *tf = m.tf;
@@ -159,6 +159,7 @@ __device__ double gbackward(const GModel &m, const uint8_t *seq, int L, GLen c, 
     }
     if (MODE == 0 && lane == 0) { double *t = xs + (size_t)i * xNSPEC; t[xN] = xNv; t[xB] = xBv; t[xE] = xEv; t[xJ] = xJv; t[xC] = xCv; t[xCLS] = ls; }
     nN = xNv; nJ = xJv; nC = xCv;
+    if (i == 0 && bwd_out) *bwd_out = ls + log(xNv);
   }
   wave_mem_sync();
   return xfactor;
@@ -392,7 +393,12 @@ __global__ __launch_bounds__(64, 2) void generic_align_kernel(GenericAlignArgs a
     const GLen c = glen_config(L, false);
     const double fwd = gforward<true>(m, seq, L, c, mx, lane);
     if (!isfinite(fwd)) { if (lane == 0 && a.status) a.status[p] = 1; continue; }
-    (void)gbackward<2>(m, seq, L, c, mx, mx.row(a.Lcap + 2), mx.row(a.Lcap + 3), pps, fwd, nullptr, nullptr, lane);
+    double bwd = 0.0;
+    (void)gbackward<2>(m, seq, L, c, mx, mx.row(a.Lcap + 2), mx.row(a.Lcap + 3), pps, fwd, nullptr, nullptr, lane, &bwd);
+    // Two hits thousands of bits apart in ONE unihit alignment leave the range of a scaled double (the flank state
+    // that carries the weaker hit underflows against the row's scale): Forward and Backward then disagree.  hmmalign
+    // switches to log space there; this kernel has no such pass - the pair is reported and left unaligned.
+    if (!(fabs(fwd - bwd) <= 1e-6 * fabs(fwd) + 1e-3)) { if (lane == 0 && a.status) a.status[p] = 3; continue; }
     // ---------------- optimal-accuracy fill, in place: row i holds ppM / ppI on entry, oM / oI / oD on exit
     const float tNl = c.loop > 0.0 ? 1.0f : 0.0f, tNm = c.move > 0.0 ? 1.0f : 0.0f;
     const float tEJ = c.EJ > 0.0 ? 1.0f : 0.0f, tEC = c.EC > 0.0 ? 1.0f : 0.0f;

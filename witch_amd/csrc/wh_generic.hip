@@ -46,6 +46,25 @@ __device__ __forceinline__ double next_node(const double *base, int Q, int q, in
   return 0.0;
 }
 
+// four nodes q0..q0+3 of a lane (two adjacent pairs: 16-byte accesses), and those plus the node that follows them
+template <bool NT>
+__device__ __forceinline__ void load4(const double *base, int q0, int lane, double *v) {
+  if (!base) { v[0] = v[1] = v[2] = v[3] = 0.0; return; }
+  const d2_t a = NT ? nt_load_d2(base + ofs2(q0, lane)) : ld_d2(base + ofs2(q0, lane));
+  const d2_t b = NT ? nt_load_d2(base + ofs2(q0 + 2, lane)) : ld_d2(base + ofs2(q0 + 2, lane));
+  v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+}
+template <bool NT>
+__device__ __forceinline__ void load5(const double *base, int Q, int q0, int lane, double *v) {
+  if (!base) { v[0] = v[1] = v[2] = v[3] = v[4] = 0.0; return; }
+  load4<NT>(base, q0, lane, v);
+  v[4] = next_node(base, Q, q0 + 3, lane);
+}
+__device__ __forceinline__ void store4(double *base, int q0, int lane, const double *v) {
+  st_d2(base + ofs2(q0, lane), v[0], v[1]);
+  st_d2(base + ofs2(q0 + 2, lane), v[2], v[3]);
+}
+
 // Backward sweep (A.2), float64, over seq[0..L-1] with length model c.  Two alternating rows (brow[0], brow[1]:
 // 3 x Q x 64 doubles each; row i in brow[i & 1]).
 //   MODE 0: the special states of every row go to xs ((L+1) x xNSPEC doubles: N B E J C, xCLS = cumulated scale).
@@ -88,26 +107,34 @@ __device__ double gbackward(const GModel &m, const uint8_t *seq, int L, GLen c, 
       double *cr = i & 1 ? brow1 : brow0;
       const double *odn = have_next ? m.te + (size_t)seq[i] * SQ : nullptr;     // residue x_{i+1}
       const double *odc = m.te + (size_t)seq[i - 1] * SQ;                       // residue x_i
+      // Four nodes per step (Q is a multiple of 4), every load of the step requested before the first is used - a
+      // step then costs one memory round trip instead of one per node.  "next" arrays (values at node k+1) are read
+      // as the step's four nodes plus the one that follows them (the next step's first, or lane+1's first node).
       // pass 1, nodes of the lane from the last to the first: I, the M terms that do not need D, the D chain with
       // nothing entering from the right
       double dloc = 0.0, P = 1.0;
-      for (int q = Q - 1; q >= 0; q--) {
-        const int k = lane * Q + q + 1;
-        const size_t o = ofs2(q, lane);
-        double mnext = 0.0, in = 0.0;
-        if (have_next) {
-          mnext = next_node(nr, Q, q, lane) * next_node(odn, Q, q, lane) * rs;
-          in = __builtin_nontemporal_load(nr + SQ + o) * rs;
+      for (int q0 = Q - 4; q0 >= 0; q0 -= 4) {
+        double mn[5], on[5], tAn[5], tBn[5], tCn[5], tDn[5], inn[4], tII4[4], tMI4[4];
+        load5<true>(have_next ? nr : nullptr, Q, q0, lane, mn);
+        load5<true>(odn, Q, q0, lane, on);
+        load5<true>(tf + gA * SQ, Q, q0, lane, tAn); load5<true>(tf + gB * SQ, Q, q0, lane, tBn);
+        load5<true>(tf + gC * SQ, Q, q0, lane, tCn); load5<true>(tf + gD2 * SQ, Q, q0, lane, tDn);
+        load4<true>(have_next ? nr + SQ : nullptr, q0, lane, inn);
+        load4<false>(tf + gII * SQ, q0, lane, tII4); load4<false>(tf + gMI * SQ, q0, lane, tMI4);
+        double oM4[4], oI4[4], oD4[4];
+#pragma unroll
+        for (int u = 3; u >= 0; u--) {
+          const int k = lane * Q + q0 + u + 1;
+          const double mnext = mn[u + 1] * on[u + 1] * rs, in = inn[u] * rs;
+          double iv = mnext * tBn[u + 1] + in * tII4[u];
+          double mpart = mnext * tAn[u + 1] + in * tMI4[u] + xEv;
+          double av = mnext * tCn[u + 1] + xEv;
+          if (k >= M) { iv = 0.0; if (k == M) { mpart = xEv; av = xEv; } else { mpart = 0.0; av = 0.0; } }
+          dloc = k > M ? 0.0 : av + tDn[u + 1] * dloc;
+          P = k > M ? 0.0 : P * tDn[u + 1];
+          oM4[u] = mpart; oI4[u] = iv; oD4[u] = dloc;
         }
-        const double tMMn = next_node(tf + gA * SQ, Q, q, lane), tIMn = next_node(tf + gB * SQ, Q, q, lane);
-        const double tDMn = next_node(tf + gC * SQ, Q, q, lane), tDDn = next_node(tf + gD2 * SQ, Q, q, lane);
-        double iv = mnext * tIMn + in * tf[gII * SQ + o];
-        double mpart = mnext * tMMn + in * tf[gMI * SQ + o] + xEv;
-        double av = mnext * tDMn + xEv;
-        if (k >= M) { iv = 0.0; if (k == M) { mpart = xEv; av = xEv; } else { mpart = 0.0; av = 0.0; } }
-        dloc = k > M ? 0.0 : av + tDDn * dloc;
-        P = k > M ? 0.0 : P * tDDn;
-        cr[o] = mpart; cr[SQ + o] = iv; cr[2 * SQ + o] = dloc;
+        store4(cr, q0, lane, oM4); store4(cr + SQ, q0, lane, oI4); store4(cr + 2 * SQ, q0, lane, oD4);
       }
       // cross-lane: D(first node of lane r) = dloc + P * D(first node of lane r+1), from the last lane down
       double Bv = dloc, Av = P;
@@ -122,28 +149,30 @@ __device__ double gbackward(const GModel &m, const uint8_t *seq, int L, GLen c, 
       const double *fr = MODE != 0 ? fmx.row(i) : nullptr;
       double sc = 0.0;
       if (MODE != 0) sc = exp(__builtin_nontemporal_load(fr + 3 * SQ + xCLS) + ls - fwdsc);
-      for (int q = Q - 1; q >= 0; q--) {
-        const int k = lane * Q + q + 1;
-        const size_t o = ofs2(q, lane);
-        const double tDDn = next_node(tf + gD2 * SQ, Q, q, lane), tMDn = next_node(tf + gD1 * SQ, Q, q, lane);
-        Pq = k > M ? 0.0 : Pq * tDDn;
-        double dv = __builtin_nontemporal_load(cr + 2 * SQ + o) + Pq * din;
-        double mv = __builtin_nontemporal_load(cr + o) + (k < M ? dnext * tMDn : 0.0);
-        if (k > M) { dv = 0.0; mv = 0.0; }
-        cr[o] = mv; cr[2 * SQ + o] = dv;
-        dnext = dv;
-        xbsum += mv * odc[o] * tf[gE * SQ + o];
-        if (MODE == 1) {
-          const double iv = __builtin_nontemporal_load(cr + SQ + o);
-          accM[o] = __builtin_nontemporal_load(accM + o) + __builtin_nontemporal_load(fr + o) * mv * sc;
-          accI[o] = __builtin_nontemporal_load(accI + o) + __builtin_nontemporal_load(fr + SQ + o) * iv * sc;
+      for (int q0 = Q - 4; q0 >= 0; q0 -= 4) {
+        double tDn[5], tMDn[5], dl[4], mp[4], oc[4], te4[4], iv4[4], fM4[4], fI4[4], aM4[4], aI4[4];
+        load5<true>(tf + gD2 * SQ, Q, q0, lane, tDn); load5<true>(tf + gD1 * SQ, Q, q0, lane, tMDn);
+        load4<true>(cr + 2 * SQ, q0, lane, dl); load4<true>(cr, q0, lane, mp);
+        load4<false>(odc, q0, lane, oc); load4<false>(tf + gE * SQ, q0, lane, te4);
+        if (MODE != 0) { load4<true>(cr + SQ, q0, lane, iv4); load4<true>(fr, q0, lane, fM4); load4<true>(fr + SQ, q0, lane, fI4); }
+        if (MODE == 1) { load4<true>(accM, q0, lane, aM4); load4<true>(accI, q0, lane, aI4); }
+        double oM4[4], oD4[4];
+#pragma unroll
+        for (int u = 3; u >= 0; u--) {
+          const int k = lane * Q + q0 + u + 1;
+          Pq = k > M ? 0.0 : Pq * tDn[u + 1];
+          double dv = dl[u] + Pq * din;
+          double mv = mp[u] + (k < M ? dnext * tMDn[u + 1] : 0.0);
+          if (k > M) { dv = 0.0; mv = 0.0; }
+          oM4[u] = mv; oD4[u] = dv;
+          dnext = dv;
+          xbsum += mv * oc[u] * te4[u];
+          if (MODE == 1) { aM4[u] = aM4[u] + fM4[u] * mv * sc; aI4[u] = aI4[u] + fI4[u] * iv4[u] * sc; }
+          if (MODE == 2) { fM4[u] = (double)(float)(fM4[u] * mv * sc); fI4[u] = (double)(float)(fI4[u] * iv4[u] * sc); }
         }
-        if (MODE == 2) {
-          const double iv = __builtin_nontemporal_load(cr + SQ + o);
-          double *fw = const_cast<double *>(fr);
-          const float pm = (float)(__builtin_nontemporal_load(fr + o) * mv * sc), pi = (float)(__builtin_nontemporal_load(fr + SQ + o) * iv * sc);
-          fw[o] = (double)pm; fw[SQ + o] = (double)pi;
-        }
+        store4(cr, q0, lane, oM4); store4(cr + 2 * SQ, q0, lane, oD4);
+        if (MODE == 1) { store4(accM, q0, lane, aM4); store4(accI, q0, lane, aI4); }
+        if (MODE == 2) { double *fw = const_cast<double *>(fr); store4(fw, q0, lane, fM4); store4(fw + SQ, q0, lane, fI4); }
       }
       xbsum_prev = xbsum;
       if (MODE != 0) {
@@ -173,7 +202,7 @@ constexpr double kRt1 = 0.25, kRt2 = 0.10, kRt3 = 0.20;
 }  // namespace
 
 size_t generic_front_doubles(int Lcap, int Qmax) {
-  return (size_t)(Lcap + 4) * generic_rowlen(Qmax) + 2 * (size_t)(Lcap + 2) * xNSPEC + 5 * (size_t)(Lcap + 2) + 2 * (size_t)Qmax * 64 + 8;
+  return (size_t)(Lcap + 4) * generic_rowlen(Qmax) + 2 * (size_t)(Lcap + 2) * xNSPEC + 5 * (size_t)(Lcap + 4) + 2 * (size_t)Qmax * 64 + 8;
 }
 size_t generic_align_doubles(int Lcap, int Qmax) {
   return (size_t)(Lcap + 4) * generic_rowlen(Qmax) + 2 * (size_t)(Lcap + 2) * xNSPEC + 8;
@@ -205,9 +234,10 @@ __global__ __launch_bounds__(64, 2) void generic_front_kernel(GenericArgs a) {
     mx.Q = m.Q; mx.rowlen = generic_rowlen(m.Q); mx.p = slab;
     double *xsF = slab + (size_t)(a.Lcap + 4) * generic_rowlen(a.Qmax);
     double *xsB = xsF + (size_t)(a.Lcap + 2) * xNSPEC;
-    double *pbv = xsB + (size_t)(a.Lcap + 2) * xNSPEC, *pev = pbv + (a.Lcap + 2), *moccv = pev + (a.Lcap + 2);
-    double *btotv = moccv + (a.Lcap + 2), *etotv = btotv + (a.Lcap + 2);
-    double *accM = etotv + (a.Lcap + 2), *accI = accM + (size_t)a.Qmax * 64;
+    const int Lp2 = (a.Lcap + 3) & ~1;       // (even: the accumulator arrays behind are moved in 16-byte pairs)
+    double *pbv = xsB + (size_t)(a.Lcap + 2) * xNSPEC, *pev = pbv + Lp2, *moccv = pev + Lp2;
+    double *btotv = moccv + Lp2, *etotv = btotv + Lp2;
+    double *accM = etotv + Lp2, *accI = accM + (size_t)a.Qmax * 64;
     const int64_t off = a.offsets[qi];
     const int L = (int)(a.offsets[qi + 1] - off);
     const size_t out = (size_t)qi * a.H + h;

@@ -45,7 +45,7 @@ extern "C" {
 #define WH_EIO        -2   /* cannot open / parse an HMM file                */
 #define WH_ENODEV     -3   /* no usable HIP device                           */
 #define WH_EHIP       -4   /* a HIP runtime call failed                      */
-#define WH_ERANGE     -5   /* model or query longer than this build supports */
+#define WH_ERANGE     -5   /* model (> 16384 nodes) or query longer than this build supports */
 #define WH_ENOMEM     -6
 
 #define WH_ALPH_DNA    0

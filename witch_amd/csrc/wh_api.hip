@@ -989,12 +989,14 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       std::vector<int32_t> st((size_t)npairs);
       HIPCHK(hipMemcpyAsync(st.data(), e->d_recs.p, sizeof(int32_t) * st.size(), hipMemcpyDeviceToHost, s));
       HIPCHK(hipStreamSynchronize(s));     // gitems is a local
-      int n_range = 0;
-      for (int32_t v : st) n_range += v == 3;
+      int n_range = 0, n_log = 0;
+      for (int32_t v : st) { n_range += v == 3; n_log += v == 4; }
       e->last_align_unaligned = n_range;
+      e->last_align_redo += n_log;
+      if (e->knobs.trace && n_log > 0) fprintf(stderr, "[wh] any-size alignment: %d pairs left float64 range, redone in log space\n", n_log);
       if (n_range > 0)
-        fprintf(stderr, "[wh] warning: %d pair(s) on models of more than %d nodes hold hits beyond float64 range in one alignment; "
-                        "they are returned unaligned (all residues -1)\n", n_range, kMaxQ * kWave);
+        fprintf(stderr, "[wh] warning: %d pair(s) on models of more than %d nodes could not be aligned (Forward and Backward disagree "
+                        "even in log space); they are returned unaligned (all residues -1)\n", n_range, kMaxQ * kWave);
     }
   }
   if (timer_end(e, 2, s, launches)) return WH_EHIP;

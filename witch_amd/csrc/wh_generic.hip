@@ -194,6 +194,165 @@ __device__ double gbackward(const GModel &m, const uint8_t *seq, int L, GLen c, 
   return xfactor;
 }
 
+// ------------------------------------------------------------------ log-space twins for the alignment's rare pass
+// Two hits of thousands of bits each inside ONE unihit alignment leave the range of a scaled double (the flank
+// state that carries the weaker hit underflows against its row's scale); hmmalign switches to its log-space
+// "generic" code there.  Same layout, every value a natural-log probability, -inf
+// for zero, no scaling; logs of the table entries are taken on the fly.  Speed does not matter here.
+__device__ __forceinline__ double lse2(double a, double b) {
+  const double mx = a > b ? a : b, mn = a > b ? b : a;
+  if (mx == -INFINITY) return mx;
+  return mx + log1p(exp(mn - mx));
+}
+__device__ __forceinline__ double llog(double p) { return p > 0.0 ? log(p) : -INFINITY; }
+__device__ __forceinline__ double wave_lse(double x) {
+  const double mx = wave_max_d(x);
+  if (mx == -INFINITY) return mx;
+  return mx + log(wave_sum_d(exp(x - mx)));
+}
+
+// Forward, rows 0..L kept (log M, I, D; log N B E J C in the row tails).  Returns log Z.
+__device__ double gforward_log(const GModel &m, const uint8_t *seq, int L, GLen c, const GMx &mx, int lane) {
+  const int Q = m.Q;
+  const size_t SQ = (size_t)Q * 64;
+  const double *tf = m.tf;
+  const double lloop = llog(c.loop), lmove = llog(c.move), lEJ = llog(c.EJ), lEC = llog(c.EC);
+  {
+    double *r0 = mx.row(0);
+    for (int q = 0; q < Q; q++) { const size_t o = ofs2(q, lane); r0[o] = -INFINITY; r0[SQ + o] = -INFINITY; r0[2 * SQ + o] = -INFINITY; }
+    if (lane == 0) { double *s = r0 + 3 * SQ; s[xN] = 0.0; s[xB] = lmove; s[xE] = -INFINITY; s[xJ] = -INFINITY; s[xC] = -INFINITY; }
+  }
+  double pN = 0.0, pB = lmove, pJ = -INFINITY, pC = -INFINITY;
+  double Psum = 0.0;                      // sum of log D->D over the lane's nodes 2..Q
+  for (int q = 1; q < Q; q++) Psum += llog(tf[gD2 * SQ + ofs2(q, lane)]);
+  const double d10 = llog(tf[gD1 * SQ + ofs2(0, lane)]), d20 = llog(tf[gD2 * SQ + ofs2(0, lane)]);
+  for (int i = 1; i <= L; i++) {
+    wave_mem_sync();
+    const double *pr = mx.row(i - 1);
+    double *cr = mx.row(i);
+    const double *od = m.te + (size_t)seq[i - 1] * SQ;
+    double pm1 = -INFINITY, pi1 = -INFINITY, pd1 = -INFINITY;
+    if (lane > 0) { const size_t ol = ofs2(Q - 1, lane - 1); pm1 = __builtin_nontemporal_load(pr + ol); pi1 = __builtin_nontemporal_load(pr + SQ + ol); pd1 = __builtin_nontemporal_load(pr + 2 * SQ + ol); }
+    double mprev = -INFINITY, dloc = -INFINITY, xe = -INFINITY;
+    for (int q = 0; q < Q; q++) {
+      const size_t o = ofs2(q, lane);
+      const double oM = __builtin_nontemporal_load(pr + o), oI = __builtin_nontemporal_load(pr + SQ + o), oD = __builtin_nontemporal_load(pr + 2 * SQ + o);
+      const double mm = llog(od[o]) + lse2(lse2(pm1 + llog(tf[gA * SQ + o]), pi1 + llog(tf[gB * SQ + o])),
+                                           lse2(pd1 + llog(tf[gC * SQ + o]), pB + llog(tf[gE * SQ + o])));
+      const double ins = lse2(oM + llog(tf[gMI * SQ + o]), oI + llog(tf[gII * SQ + o]));
+      dloc = q > 0 ? lse2(mprev + llog(tf[gD1 * SQ + o]), dloc + llog(tf[gD2 * SQ + o])) : -INFINITY;
+      cr[o] = mm; cr[SQ + o] = ins; cr[2 * SQ + o] = dloc;
+      xe = lse2(xe, mm);
+      pm1 = oM; pi1 = oI; pd1 = oD; mprev = mm;
+    }
+    const double mup = shfl_up_d(mprev, 1);
+    const double mleft = lane > 0 ? mup : -INFINITY;
+    double Bv = lse2(dloc, Psum + d10 + mleft), Av = Psum + d20;
+    for (int d = 1; d < 64; d <<= 1) {
+      const double Bo = shfl_up_d(Bv, d), Ao = shfl_up_d(Av, d);
+      if (lane >= d) { Bv = lse2(Bv, Av + Bo); Av = Av + Ao; }
+    }
+    const double dup = shfl_up_d(Bv, 1);
+    const double dleft = lane > 0 ? dup : -INFINITY;
+    const double c0 = lane > 0 ? lse2(d10 + mleft, d20 + dleft) : -INFINITY;
+    double Pq = 0.0;
+    for (int q = 0; q < Q; q++) {
+      const size_t o = ofs2(q, lane);
+      if (q > 0) Pq += llog(tf[gD2 * SQ + o]);
+      const double dv = lse2(__builtin_nontemporal_load(cr + 2 * SQ + o), Pq + c0);
+      cr[2 * SQ + o] = dv;
+      xe = lse2(xe, dv);
+    }
+    xe = wave_lse(xe);
+    const double xn = pN + lloop, xc = lse2(pC + lloop, xe + lEC), xj = lse2(pJ + lloop, xe + lEJ);
+    const double xb = lse2(xj + lmove, xn + lmove);
+    if (lane == 0) { double *s = cr + 3 * SQ; s[xN] = xn; s[xB] = xb; s[xE] = xe; s[xJ] = xj; s[xC] = xc; }
+    pN = xn; pB = xb; pJ = xj; pC = xc;
+  }
+  wave_mem_sync();
+  return pC + lmove;
+}
+
+// Backward against the kept log Forward rows; posteriors in place like gbackward<2>.  Returns log Z of Backward.
+__device__ double gbackward_log(const GModel &m, const uint8_t *seq, int L, GLen c, const GMx &fmx, double *brow0, double *brow1,
+                                double *xs, double fwd, int lane) {
+  const int Q = m.Q, M = m.M;
+  const size_t SQ = (size_t)Q * 64;
+  const double *tf = m.tf;
+  const double lloop = llog(c.loop), lmove = llog(c.move), lEJ = llog(c.EJ), lEC = llog(c.EC);
+  double nN = -INFINITY, nJ = -INFINITY, nC = lmove, xb_prev = -INFINITY, bwd = -INFINITY;
+  for (int i = L; i >= 0; i--) {
+    double xBv, xJv, xCv, xNv;
+    if (i == L) { xCv = lmove; xJv = -INFINITY; xNv = -INFINITY; xBv = -INFINITY; }
+    else {
+      xBv = wave_lse(xb_prev);
+      xJv = lse2(nJ + lloop, xBv + lmove);
+      xCv = nC + lloop;
+      xNv = lse2(nN + lloop, xBv + lmove);
+    }
+    const double xEv = lse2(xCv + lEC, xJv + lEJ);
+    if (i >= 1) {
+      wave_mem_sync();
+      const bool have_next = i < L;
+      const double *nr = (i + 1) & 1 ? brow1 : brow0;
+      double *cr = i & 1 ? brow1 : brow0;
+      const double *odn = have_next ? m.te + (size_t)seq[i] * SQ : nullptr;
+      const double *odc = m.te + (size_t)seq[i - 1] * SQ;
+      double dloc = -INFINITY, P = 0.0;
+      for (int q = Q - 1; q >= 0; q--) {
+        const int k = lane * Q + q + 1;
+        const size_t o = ofs2(q, lane);
+        double mnext = -INFINITY, in = -INFINITY;
+        if (have_next) { mnext = next_node(nr, Q, q, lane) + llog(next_node(odn, Q, q, lane)); in = __builtin_nontemporal_load(nr + SQ + o); }
+        const double lMM = llog(next_node(tf + gA * SQ, Q, q, lane)), lIM = llog(next_node(tf + gB * SQ, Q, q, lane));
+        const double lDM = llog(next_node(tf + gC * SQ, Q, q, lane)), lDD = llog(next_node(tf + gD2 * SQ, Q, q, lane));
+        double iv = lse2(mnext + lIM, in + llog(tf[gII * SQ + o]));
+        double mpart = lse2(lse2(mnext + lMM, in + llog(tf[gMI * SQ + o])), xEv);
+        double av = lse2(mnext + lDM, xEv);
+        if (k >= M) { iv = -INFINITY; if (k == M) { mpart = xEv; av = xEv; } else { mpart = -INFINITY; av = -INFINITY; } }
+        dloc = k > M ? -INFINITY : lse2(av, lDD + dloc);
+        P = k > M ? -INFINITY : P + lDD;
+        cr[o] = mpart; cr[SQ + o] = iv; cr[2 * SQ + o] = dloc;
+      }
+      double Bv = dloc, Av = P;
+      for (int d = 1; d < 64; d <<= 1) {
+        const double Bo = shfl_down_d(Bv, d), Ao = shfl_down_d(Av, d);
+        if (lane + d < 64) { Bv = lse2(Bv, Av + Bo); Av = Av + Ao; }
+      }
+      const double dn = shfl_down_d(Bv, 1);
+      const double din = lane < 63 ? dn : -INFINITY;
+      double Pq = 0.0, dnext = din, xb = -INFINITY;
+      double *fr = fmx.row(i);
+      for (int q = Q - 1; q >= 0; q--) {
+        const int k = lane * Q + q + 1;
+        const size_t o = ofs2(q, lane);
+        const double lDD = llog(next_node(tf + gD2 * SQ, Q, q, lane)), lMD = llog(next_node(tf + gD1 * SQ, Q, q, lane));
+        Pq = k > M ? -INFINITY : Pq + lDD;
+        double dv = lse2(__builtin_nontemporal_load(cr + 2 * SQ + o), Pq + din);
+        double mv = __builtin_nontemporal_load(cr + o);
+        if (k < M) mv = lse2(mv, dnext + lMD);
+        if (k > M) { dv = -INFINITY; mv = -INFINITY; }
+        cr[o] = mv; cr[2 * SQ + o] = dv;
+        dnext = dv;
+        xb = lse2(xb, mv + llog(odc[o]) + llog(tf[gE * SQ + o]));
+        const double iv = __builtin_nontemporal_load(cr + SQ + o);
+        const float pm = (float)exp(__builtin_nontemporal_load(fr + o) + mv - fwd), pi = (float)exp(__builtin_nontemporal_load(fr + SQ + o) + iv - fwd);
+        fr[o] = (double)pm; fr[SQ + o] = (double)pi;
+      }
+      xb_prev = xb;
+      const double *fp = fmx.row(i - 1) + 3 * SQ;
+      const double pn = exp(__builtin_nontemporal_load(fp + xN) + xNv + lloop - fwd);
+      const double pj = exp(__builtin_nontemporal_load(fp + xJ) + xJv + lloop - fwd);
+      const double pc = exp(__builtin_nontemporal_load(fp + xC) + xCv + lloop - fwd);
+      if (lane == 0) { double *t = xs + (size_t)i * xNSPEC; t[0] = (double)(float)pn; t[1] = (double)(float)pj; t[2] = (double)(float)pc; }
+    }
+    nN = xNv; nJ = xJv; nC = xCv;
+    if (i == 0) bwd = xNv;
+  }
+  wave_mem_sync();
+  return bwd;
+}
+
 // per-wave slab of the front kernel (doubles): rows 0..Lcap+3 | xsF | xsB | pb pe mocc btot etot | accM accI
 __host__ __device__ inline size_t generic_rowlen(int Q) { return (size_t)3 * Q * 64 + xNSPEC; }
 
@@ -426,9 +585,14 @@ __global__ __launch_bounds__(64, 2) void generic_align_kernel(GenericAlignArgs a
     double bwd = 0.0;
     (void)gbackward<2>(m, seq, L, c, mx, mx.row(a.Lcap + 2), mx.row(a.Lcap + 3), pps, fwd, nullptr, nullptr, lane, &bwd);
     // Two hits thousands of bits apart in ONE unihit alignment leave the range of a scaled double (the flank state
-    // that carries the weaker hit underflows against the row's scale): Forward and Backward then disagree.  hmmalign
-    // switches to log space there; this kernel has no such pass - the pair is reported and left unaligned.
-    if (!(fabs(fwd - bwd) <= 1e-6 * fabs(fwd) + 1e-3)) { if (lane == 0 && a.status) a.status[p] = 3; continue; }
+    // that carries the weaker hit underflows against the row's scale): Forward and Backward then disagree, and the
+    // pair is redone in log space, as hmmalign does.
+    if (!(fabs(fwd - bwd) <= 1e-6 * fabs(fwd) + 1e-3)) {
+      const double lf = gforward_log(m, seq, L, c, mx, lane);
+      const double lb = gbackward_log(m, seq, L, c, mx, mx.row(a.Lcap + 2), mx.row(a.Lcap + 3), pps, lf, lane);
+      if (lane == 0 && a.status) a.status[p] = (fabs(lf - lb) <= 1e-6 * fabs(lf) + 1e-3) ? 4 : 3;
+      if (!(fabs(lf - lb) <= 1e-6 * fabs(lf) + 1e-3)) continue;       // (never seen: reported, left unaligned)
+    }
     // ---------------- optimal-accuracy fill, in place: row i holds ppM / ppI on entry, oM / oI / oD on exit
     const float tNl = c.loop > 0.0 ? 1.0f : 0.0f, tNm = c.move > 0.0 ? 1.0f : 0.0f;
     const float tEJ = c.EJ > 0.0 ? 1.0f : 0.0f, tEC = c.EC > 0.0 ? 1.0f : 0.0f;

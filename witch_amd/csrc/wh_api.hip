@@ -535,7 +535,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
     const size_t glds = generic_lds_bytes(Lc);
     if (glds > kLdsBudget) { set_error("query length %d does not fit the any-size kernel's LDS", max_len); return WH_ERANGE; }
     const int64_t n_items = nq * (int64_t)e->generic.size();
-    int blocks = (int)std::min<int64_t>(n_items, (int64_t)e->cu_count * std::min<size_t>(8, kLdsBudget / glds));
+    int blocks = (int)std::min<int64_t>(n_items, (int64_t)e->cu_count * std::min<size_t>(12, kLdsBudget / glds));
     blocks = clamp_blocks(blocks, g.slab_stride * sizeof(double), e->d_rmx);
     if (e->d_rmx.ensure((size_t)blocks * g.slab_stride * sizeof(double))) return WH_ENOMEM;
     g.slab = (double *)e->d_rmx.p;
@@ -977,7 +977,7 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       g.slab_stride = (generic_align_doubles(Lc, e->max_Q) + 1) & ~(size_t)1;
       const size_t glds = (size_t)Lc + 64;
       if (glds > kLdsBudget) { set_error("query length %d does not fit the any-size kernel's LDS", max_len); return WH_ERANGE; }
-      int blocks = (int)std::min<size_t>(gitems.size(), (size_t)e->cu_count * std::min<size_t>(8, kLdsBudget / glds));
+      int blocks = (int)std::min<size_t>(gitems.size(), (size_t)e->cu_count * std::min<size_t>(12, kLdsBudget / glds));
       blocks = clamp_blocks(blocks, g.slab_stride * sizeof(double), e->d_rmx);
       if (e->d_rmx.ensure((size_t)blocks * g.slab_stride * sizeof(double))) return WH_ENOMEM;
       g.slab = (double *)e->d_rmx.p;

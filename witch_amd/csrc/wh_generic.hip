@@ -368,7 +368,7 @@ size_t generic_align_doubles(int Lcap, int Qmax) {
 }
 size_t generic_lds_bytes(int Lcap) { return (size_t)(Lcap + 16) + 64 * 4 + 4 * WH_MAX_ENVELOPES * 4 + 64; }
 
-__global__ __launch_bounds__(64, 2) void generic_front_kernel(GenericArgs a) {
+__global__ __launch_bounds__(64, 3) void generic_front_kernel(GenericArgs a) {
   extern __shared__ __attribute__((aligned(16))) int lds_raw[];
   const int lane = threadIdx.x;
   float *null2 = reinterpret_cast<float *>(lds_raw);                 // 32 floats (+ 32 spare)
@@ -547,7 +547,7 @@ __device__ __forceinline__ float gatef(double t, float v) { return t > 0.0 ? v :
 __device__ __forceinline__ float ldf(const double *p) { return (float)__builtin_nontemporal_load(p); }
 }  // namespace
 
-__global__ __launch_bounds__(64, 2) void generic_align_kernel(GenericAlignArgs a) {
+__global__ __launch_bounds__(64, 3) void generic_align_kernel(GenericAlignArgs a) {
   extern __shared__ __attribute__((aligned(16))) int lds_raw[];
   const int lane = threadIdx.x;
   uint8_t *seq = reinterpret_cast<uint8_t *>(lds_raw);

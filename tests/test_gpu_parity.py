@@ -531,24 +531,25 @@ def test_resolver_on_every_forward_class(root_len, orc, tmp_path):
     e.close()
 
 
-@pytest.mark.parametrize("root_len", [3300, 5200])
-def test_models_beyond_3072_nodes_take_the_any_size_kernels(root_len, orc, tmp_path):
+@pytest.mark.parametrize("root_len,alphabet", [(3300, "dna"), (5200, "dna"), (3200, "amino")])
+def test_models_beyond_3072_nodes_take_the_any_size_kernels(root_len, alphabet, orc, tmp_path):
     """Models the register-resident kernels cannot hold (wh_generic.hip: float64, rows in HBM): scores, flags and
     aligned columns against the oracle - short fragments, fragments in random flanks, and queries with two copies
     of the family (multidomain regions: front end + resolver)."""
     _need_gpu()
     from witch_amd import synth
     from witch_amd.ehmm import EHMM, pack_queries
-    fam = synth.make_family(9100 + root_len, root_len, 16, "dna", 0.03, 1e-4)
+    fam = synth.make_family(9100 + root_len, root_len, 16, alphabet, 0.03, 1e-4)
     eh = synth.make_ehmm(fam, 2, str(tmp_path), witch_layout=False)
     # one more model of ordinary size: the two paths share a call
-    fam2 = synth.make_family(9200 + root_len, 400, 16, "dna", 0.03, 1e-4)
+    fam2 = synth.make_family(9200 + root_len, 400, 16, alphabet, 0.03, 1e-4)
     eh2 = synth.make_ehmm(fam2, 1, str(tmp_path / "small"), witch_layout=False)
     paths = eh.paths + eh2.paths
     e = EHMM(paths, hmm_index=list(range(len(paths))), nseq=eh.nseq + eh2.nseq)
     assert int(e.M.max()) > 3072
     rng = np.random.default_rng(root_len)
-    bg = synth.background("dna")
+    bg = synth.background(alphabet)
+    K = len(bg)
     _, short = synth.make_queries(fam, 5, 4, 150)
     _, mid = synth.make_queries(fam, 6, 3, 600)
     _, multi = synth.make_queries(fam, 7, 3, (root_len + 500, 2 * root_len), flank_frac=0.3)
@@ -556,7 +557,7 @@ def test_models_beyond_3072_nodes_take_the_any_size_kernels(root_len, orc, tmp_p
     seqs = [s_.astype(np.uint8) for s_ in short]
     for s_ in mid:
         a = int(rng.integers(10, 80))
-        seqs.append(np.concatenate([rng.choice(4, size=a, p=bg), s_, rng.choice(4, size=90 - a, p=bg)]).astype(np.uint8))
+        seqs.append(np.concatenate([rng.choice(K, size=a, p=bg), s_, rng.choice(K, size=90 - a, p=bg)]).astype(np.uint8))
     seqs += [s_.astype(np.uint8) for s_ in multi] + [s_.astype(np.uint8) for s_ in other]
     res, offs = pack_queries(seqs)
     deci, flags, fwd = e.score(res, offs, want_fwd=True)

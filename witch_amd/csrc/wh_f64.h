@@ -253,7 +253,11 @@ __device__ __attribute__((noinline)) double gforward_reg(const double *tf_, cons
   // table / slab pointers are given their address space back, or every access becomes a flat_ instruction with a
   // per-lane address and every guard a divergent branch.  Inlined at its eight call sites the function cost the
   // kernel 491 spilled registers and ran 15 % slower than called.)
-  const int Q = __builtin_amdgcn_readfirstlane(Q_), L = __builtin_amdgcn_readfirstlane(L_);
+  // (the dispatch calls gforward_reg<QC> only with Q == QC: a compile-time Q leaves the row straight-line code, so the
+  // table reads of all its 4-node groups can be requested together instead of one group per round trip)
+  (void)Q_;
+  constexpr int Q = QC;
+  const int L = __builtin_amdgcn_readfirstlane(L_);
   const bool store = __builtin_amdgcn_readfirstlane((int)store_) != 0;
   const gdbl *tf = as_global(tf_), *te = as_global(te_);
   gdbl *slab = as_global(slab_);

@@ -98,7 +98,7 @@ size_t resolve_lds_bytes(int Lcap, int Mmax) { return resolve_lds_ints(Lcap, Mma
 size_t resolve_seg_ints(int Lcap, int Mmax) { return (size_t)6 * kSegCap + (size_t)(Lcap > Mmax ? Lcap : Mmax) + 8 + 2 * ((size_t)Lcap + 8); }
 int resolve_seg_cap() { return kSegCap; }
 // the walk's cache of threshold lines: 2^kDcBits lines of 64 x 16 bytes + their 8-byte tags, in doubles
-constexpr int kDcBits = 11;
+constexpr int kDcBits = 13;
 size_t resolve_dcache_doubles() { return (size_t)129 * (1 << kDcBits); }
 typedef unsigned u4_t __attribute__((ext_vector_type(4)));
 int resolve_waves_per_cu() { return 4 * WH_RES_OCC; }

@@ -358,7 +358,6 @@ static int clamp_blocks(int blocks, size_t per_block, const DevBuf &have) {
 int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets, int64_t nq,
                  int64_t total_residues, int32_t max_len, int32_t *d_decibits, uint8_t *d_flags,
                  float *d_fwd_bits, wh_pair_detail *d_detail, void *stream) {
-  (void)total_residues;
   if (!e || !d_residues || !d_offsets || !d_decibits || !d_flags || nq < 0 || max_len < 0) {
     set_error("wh_score_dev: bad argument");
     return WH_EINVAL;
@@ -389,8 +388,13 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
     // pairs start first.  (One D2H copy of the offsets and a host sort; only when such a class exists.)
     bool any_long = false;
     for (auto &kv : e->by_q) any_long = any_long || kv.first >= 20;
+    // ... and the phase-call kernel deals the queries of a work item to its waves in fixed turns: with lengths of
+    // 50-2 000 residues in one batch a wave that drew long queries keeps the eleven others waiting at the item's
+    // end (about 30 % of the launch on the protein workload) - same cure.  Batches of near-equal lengths (the
+    // headline: all 150 nt) skip the copy and the sort.
+    const bool mixed = total_residues > 0 && (double)max_len > 1.25 * (double)total_residues / (double)nq;
     const int32_t *d_qorder = nullptr;
-    if (any_long && nq > 4 && nq < 0x7FFFFFFF) {
+    if ((any_long || mixed) && nq > 4 && nq < 0x7FFFFFFF) {
       std::vector<int64_t> offs((size_t)nq + 1);
       HIPCHK(hipMemcpyAsync(offs.data(), d_offsets, sizeof(int64_t) * offs.size(), hipMemcpyDeviceToHost, s));
       HIPCHK(hipStreamSynchronize(s));
@@ -465,7 +469,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
         specg = true;
       }
       a.SP = SP; a.wave_lds = wave_lds;
-      a.qorder = big ? d_qorder : nullptr;
+      a.qorder = (big || mixed) ? d_qorder : nullptr;
       a.QB = big ? waves * 2 : waves * 4;   // long models: a pair is milliseconds, smaller items shorten the tail of the launch
       a.n_qblocks = (int)((nq + a.QB - 1) / a.QB);
       a.n_items = a.n_list * a.n_qblocks;

@@ -396,7 +396,10 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
     }
     c.emG = (const glb_f *)(a.tables + hm->em_off);
 
-    for (int64_t qi = q_lo + wave; qi < q_hi; qi += nwaves) {
+    for (int64_t qpos = q_lo + wave; qpos < q_hi; qpos += nwaves) {
+      // (mixed-length batches arrive in descending length order: the waves of a work item then get queries of
+      // about the same length and reach the item's end together)
+      const int64_t qi = a.qorder ? a.qorder[qpos] : qpos;
       const int64_t off = a.offsets[qi];
       const int L = (int)(a.offsets[qi + 1] - off);
       const size_t out = (size_t)qi * a.H + h;

@@ -47,6 +47,9 @@ WORKLOADS = {
     # SURVEY.md section 8d config 5 (reported in DESIGN.md, not the headline): protein family,
     # 500-HMM eHMM, 50k queries of 50..2000 residues built from family windows and random flanks
     "aa_50k_x500": ("amino", 20251206, 600, 2048, 0.03, 1e-4, 500, 50000, (50, 2000), 10),
+    # development only: an eHMM whose models exceed 3072 nodes (16S-like backbone of ~6000 columns): every pair goes
+    # through the any-size float64 kernels (wh_generic.hip)
+    "dna_6k_nodes": ("dna", 20251208, 6000, 64, 0.03, 1e-4, 8, 2000, (150, 1500), 4),
 }
 
 
@@ -294,7 +297,7 @@ def main():
                         traffic_src = "profiles/traffic.json <- %s; counters of an earlier run of this command, NOT measured in this run" % tj.get("source", "?").split(" ")[0]
                 except Exception:
                     traffic = None
-            roofline = {"bound": "valu", "kernel": "wh::score_big_kernel" if int(np.max(e.M)) > 1536 else "wh::k7::score_kernel7", "achieved": round(s_tflops, 2), "peak": 157.3,
+            roofline = {"bound": "valu", "kernel": "wh::generic_front_kernel" if int(np.max(e.M)) > 3072 else "wh::score_big_kernel" if int(np.max(e.M)) > 1536 else "wh::k7::score_kernel7", "achieved": round(s_tflops, 2), "peak": 157.3,
                         "unit": "TFLOP/s", "frac": round(s_tflops / 157.3, 4), "traffic": traffic, "traffic_source": traffic_src,
                         "flop_per_cell": 77, "cells_per_launch": cells_launch,
                         "kernel_ms_avg": round(score_ms, 3), "launches": score_launches,
@@ -305,7 +308,7 @@ def main():
             # (one per model size class, plus the log-space redo pass when pairs leave float32 range).
             align_ms = kern_ms[2] / args.steps
             a_gbs = hot_path_step.aligned_cells * 52.0 / (align_ms * 1e-3) / 1e9 if align_ms > 0 else 0.0
-            roofline_align = {"bound": "hbm", "kernel": "wh::align_kernel", "achieved": round(a_gbs, 1), "peak": 8000.0,
+            roofline_align = {"bound": "hbm", "kernel": "wh::generic_align_kernel" if int(np.max(e.M)) > 3072 else "wh::align_kernel", "achieved": round(a_gbs, 1), "peak": 8000.0,
                               "unit": "GB/s", "frac": round(a_gbs / 8000.0, 4), "bytes_per_cell": 52,
                               "cells_per_step": hot_path_step.aligned_cells, "stage_ms": round(align_ms, 3),
                               "launches_per_step": kern_n[2] / args.steps, "traffic": traffic_align, "traffic_source": traffic_src}

@@ -463,10 +463,12 @@ __global__ __launch_bounds__(64, WH_RES_OCC) void resolve_kernel(ResolveArgs a) 
               }
             }
 #pragma unroll
-            for (int x4 = 0; x4 < 5; x4++) { part[4 * x4] += v0[x4].x; part[4 * x4 + 1] += v0[x4].y; part[4 * x4 + 2] += v0[x4].z; part[4 * x4 + 3] += v0[x4].w; }
+            for (int x4 = 0; x4 < 5; x4++)
+              if (x4 < nq4) { part[4 * x4] += v0[x4].x; part[4 * x4 + 1] += v0[x4].y; part[4 * x4 + 2] += v0[x4].z; part[4 * x4 + 3] += v0[x4].w; }
             if (has1) {
 #pragma unroll
-              for (int x4 = 0; x4 < 5; x4++) { part[4 * x4] += v1[x4].x; part[4 * x4 + 1] += v1[x4].y; part[4 * x4 + 2] += v1[x4].z; part[4 * x4 + 3] += v1[x4].w; }
+              for (int x4 = 0; x4 < 5; x4++)
+                if (x4 < nq4) { part[4 * x4] += v1[x4].x; part[4 * x4 + 1] += v1[x4].y; part[4 * x4 + 2] += v1[x4].z; part[4 * x4 + 3] += v1[x4].w; }
             }
           }
 #pragma unroll

@@ -117,6 +117,8 @@ __global__ __launch_bounds__(64, WH_RES_OCC) void resolve_kernel(ResolveArgs a) 
   unsigned short *s_a = reinterpret_cast<unsigned short *>(stk + Lp + 4);   // Easel's vertex stacks of the clustering
   unsigned short *s_b = s_a + SEGCAP;
   int *misc = reinterpret_cast<int *>(s_b + SEGCAP);             // 7 x kEnvMax ints: envelope and cluster lists of the pair
+  // 64 float64 bins of the E-state row pass, over the (then idle) clustering stacks, 8-byte aligned
+  double *bins = reinterpret_cast<double *>(lds_raw) + ((reinterpret_cast<char *>(s_a) - reinterpret_cast<char *>(lds_raw)) + 7) / 8;
   int32_t *sg = a.segs + (size_t)blockIdx.x * a.seg_stride;      // per wave in HBM: 6 arrays of SEGCAP ints + the histogram
   int32_t *s_idx = sg, *s_i = sg + SEGCAP, *s_j = sg + 2 * SEGCAP, *s_k = sg + 3 * SEGCAP, *s_m = sg + 4 * SEGCAP;
   int32_t *s_as = sg + 5 * SEGCAP;
@@ -365,15 +367,39 @@ __global__ __launch_bounds__(64, WH_RES_OCC) void resolve_kernel(ResolveArgs a) 
               // (the line is requested together with its valid flag: one round trip on a hit, a harmless read on a miss)
               double incl = __builtin_nontemporal_load(ecache + (size_t)i * 65 + lane);
               if (__builtin_nontemporal_load(ecache + (size_t)i * 65 + 64) == 0.0) {
-                double mine = 0.0;
-                for (int pb = p0; pb < p1; pb += 16) {         // sixteen loads in flight per step
-                  double tv[16];
+                // The chunk sums from ONE coalesced pass over the row: every lane reads its own nodes (16-byte pairs, 1 KB
+                // per wave instruction) and adds each term into the bin of the chunk that holds the node's striped position -
+                // 64 float64 bins in LDS (the clustering stacks' block, idle during the traces; one wave per workgroup, so
+                // the order of the LDS adds is the program's).  Reading the terms in striped order instead took 81 scattered
+                // 8-byte loads per lane: ~330 KB of cache lines for 45 KB of cells, and this step was bound by exactly that.
+                bins[lane] = 0.0;
+                __builtin_amdgcn_wave_barrier();
+                {
+                  const double *rowp = mx.row(i);
+                  const size_t SQm = (size_t)m.Q * 64;
+                  int kn = lane * m.Q + 1;
+                  int rr = (kn - 1) / Qs, qs = (kn - 1) % Qs;          // node kn sits at striped position qs*8 + state*4 + rr
+                  int cb = (qs * 8 + rr) / chunk, rem = (qs * 8 + rr) % chunk;
+                  for (int q0 = 0; q0 < m.Q; q0 += 4) {
+                    const d2_t m0 = ld_d2(rowp + ofs2(q0, lane)), m1 = ld_d2(rowp + ofs2(q0 + 2, lane));
+                    const d2_t d0 = ld_d2(rowp + 2 * SQm + ofs2(q0, lane)), d1 = ld_d2(rowp + 2 * SQm + ofs2(q0 + 2, lane));
+                    const double vM[4] = {m0.x, m0.y, m1.x, m1.y}, vD[4] = {d0.x, d0.y, d1.x, d1.y};
 #pragma unroll
-                  for (int u = 0; u < 16; u++) tv[u] = pb + u < p1 ? term(pb + u) : 0.0;
-#pragma unroll
-                  for (int u = 0; u < 16; u++) mine += tv[u];
+                    for (int u = 0; u < 4; u++) {
+                      if (kn <= m.M) {
+                        atomicAdd(bins + cb, (double)(float)(vM[u] * norm));
+                        int cd = cb, remd = rem + 4;
+                        while (remd >= chunk) { remd -= chunk; cd++; }
+                        atomicAdd(bins + cd, (double)(float)(vD[u] * norm));
+                      }
+                      kn++; qs++; rem += 8;
+                      if (qs == Qs) { qs = 0; rr++; cb = rr / chunk; rem = rr % chunk; }
+                      else while (rem >= chunk) { rem -= chunk; cb++; }
+                    }
+                  }
                 }
-                incl = mine;
+                __builtin_amdgcn_wave_barrier();
+                incl = bins[lane];
                 for (int d = 1; d < 64; d <<= 1) { const double o = shfl_up_d(incl, d); if (lane >= d) incl += o; }
                 ecache[(size_t)i * 65 + lane] = incl;
                 if (lane == 0) ecache[(size_t)i * 65 + 64] = 1.0;

@@ -574,7 +574,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       r.Lcap = Lc; r.Mmax = e->max_M;
       // a wave's slab: matrix rows | threshold-line cache of the walk | E-state row cache (at the end)
       r.dc_off = ((size_t)(Lc + 2) * ((size_t)3 * Qmax * kWave + 8) + 1) & ~(size_t)1;
-      r.mx_stride = r.dc_off + resolve_dcache_doubles() + (size_t)(Lc + 2) * 65;
+      r.mx_stride = r.dc_off + resolve_dcache_doubles() + (size_t)(Lc + 2) * resolve_tail_row_doubles();
       r.mx_stride = (r.mx_stride + 1) & ~(size_t)1;      // every wave's slab 16-byte aligned: the Forward sweep moves node pairs
       r.seg_cap = resolve_seg_cap();
       r.seg_stride = resolve_seg_ints(Lc, e->max_M);

@@ -94,6 +94,7 @@ int resolve_seg_cap();
 int resolve_waves_per_cu();
 size_t resolve_seg_ints(int Lcap, int Mmax);
 size_t resolve_dcache_doubles();
+size_t resolve_tail_row_doubles();
 
 // models of any size (wh_generic.hip)
 struct GenericArgs {

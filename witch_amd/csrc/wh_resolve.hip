@@ -99,6 +99,9 @@ size_t resolve_seg_ints(int Lcap, int Mmax) { return (size_t)6 * kSegCap + (size
 int resolve_seg_cap() { return kSegCap; }
 // the walk's cache of threshold lines: 2^kDcBits lines of 64 x 16 bytes + their 8-byte tags, in doubles
 constexpr int kDcBits = 13;
+// doubles per sequence row behind the threshold-line cache: 65 of the E-state row cache + 6 compact special-state arrays
+constexpr int kTailRow = 72;
+size_t resolve_tail_row_doubles() { return kTailRow; }
 size_t resolve_dcache_doubles() { return (size_t)129 * (1 << kDcBits); }
 typedef unsigned u4_t __attribute__((ext_vector_type(4)));
 int resolve_waves_per_cu() { return 4 * WH_RES_OCC; }
@@ -194,7 +197,14 @@ __global__ __launch_bounds__(64, WH_RES_OCC) void resolve_kernel(ResolveArgs a) 
       for (int t = lane; t <= Lr + 1; t += 64) acc[t] = 0.f;
       // E-state choice: per row of the region a lazily filled line of 64 chunk prefix sums + a valid flag, at the
       // end of the wave's slab
-      double *ecache = mx.p + a.mx_stride - (size_t)(a.Lcap + 2) * 65;
+      double *ecache = mx.p + a.mx_stride - (size_t)(a.Lcap + 2) * kTailRow;
+      // The walk reads special states of 64 CONSECUTIVE rows per decision fetch (B of rows i-1-t for an M run, C / J / E of
+      // a flank run): in the row tails that is 64 cache lines, in compact per-state arrays four.  Copied once per region.
+      double *cN = ecache + (size_t)(a.Lcap + 2) * 65, *cB = cN + (a.Lcap + 2), *cE = cB + (a.Lcap + 2), *cJ = cE + (a.Lcap + 2);
+      double *cC = cJ + (a.Lcap + 2), *cLS = cC + (a.Lcap + 2);
+      for (int t = lane; t <= Lr; t += 64) {
+        cN[t] = mx.spec(t, xN); cB[t] = mx.spec(t, xB); cE[t] = mx.spec(t, xE); cJ[t] = mx.spec(t, xJ); cC[t] = mx.spec(t, xC); cLS[t] = mx.spec(t, xLS);
+      }
       u4_t *dlines = reinterpret_cast<u4_t *>(mx.p + a.dc_off);
       unsigned long long *dtags = reinterpret_cast<unsigned long long *>(mx.p + a.dc_off + (size_t)128 * (1 << kDcBits));
       for (int t = lane; t <= Lr; t += 64) ecache[(size_t)t * 65 + 64] = 0.0;
@@ -254,7 +264,7 @@ __global__ __launch_bounds__(64, WH_RES_OCC) void resolve_kernel(ResolveArgs a) 
               double pd[4] = {0.0, 0.0, 0.0, 0.0};
               if (s0 == stM) {
                 if (it >= 1 && kt >= 1) {
-                  pd[0] = mx.specc(it - 1, xB) * m.t(gE, kt);
+                  pd[0] = cB[it - 1] * m.t(gE, kt);
                   pd[1] = mx.cellc(it - 1, kt - 1, 0) * m.t(gA, kt);
                   pd[2] = mx.cellc(it - 1, kt - 1, 1) * m.t(gB, kt);
                   pd[3] = mx.cellc(it - 1, kt - 1, 2) * m.t(gC, kt);
@@ -265,8 +275,8 @@ __global__ __launch_bounds__(64, WH_RES_OCC) void resolve_kernel(ResolveArgs a) 
                   pd[1] = mx.cellc(it, kt - 1, 2) * m.t(gD2, kt);
                 }
               } else if (it >= 1) {
-                pd[0] = mx.specc(it - 1, s0 == stC ? xC : xJ) * cm.loop;
-                pd[1] = mx.specc(it, xE) * (s0 == stC ? cm.EC : cm.EJ) * exp(mx.specc(it, xLS));
+                pd[0] = (s0 == stC ? cC : cJ)[it - 1] * cm.loop;
+                pd[1] = cE[it] * (s0 == stC ? cm.EC : cm.EJ) * exp(cLS[it]);
               }
               const int nch = s0 == stM ? 4 : 2;
               double tot = 0.0;
@@ -355,7 +365,7 @@ __global__ __launch_bounds__(64, WH_RES_OCC) void resolve_kernel(ResolveArgs a) 
               const long long te0 = a.stats ? __builtin_readcyclecounter() : 0;
               // FChoose over M(i,*) and D(i,*) in HMMER's striped order: position p = q*8 + state*4 + r
               // holds node r*Qs + q + 1.  Lanes take contiguous chunks, an exclusive scan finds the chunk.
-              const double roll = rng_next(rng), norm = 1.0 / mx.specc(i, xE);
+              const double roll = rng_next(rng), norm = 1.0 / cE[i];
               const int total = 8 * Qs, chunk = (total + 63) / 64;
               const int p0 = lane * chunk, p1 = min(total, p0 + chunk);
               auto term = [&](int p) -> double {
@@ -435,8 +445,8 @@ __global__ __launch_bounds__(64, WH_RES_OCC) void resolve_kernel(ResolveArgs a) 
               break;
             }
             case stB:
-              path[0] = mx.specc(i, xN) * cm.move;
-              path[1] = mx.specc(i, xJ) * cm.move;
+              path[0] = cN[i] * cm.move;
+              path[1] = cJ[i] * cm.move;
               s1 = __builtin_amdgcn_readfirstlane(rng_choose(rng, path, 2)) == 0 ? stN : stJ;
               break;
             default: s1 = stS; break;

@@ -139,6 +139,36 @@ def test_numpy_restatement_agrees():
             assert np.max(np.abs(got - want)) < 2e-5, (case, k)
 
 
+def test_backbone_of_more_than_3072_columns():
+    """Large backbones (every populated column becomes a node under --symfrac 0.0): the builder has no size limit of
+    its own; the model it writes parses back with as many nodes as the alignment has populated columns, and the
+    numpy restatement agrees on its probabilities."""
+    from oracle import hmmbuild_np as hb
+    from oracle import oracle as orc
+    fam = synth.make_family(77, 3400, 8, "dna", 0.03, 1e-3)
+    sym = "ACGT"
+    rows = ["".join(sym[c] if c >= 0 else "-" for c in fam.msa[i]) for i in range(fam.msa.shape[0])]
+    populated = int((fam.msa >= 0).any(axis=0).sum())
+    text, M, neff = hmmbuild_text(rows, "dna", "big")
+    assert M == populated and M > 3072
+    m = hb.build(rows, "dna")
+    assert M == m["M"] and abs(neff - m["neff"]) < 1e-9
+    lines = text.splitlines()
+    start = next(i for i, l in enumerate(lines) if l.startswith("  COMPO")) + 3
+    for k in (1, 2, M // 2, M - 1, M):
+        got = np.array([float(x) for x in lines[start + 3 * (k - 1)].split()[1:5]])
+        with np.errstate(divide="ignore"):
+            want = -np.log(m["mat"][k].astype(np.float64))
+        assert np.max(np.abs(got - want)) < 2e-5, k
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".hmm", delete=False) as fh:
+        fh.write(text)
+    try:
+        assert orc.OracleHMM(fh.name).M == M
+    finally:
+        os.unlink(fh.name)
+
+
 def test_bad_input_is_refused():
     from witch_amd._lib import WitchHipError
     with pytest.raises(ValueError):

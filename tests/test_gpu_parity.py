@@ -580,7 +580,8 @@ def test_models_beyond_3072_nodes_take_the_any_size_kernels(root_len, alphabet, 
     e.close()
 
 
-def test_level1_chain_with_a_backbone_of_more_than_3072_columns(tmp_path):
+@pytest.mark.parametrize("ehmm_source", ["model_files", "wh_hmmbuild"])
+def test_level1_chain_with_a_backbone_of_more_than_3072_columns(tmp_path, ehmm_source):
     """The reference-shaped functions end to end on a family whose models have ~3 300 nodes: engine (scores, top-k,
     alignment, consensus), the per-query strings and both mergers.  Every query row of the merged alignment spells its
     query, and the device merge writes the host merger's bytes."""
@@ -599,6 +600,15 @@ def test_level1_chain_with_a_backbone_of_more_than_3072_columns(tmp_path):
     retained = {i: (h.map_cols[1:] - 1).tolist() for i, h in zip(se.index, se.hmms)}
     nongaps = {i: h.nongaps.tolist() for i, h in zip(se.index, se.hmms)}
     B = fam.msa.shape[1]
+    if ehmm_source == "wh_hmmbuild":
+        # the same three subsets built from the backbone rows by the hmmbuild equivalent (no model file from elsewhere)
+        sym = "ACGT"
+        rows = ["".join(sym[c] if c >= 0 else "-" for c in fam.msa[i]) for i in range(fam.msa.shape[0])]
+        subsets = [("A_0_%d" % idx, list(range(lo, hi))) for idx, (lo, hi) in enumerate(synth.bfs_subsets(fam.n_leaves, 3))]
+        built = gcmm.build_ehmm(list(fam.names), rows, subsets, "dna", str(tmp_path / "built"))
+        index_to_hmm = {idx: _Sub(b[0], len(subsets[idx][1])) for idx, b in enumerate(built)}
+        retained = {idx: list(b[2]) for idx, b in enumerate(built)}
+        nongaps = {idx: list(b[3]) for idx, b in enumerate(built)}
     texts = [synth.to_text(s_, "dna") for s_ in seqs]
     bpath = str(tmp_path / "backbone.fasta")
     synth.write_msa_fasta(bpath, fam, 0, 16)

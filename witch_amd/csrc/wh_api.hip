@@ -471,6 +471,14 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       a.SP = SP; a.wave_lds = wave_lds;
       a.qorder = (big || mixed) ? d_qorder : nullptr;
       a.QB = big ? waves * 2 : waves * 4;   // long models: a pair is milliseconds, smaller items shorten the tail of the launch
+      // small batches (the reference's example as shipped: 500 fragments x 15 models): with the default item size there
+      // are fewer than a handful of items per workgroup and the launch ends on its stragglers - one query per wave and
+      // item then (the tables of a model are re-staged more often, which a small batch can afford)
+      {
+        const int max_blocks = big ? e->cu_count : e->cu_count * std::max(1, 8 / waves);
+        const int64_t items_default = (int64_t)a.n_list * ((nq + a.QB - 1) / a.QB);
+        if (items_default < 4 * (int64_t)max_blocks) a.QB = waves;
+      }
       a.n_qblocks = (int)((nq + a.QB - 1) / a.QB);
       a.n_items = a.n_list * a.n_qblocks;
       a.scratch_stride = (size_t)(a.Lcap + 1) * 2 * Q * kWave;   // Forward slab per wave

@@ -207,3 +207,108 @@ def test_result_files_read_back_by_the_reference_reader():
     assert set(ranked) == set(g["ranked"])
     for t, want in g["ranked"].items():
         assert [[i, s] for i, s in ranked[t]] == want, t
+
+
+def _wire():
+    import gzip
+    import json
+    from tests.conftest import GOLDEN
+    with gzip.open(os.path.join(GOLDEN, "wire", "wire.json.gz"), "rt") as f:
+        return json.load(f), os.path.join(GOLDEN, "wire")
+
+
+def test_weights_txt_against_the_reference_writer_and_reader(tmp_path):
+    """f4, both directions, on data made by tests/golden/make_golden_wire.py with the REFERENCE's own
+    writeWeightsToLocal / readWeightsFromLocal (witch_msa/gcmm/weighting.py:174-194):
+    (i) the file the reference wrote (numpy-2 text: 'np.float64(...)' inside the tuples) is read by this
+    package's reader and holds the engine's weights; (ii) what the reference read from the file this
+    package wrote is, bit for bit, what the engine answers."""
+    from tests.conftest import load_case
+    meta, d = _wire()
+    case = load_case(meta["weights_case"])
+    _engine_from_golden(case)
+    index_to_hmm = {i: _Sub(p, n) for i, p, n in zip(case.hmm_index, case.hmm_paths, case.nseq)}
+    weights = gcmm.writeWeights(index_to_hmm, gcmm.rankBitscores(index_to_hmm, {}), None)
+    ref = gcmm.readWeightsFromLocal(os.path.join(d, "ref_weights.txt"))
+    assert "np.float64(" in open(os.path.join(d, "ref_weights.txt")).readline()
+    assert list(ref.keys()) == list(weights.keys())                     # same taxa, same line order
+    n_exact = 0
+    for t, got in weights.items():
+        want = ref[t]
+        assert all(isinstance(x[1], np.float64) for x in want)
+        assert len(want) == len(got)
+        assert [x[1] for x in got] == pytest.approx([x[1] for x in want], rel=1e-12)
+        if len(set(x[1] for x in want)) == len(want):                   # no exact weight ties: same order of models
+            assert [x[0] for x in got] == [x[0] for x in want]
+            n_exact += 1
+    assert n_exact > 10
+    back = meta["ref_read_of_repo_weights"]
+    assert sorted(back.keys()) == sorted(weights.keys())                # (the JSON fixture is stored with sorted keys)
+    for t, got in weights.items():
+        assert [[int(i), float(w).hex()] for i, w in got] == back[t]
+    # and this package's own round trip of the reference's file reproduces it value for value
+    p = str(tmp_path / "w.txt")
+    gcmm.writeWeightsToLocal(ref, p)
+    again = gcmm.readWeightsFromLocal(p)
+    assert {t: [(i, float(w)) for i, w in v] for t, v in again.items()} == {t: [(i, float(w)) for i, w in v] for t, v in ref.items()}
+
+
+def test_checkpoint_file_against_the_reference_writer_and_reader(tmp_path):
+    """f4, both directions (callback.py:9-29, loader.py:95-150): (i) the gzip file the reference's
+    callback_queryAlignment appended (one member per finished query, a failed and a retried one, one taxon
+    twice) is read by this package; this package's writer reproduces its BYTES from the same strings;
+    (ii) what the reference's readCheckpointAlignments read from this package's file = the strings and labels
+    this package holds."""
+    import gzip
+    from tests.conftest import load_case
+    from witch_amd.gcmm.merge import QueryAlignment
+    meta, d = _wire()
+    case = load_case(meta["checkpoint_case"])
+    merged = case.g["merged"]
+    ref_path = os.path.join(d, "ref_checkpoint_alignments.txt.gz")
+    order = meta["ref_callback"]["order"]
+    assert meta["ref_callback"]["ignored"] == ["empty_query"] and meta["ref_callback"]["retry"] == [901]
+    assert meta["ref_callback"]["n_success"] == len(order) == len(merged) + 1
+    back = gcmm.readCheckpointAlignments(ref_path)
+    first = order[0]
+    assert set(back) == set(merged)
+    for qn, text in merged.items():
+        want = text if qn != first else text.replace("-", "", 1) + "-"      # the later line wins
+        assert back[qn][qn] == want
+        low = [c.islower() for c in want]
+        assert [x < 0 for x in back[qn]._col_labels] == low
+    # same strings through this package's writer: the decompressed stream and the member structure are the
+    # reference's (the gzip header carries a timestamp, so the raw bytes differ only there)
+    qas = []
+    for qn in order[:-1]:
+        a = QueryAlignment()
+        a[qn] = merged[qn]
+        qas.append(a)
+    a = QueryAlignment()
+    a[first] = merged[first].replace("-", "", 1) + "-"
+    qas.append(a)
+    mine = str(tmp_path / "checkpoint_alignments.txt.gz")
+    success, ignored, retry = [], [], []
+    for n, q in enumerate(qas):
+        gcmm.callback_queryAlignment(success, ignored, retry, 0, q, n, next(iter(q)), mine)
+    raw_ref, raw_mine = open(ref_path, "rb").read(), open(mine, "rb").read()
+    assert gzip.decompress(raw_mine) == gzip.decompress(raw_ref)
+    assert raw_mine.count(b"\x1f\x8b\x08") == raw_ref.count(b"\x1f\x8b\x08") == len(order)
+    batch = str(tmp_path / "batch.txt.gz")
+    assert gcmm.writeCheckpointAlignments(qas, batch) == len(order)
+    assert gzip.decompress(open(batch, "rb").read()) == gzip.decompress(raw_ref)
+    # (ii) the reference read this package's file
+    got = meta["ref_read_of_repo_checkpoint"]
+    qas = []
+    for qn, text in merged.items():
+        a = QueryAlignment()
+        a[qn] = text
+        qas.append(a)
+    tabbed = QueryAlignment()
+    tabbed["name\twith tab"] = "acGT-x"
+    qas.insert(3, tabbed)
+    assert set(got) == {next(iter(q)) for q in qas}
+    for q in qas:
+        t = next(iter(q))
+        assert got[t][0] == q[t]
+        assert got[t][1] == q._col_labels

@@ -1,4 +1,6 @@
 """writeWeights and friends with the reference's signatures (witch_msa/gcmm/weighting.py)."""
+import re
+
 import numpy as np
 
 from .engine import current_engine
@@ -48,14 +50,20 @@ def writeWeightsToLocal(taxon_to_weights, path):
             f.write('{}:{}\n'.format(taxon, tuple((int(i), float(w)) for i, w in weights)))
 
 
+_NP_SCALAR = re.compile(r'(?:np|numpy)\.(?:float64|int64|int32)\(([^()]*)\)')
+
+
 def readWeightsFromLocal(path):
-    """Inverse of writeWeightsToLocal (weighting.py:185-194), without eval()."""
+    """Inverse of writeWeightsToLocal (weighting.py:185-194), without eval().  Accepts both texts the
+    reference's writer produces: plain numbers (numpy 1 prints np.float64 as '0.5') and numpy 2's
+    'np.float64(0.5)' (tests/golden/wire/ref_weights.txt is such a file, written by the reference)."""
     import ast
     out = {}
     with open(path, 'r') as f:
         for line in f:
             if not line.strip():
                 continue
-            taxon, raw = line.split(':', 1)
-            out[taxon] = tuple((int(i), np.float64(w)) for i, w in ast.literal_eval(raw.strip()))
+            taxon, raw = line.rsplit(':', 1)
+            raw = _NP_SCALAR.sub(r'\1', raw.strip())
+            out[taxon] = tuple((int(i), np.float64(w)) for i, w in ast.literal_eval(raw))
     return out

@@ -203,7 +203,11 @@ def main():
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # WITCH_FORCE_COLLECTIVES=1: the RCCL group and the top-k all-gather also at world 1 (smoke test of the nccl path
+    # on a one-GPU box, started under torch.distributed.run --nproc-per-node 1); the driver's runs never set it
+    from witch_amd.distributed import collectives_forced
+    use_dist = world > 1 or collectives_forced()
+    if use_dist:
         if rehearsal:
             dist.init_process_group("gloo")
         else:
@@ -224,7 +228,7 @@ def main():
         off_t = torch.from_numpy(offs).cuda()
 
         gather = None
-        if world > 1:
+        if use_dist:
             from witch_amd.distributed import gather_topk
             # the path's one exchange step: per-query top-k records to every rank over RCCL
             gather = gather_topk
@@ -234,7 +238,7 @@ def main():
 
         def barrier():
             torch.cuda.synchronize()
-            if world > 1:
+            if use_dist:
                 dist.barrier()
             torch.cuda.synchronize()
 
@@ -254,7 +258,7 @@ def main():
                 kern_n[which] += n
         barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             tmax = torch.tensor([dt], device="cpu" if rehearsal else "cuda", dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
@@ -333,7 +337,7 @@ def main():
                 "config": {"workload": args.workload, "n_queries": nq_total, "n_hmms": H,
                            "query_len": int(round(L)), "model_len_min": int(M.min()), "model_len_max": int(M.max()),
                            "model_len_mean": round(float(M.mean()), 1),
-                           "k": k, "aligned_pairs_per_step": npairs, "sharding": "queries/%d" % world,
+                           "k": k, "aligned_pairs_per_step": npairs, "sharding": "queries/%d" % world, "collective_backend": (dist.get_backend() if use_dist else None),
                            "pairs_reported_rank0": hot_path_step.reported, "pairs_multidomain_rank0": hot_path_step.multidomain,
                            "pairs_dense_redo_rank0": hot_path_step.dense_redo,
                            "topk_crc32": crc_of(out[0].numpy(), out[1].numpy(), out[2].numpy(), out[3].numpy())},
@@ -374,7 +378,7 @@ def main():
         e.close()
     finally:
         shutil.rmtree(workdir, ignore_errors=True)
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
 
 

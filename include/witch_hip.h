@@ -124,6 +124,14 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
                  const int64_t *d_pair_q, const int32_t *d_pair_h, int64_t npairs,
                  const int64_t *d_col_offsets, int32_t *d_cols, void *stream);
 
+/* Outcome classes of the last wh_align / wh_align_dev call on this handle (the call itself returns WH_OK for
+ * them): n_logspace = pairs that left the float range and were redone in log space (same columns as hmmalign's
+ * own log-space fallback); n_unaligned = pairs on models of more than 3072 nodes whose Forward and Backward
+ * scores disagree even in log space: their columns are ALL -1, where hmmalign (aligner.py:96-142) would have
+ * produced an alignment.  Their pair numbers (positions in pair_q / pair_h) are copied to unaligned_pairs[0..cap).
+ * Callers must not feed such pairs into wh_consensus as if they were all-insertion alignments. */
+int wh_last_align_status(wh_ehmm *e, int64_t *n_logspace, int64_t *n_unaligned, int64_t *unaligned_pairs, int64_t cap);
+
 /* Weighted consensus of each query's per-HMM alignments (witch-ng merge DP; replaces the Python
  * loops of alignSubQueriesNew, witch_msa/gcmm/aligner.py:376-473).  Pairs are grouped by
  * query in top-k order: query q owns pairs qpair_off[q] .. qpair_off[q+1]; pair p aligned

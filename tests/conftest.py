@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-CASES = ["dna_hmmbuild", "dna_synth", "amino_hmmbuild", "example_sub30", "example_ehmm"]
+CASES = ["dna_hmmbuild", "dna_synth", "amino_hmmbuild", "example_sub30", "example_ehmm", "amino_multidomain"]
 
 
 def pytest_configure(config):

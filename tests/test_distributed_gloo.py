@@ -122,3 +122,16 @@ def test_sharded_engine_answers_like_the_unsharded_one(tmp_path):
     mp.spawn(_engine_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         assert open(tmp_path / ("erank%d" % r)).read() == "ok"
+
+
+def _forced_worker(rank, world, port, outdir):
+    os.environ["WITCH_FORCE_COLLECTIVES"] = "1"
+    _worker(rank, world, port, 37, 10, outdir)
+
+
+def test_forced_collectives_in_a_group_of_one(tmp_path):
+    """WITCH_FORCE_COLLECTIVES=1 (the RCCL smoke of a one-GPU box, tests/test_gpu_parity.py) sends the gather through
+    the collectives even at world 1: same tables back."""
+    import torch.multiprocessing as mp
+    mp.spawn(_forced_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    assert open(tmp_path / "rank0").read() == "ok"

@@ -25,7 +25,9 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     rehearsal = os.environ.get("WITCH_LEVEL1_REHEARSAL") == "1"
     device = 0 if rehearsal else local
-    if world > 1:
+    from witch_amd.distributed import collectives_forced
+    use_dist = world > 1 or collectives_forced()         # WITCH_FORCE_COLLECTIVES=1: the nccl path at one rank
+    if use_dist:
         if rehearsal:
             dist.init_process_group("gloo")
         else:
@@ -48,13 +50,13 @@ def main():
         index_to_hmm, list(zip(case.qnames, case.qseqs)), case.k, device=device, world=world, rank=rank,
         subset_to_retained_columns=retained, subset_to_nongaps_per_column=nongaps, backbone_length=B))
     full, masked = gcmm.mergeAlignmentsDevice(bpath, {}, output_path=out)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     if rank == 0:
-        print(json.dumps({"world": world, "rows_local": [eng.row_lo, eng.row_hi],
+        print(json.dumps({"world": world, "backend": dist.get_backend() if use_dist else None, "rows_local": [eng.row_lo, eng.row_hi],
                           "full": hashlib.sha256(open(full, "rb").read()).hexdigest(),
                           "masked": hashlib.sha256(open(masked, "rb").read()).hexdigest()}), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

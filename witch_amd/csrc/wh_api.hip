@@ -90,6 +90,7 @@ struct wh_ehmm {
   int max_Q = 4;                              // largest cells-per-lane of any model (sizes the float64 slabs)
   int last_align_redo = 0;          // pairs of the last wh_align call that went through the log-space pass
   int last_align_unaligned = 0;     // ... that the any-size kernel could not align (float64 range)
+  std::vector<int64_t> last_unaligned_pairs;   // their pair numbers (wh_last_align_status)
 };
 
 static int g_device = -1;
@@ -307,6 +308,14 @@ static int timer_end(wh_ehmm *e, int which, hipStream_t s, int launches) {
   if (!e->timing) return WH_OK;
   HIPCHK(hipEventRecord(t.e1, s));
   t.pending = true;
+  return WH_OK;
+}
+
+int wh_last_align_status(wh_ehmm *e, int64_t *n_logspace, int64_t *n_unaligned, int64_t *unaligned_pairs, int64_t cap) {
+  if (!e || cap < 0 || (cap > 0 && !unaligned_pairs)) { set_error("wh_last_align_status: bad argument"); return WH_EINVAL; }
+  if (n_logspace) *n_logspace = e->last_align_redo;
+  if (n_unaligned) *n_unaligned = (int64_t)e->last_unaligned_pairs.size();
+  for (int64_t t = 0; t < cap && t < (int64_t)e->last_unaligned_pairs.size(); t++) unaligned_pairs[t] = e->last_unaligned_pairs[(size_t)t];
   return WH_OK;
 }
 
@@ -968,6 +977,7 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
   }
   e->last_align_redo = n_redo;
   e->last_align_unaligned = 0;
+  e->last_unaligned_pairs.clear();
   if (!e->generic.empty()) {
     // pairs on models of more than 3072 nodes: the any-size float64 alignment kernel, one wavefront per pair
     std::vector<int32_t> gitems;
@@ -1002,7 +1012,10 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       HIPCHK(hipMemcpyAsync(st.data(), e->d_recs.p, sizeof(int32_t) * st.size(), hipMemcpyDeviceToHost, s));
       HIPCHK(hipStreamSynchronize(s));     // gitems is a local
       int n_range = 0, n_log = 0;
-      for (int32_t v : st) { n_range += v == 3; n_log += v == 4; }
+      for (size_t p = 0; p < st.size(); p++) {
+        n_range += st[p] == 3; n_log += st[p] == 4;
+        if (st[p] == 3) e->last_unaligned_pairs.push_back((int64_t)p);
+      }
       e->last_align_unaligned = n_range;
       e->last_align_redo += n_log;
       if (e->knobs.trace && n_log > 0) fprintf(stderr, "[wh] any-size alignment: %d pairs left float64 range, redone in log space\n", n_log);

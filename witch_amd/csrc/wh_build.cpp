@@ -30,6 +30,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "../../include/witch_hip.h"
@@ -128,13 +129,13 @@ struct Prior { Mix tm, ti, td, em, ei; };
 double esl_loggamma(double x);
 
 Prior prior_for(int K) {
+  // wh_hmmbuild is called from thread pools (ctypes releases the GIL): the tables are filled exactly once
   static double lg_nuc[16], lg_nuc_sum[4], lg_aa[180], lg_aa_sum[9];
-  static bool ready = false;
-  if (!ready) {
+  static std::once_flag once;
+  std::call_once(once, [] {
     for (int q = 0; q < 4; q++) { double sum = 0.0; for (int x = 0; x < 4; x++) { lg_nuc[4 * q + x] = esl_loggamma(nuc_em[4 * q + x]); sum += nuc_em[4 * q + x]; } lg_nuc_sum[q] = esl_loggamma(sum); }
     for (int q = 0; q < 9; q++) { double sum = 0.0; for (int x = 0; x < 20; x++) { lg_aa[20 * q + x] = esl_loggamma(aa_em[20 * q + x]); sum += aa_em[20 * q + x]; } lg_aa_sum[q] = esl_loggamma(sum); }
-    ready = true;
-  }
+  });
   if (K == 4) {
     Prior p{{1, 3, one, nuc_tm}, {1, 2, one, nuc_ti}, {1, 2, one, nuc_td}, {4, 4, nuc_emq, nuc_em}, {1, 4, one, nuc_ei}};
     p.em.lg_alpha = lg_nuc; p.em.lg_alpha_sum = lg_nuc_sum;

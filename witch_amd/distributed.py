@@ -6,6 +6,14 @@ tensors too (that is what the CPU tests use)."""
 from __future__ import annotations
 
 
+def collectives_forced() -> bool:
+    """WITCH_FORCE_COLLECTIVES=1: run the path's exchange steps (top-k all-gather, the merge's MAX all-reduce and
+    row gather) through torch.distributed even in a group of ONE rank - the RCCL smoke test of a one-GPU box
+    (tests/test_gpu_parity.py::test_rccl_collectives_on_one_gpu): same code path, same results as without."""
+    import os
+    return os.environ.get("WITCH_FORCE_COLLECTIVES") == "1"
+
+
 def shard_range(n: int, rank: int, world: int):
     """Contiguous block of queries owned by <rank>."""
     return n * rank // world, n * (rank + 1) // world
@@ -18,7 +26,7 @@ def gather_topk(idx, w, nk, nu, group=None):
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not collectives_forced():
         return idx, w, nk, nu
     n_local = torch.tensor([idx.shape[0]], device=idx.device, dtype=torch.int64)
     sizes = [torch.zeros_like(n_local) for _ in range(world)]

@@ -147,6 +147,16 @@ class EHMM:
                                  cols.ctypes.data), "wh_align")
         return cols, co
 
+    def last_align_status(self):
+        """(pairs redone in log space, pair numbers the last align call returned UNALIGNED - all columns -1 -
+        because the any-size kernel could not align them; include/witch_hip.h: wh_last_align_status)."""
+        nlog, nun = C.c_int64(0), C.c_int64(0)
+        check(lib().wh_last_align_status(self._h, C.byref(nlog), C.byref(nun), None, 0), "wh_last_align_status")
+        pairs = np.zeros(nun.value, dtype=np.int64)
+        if nun.value:
+            check(lib().wh_last_align_status(self._h, None, None, pairs.ctypes.data, nun.value), "wh_last_align_status")
+        return int(nlog.value), pairs
+
     def consensus(self, offsets, qpair_off, pair_h, pair_w, col_offsets, cols, retained, nongaps, backbone_length):
         """Weighted consensus DP (wh_consensus).  retained / nongaps: one int array per model."""
         offsets = np.ascontiguousarray(offsets, dtype=np.int64)

@@ -46,6 +46,8 @@ class QueryAlignmentEngine:
         self.merged = None            # int32 CSR by query: consensus codes (gcmm/merge.py)
         self.query_offsets = None     # int64 [nq+1]
         self.merged_minmax = None
+        self.truncated_pairs = []     # (taxon, hmm label) with WH_FLAG_TRUNC
+        self.unaligned_pairs = []     # (taxon, hmm label) the alignment stage returned unaligned
         self.query_text = None        # uint8: the local queries' characters (upper-cased on read), concatenated like query_offsets
         self.device = 0
         # multi-GPU (one process per GPU): this rank scored, aligned and merged the
@@ -69,6 +71,9 @@ class QueryAlignmentEngine:
         rank-local.  multidomain_policy: "resolve" (HMMER's stochastic resolver, default) or "drop"
         (pairs with a multidomain region are not reported)."""
         import time
+        import warnings
+        if multidomain_policy not in ("resolve", "drop", "envelope"):
+            raise ValueError("multidomain_policy must be 'resolve', 'drop' or 'envelope', not %r" % (multidomain_policy,))
         from ..distributed import shard_range
         from ..ehmm import EHMM, pack_queries
         from .algorithm import check_query_names
@@ -79,6 +84,8 @@ class QueryAlignmentEngine:
         nseq = [int(index_to_hmm[i].num_taxa) for i in labels]
         t_load = time.time()
         e = EHMM(paths, hmm_index=labels, nseq=nseq, device=device)
+        if multidomain_policy == "envelope":                  # round-1 behaviour: a multidomain region stays ONE envelope
+            e.set_option("WH_NO_RESOLVE", "1")
         t_load = time.time() - t_load
         self = cls()
         self.num_hmms = int(num_hmms)
@@ -101,6 +108,13 @@ class QueryAlignmentEngine:
         if multidomain_policy == "drop":
             drop = (self.flags & 2) != 0
             self.flags = np.where(drop, self.flags & ~np.uint8(1), self.flags).astype(np.uint8)
+        trunc = np.argwhere((self.flags & 8) != 0)
+        if len(trunc):
+            # WH_FLAG_TRUNC: the pair has more envelopes than the kernels keep (WH_MAX_ENVELOPES); its null2 correction
+            # misses the dropped ones, so its score may differ from hmmsearch's.  Never silent.
+            self.truncated_pairs = [(self.taxa[int(q) + self.row_lo], int(labels[int(h)])) for q, h in trunc]
+            warnings.warn("witch_amd: %d (query, HMM) pair(s) have more than 8 envelopes; their scores may differ from "
+                          "hmmsearch's (first: %s vs A_0_%d)" % ((len(trunc),) + self.truncated_pairs[0]), RuntimeWarning)
         t1 = time.time()
         self.topk_idx, self.topk_w, self.n_kept, self.n_used = e.topk(self.decibits, self.flags, self.num_hmms)
         self.topk_rows = (self.row_lo, self.row_hi)
@@ -114,6 +128,16 @@ class QueryAlignmentEngine:
         lut[self.hmm_index] = np.arange(len(labels), dtype=np.int32)
         ph = lut[plab]
         self.cols, self.col_offsets = e.align(res, offs, pq, ph)
+        _, unal_pairs = e.last_align_status()
+        pw_mask = np.ones(len(pq), dtype=bool)
+        if len(unal_pairs):
+            # pairs the any-size kernel could not align come back all -1: they are NOT all-insertion alignments.
+            # They are dropped from the consensus (weight 0: the max-weight trace is invariant to the common
+            # scale of the remaining weights) and reported.
+            pw_mask[unal_pairs] = False
+            self.unaligned_pairs = [(self.taxa[int(pq[p]) + self.row_lo], int(plab[p])) for p in unal_pairs]
+            warnings.warn("witch_amd: %d pair(s) on models of more than 3072 nodes could not be aligned and are left out "
+                          "of the consensus (first: %s vs A_0_%d)" % ((len(unal_pairs),) + self.unaligned_pairs[0]), RuntimeWarning)
         self.pair_of = {(int(q) + self.row_lo, int(lab)): p for p, (q, lab) in enumerate(zip(pq.tolist(), plab.tolist()))}
         t3 = time.time()
         # same three stage names the reference logs (algorithm.py:333-335, weighting.py:165-168, aligner.py:520-525)
@@ -123,14 +147,15 @@ class QueryAlignmentEngine:
             # the weighted consensus DP of alignSubQueriesNew (aligner.py:376-473), all local queries at once
             qpo = np.zeros(nloc + 1, dtype=np.int64)
             qpo[1:] = np.cumsum(self.n_used)
-            pw = self.topk_w[keep].astype(np.float64)
+            pw = np.where(pw_mask, self.topk_w[keep].astype(np.float64), 0.0)
             ret = [np.asarray(subset_to_retained_columns[i], dtype=np.int32) for i in labels]
             ng = [np.asarray(subset_to_nongaps_per_column[i], dtype=np.int32) for i in labels]
             self.merged, self.merged_minmax = e.consensus(offs, qpo, ph, pw, self.col_offsets, self.cols, ret, ng,
                                                           int(backbone_length))
             self.timings["merge"] = time.time() - t3
         e.close()
-        if self.world > 1:
+        from ..distributed import collectives_forced
+        if self.world > 1 or collectives_forced():
             self.gather(group)
         return self
 
@@ -140,8 +165,8 @@ class QueryAlignmentEngine:
         every rank.  Scores, aligned columns and consensus results stay with the rank that owns the query."""
         import torch
         import torch.distributed as dist
-        from ..distributed import gather_topk
-        if self.world <= 1:
+        from ..distributed import collectives_forced, gather_topk
+        if self.world <= 1 and not collectives_forced():
             return self
         dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
         t0 = __import__("time").time()

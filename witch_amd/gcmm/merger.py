@@ -210,9 +210,11 @@ def mergeAlignmentsDevice(backbone_alignment_path, renamed_taxa=None, output_pat
     codes = np.ascontiguousarray(eng.merged, dtype=np.int32)
     offs = np.ascontiguousarray(eng.query_offsets, dtype=np.int64)
     text = np.ascontiguousarray(eng.query_text, dtype=np.uint8)
+    from ..distributed import collectives_forced
     world = world_of(eng)
+    exchange = world > 1 or collectives_forced()      # forced: the RCCL smoke of a one-GPU box takes the N-rank path
     W = None
-    if world > 1:
+    if exchange:
         import torch
         import torch.distributed as dist
         Wl = np.zeros(B + 1, dtype=np.int32)
@@ -239,7 +241,7 @@ def mergeAlignmentsDevice(backbone_alignment_path, renamed_taxa=None, output_pat
     mine = sorted(g for g, _ in appended if lo <= g < hi)
     local_row = {g: nb + i for i, g in enumerate(mine)}
     mpath = masked_path(output_path)
-    if world > 1:
+    if exchange:
         import torch.distributed as dist
         part = {g: (full[local_row[g]].tobytes(), masked[local_row[g]].tobytes()) for g in mine}
         parts = [None] * world

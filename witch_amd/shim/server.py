@@ -316,10 +316,16 @@ class Server:
         import fcntl
         private_socket_dir(self.sock_path)
         self._lockf = open(self.sock_path + ".lock", "w")
-        try:
-            fcntl.flock(self._lockf, fcntl.LOCK_EX | fcntl.LOCK_NB)
-        except OSError:
-            return False                                  # another server owns this socket
+        for attempt in range(100):
+            try:
+                fcntl.flock(self._lockf, fcntl.LOCK_EX | fcntl.LOCK_NB)
+                break
+            except OSError:
+                # another server owns this socket - unless it is just leaving (idle shutdown: path already
+                # unlinked, lock released a moment later): then wait for the lock instead of giving up
+                if os.path.exists(self.sock_path) or attempt == 99:
+                    return False
+                time.sleep(0.05)
         if os.path.exists(self.sock_path):
             os.unlink(self.sock_path)
         old_umask = os.umask(0o077)
@@ -340,10 +346,28 @@ class Server:
             except socket.timeout:
                 if threading.active_count() > 2:          # requests still running: keep going
                     continue
+                # Leave without dropping anyone: unlink the path FIRST (a client arriving from now on finds no
+                # socket and starts a fresh server, which waits on the flock until this one is gone), then serve
+                # whatever is already in the listen backlog before closing.
                 try:
                     os.unlink(self.sock_path)
                 except OSError:
                     pass
+                fcntl.flock(self._lockf, fcntl.LOCK_UN)    # a successor may bind a new socket while the backlog drains
+                srv.setblocking(False)
+                late = []
+                while True:
+                    try:
+                        conn, _ = srv.accept()
+                    except (BlockingIOError, OSError):
+                        break
+                    conn.settimeout(None)
+                    t = threading.Thread(target=self.handle, args=(conn,), daemon=True)
+                    t.start()
+                    late.append(t)
+                for t in late:
+                    t.join()
+                srv.close()
                 return True
             conn.settimeout(None)
             threading.Thread(target=self.handle, args=(conn,), daemon=True).start()

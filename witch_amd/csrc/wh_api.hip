@@ -61,6 +61,7 @@ struct Knobs {
   int max_waves = 0;         // cap on waves per workgroup (0 = planner's choice)
   bool force_specg = false;  // force the HBM special-state mode
   bool no_logspace = false;  // skip the log-space alignment pass
+  bool no_window = false;    // envelope Backward sweeps run full width (no node window; A/B and debugging)
   bool no_resolve = false;   // multidomain regions stay ONE envelope (round-1 behaviour) instead of HMMER's stochastic resolver
   bool stats = false, trace = false;
   int dbg = 0;
@@ -275,6 +276,7 @@ int wh_set_option(wh_ehmm *e, const char *name, const char *value) {
   else if (!strcmp(name, "WH_FORCE_SPECG")) k.force_specg = on;
   else if (!strcmp(name, "WH_NO_LOGSPACE")) k.no_logspace = on;
   else if (!strcmp(name, "WH_NO_RESOLVE")) k.no_resolve = on;
+  else if (!strcmp(name, "WH_NO_WINDOW")) k.no_window = on;
   else if (!strcmp(name, "WH_STATS")) k.stats = on;
   else if (!strcmp(name, "WH_TRACE")) k.trace = on;
   else if (!strcmp(name, "WH_DBG")) k.dbg = atoi(v);
@@ -284,7 +286,7 @@ int wh_set_option(wh_ehmm *e, const char *name, const char *value) {
 }
 
 static void knobs_from_env(wh_ehmm *e) {
-  for (const char *name : {"WH_SCORE_KERNEL", "WH_KEEP_LOG2", "WH_MAX_WAVES", "WH_FORCE_SPECG", "WH_NO_LOGSPACE", "WH_NO_RESOLVE", "WH_STATS", "WH_TRACE", "WH_DBG", "WH_RDBG"})
+  for (const char *name : {"WH_SCORE_KERNEL", "WH_KEEP_LOG2", "WH_MAX_WAVES", "WH_FORCE_SPECG", "WH_NO_LOGSPACE", "WH_NO_RESOLVE", "WH_NO_WINDOW", "WH_STATS", "WH_TRACE", "WH_DBG", "WH_RDBG"})
     if (const char *v = getenv(name)) (void)wh_set_option(e, name, v);
 }
 
@@ -436,6 +438,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       a.decibits = d_decibits; a.flags = d_flags; a.fwd_bits = d_fwd_bits; a.detail = d_detail;
       a.H = H; a.K = e->K; a.Kp = e->Kp;
       a.dbg = kn.dbg;
+      a.no_window = kn.no_window ? 1 : 0;
       a.keep_scale = kn.keep_scale;
       if (resolve) { a.rrecs = (ResolveRec *)e->d_rrecs.p; a.rcount = d_rcount; a.rcap = (int)npairs_all; }
       memcpy(a.degen, e->degen, sizeof a.degen);
@@ -526,6 +529,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
         const double tot = (double)(st[4] + st[5] + st[6] + st[7] + st[8] + st[9] + st[10] + st[11]);
         fprintf(stderr, "[wh] Q=%d wave cycles: P1 %.1f%%  P2 %.1f%%  regions %.1f%%  P3 %.1f%%  P4 %.1f%%  null2 %.1f%%  swaps+barriers %.1f%%  other %.1f%%  (total %.3g ticks)\n", Q, 100.0 * st[4] / tot,
                 100.0 * st[5] / tot, 100.0 * st[6] / tot, 100.0 * st[7] / tot, 100.0 * st[8] / tot, 100.0 * st[9] / tot, 100.0 * st[10] / tot, 100.0 * st[11] / tot, tot);
+        fprintf(stderr, "[wh] Q=%d envelope Backward sweeps: %llu on a 256-node window, %llu on a 512-node window, %llu windows failed the mass certificate, %llu full width; union of the stored lane blocks: span %.1f blocks (with margin), %.1f blocks set, of %llu envelopes\n", Q, st[0], st[1], st[2], st[3], (double)st[12] / (double)std::max(1ull, st[14]), (double)st[15] / (double)std::max(1ull, st[14]), st[14]);
       }
     }
     }

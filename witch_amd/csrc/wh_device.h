@@ -273,6 +273,9 @@ __device__ __forceinline__ void forward_sweep(const TransTab<Q, TREG> &T, const 
   for (int q = 0; q < Q; q++) { Mp[q] = 0.f; Ip[q] = 0.f; Dp[q] = 0.f; }
   float xN = 1.0f, xB = cfg.move, xJ = 0.f, xC = 0.f, xE = 0.f;
   int ef = 0;
+  unsigned long long umask = 0;      // STORE: union over the rows of the lane block that holds a cell above E(row)/2: where the
+                                     // envelope's dominant alignment runs.  The first rows set no bit: it takes ~25 nucleotides
+                                     // until the true diagonal outweighs the chance matches among ~1000 others
   if (lane == 0) {
     spec[SP_N * SP] = xN; spec[SP_B * SP] = xB; spec[SP_E * SP] = 0.f; spec[SP_J * SP] = 0.f;
     spec[SP_C * SP] = 0.f; reinterpret_cast<int *>(spec)[SP_S * SP] = 0;
@@ -358,6 +361,7 @@ __device__ __forceinline__ void forward_sweep(const TransTab<Q, TREG> &T, const 
       for (int q = 0; q < Q; q += 2) lmax = fmaxf(lmax, fmaxf(fmaxf(Mp[q], Mp[q + 1]), fmaxf(Ip[q], Ip[q + 1])));
       const bool keep = lmax > keep_scale * xE;
       const unsigned long long mask = __ballot(keep);
+      umask |= __ballot(lmax > 0.5f * xE);
       if (lane == 0) {
         reinterpret_cast<unsigned *>(spec)[SP_ML * SP + i] = (unsigned)(mask & 0xFFFFFFFFull);
         reinterpret_cast<unsigned *>(spec)[SP_MH * SP + i] = (unsigned)(mask >> 32);
@@ -372,6 +376,11 @@ __device__ __forceinline__ void forward_sweep(const TransTab<Q, TREG> &T, const 
         }
       }
     }
+  }
+  if (STORE && lane == 0) {
+    // row 0 of the two mask arrays is free (rows are 1..L): the dominant-path mask of the sweep
+    reinterpret_cast<unsigned *>(spec)[SP_ML * SP] = (unsigned)(umask & 0xFFFFFFFFull);
+    reinterpret_cast<unsigned *>(spec)[SP_MH * SP] = (unsigned)(umask >> 32);
   }
   xC_out = xC;
   ef_out = ef;

@@ -47,6 +47,7 @@ struct ScoreArgs {
   int K, Kp;
   uint32_t degen[32];
   int Klds;                    // emission rows staged in LDS (= K, or 0: read from L2)
+  int no_window;               // 1: envelope Backward sweeps at full width only (WH_NO_WINDOW)
   int dbg;                     // timing experiments only: 1 = skip Forward-row stores, 2 = skip Forward-row loads
   float keep_scale;            // Forward-row spill threshold relative to E(row); 0 = the kernel's default (2^-24)
   ResolveRec *rrecs;           // queue of pairs with a multidomain region (NULL: such regions become one envelope)

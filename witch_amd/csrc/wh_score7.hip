@@ -289,6 +289,160 @@ __device__ __noinline__ P4Out sweep_backward_null2(const WaveCtx c, lds_u8 *eseq
   return o;
 }
 
+// ---------------------------------------------------------------- P4 on a node window
+// The envelope's Backward sweep restricted to the window of 64*QB consecutive nodes that holds every lane block the
+// Forward sweep stored (the union of its per-row masks): a 150-residue query walks ~200 of a model's ~900 nodes, so
+// the window sweep does a quarter of the cells.  Window lane r owns the reversed nodes m0 + r*QB .. + QB-1 (m0 a
+// multiple of QB, QB a divisor of Q, so a window lane's nodes lie in ONE forward lane block); its eight transition
+// arrays are gathered ONCE from the lane-blocked LDS copy into registers (8 * QB/4 float4), emission pieces and
+// the stored Forward rows are fetched per row through per-lane offsets.  Restricting the Backward sweep drops the
+// paths that leave the window; the Forward rows are exact, so every accumulated posterior is a lower bound and the
+// SAME mass certificate that guards the sparse spill guards the window: mass must reach Ld (1 - tol), otherwise the
+// caller runs the full-width sweep on the same rows.
+template <int QB, int Q, int TH, bool SG>
+__device__ __noinline__ P4Out sweep_backward_null2_win(const WaveCtx c, lds_u8 *eseq3, int Ld, LenCfg cu, float invZe, float mass_tol, int m0) {
+  static_assert(Q % QB == 0 && QB % 4 == 0, "a window lane must stay inside one forward lane block");
+  constexpr int Q4 = Q / 4, B4 = QB / 4;
+  const uint8_t *eseq = (const uint8_t *)eseq3;
+  const int lane = c.lane, SP = c.SP, Klds = ctxKlds(c);
+  const float *spec = SG ? (const float *)c.specg : (const float *)c.spec;
+  auto ldf = [&](int idx) -> float { return SG ? __builtin_nontemporal_load(spec + idx) : spec[idx]; };
+  auto ldi = [&](int idx) -> int { return SG ? __builtin_nontemporal_load(reinterpret_cast<const int *>(spec) + idx) : reinterpret_cast<const int *>(spec)[idx]; };
+  auto ldu = [&](int idx) -> unsigned { return SG ? __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(spec) + idx) : reinterpret_cast<const unsigned *>(spec)[idx]; };
+  // float4 slots: reversed piece p4 of this lane is slot rev[p4] of a reversed-order array, and (components
+  // reversed) slot fwd[p4] of a forward-order array (emission rows, stored Forward rows)
+  int fwd[B4];
+  TransTab<QB, true> T;
+  {
+    const float4 *bw4 = reinterpret_cast<const float4 *>((const float *)c.bwL);
+#pragma unroll
+    for (int p4 = 0; p4 < B4; p4++) {
+      const int m4 = (m0 >> 2) + lane * B4 + p4;
+      const int rev = (m4 % Q4) * kWave + m4 / Q4;
+      const int jf = 16 * Q - 1 - m4;
+      fwd[p4] = (jf % Q4) * kWave + jf / Q4;
+#pragma unroll
+      for (int a = 0; a < BW_NARR; a++) T.v[a][p4] = bw4[a * Q4 * kWave + rev];
+    }
+  }
+  const int lanef = (16 * Q - 1 - ((m0 >> 2) + lane * B4)) / Q4;     // forward lane block of my nodes
+  const ScanC sc = scan_prepare(lane_product<QB, true>(T, BW_DD));
+  const float4 *em4L = reinterpret_cast<const float4 *>((const float *)c.emL);
+  const float4 *em4G = reinterpret_cast<const float4 *>((const float *)c.emG);
+  float Mb[QB], Ib[QB], fM[QB];
+#pragma unroll
+  for (int p = 0; p < QB; p++) { Mb[p] = 0.f; Ib[p] = 0.f; fM[p] = 0.f; }
+  float xC = cu.move, xJ = 0.f, xN = 0.f, xB = 0.f, xfac = 0.f, fIs = 0.f;
+  int S_next = 0;
+  // the stored Forward cells of a row are requested ONE ROW AHEAD (2 * QB registers: affordable here, not at full
+  // width), so their HBM round trip runs beside a whole row of arithmetic
+  float4 fm_n[B4], fi_n[B4];
+  bool have_n = false;
+  auto request_row = [&](int r) {
+    const unsigned mword = lanef < 32 ? ldu(SP_ML * SP + r) : ldu(SP_MH * SP + r);
+    have_n = (mword >> (lanef & 31)) & 1u;
+    if (have_n) {
+      const float4 *row = reinterpret_cast<const float4 *>((const float *)c.Fs) + (size_t)r * (2 * Q4 * kWave);
+#pragma unroll
+      for (int p4 = 0; p4 < B4; p4++) { fm_n[p4] = nt_load4(row + fwd[p4]); fi_n[p4] = nt_load4(row + Q4 * kWave + fwd[p4]); }
+    }
+  };
+  request_row(Ld);
+#pragma unroll 1
+  for (int i = Ld; i >= 1; i--) {
+    asm volatile("" ::: "memory");
+    float4 fm_c[B4], fi_c[B4];
+#pragma unroll
+    for (int p4 = 0; p4 < B4; p4++) { fm_c[p4] = fm_n[p4]; fi_c[p4] = fi_n[p4]; }
+    const bool have = have_n;
+    if (i > 1) request_row(i - 1);
+    const int S_i = ldi(SP_S * SP + i);
+    const int dS = S_i - ldi(SP_S * SP + i - 1);
+    if (i < Ld) {
+      mirror_scale<QB>(S_next - S_i, Mb, Ib, xJ, xC, xN);
+      const int x = __builtin_amdgcn_readfirstlane((int)eseq[i]);
+      float part = 0.f;
+#pragma unroll
+      for (int p4 = 0; p4 < B4; p4++) {
+        const float4 E = T.v[BW_E][p4];
+        const float4 O = x < Klds ? em4L[x * (Q * 16) + fwd[p4]] : em4G[(size_t)x * (Q * 16) + fwd[p4]];
+        Mb[4 * p4 + 0] *= O.w; part = fmaf(E.x, Mb[4 * p4 + 0], part);
+        Mb[4 * p4 + 1] *= O.z; part = fmaf(E.y, Mb[4 * p4 + 1], part);
+        Mb[4 * p4 + 2] *= O.y; part = fmaf(E.z, Mb[4 * p4 + 2], part);
+        Mb[4 * p4 + 3] *= O.x; part = fmaf(E.w, Mb[4 * p4 + 3], part);
+      }
+      xB = wave_sum(part);
+      xJ = fmaf(xJ, cu.loop, xB * cu.move);
+      xC = xC * cu.loop;
+      xN = fmaf(xN, cu.loop, xB * cu.move);
+    }
+    const float xE = fmaf(xC, cu.EC, xJ * cu.EJ);
+    backward_cells<QB, true, false>(T, sc, Mb, Ib, xE);
+    clamp_backward<QB>(Mb, Ib, xB, xJ, xC, xN);
+    const float s_i = invZe;
+    const float s_p = ldexpf(invZe, -dS);
+    if (have) {
+      float idot = 0.f;
+#pragma unroll
+      for (int p4 = 0; p4 < B4; p4++) {
+        const float4 fm = fm_c[p4];
+        const float4 fi = fi_c[p4];
+        fM[4 * p4 + 0] = fmaf(fm.w * Mb[4 * p4 + 0], s_i, fM[4 * p4 + 0]);
+        fM[4 * p4 + 1] = fmaf(fm.z * Mb[4 * p4 + 1], s_i, fM[4 * p4 + 1]);
+        fM[4 * p4 + 2] = fmaf(fm.y * Mb[4 * p4 + 2], s_i, fM[4 * p4 + 2]);
+        fM[4 * p4 + 3] = fmaf(fm.x * Mb[4 * p4 + 3], s_i, fM[4 * p4 + 3]);
+        idot = fmaf(fi.w, Ib[4 * p4 + 0], idot); idot = fmaf(fi.z, Ib[4 * p4 + 1], idot);
+        idot = fmaf(fi.y, Ib[4 * p4 + 2], idot); idot = fmaf(fi.x, Ib[4 * p4 + 3], idot);
+      }
+      fIs = fmaf(idot, s_i, fIs);
+    }
+    float nj = ldf(SP_N * SP + i - 1) * xN;
+    nj = fmaf(ldf(SP_J * SP + i - 1), xJ, nj);
+    nj = fmaf(ldf(SP_C * SP + i - 1), xC, nj);
+    S_next = S_i;
+    xfac = fmaf(nj * cu.loop, s_p, xfac);
+  }
+  float sm = 0.f;
+#pragma unroll
+  for (int p = 0; p < QB; p++) sm += fM[p];
+  sm = wave_sum(sm);
+  const float si = wave_sum(fIs);
+  const float mass = sm + si + xfac;
+  P4Out o;
+  o.mass = mass; o.domcorr = 0.f;
+  if (!(fabsf((float)Ld - mass) <= mass_tol * (float)Ld)) return o;   // the window lost mass: the caller runs the full-width sweep
+  const float norm = 1.0f / (float)Ld;
+  float mine = 1.0f;
+  for (int x = 0; x < ctxK(c); x++) {
+    float s = 0.f;
+#pragma unroll
+    for (int p4 = 0; p4 < B4; p4++) {
+      const float4 O = x < Klds ? em4L[x * (Q * 16) + fwd[p4]] : em4G[(size_t)x * (Q * 16) + fwd[p4]];
+      s = fmaf(fM[4 * p4 + 0], O.w, s); s = fmaf(fM[4 * p4 + 1], O.z, s);
+      s = fmaf(fM[4 * p4 + 2], O.y, s); s = fmaf(fM[4 * p4 + 3], O.x, s);
+    }
+    s = wave_sum(s);
+    if (lane == x) mine = (s + si) * norm + xfac * norm;
+  }
+  float *n2tab = (float *)c.n2tab;
+  __builtin_amdgcn_wave_barrier();
+  if (lane < ctxK(c)) n2tab[lane] = mine;
+  __builtin_amdgcn_wave_barrier();
+  if (lane >= ctxK(c) && lane < ctxKp(c)) {
+    const uint32_t m = c.degen;
+    float s = 0.f; int n = 0;
+    for (int x = 0; x < ctxK(c); x++) if (m & (1u << x)) { s += n2tab[x]; n++; }
+    mine = n > 0 ? s / (float)n : 1.0f;
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (lane < ctxKp(c)) n2tab[lane] = logf(mine);
+  __builtin_amdgcn_wave_barrier();
+  float dc = 0.f;
+  for (int t = lane; t < Ld; t += kWave) dc += n2tab[eseq[t]];
+  o.domcorr = wave_sum(dc);
+  return o;
+}
+
 // ---------------------------------------------------------------- region scan (A.4)
 template <int TH, bool SG>
 __device__ __noinline__ RegOut region_scan(lds_f *spec3, glb_f *specg, int SP, int L, lds_i *regs3, int lane) {
@@ -462,7 +616,37 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
                 if (!(f3.xC > 0.f)) break;
                 WH_TICK7(7);
                 const float tol = attempt == 0 ? kMassTol7 : INFINITY;
-                const P4Out p4 = sweep_backward_null2<Q, TH, SG>(c, (lds_u8 *)eseq, Ld, cu, 1.0f / (f3.xC * cu.move), f3.ef, tol);
+                P4Out p4;
+                bool have4 = false;
+                if constexpr (Q >= 8) {
+                  if (attempt == 0 && !a.no_window) {
+                    // the node window around the lane blocks the dominant alignment runs through (two blocks in
+                    // front: the envelope's first ~25 rows set no bit and lie that many nodes ahead; one block behind)
+                    const unsigned *su = reinterpret_cast<const unsigned *>(SG ? (const float *)c.specg : (const float *)c.spec);
+                    const unsigned long long um = ((unsigned long long)su[SP_MH * SP] << 32) | su[SP_ML * SP];
+                    if (um != 0) {
+                      int lo = __builtin_ctzll(um), hi = 63 - __builtin_clzll(um);
+                      lo = lo > 1 ? lo - 2 : 0; hi = hi < 63 ? hi + 1 : 63;
+                      const int nodes = (hi - lo + 1) * Q;
+                      if (a.stats && lane == 0) { atomicAdd(a.stats + 12, (unsigned long long)(hi - lo + 1)); atomicAdd(a.stats + 14, 1ull); atomicAdd(a.stats + 15, (unsigned long long)__builtin_popcountll(um)); }
+                      if (nodes <= 4 * kWave) {
+                        const int m0 = min((63 - hi) * Q, kWave * (Q - 4));
+                        p4 = sweep_backward_null2_win<4, Q, TH, SG>(c, (lds_u8 *)eseq, Ld, cu, 1.0f / (f3.xC * cu.move), tol, m0);
+                        have4 = fabsf((float)Ld - p4.mass) <= kMassTol7 * (float)Ld;
+                        if (a.stats && lane == 0) atomicAdd(a.stats + (have4 ? 0 : 2), 1ull);
+                      } else if (Q % 8 == 0 && Q > 8 && nodes <= 8 * kWave) {
+                        const int m0 = min((63 - hi) * Q, kWave * (Q - 8));
+                        p4 = sweep_backward_null2_win<(Q % 8 == 0 ? 8 : 4), Q, TH, SG>(c, (lds_u8 *)eseq, Ld, cu, 1.0f / (f3.xC * cu.move), tol, m0);
+                        have4 = fabsf((float)Ld - p4.mass) <= kMassTol7 * (float)Ld;
+                        if (a.stats && lane == 0) atomicAdd(a.stats + (have4 ? 1 : 2), 1ull);
+                      }
+                    }
+                  }
+                }
+                if (!have4) {
+                  p4 = sweep_backward_null2<Q, TH, SG>(c, (lds_u8 *)eseq, Ld, cu, 1.0f / (f3.xC * cu.move), f3.ef, tol);
+                  if (a.stats && lane == 0) atomicAdd(a.stats + 3, 1ull);
+                }
                 domcorr = p4.domcorr;
                 WH_TICK7(8);
                 if (attempt == 0 && !(fabsf((float)Ld - p4.mass) <= kMassTol7 * (float)Ld)) continue;

@@ -509,8 +509,8 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       a.scratch = (float *)e->d_scratch.p;
       if (specg) a.spec_scratch = (float *)e->d_spec.p;
       if (kn.stats) {
-        if (e->d_recs.ensure(128)) return WH_ENOMEM;
-        HIPCHK(hipMemsetAsync(e->d_recs.p, 0, 128, s));
+        if (e->d_recs.ensure(256)) return WH_ENOMEM;
+        HIPCHK(hipMemsetAsync(e->d_recs.p, 0, 256, s));
         { unsigned long long bigv = ~0ull; HIPCHK(hipMemcpyAsync((char *)e->d_recs.p + 13 * 8, &bigv, 8, hipMemcpyHostToDevice, s)); }
         a.stats = (unsigned long long *)e->d_recs.p;
       }
@@ -523,13 +523,15 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       if (err != hipSuccess) { set_error("score kernel launch (Q=%d) failed: %s", Q, hipGetErrorString(err)); return WH_EHIP; }
       launches++;
       if (a.stats) {
-        unsigned long long st[16];
+        unsigned long long st[32];
         HIPCHK(hipMemcpyAsync(st, a.stats, sizeof st, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         const double tot = (double)(st[4] + st[5] + st[6] + st[7] + st[8] + st[9] + st[10] + st[11]);
         fprintf(stderr, "[wh] Q=%d wave cycles: P1 %.1f%%  P2 %.1f%%  regions %.1f%%  P3 %.1f%%  P4 %.1f%%  null2 %.1f%%  swaps+barriers %.1f%%  other %.1f%%  (total %.3g ticks)\n", Q, 100.0 * st[4] / tot,
                 100.0 * st[5] / tot, 100.0 * st[6] / tot, 100.0 * st[7] / tot, 100.0 * st[8] / tot, 100.0 * st[9] / tot, 100.0 * st[10] / tot, 100.0 * st[11] / tot, tot);
         fprintf(stderr, "[wh] Q=%d envelope Backward sweeps: %llu on a 256-node window, %llu on a 512-node window, %llu windows failed the mass certificate, %llu full width; union of the stored lane blocks: span %.1f blocks (with margin), %.1f blocks set, of %llu envelopes\n", Q, st[0], st[1], st[2], st[3], (double)st[12] / (double)std::max(1ull, st[14]), (double)st[15] / (double)std::max(1ull, st[14]), st[14]);
+        fprintf(stderr, "[wh] Q=%d |Ld - mass| / Ld  (<3e-7, <1e-6, <3e-6, <1e-5, <2e-5, more): window sweeps %llu %llu %llu %llu %llu %llu; full-width sweeps %llu %llu %llu %llu %llu %llu\n", Q,
+                st[16], st[17], st[18], st[19], st[20], st[21], st[22], st[23], st[24], st[25], st[26], st[27]);
       }
     }
     }

@@ -148,6 +148,45 @@ def merge_stage(fam, seqs_local, off_t, nu_t, alphabet):
     return ms, rows, width
 
 
+def level1_stage(fam, synth_ehmm, names, seqs, k, alphabet, workdir, nq=20000, device=0):
+    """The LEVEL-1 path a WITCH maintainer calls (witch_amd.gcmm), end to end on the first
+    <nq> queries of the workload: query TEXT in -> QueryAlignmentEngine.run (digitise, score, top-k, align, consensus)
+    -> rankBitscores -> writeWeights -> mergeAlignmentsDevice -> the two merged FASTA files on disk.  Wall time of a
+    warm process (library loaded, HIP context up); a fresh model handle, so eHMM parsing / upload and every
+    first-call allocation are inside.  Reported beside <value>, never part of it."""
+    from witch_amd import gcmm, synth
+
+    class _Sub:
+        def __init__(self, path, n):
+            self.hmm_model_path, self.num_taxa = path, n
+    nq = min(nq, len(seqs))
+    index_to_hmm = {i: _Sub(p, n) for i, p, n in zip(synth_ehmm.index, synth_ehmm.paths, synth_ehmm.nseq)}
+    retained = {i: (h.map_cols[1:] - 1).tolist() for i, h in zip(synth_ehmm.index, synth_ehmm.hmms)}
+    nongaps = {i: h.nongaps.tolist() for i, h in zip(synth_ehmm.index, synth_ehmm.hmms)}
+    B = fam.msa.shape[1]
+    texts = [synth.to_text(s_, alphabet) for s_ in seqs[:nq]]
+    bpath = os.path.join(workdir, "level1_backbone.fasta")
+    synth.write_msa_fasta(bpath, fam, 0, 64)
+    gcmm.warm_up(device)
+    t0 = time.perf_counter()
+    eng = gcmm.install(gcmm.QueryAlignmentEngine.run(index_to_hmm, list(zip(names[:nq], texts)), k, device=device,
+                                                     subset_to_retained_columns=retained, subset_to_nongaps_per_column=nongaps,
+                                                     backbone_length=B))
+    t1 = time.perf_counter()
+    ranked = gcmm.rankBitscores(index_to_hmm, {})
+    weights = gcmm.writeWeights(index_to_hmm, ranked)
+    t2 = time.perf_counter()
+    out = os.path.join(workdir, "level1_out.fasta")
+    gcmm.mergeAlignmentsDevice(bpath, {}, output_path=out, taxa=[t for t in names[:nq] if t in weights])
+    t3 = time.perf_counter()
+    rows = sum(1 for line in open(out) if line.startswith(">"))
+    return {"queries": nq, "seconds": round(t3 - t0, 3), "queries_per_s": round(nq / (t3 - t0), 1),
+            "stages_s": {"engine_run": round(t1 - t0, 3), "rank_and_weights": round(t2 - t1, 3), "device_merge_and_files": round(t3 - t2, 3),
+                         **{"engine_" + kk: round(v, 3) for kk, v in eng.timings.items()}},
+            "rows_written": rows,
+            "note": "text queries in -> two merged FASTA files out through witch_amd.gcmm (level 1), warm process, fresh model handle; outside the timed region"}
+
+
 def crc_of(*arrays):
     import zlib
     c = 0
@@ -188,6 +227,7 @@ def main():
     ap.add_argument("--nq", type=int, default=0, help="override the query count (development only)")
     ap.add_argument("--nh", type=int, default=0, help="override the HMM count (development only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-level1", action="store_true", help="skip the level-1 end-to-end stage (reported beside the hot-path value)")
     args = ap.parse_args()
 
     import torch
@@ -250,12 +290,17 @@ def main():
         kern_ms = [0.0, 0.0, 0.0, 0.0, 0.0]     # scoring kernels, topk, align, (consensus: timed apart), multidomain resolver
         kern_n = [0, 0, 0, 0, 0]
         npairs = ncols = 0
+        class_ms = {}                            # (cells per lane, kernel family) -> [ms, launches] of the scoring launches
         for st in range(args.steps):
             out, npairs, ncols = hot_path_step(e, res_t, off_t, maxlen, k, gather, keep_device=(st == args.steps - 1))
             for which in (0, 1, 2, 4):
                 ms, n = e.last_kernel_ms(which)
                 kern_ms[which] += ms
                 kern_n[which] += n
+            for qc, kind, ms in e.last_score_launches():
+                cls = class_ms.setdefault((qc, kind), [0.0, 0])
+                cls[0] += ms
+                cls[1] += 1
         barrier()
         dt = time.perf_counter() - t0
         if use_dist:
@@ -285,10 +330,27 @@ def main():
             # null2) over the envelope's cells; the envelope of a full-length hit is the whole query, so
             # 77 flop/cell over L x M cells per pair.  Peak: 157.3 TFLOP/s fp32 vector (packed rate; the
             # plain v_fma_f32 the sweeps use reaches the same SIMD throughput on gfx950).
-            score_launches = max(kern_n[0], 1)
-            score_ms = kern_ms[0] / score_launches
+            # the dominant kernel = the launch class with the largest measured share of the scoring time (a mixed eHMM has
+            # several: one launch per cells-per-lane class); its cells = the local residues x the nodes of ITS models
+            fam_names = {0: "wh::k7::score_kernel7", 1: "wh::score_big_kernel", 2: "wh::generic_front_kernel"}
+            def cls_of(m):      # cells-per-lane class of a model (witch_amd/csrc/wh_hmm.cpp choose_Q: next multiple of 4)
+                return max(4, (-(-int(m) // 64) + 3) // 4 * 4)
+            if class_ms:
+                (dom_q, dom_kind), (dom_ms, dom_n) = max(class_ms.items(), key=lambda kv: kv[1][0])
+                if dom_kind == 2:
+                    dom_M = M[M > 3072]
+                else:
+                    dom_M = M[np.array([cls_of(m) == dom_q for m in M])]
+                score_launches, score_ms = max(dom_n, 1), dom_ms / max(dom_n, 1)
+                cells_launch = float(lens_local.sum() * dom_M.sum()) * args.steps / score_launches
+                dom_name = "%s<%d cells per lane>" % (fam_names.get(dom_kind, "?"), dom_q) if dom_kind != 2 else fam_names[2]
+                dom_share = dom_ms / max(kern_ms[0], 1e-9)
+            else:
+                score_launches = max(kern_n[0], 1)
+                score_ms = kern_ms[0] / score_launches
+                cells_launch = float(lens_local.sum() * M.sum()) * args.steps / score_launches
+                dom_name, dom_share = "wh::k7::score_kernel7", 1.0
             cells_step = float(lens_local.sum() * M.sum())              # every local query x every model
-            cells_launch = cells_step * args.steps / score_launches
             s_tflops = cells_launch * 77.0 / (score_ms * 1e-3) / 1e12 if score_ms > 0 else 0.0
             traffic, traffic_src, traffic_align = None, None, None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -301,7 +363,9 @@ def main():
                         traffic_src = "profiles/traffic.json <- %s; counters of an earlier run of this command, NOT measured in this run" % tj.get("source", "?").split(" ")[0]
                 except Exception:
                     traffic = None
-            roofline = {"bound": "valu", "kernel": "wh::generic_front_kernel" if int(np.max(e.M)) > 3072 else "wh::score_big_kernel" if int(np.max(e.M)) > 1536 else "wh::k7::score_kernel7", "achieved": round(s_tflops, 2), "peak": 157.3,
+            roofline = {"bound": "valu", "kernel": dom_name, "kernel_share_of_scoring_time": round(dom_share, 4),
+                        "scoring_launch_classes": {"%s/%d" % (fam_names.get(kd, "?").split("::")[-1], qc): round(v[0] / args.steps, 3) for (qc, kd), v in sorted(class_ms.items())},
+                        "achieved": round(s_tflops, 2), "peak": 157.3,
                         "unit": "TFLOP/s", "frac": round(s_tflops / 157.3, 4), "traffic": traffic, "traffic_source": traffic_src,
                         "flop_per_cell": 77, "cells_per_launch": cells_launch,
                         "kernel_ms_avg": round(score_ms, 3), "launches": score_launches,
@@ -353,6 +417,12 @@ def main():
                 "roofline_time_weighted_frac": round(combined, 4),
                 "distributions": dist3,
             }
+            if not args.no_level1 and world == 1:
+                try:
+                    line["level1_e2e"] = level1_stage(fam, synth_ehmm, names, seqs, k, WORKLOADS[args.workload][0], workdir, 20000, local_rank)
+                    line["level1_e2e_queries_per_s"] = line["level1_e2e"]["queries_per_s"]
+                except Exception as ex:       # an extra stage must never take the bench line down
+                    line["level1_e2e"] = {"failed": "%s: %s" % (type(ex).__name__, ex)}
             if not args.no_cpu_baseline:
                 threads = min(os.cpu_count() or 1, 64)
                 # about 15 s of CPU work on 64 host threads: 384 queries of the headline (150 nt x 200 models of ~900

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <thread>
 #include <array>
 #include <cstdio>
@@ -79,6 +80,7 @@ struct wh_ehmm {
   std::map<int, std::vector<int32_t>> by_q;   // Q class -> model positions
   std::vector<int32_t> generic;               // models beyond the register-resident classes (wh_generic.hip)
   DevBuf d_hmms, d_tables, d_nseq, d_index, d_lists, d_counter, d_scratch;
+  DevBuf d_ascratch;                        // per-wave slabs of the alignment kernels (allocated while the scoring kernels run)
   DevBuf d_gtab, d_rrecs, d_rmx, d_rsegs;   // multidomain resolver: float64 tables, pair queue, matrix slabs, segment arrays
   int last_resolved = 0;                    // pairs the resolver finished in the last wh_score call
   // staging for the host-pointer entry points
@@ -92,6 +94,11 @@ struct wh_ehmm {
   int last_align_redo = 0;          // pairs of the last wh_align call that went through the log-space pass
   int last_align_unaligned = 0;     // ... that the any-size kernel could not align (float64 range)
   std::vector<int64_t> last_unaligned_pairs;   // their pair numbers (wh_last_align_status)
+  // timing only: one event in front of every scoring launch of the last call (+ one behind the last), its cells-per-lane class
+  // and kernel family (0 phase-call, 1 pass-synchronous, 2 any-size front end): wh_last_score_launches
+  std::vector<hipEvent_t> cls_ev;
+  std::vector<int> cls_q, cls_kind;
+  int cls_n = 0;
 };
 
 static int g_device = -1;
@@ -112,6 +119,7 @@ int wh_init(int device) {
     return WH_EINVAL;
   }
   HIPCHK(hipSetDevice(device));
+  (void)hipFree(nullptr);        // creates the device context now (otherwise the first hipMalloc of wh_ehmm_load pays for it)
   g_device = device;
   return WH_OK;
 }
@@ -134,12 +142,13 @@ int wh_digitize(int alphabet, const char *text, int64_t n, uint8_t *out) {
 
 void wh_ehmm_free(wh_ehmm *e) {
   if (!e) return;
-  for (DevBuf *b : {&e->d_gtab, &e->d_rrecs, &e->d_rmx, &e->d_rsegs, &e->d_hmms, &e->d_tables, &e->d_nseq, &e->d_index, &e->d_lists, &e->d_counter, &e->d_scratch,
+  for (DevBuf *b : {&e->d_gtab, &e->d_rrecs, &e->d_rmx, &e->d_rsegs, &e->d_hmms, &e->d_tables, &e->d_nseq, &e->d_index, &e->d_lists, &e->d_counter, &e->d_scratch, &e->d_ascratch,
                     &e->s_res, &e->s_off, &e->s_deci, &e->s_flags, &e->s_fwd, &e->s_det, &e->s_idx, &e->s_w,
                     &e->s_nk, &e->s_nu, &e->s_pq, &e->s_ph, &e->s_co, &e->s_cols, &e->s_pos, &e->d_rkeys, &e->d_rorder, &e->d_qorder, &e->d_order, &e->d_items, &e->d_recs, &e->d_spec, &e->d_back, &e->d_cwj, &e->d_cwv, &e->d_cwn,
                     &e->c_buf[0], &e->c_buf[1], &e->c_buf[2], &e->c_buf[3], &e->c_buf[4], &e->c_buf[5], &e->c_buf[6],
                     &e->c_buf[7], &e->c_buf[8], &e->c_buf[9]})
     b->release();
+  for (hipEvent_t ev : e->cls_ev) (void)hipEventDestroy(ev);
   for (auto &t : e->timers) {
     if (t.e0) (void)hipEventDestroy(t.e0);
     if (t.e1) (void)hipEventDestroy(t.e1);
@@ -154,6 +163,9 @@ wh_ehmm *wh_ehmm_load(const char *const *hmm_paths, const int32_t *hmm_index, co
   if (g_device < 0 && wh_init(0) != WH_OK) return nullptr;
   std::unique_ptr<wh_ehmm, void (*)(wh_ehmm *)> e(new wh_ehmm, wh_ehmm_free);
   e->device = g_device;
+  const bool trace_load = getenv("WH_TRACE") != nullptr;
+  auto now_ms = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_l0 = now_ms();
   e->hmms.resize((size_t)n);
   std::vector<float> tables;
   std::vector<double> gtab;
@@ -191,6 +203,7 @@ wh_ehmm *wh_ehmm_load(const char *const *hmm_paths, const int32_t *hmm_index, co
     work();
     for (auto &t : pool) t.join();
   }
+  const double t_l1 = now_ms();
   for (int i = 0; i < n; i++) {
     HostHMM &h = e->hmms[(size_t)i];
     Built &b = built[(size_t)i];
@@ -221,6 +234,7 @@ wh_ehmm *wh_ehmm_load(const char *const *hmm_paths, const int32_t *hmm_index, co
   }
   degen_masks(e->alphabet, e->degen);
   knobs_from_env(e.get());
+  const double t_l2 = now_ms();
   hipDeviceProp_t p;
   if (hipGetDeviceProperties(&p, e->device) == hipSuccess) e->cu_count = p.multiProcessorCount;
   std::vector<int32_t> ns((size_t)n), ix((size_t)n);
@@ -239,6 +253,8 @@ wh_ehmm *wh_ehmm_load(const char *const *hmm_paths, const int32_t *hmm_index, co
     set_error("upload of the eHMM tables failed");
     return nullptr;
   }
+  if (trace_load) fprintf(stderr, "[wh] eHMM load: %d models parsed + tables built in %.1f ms, concatenated in %.1f ms, uploaded (%.1f MB float + %.1f MB float64) in %.1f ms\n", n,
+                          t_l1 - t_l0, t_l2 - t_l1, tables.size() * 4e-6, gtab.size() * 8e-6, now_ms() - t_l2);
   return e.release();
 }
 
@@ -296,6 +312,16 @@ int wh_set_timing(wh_ehmm *e, int enabled) {
   return WH_OK;
 }
 
+// one event per scoring launch (timing mode only); events are created once and reused
+static int class_mark(wh_ehmm *e, hipStream_t s, int Q, int kind) {
+  if (!e->timing) return WH_OK;
+  if ((int)e->cls_ev.size() <= e->cls_n) { hipEvent_t ev; HIPCHK(hipEventCreate(&ev)); e->cls_ev.push_back(ev); e->cls_q.push_back(0); e->cls_kind.push_back(0); }
+  HIPCHK(hipEventRecord(e->cls_ev[(size_t)e->cls_n], s));
+  e->cls_q[(size_t)e->cls_n] = Q; e->cls_kind[(size_t)e->cls_n] = kind;
+  e->cls_n++;
+  return WH_OK;
+}
+
 static int timer_begin(wh_ehmm *e, int which, hipStream_t s) {
   KernelTimer &t = e->timers[which];
   t.pending = false; t.ms = 0.0; t.launches = 0;
@@ -319,6 +345,20 @@ int wh_last_align_status(wh_ehmm *e, int64_t *n_logspace, int64_t *n_unaligned, 
   if (n_unaligned) *n_unaligned = (int64_t)e->last_unaligned_pairs.size();
   for (int64_t t = 0; t < cap && t < (int64_t)e->last_unaligned_pairs.size(); t++) unaligned_pairs[t] = e->last_unaligned_pairs[(size_t)t];
   return WH_OK;
+}
+
+int wh_last_score_launches(wh_ehmm *e, int32_t *cells_per_lane, int32_t *kind, double *ms, int cap) {
+  if (!e || cap < 0) { set_error("wh_last_score_launches: bad argument"); return WH_EINVAL; }
+  const int n = e->cls_n > 0 ? e->cls_n - 1 : 0;
+  for (int t = 0; t < n && t < cap; t++) {
+    HIPCHK(hipEventSynchronize(e->cls_ev[(size_t)t + 1]));
+    float f = 0.f;
+    HIPCHK(hipEventElapsedTime(&f, e->cls_ev[(size_t)t], e->cls_ev[(size_t)t + 1]));
+    if (cells_per_lane) cells_per_lane[t] = e->cls_q[(size_t)t];
+    if (kind) kind[t] = e->cls_kind[(size_t)t];
+    if (ms) ms[t] = f;
+  }
+  return n;
 }
 
 int wh_last_kernel_ms(wh_ehmm *e, int which, double *ms, int *launches) {
@@ -376,6 +416,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
   hipStream_t s = (hipStream_t)stream;
   HIPCHK(hipSetDevice(e->device));
   if (timer_begin(e, 0, s)) return WH_EHIP;
+  e->cls_n = 0;
   int launches = 0;
   if (nq > 0) {
     if ((int)e->by_q.size() > kMaxLaunches) { set_error("too many model size classes (%zu)", e->by_q.size()); return WH_ERANGE; }
@@ -517,6 +558,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       if (kn.trace) fprintf(stderr, "[wh] score Q=%d kernel=%s specg=%d waves=%d blocks=%d lds=%zu SP=%d wave_lds=%d items=%d Lcap=%d\n", Q,
                             big ? "pass-synchronous" : kn.kernel == 8 ? "phase-call(B)" : "phase-call", (int)specg, waves, blocks, lds, SP, wave_lds, a.n_items, a.Lcap);
       HIPCHK(hipMemsetAsync(a.counter, 0, sizeof(int), s));
+      if (class_mark(e, s, Q, big ? 1 : 0)) return WH_EHIP;
       hipError_t err = big ? launch_score_big(Q, a, blocks, waves * kWave, lds, s)
                        : kn.kernel == 8 ? launch_score7b(Q, a, blocks, waves * kWave, lds, s)
                                         : launch_score7(Q, a, blocks, waves * kWave, lds, s);
@@ -569,11 +611,21 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
     HIPCHK(hipMemsetAsync(g.counter, 0, sizeof(int), s));
     if (e->knobs.trace) fprintf(stderr, "[wh] any-size front end: %lld pairs on %zu models (up to %d nodes), %d wavefronts, slab %zu MB per wave\n",
                                 (long long)n_items, e->generic.size(), e->max_M, blocks, g.slab_stride * 8 >> 20);
+    if (class_mark(e, s, e->max_Q, 2)) return WH_EHIP;
     hipError_t gerr = launch_generic_front(g, blocks, glds, s);
     if (gerr != hipSuccess) { set_error("any-size front kernel launch failed: %s", hipGetErrorString(gerr)); return WH_EHIP; }
     launches++;
   }
+  if (class_mark(e, s, 0, -1)) return WH_EHIP;        // closes the last launch's interval
   if (timer_end(e, 0, s, launches)) return WH_EHIP;
+  if (nq > 0 && !e->by_q.empty()) {
+    // While the scoring kernels run, the host sets up what the NEXT stage needs: the alignment kernels' per-wave slabs
+    // ((L+1) x 5 x Q x 64 floats per resident wave: 6 GB at L = 150, Q = 16 - a first-call hipMalloc of 0.3 s that used to
+    // sit between the two stages).  Bounded: skipped when it would take more than a tenth of the free HBM.
+    const size_t need = (size_t)8 * (size_t)e->cu_count * (size_t)(std::max(max_len, 1) + 1) * 5 * (size_t)e->by_q.rbegin()->first * kWave * sizeof(float);
+    size_t free_b = 0, total_b = 0;
+    if (need > e->d_ascratch.cap && hipMemGetInfo(&free_b, &total_b) == hipSuccess && need < free_b / 10) (void)e->d_ascratch.ensure(need);
+  }
   if (timer_begin(e, 4, s)) return WH_EHIP;
   int rlaunches = 0;
   if (nq > 0 && !e->knobs.no_resolve && e->d_rrecs.p) {
@@ -916,7 +968,7 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
   if (e->d_items.ensure(sizeof(int32_t) * soa.size() + 16)) return WH_ENOMEM;
   HIPCHK(hipMemcpyAsync(e->d_items.p, soa.data(), sizeof(int32_t) * soa.size(), hipMemcpyHostToDevice, s));
   for (int pass = 0; pass < 2; pass++) {        // pass 0: size the workspace of every class, allocate once; pass 1: launch
-  if (pass == 1 && (e->d_scratch.ensure(need_scratch) || (need_spec && e->d_spec.ensure(need_spec)))) return WH_ENOMEM;
+  if (pass == 1 && (e->d_ascratch.ensure(need_scratch) || (need_spec && e->d_spec.ensure(need_spec)))) return WH_ENOMEM;
   for (size_t pl = 0; pl < plans.size(); pl++) {
     const int Q = plans[pl][0], first = plans[pl][1], n = plans[pl][2], waves = plans[pl][3];
     AlignArgs a;
@@ -939,17 +991,17 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
     int blocks = std::min(n, e->cu_count * std::max(1, 8 / waves));
     a.scratch_stride = (size_t)(a.Lcap + 1) * 5 * Q * kWave;
     a.spec_stride = plans[pl][5] < 0 ? (size_t)13 * a.SP : 0;
-    blocks = clamp_blocks(blocks, (size_t)waves * (a.scratch_stride + a.spec_stride) * sizeof(float), e->d_scratch);
+    blocks = clamp_blocks(blocks, (size_t)waves * (a.scratch_stride + a.spec_stride) * sizeof(float), e->d_ascratch);
     if (pass == 0) {
       need_scratch = std::max(need_scratch, (size_t)blocks * waves * a.scratch_stride * sizeof(float));
       if (plans[pl][5] < 0) need_spec = std::max(need_spec, (size_t)blocks * waves * a.spec_stride * sizeof(float));
       continue;
     }
-    blocks = (int)std::min<size_t>((size_t)blocks, e->d_scratch.cap / ((size_t)waves * a.scratch_stride * sizeof(float)));
+    blocks = (int)std::min<size_t>((size_t)blocks, e->d_ascratch.cap / ((size_t)waves * a.scratch_stride * sizeof(float)));
     if (plans[pl][5] < 0) blocks = (int)std::min<size_t>((size_t)blocks, e->d_spec.cap / ((size_t)waves * a.spec_stride * sizeof(float)));
     if (blocks < 1) { set_error("workspace planning failed (Q=%d)", Q); return WH_ENOMEM; }
     if (plans[pl][5] < 0) a.spec_scratch = (float *)e->d_spec.p;
-    a.scratch = (float *)e->d_scratch.p;
+    a.scratch = (float *)e->d_ascratch.p;
     HIPCHK(hipMemsetAsync(a.counter, 0, sizeof(int), s));
     hipError_t err = launch_align(Q, a, blocks, waves * kWave, ldss[pl], s);
     if (err != hipSuccess) { set_error("align kernel launch (Q=%d) failed: %s", Q, hipGetErrorString(err)); return WH_EHIP; }

@@ -100,6 +100,15 @@ class EHMM:
         check(lib().wh_last_kernel_ms(self._h, which, C.byref(ms), C.byref(n)), "wh_last_kernel_ms")
         return ms.value, n.value
 
+    def last_score_launches(self):
+        """[(cells per lane, kernel family, ms)] of the scoring launches of the last score call (timing mode)."""
+        q = np.zeros(64, dtype=np.int32)
+        kind = np.zeros(64, dtype=np.int32)
+        ms = np.zeros(64, dtype=np.float64)
+        n = lib().wh_last_score_launches(self._h, q.ctypes.data, kind.ctypes.data, ms.ctypes.data, 64)
+        check(min(n, 0), "wh_last_score_launches")
+        return [(int(q[t]), int(kind[t]), float(ms[t])) for t in range(min(n, 64))]
+
     # ------------------------------------------------------------------ host (numpy) operators
     def score(self, residues, offsets, want_fwd=False, want_detail=False):
         residues = np.ascontiguousarray(residues, dtype=np.uint8)

@@ -17,7 +17,7 @@ behaviour and serve their answers from that precomputed table:
 
 INTEGRATION.md shows the three-line change in witch_msa/gcmm/gcmm.py that installs them.
 """
-from .engine import QueryAlignmentEngine, install, current_engine  # noqa: F401
+from .engine import QueryAlignmentEngine, install, current_engine, warm_up  # noqa: F401
 from .loader import rankBitscores, readAndRankBitscoreMP  # noqa: F401
 from .weighting import writeWeights, calculateWeights, writeWeightsToLocal, readWeightsFromLocal  # noqa: F401
 from .aligner import getBackbones  # noqa: F401

@@ -19,6 +19,18 @@ def install(engine):
     return engine
 
 
+def warm_up(device: int = 0):
+    """Process start-up work, once: load libwitch_hip.so (and with it the HIP runtime PyTorch bundles) and create the
+    HIP context of ``device``.  Optional - QueryAlignmentEngine.run does it on first use - but a caller that times its
+    first batch (tools/bench_level1.py) or wants the ~0.7 s out of its first call does it beside its own imports."""
+    from .._lib import check, lib
+    L = lib()
+    check(L.wh_init(int(device)), "wh_init")
+    name = (__import__("ctypes").c_char * 64)()
+    check(L.wh_device_info(name, 64, None, None), "wh_device_info")
+    return name.value.decode()
+
+
 def current_engine():
     if _ENGINE is None:
         raise RuntimeError("witch_amd.gcmm: no QueryAlignmentEngine installed "

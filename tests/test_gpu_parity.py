@@ -1443,3 +1443,47 @@ def test_two_rank_rehearsal_of_the_protein_shape(tmp_path):
     assert j2["n_gpus"] == 2 and j2["config"]["n_hmms"] == 500 and j2["config"]["n_queries"] == 2000
     assert j1["config"]["topk_crc32"] == j2["config"]["topk_crc32"]
     assert j1["distributions"]["n_used"] == j2["distributions"]["n_used"]
+
+
+@pytest.mark.gpu
+def test_consensus_with_twenty_models_on_a_20000_column_backbone():
+    """The consensus kernel beyond its round-2 limits (k <= 16, backbones of <= ~19 000 columns: the DP row in LDS):
+    k = 20 kept models per query and a backbone of 20 000 columns (the DP row then lives in the wave's HBM region).
+    The 20 protein models of amino_multidomain, their match states mapped to random increasing columns of a
+    20 000-column backbone, short query windows aligned to ALL 20 models with random weights; codes and touched
+    range must equal the Python restatement of aligner.py:376-473."""
+    _need_gpu()
+    from oracle import consensus as ocons
+    from tests.conftest import load_case
+    from witch_amd.ehmm import EHMM, pack_queries
+    case = load_case("amino_multidomain")
+    e = EHMM(case.hmm_paths, hmm_index=case.hmm_index, nseq=case.nseq)
+    assert e.H == 20
+    rng = np.random.default_rng(11)
+    B = 20000
+    retained = [np.sort(rng.choice(B, size=int(m), replace=False)).astype(np.int32) for m in e.M]
+    nongaps = [rng.integers(1, 60, size=int(m)).astype(np.int32) for m in e.M]
+    # windows of the first queries: 40-70 residues from inside a family domain
+    seqs = []
+    for qi in range(5):
+        full = e.digitize(case.qseqs[qi])
+        lo = int(rng.integers(0, max(1, len(full) - 80)))
+        seqs.append(full[lo:lo + int(rng.integers(40, 71))])
+    res, offs = pack_queries(seqs)
+    pq = [q for q in range(len(seqs)) for _ in range(e.H)]
+    ph = [h for _ in range(len(seqs)) for h in range(e.H)]
+    cols, co = e.align(res, offs, pq, ph)
+    w = rng.random(len(pq))
+    qpo = np.arange(len(seqs) + 1, dtype=np.int64) * e.H
+    codes, mm = e.consensus(offs, qpo, ph, w, co, cols, retained, nongaps, B)
+    n_span = 0
+    for q in range(len(seqs)):
+        L = len(seqs[q])
+        aligned = [(h, cols[co[q * e.H + h]:co[q * e.H + h + 1]].tolist()) for h in range(e.H)]
+        want, (mn, mx) = ocons.consensus_trace(L, aligned, {h: w[q * e.H + h] for h in range(e.H)},
+                                               {h: retained[h] for h in range(e.H)}, {h: nongaps[h] for h in range(e.H)}, B)
+        assert codes[offs[q]:offs[q + 1]].tolist() == want, q
+        assert (int(mm[q, 0]), int(mm[q, 1])) == (mn, mx), q
+        n_span = max(n_span, mx - mn + 1)
+    assert n_span > 3000          # the DP really ran over thousands of columns
+    e.close()

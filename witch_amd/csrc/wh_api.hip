@@ -85,7 +85,7 @@ struct wh_ehmm {
   int last_resolved = 0;                    // pairs the resolver finished in the last wh_score call
   // staging for the host-pointer entry points
   DevBuf s_res, s_off, s_deci, s_flags, s_fwd, s_det, s_idx, s_w, s_nk, s_nu, s_pq, s_ph, s_co, s_cols, s_pos;
-  DevBuf d_rkeys, d_rorder, d_qorder, d_order, d_items, d_recs, d_spec, d_back, d_cwj, d_cwv, d_cwn, c_buf[10];
+  DevBuf d_rkeys, d_rorder, d_qorder, d_order, d_items, d_recs, d_spec, d_back, d_cwj, d_cwv, d_cwn, d_crow, c_buf[10];
   uint32_t degen[32];
   bool timing = false;
   KernelTimer timers[5];
@@ -144,7 +144,7 @@ void wh_ehmm_free(wh_ehmm *e) {
   if (!e) return;
   for (DevBuf *b : {&e->d_gtab, &e->d_rrecs, &e->d_rmx, &e->d_rsegs, &e->d_hmms, &e->d_tables, &e->d_nseq, &e->d_index, &e->d_lists, &e->d_counter, &e->d_scratch, &e->d_ascratch,
                     &e->s_res, &e->s_off, &e->s_deci, &e->s_flags, &e->s_fwd, &e->s_det, &e->s_idx, &e->s_w,
-                    &e->s_nk, &e->s_nu, &e->s_pq, &e->s_ph, &e->s_co, &e->s_cols, &e->s_pos, &e->d_rkeys, &e->d_rorder, &e->d_qorder, &e->d_order, &e->d_items, &e->d_recs, &e->d_spec, &e->d_back, &e->d_cwj, &e->d_cwv, &e->d_cwn,
+                    &e->s_nk, &e->s_nu, &e->s_pq, &e->s_ph, &e->s_co, &e->s_cols, &e->s_pos, &e->d_rkeys, &e->d_rorder, &e->d_qorder, &e->d_order, &e->d_items, &e->d_recs, &e->d_spec, &e->d_back, &e->d_cwj, &e->d_cwv, &e->d_cwn, &e->d_crow,
                     &e->c_buf[0], &e->c_buf[1], &e->c_buf[2], &e->c_buf[3], &e->c_buf[4], &e->c_buf[5], &e->c_buf[6],
                     &e->c_buf[7], &e->c_buf[8], &e->c_buf[9]})
     b->release();
@@ -1119,7 +1119,7 @@ int wh_align(wh_ehmm *e, const uint8_t *residues, const int64_t *offsets, int64_
 }
 
 // ------------------------------------------------------------------------------------ consensus
-static const int kConsKmax = 16;
+static const int kConsKmax = 4096;   // sanity bound only: the per-residue edge lists live in HBM scratch sized by the call's own k
 
 int wh_consensus_dev(wh_ehmm *e, const int64_t *d_offsets, int64_t nq, int32_t max_len, const int64_t *d_qpair_off,
                      const int32_t *d_pair_h, const double *d_pair_w, const int64_t *d_col_offsets,
@@ -1131,7 +1131,7 @@ int wh_consensus_dev(wh_ehmm *e, const int64_t *d_offsets, int64_t nq, int32_t m
     set_error("wh_consensus_dev: bad argument");
     return WH_EINVAL;
   }
-  if (max_pairs_per_query > kConsKmax) { set_error("more than %d HMMs per query are not supported by the consensus kernel", kConsKmax); return WH_ERANGE; }
+  if (max_pairs_per_query > kConsKmax || max_pairs_per_query < 0) { set_error("more than %d HMMs per query are not supported by the consensus kernel", kConsKmax); return WH_ERANGE; }
   hipStream_t s = (hipStream_t)stream;
   HIPCHK(hipSetDevice(e->device));
   if (timer_begin(e, 3, s)) return WH_EHIP;
@@ -1141,14 +1141,20 @@ int wh_consensus_dev(wh_ehmm *e, const int64_t *d_offsets, int64_t nq, int32_t m
     a.offsets = d_offsets; a.nq = nq; a.qpair_off = d_qpair_off; a.pair_h = d_pair_h; a.pair_w = d_pair_w;
     a.col_offsets = d_col_offsets; a.cols = d_cols; a.ret_off = d_ret_off; a.retained = d_retained; a.nongaps = d_nongaps;
     a.backbone_length = backbone_length; a.out = d_out; a.minmax = d_minmax;
-    a.Lcap = std::max(max_len, 1); a.Wcap = backbone_length + 1; a.KMAX = kConsKmax;
+    // a residue collects at most one edge per kept HMM (the reference takes any -k, weighting.py:71-73)
+    a.Lcap = std::max(max_len, 1); a.Wcap = backbone_length + 1; a.KMAX = std::max(4, (int)max_pairs_per_query);
     int waves = 4;
     while (waves >= 1 && (size_t)waves * (a.Wcap + 2) * sizeof(double) > kLdsBudget) waves--;
-    if (waves < 1) { set_error("backbone of %d columns does not fit the consensus kernel's LDS row", backbone_length); return WH_ERANGE; }
-    const size_t lds = (size_t)waves * (a.Wcap + 2) * sizeof(double);
+    const bool row_in_hbm = waves < 1;        // backbones beyond ~19 000 columns: the DP row moves to the wave's HBM region
+    if (row_in_hbm) waves = 4;
+    const size_t lds = row_in_hbm ? 0 : (size_t)waves * (a.Wcap + 2) * sizeof(double);
     int blocks = (int)std::min<int64_t>((nq + waves - 1) / waves, (int64_t)e->cu_count * 2);
-    blocks = clamp_blocks(blocks, (size_t)waves * ((size_t)(a.Lcap + 1) * (a.Wcap + 2) + (size_t)a.Lcap * a.KMAX * 12 + (size_t)a.Lcap * 4), e->d_back);
+    blocks = clamp_blocks(blocks, (size_t)waves * ((size_t)(a.Lcap + 1) * (a.Wcap + 2) + (size_t)a.Lcap * a.KMAX * 12 + (size_t)a.Lcap * 4 + (size_t)(a.Wcap + 2) * 8), e->d_back);
     const size_t nw = (size_t)blocks * waves;
+    if (row_in_hbm) {
+      if (e->d_crow.ensure(nw * (size_t)(a.Wcap + 2) * sizeof(double))) return WH_ENOMEM;
+      a.rowg = (double *)e->d_crow.p;
+    }
     if (e->d_back.ensure(nw * (size_t)(a.Lcap + 1) * (a.Wcap + 2)) || e->d_cwj.ensure(nw * (size_t)a.Lcap * a.KMAX * sizeof(int32_t)) ||
         e->d_cwv.ensure(nw * (size_t)a.Lcap * a.KMAX * sizeof(double)) || e->d_cwn.ensure(nw * (size_t)a.Lcap * sizeof(int32_t)))
       return WH_ENOMEM;

@@ -7,8 +7,8 @@
 //   * traceback from (len, max_col+1)                                                      (:452-473)
 // All arithmetic is IEEE float64 in the reference's operation order, so results are
 // bit-identical to the reference's Python floats.  One wavefront per query: lanes run over
-// backbone columns; the "left" dependency is an exact prefix-max scan; the DP row lives in LDS,
-// the 2-bit back-pointers in a per-wave HBM slab.
+// backbone columns; the "left" dependency is an exact prefix-max scan; the DP row lives in LDS (in HBM
+// for backbones wider than ~19 000 columns), the 2-bit back-pointers in a per-wave HBM slab.
 // Output per residue: backbone column (>= 0) for a match, -1 - nc for an insertion that sits
 // before backbone column nc; the host rebuilds the reference's string from it.
 #include <hip/hip_runtime.h>
@@ -33,8 +33,10 @@ __device__ __forceinline__ int wave_max_i32c(int x) { for (int m = 32; m >= 1; m
 __global__ __launch_bounds__(256) void consensus_kernel(ConsArgs a) {
   extern __shared__ __attribute__((aligned(16))) double rows_raw[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-  double *row = rows_raw + (size_t)wave * (a.Wcap + 2);
   const size_t wid = (size_t)blockIdx.x * nwaves + wave;
+  // the DP row: in LDS while a backbone row fits there (up to ~19 000 columns), else in the wave's HBM region - a lane
+  // re-reads only what it wrote itself (column jj stays with lane (jj - 1) % 64), so no ordering beyond program order is needed
+  double *row = a.rowg ? a.rowg + wid * (size_t)(a.Wcap + 2) : rows_raw + (size_t)wave * (a.Wcap + 2);
   uint8_t *back = a.back + wid * (size_t)(a.Lcap + 1) * (a.Wcap + 2);
   int32_t *cwj = a.cwj + wid * (size_t)a.Lcap * a.KMAX;
   double *cwv = a.cwv + wid * (size_t)a.Lcap * a.KMAX;

@@ -224,6 +224,7 @@ struct ConsArgs {
   int32_t *cwj;                // per wave Lcap x KMAX edge columns
   double *cwv;                 // per wave Lcap x KMAX edge weights
   int32_t *cwn;                // per wave Lcap edge counts
+  double *rowg;                // per wave Wcap+2 doubles: the DP row when it does not fit in LDS (else NULL)
 };
 hipError_t launch_consensus(const ConsArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
 

@@ -10,8 +10,8 @@ set -e
 tag=${1:-r02}; shift || true
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 out=gpurun_out/$tag; mkdir -p $out
-timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $out/trace -o trace --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $out/trace.log 2>&1
+timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $out/trace -o trace --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-level1 "$@" > $out/trace.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 600 rocprofv3 --pmc $c -d $out/pmc_$c -o pmc --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > $out/pmc_$c.log 2>&1
+  timeout -k 10 600 rocprofv3 --pmc $c -d $out/pmc_$c -o pmc --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-level1 "$@" > $out/pmc_$c.log 2>&1
 done
 python3 tools/prof_summary.py $out

@@ -101,7 +101,7 @@ def test_score_against_oracle_and_golden(golden_case, orc):
                 assert (d.env_i[t], d.env_j[t]) == (r.env_i[t], r.env_j[t]), (case.name, qi, hj, t)
                 assert abs(d.envsc[t] - r.envsc[t]) <= 2e-4 * max(1.0, abs(r.envsc[t]) / 50), (case.name, qi, hj, d.envsc[t], r.envsc[t])
                 # (a sum of float32 logs over the envelope: the bound grows with its length - 600-residue protein envelopes)
-                len_t = max(1.0, (r.env_j[t] - r.env_i[t] + 1) / 300.0)
+                len_t = max(1.0, (r.env_j[t] - r.env_i[t] + 1) / 250.0)
                 assert abs(d.domcorr[t] - r.domcorr[t]) <= (2e-2 if r.env_multi[t] else 1e-3 * len_t), (case.name, qi, hj, d.domcorr[t], r.domcorr[t])
     # deci-bits
     rep = (of & 1) == 1

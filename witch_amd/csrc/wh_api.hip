@@ -79,6 +79,11 @@ struct wh_ehmm {
   std::vector<DevHMM> dev;          // host copy of the descriptors
   std::map<int, std::vector<int32_t>> by_q;   // Q class -> model positions
   std::vector<int32_t> generic;               // models beyond the register-resident classes (wh_generic.hip)
+  std::vector<int32_t> generic_front;         // ... of them, those SCORED by the float64 front end (the others: wide_by_w)
+  std::map<int, std::vector<int32_t>> wide_by_w;   // waves per pair -> models scored by wh_score_wide.hip (3 073 - 12 288 nodes)
+  int wide_q = 0;                             // cells per lane of the wide tables (kWideQ; 4 with WH_FORCE_WIDE=4: tests)
+  bool force_wide = false;                    // WH_FORCE_WIDE: EVERY model is scored by the wide kernel (test hook)
+  DevBuf d_wscratch;                          // Forward slabs of the wide kernel's workgroups
   DevBuf d_hmms, d_tables, d_nseq, d_index, d_lists, d_counter, d_scratch;
   DevBuf d_ascratch;                        // per-wave slabs of the alignment kernels (allocated while the scoring kernels run)
   DevBuf d_gtab, d_rrecs, d_rmx, d_rsegs;   // multidomain resolver: float64 tables, pair queue, matrix slabs, segment arrays
@@ -142,7 +147,7 @@ int wh_digitize(int alphabet, const char *text, int64_t n, uint8_t *out) {
 
 void wh_ehmm_free(wh_ehmm *e) {
   if (!e) return;
-  for (DevBuf *b : {&e->d_gtab, &e->d_rrecs, &e->d_rmx, &e->d_rsegs, &e->d_hmms, &e->d_tables, &e->d_nseq, &e->d_index, &e->d_lists, &e->d_counter, &e->d_scratch, &e->d_ascratch,
+  for (DevBuf *b : {&e->d_gtab, &e->d_rrecs, &e->d_rmx, &e->d_rsegs, &e->d_hmms, &e->d_tables, &e->d_nseq, &e->d_index, &e->d_lists, &e->d_counter, &e->d_scratch, &e->d_ascratch, &e->d_wscratch,
                     &e->s_res, &e->s_off, &e->s_deci, &e->s_flags, &e->s_fwd, &e->s_det, &e->s_idx, &e->s_w,
                     &e->s_nk, &e->s_nu, &e->s_pq, &e->s_ph, &e->s_co, &e->s_cols, &e->s_pos, &e->d_rkeys, &e->d_rorder, &e->d_qorder, &e->d_order, &e->d_items, &e->d_recs, &e->d_spec, &e->d_back, &e->d_cwj, &e->d_cwv, &e->d_cwn, &e->d_crow,
                     &e->c_buf[0], &e->c_buf[1], &e->c_buf[2], &e->c_buf[3], &e->c_buf[4], &e->c_buf[5], &e->c_buf[6],
@@ -172,7 +177,14 @@ wh_ehmm *wh_ehmm_load(const char *const *hmm_paths, const int32_t *hmm_index, co
   e->dev.resize((size_t)n);
   // Parsing the text files and laying out the tables is host work per model (a few ms per 1 500-node model):
   // done on a small thread pool, then concatenated in model order so that the buffers do not depend on timing.
-  struct Built { int rc = WH_OK; std::string err; int Q = -1; std::vector<float> fw, bw, em, emn; std::vector<double> gfw, gem; };
+  struct Built { int rc = WH_OK; std::string err; int Q = -1, wideW = 0; std::vector<float> fw, bw, em, emn, wfw, wbw, wem; std::vector<double> gfw, gem; };
+  // WH_FORCE_WIDE=<4|24>: every model that fits 8 waves of that many cells per lane ALSO gets wide tables and is scored by the
+  // several-waves-per-pair kernel (tests run the golden cases through it; production: models beyond 3 072 nodes only)
+  const int force_wide_q = getenv("WH_FORCE_WIDE") ? atoi(getenv("WH_FORCE_WIDE")) : 0;
+  e->force_wide = force_wide_q == 4 || force_wide_q == kWideQ;
+  e->wide_q = e->force_wide ? force_wide_q : kWideQ;
+  const int wide_q = e->wide_q;
+  const bool force_wide = e->force_wide;
   std::vector<Built> built((size_t)n);
   {
     std::atomic<int> next{0};
@@ -188,6 +200,10 @@ wh_ehmm *wh_ehmm_load(const char *const *hmm_paths, const int32_t *hmm_index, co
         b.Q = choose_Q(h.M);
         if (b.Q < 0) continue;
         if (b.Q <= kMaxQ) build_tables(h, b.Q, b.fw, b.bw, b.em);     // (the any-size kernels read the float64 tables only)
+        if (b.Q > kMaxQ || force_wide) {
+          const int ww = (h.M + kWave * wide_q - 1) / (kWave * wide_q);
+          if (ww <= kWideWavesMax) { b.wideW = ww; build_tables(h, wide_q, b.wfw, b.wbw, b.wem, ww * kWave); }
+        }
         // node-major float32 odds of the canonical residues: the resolver's null2-by-trace reads the K values of ONE
         // node together (one lane per sampled position), not K lane-blocked arrays
         b.emn.assign((size_t)(h.M + 1) * h.K, 0.f);
@@ -225,10 +241,20 @@ wh_ehmm *wh_ehmm_load(const char *const *hmm_paths, const int32_t *hmm_index, co
     d.em_off = (int64_t)tables.size(); tables.insert(tables.end(), b.em.begin(), b.em.end());
     tables.resize((tables.size() + 3) / 4 * 4, 0.f);          // 16-byte aligned: the node-major rows are read as float4
     d.emn_off = (int64_t)tables.size(); tables.insert(tables.end(), b.emn.begin(), b.emn.end());
+    d.wideQ = 0; d.wideW = 0;
+    if (b.wideW > 0) {
+      tables.resize((tables.size() + 3) / 4 * 4, 0.f);
+      d.wideQ = wide_q; d.wideW = b.wideW;
+      d.wfw_off = (int64_t)tables.size(); tables.insert(tables.end(), b.wfw.begin(), b.wfw.end());
+      d.wbw_off = (int64_t)tables.size(); tables.insert(tables.end(), b.wbw.begin(), b.wbw.end());
+      d.wem_off = (int64_t)tables.size(); tables.insert(tables.end(), b.wem.begin(), b.wem.end());
+      e->wide_by_w[b.wideW].push_back(i);
+    }
     d.gfw_off = (int64_t)gtab.size(); gtab.insert(gtab.end(), b.gfw.begin(), b.gfw.end());
     d.gem_off = (int64_t)gtab.size(); gtab.insert(gtab.end(), b.gem.begin(), b.gem.end());
     b = Built();                                              // release the per-model copies as we go
-    if (Q <= kMaxQ) e->by_q[Q].push_back(i); else e->generic.push_back(i);
+    if (Q <= kMaxQ) e->by_q[Q].push_back(i);
+    else { e->generic.push_back(i); if (d.wideW == 0) e->generic_front.push_back(i); }
     e->max_Q = std::max(e->max_Q, Q);
     e->max_M = std::max(e->max_M, h.M);
   }
@@ -241,15 +267,16 @@ wh_ehmm *wh_ehmm_load(const char *const *hmm_paths, const int32_t *hmm_index, co
   for (int i = 0; i < n; i++) { ns[(size_t)i] = e->hmms[(size_t)i].nseq; ix[(size_t)i] = e->hmms[(size_t)i].index; }
   if (e->d_hmms.ensure(sizeof(DevHMM) * (size_t)n) || e->d_tables.ensure(sizeof(float) * tables.size()) ||
       e->d_nseq.ensure(sizeof(int32_t) * (size_t)n) || e->d_index.ensure(sizeof(int32_t) * (size_t)n) ||
-      e->d_lists.ensure(sizeof(int32_t) * (size_t)n) || e->d_counter.ensure(512) || e->d_gtab.ensure(sizeof(double) * gtab.size()))
+      e->d_lists.ensure(sizeof(int32_t) * (size_t)(2 * n + 4)) || e->d_counter.ensure(512) || e->d_gtab.ensure(sizeof(double) * gtab.size()))
     return nullptr;
   auto up = [&](void *dst, const void *src, size_t bytes) { return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess; };
   std::vector<int32_t> lists;
   for (auto &kv : e->by_q) lists.insert(lists.end(), kv.second.begin(), kv.second.end());
-  lists.insert(lists.end(), e->generic.begin(), e->generic.end());      // after the size classes
+  lists.insert(lists.end(), e->generic_front.begin(), e->generic_front.end());      // after the size classes
+  for (auto &kv : e->wide_by_w) lists.insert(lists.end(), kv.second.begin(), kv.second.end());   // ... and the wide classes
   if (!up(e->d_hmms.p, e->dev.data(), sizeof(DevHMM) * (size_t)n) || !up(e->d_tables.p, tables.data(), sizeof(float) * tables.size()) ||
       !up(e->d_nseq.p, ns.data(), sizeof(int32_t) * (size_t)n) || !up(e->d_index.p, ix.data(), sizeof(int32_t) * (size_t)n) ||
-      !up(e->d_lists.p, lists.data(), sizeof(int32_t) * (size_t)n) || !up(e->d_gtab.p, gtab.data(), sizeof(double) * gtab.size())) {
+      !up(e->d_lists.p, lists.data(), sizeof(int32_t) * lists.size()) || !up(e->d_gtab.p, gtab.data(), sizeof(double) * gtab.size())) {
     set_error("upload of the eHMM tables failed");
     return nullptr;
   }
@@ -418,6 +445,8 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
   if (timer_begin(e, 0, s)) return WH_EHIP;
   e->cls_n = 0;
   int launches = 0;
+  const int32_t *qorder_all = nullptr;     // queries in descending length order, when the call formed it
+  bool wide_done = false;
   if (nq > 0) {
     if ((int)e->by_q.size() > kMaxLaunches) { set_error("too many model size classes (%zu)", e->by_q.size()); return WH_ERANGE; }
     const int H = (int)e->hmms.size();
@@ -440,6 +469,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
     // pairs start first.  (One D2H copy of the offsets and a host sort; only when such a class exists.)
     bool any_long = false;
     for (auto &kv : e->by_q) any_long = any_long || kv.first >= 20;
+    any_long = any_long || !e->wide_by_w.empty();
     // ... and the phase-call kernel deals the queries of a work item to its waves in fixed turns: with lengths of
     // 50-2 000 residues in one batch a wave that drew long queries keeps the eleven others waiting at the item's
     // end (about 30 % of the launch on the protein workload) - same cure.  Batches of near-equal lengths (the
@@ -457,6 +487,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       HIPCHK(hipMemcpyAsync(e->d_qorder.p, ord.data(), sizeof(int32_t) * ord.size(), hipMemcpyHostToDevice, s));
       HIPCHK(hipStreamSynchronize(s));   // ord is a local
       d_qorder = (const int32_t *)e->d_qorder.p;
+      qorder_all = d_qorder;
     }
     // pass 0 sizes the per-wave workspace of every class and allocates ONCE (growing a DevBuf class by class
     // meant a hipFree + hipMalloc of tens of GB per class: ~25 ms per GB); pass 1 launches
@@ -465,6 +496,10 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
     list_off = 0;
     if (pass == 1 && (e->d_scratch.ensure(need_scratch) || (need_spec && e->d_spec.ensure(need_spec)))) return WH_ENOMEM;
     for (auto &kv : e->by_q) {
+      if (e->force_wide && e->dev[(size_t)kv.second[0]].wideW > 0) {   // test hook: these models go through the wide kernel below
+        list_off += (int)kv.second.size();
+        continue;
+      }
       const int Q = kv.first;
       ScoreArgs a;
       memset(&a, 0, sizeof a);
@@ -578,7 +613,51 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
     }
     }
   }
-  if (nq > 0 && !e->generic.empty()) {
+  if (nq > 0 && !e->wide_by_w.empty()) {
+    // ---- models of 3 073 - 12 288 nodes: several wavefronts per pair, float32 (wh_score_wide.hip); one launch per
+    // waves-per-pair class.  A query batch too long for the kernel's LDS block falls back to the float64 front end below.
+    const int Lc = std::max(max_len, 1);
+    const size_t wlds = wide_lds_bytes(Lc);
+    const int64_t npairs_all = nq * (int64_t)e->hmms.size();
+    const bool resolve = !e->knobs.no_resolve && resolve_lds_bytes(Lc, e->max_M) <= kLdsBudget && npairs_all < 0x7FFFFFFF;
+    if (wlds <= kLdsBudget) {
+      size_t woff = 0;            // (the queue of the resolver was sized and reset with the one-wave launches above)
+      for (auto &kv : e->by_q) woff += kv.second.size();
+      woff += e->generic_front.size();
+      for (auto &kv : e->wide_by_w) {
+        const int W = kv.first;
+        WideArgs a;
+        memset(&a, 0, sizeof a);
+        a.hmms = (const DevHMM *)e->d_hmms.p; a.tables = (const float *)e->d_tables.p;
+        a.hmm_list = (const int32_t *)e->d_lists.p + woff; a.n_list = (int)kv.second.size();
+        woff += kv.second.size();
+        a.residues = d_residues; a.offsets = d_offsets; a.nq = nq;
+        a.counter = (int *)e->d_counter.p + 68 + W;
+        a.Lcap = Lc; a.SP = (Lc + 1 + 3) / 4 * 4;
+        a.decibits = d_decibits; a.flags = d_flags; a.fwd_bits = d_fwd_bits; a.detail = d_detail;
+        a.H = (int)e->hmms.size(); a.K = e->K; a.Kp = e->Kp;
+        memcpy(a.degen, e->degen, sizeof a.degen);
+        if (resolve) { a.rrecs = (ResolveRec *)e->d_rrecs.p; a.rcount = (int *)e->d_counter.p + 64; a.rcap = (int)npairs_all; }
+        a.qorder = qorder_all;
+        a.scratch_stride = (size_t)(Lc + 1) * 2 * e->wide_q * W * kWave;
+        const int64_t n_items = nq * (int64_t)a.n_list;
+        const int per_cu = (W <= 4 && 2 * wlds <= kLdsBudget) ? 2 : 1;
+        int blocks = (int)std::min<int64_t>(n_items, (int64_t)e->cu_count * per_cu);
+        blocks = clamp_blocks(blocks, a.scratch_stride * sizeof(float), e->d_wscratch);
+        if (e->d_wscratch.ensure((size_t)blocks * a.scratch_stride * sizeof(float))) return WH_ENOMEM;
+        a.scratch = (float *)e->d_wscratch.p;
+        HIPCHK(hipMemsetAsync(a.counter, 0, sizeof(int), s));
+        if (e->knobs.trace) fprintf(stderr, "[wh] wide scoring: %lld pairs on %d models, %d waves per pair x %d cells per lane, %d workgroups, lds %zu, slab %zu MB per workgroup\n",
+                                    (long long)n_items, a.n_list, W, e->wide_q, blocks, wlds, a.scratch_stride * 4 >> 20);
+        if (class_mark(e, s, e->wide_q * W, 3)) return WH_EHIP;
+        hipError_t werr = launch_score_wide(e->wide_q, a, blocks, W, wlds, s);
+        if (werr != hipSuccess) { set_error("wide score kernel launch failed: %s", hipGetErrorString(werr)); return WH_EHIP; }
+        launches++;
+      }
+    }
+    wide_done = wlds <= kLdsBudget;
+  }
+  if (nq > 0 && (!e->generic_front.empty() || (!wide_done && !e->wide_by_w.empty() && !e->force_wide))) {
     // ---- models of more than 3072 nodes: the any-size float64 front end (wh_generic.hip), one wavefront per pair;
     // every pair with a region goes through the resolver's queue, which also assembles its score
     const int Lc = std::max(max_len, 1);
@@ -592,7 +671,8 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
     g.hmms = (const DevHMM *)e->d_hmms.p; g.gtab = (const double *)e->d_gtab.p;
     size_t goff = 0;
     for (auto &kv : e->by_q) goff += kv.second.size();
-    g.hmm_list = (const int32_t *)e->d_lists.p + goff; g.n_list = (int)e->generic.size();
+    const size_t n_gen = wide_done ? e->generic_front.size() : e->generic.size();     // (front list and wide lists are adjacent)
+    g.hmm_list = (const int32_t *)e->d_lists.p + goff; g.n_list = (int)n_gen;
     g.residues = d_residues; g.offsets = d_offsets; g.nq = nq;
     g.counter = (int *)e->d_counter.p + 66;
     g.Lcap = Lc; g.Qmax = e->max_Q;
@@ -603,14 +683,14 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
     g.rrecs = (ResolveRec *)e->d_rrecs.p; g.rcount = (int *)e->d_counter.p + 64; g.rcap = (int)npairs_all;
     const size_t glds = generic_lds_bytes(Lc);
     if (glds > kLdsBudget) { set_error("query length %d does not fit the any-size kernel's LDS", max_len); return WH_ERANGE; }
-    const int64_t n_items = nq * (int64_t)e->generic.size();
+    const int64_t n_items = nq * (int64_t)n_gen;
     int blocks = (int)std::min<int64_t>(n_items, (int64_t)e->cu_count * std::min<size_t>(12, kLdsBudget / glds));
     blocks = clamp_blocks(blocks, g.slab_stride * sizeof(double), e->d_rmx);
     if (e->d_rmx.ensure((size_t)blocks * g.slab_stride * sizeof(double))) return WH_ENOMEM;
     g.slab = (double *)e->d_rmx.p;
     HIPCHK(hipMemsetAsync(g.counter, 0, sizeof(int), s));
     if (e->knobs.trace) fprintf(stderr, "[wh] any-size front end: %lld pairs on %zu models (up to %d nodes), %d wavefronts, slab %zu MB per wave\n",
-                                (long long)n_items, e->generic.size(), e->max_M, blocks, g.slab_stride * 8 >> 20);
+                                (long long)n_items, n_gen, e->max_M, blocks, g.slab_stride * 8 >> 20);
     if (class_mark(e, s, e->max_Q, 2)) return WH_EHIP;
     hipError_t gerr = launch_generic_front(g, blocks, glds, s);
     if (gerr != hipSuccess) { set_error("any-size front kernel launch failed: %s", hipGetErrorString(gerr)); return WH_EHIP; }

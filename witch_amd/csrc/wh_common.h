@@ -14,6 +14,8 @@ constexpr int kMaxQ = 48;          // cells per lane of the register-resident ke
 constexpr int kMaxQGen = 256;      // ... of the any-size float64 kernels (wh_generic.hip) -> M <= 16384
 constexpr int kMaxQFast = 24;      // up to here both transition orientations stay resident in LDS
 constexpr int kQRegMax = 16;       // up to this Q the transition tables live in VGPRs
+constexpr int kWideQ = 24;         // cells per lane of the several-waves-per-pair scoring kernel
+constexpr int kWideWavesMax = 8;   // ... and its largest workgroup: models of up to 8 x 64 x 24 = 12 288 nodes
 // per-wave LDS block of the scoring kernels: region list (i, j) x WH_MAX_ENVELOPES, 8 spare ints, and the
 // envelope results (envsc, domcorr) x WH_MAX_ENVELOPES staged for the multidomain resolver's record
 constexpr int kRegsInts = 5 * WH_MAX_ENVELOPES;
@@ -51,6 +53,8 @@ struct DevHMM {
   int64_t fw_off, bw_off, em_off;    // offsets (in floats) into the table buffer
   int64_t gfw_off, gem_off;          // offsets (in doubles) into the float64 table buffer of the resolver
   int64_t emn_off;                   // node-major float32 emission odds [M+1][K] in the float table buffer (resolver: null2 by trace)
+  int32_t wideQ, wideW;              // > 0: float32 tables laid out over wideW x 64 lanes of wideQ cells (wh_score_wide.hip) at ...
+  int64_t wfw_off, wbw_off, wem_off; // ... these offsets (floats) of the table buffer
 };
 
 enum { FW_A = 0, FW_B, FW_C, FW_E, FW_MI, FW_II, FW_D1, FW_D2, FW_NARR, FW_P = FW_NARR };
@@ -62,7 +66,7 @@ enum { BW_MM = 0, BW_IM, BW_DM, BW_MI, BW_II, BW_MD, BW_DD, BW_E, BW_NARR, BW_P 
 
 int  choose_Q(int M);     // cells per lane for a model of M nodes, or -1 if unsupported
 void build_tables(const HostHMM &h, int Q, std::vector<float> &fw, std::vector<float> &bw,
-                  std::vector<float> &em);
+                  std::vector<float> &em, int lanes = kWave);   // lanes > 64: the several-waves-per-pair kernel (wh_score_wide.hip)
 // float64 tables of the multidomain resolver: 8 forward arrays and Kp emission rows, value of node
 // k = lane*Q + q + 1 at arr*Q*64 + ((q/2)*64 + lane)*2 + q%2 (the two nodes of a pair adjacent: 16-byte accesses)
 void build_tables_f64(const HostHMM &h, int Q, std::vector<double> &fw, std::vector<double> &em);

@@ -195,12 +195,12 @@ int choose_Q(int M) {
 }
 
 void build_tables(const HostHMM &h, int Q, std::vector<float> &fw, std::vector<float> &bw,
-                  std::vector<float> &em) {
+                  std::vector<float> &em, int lanes) {
   enum { tMM = 0, tMI, tMD, tIM, tII, tDM, tDD };
-  const int M = h.M, Mpad = Q * kWave, Q4 = Q / 4;
+  const int M = h.M, Mpad = Q * lanes, Q4 = Q / 4;
   auto at = [&](int arr, int pos) -> size_t {   // pos = lane*Q + q
     int lane = pos / Q, q = pos % Q;
-    return (((size_t)arr * Q4 + q / 4) * kWave + lane) * 4 + (q % 4);
+    return (((size_t)arr * Q4 + q / 4) * lanes + lane) * 4 + (q % 4);
   };
   fw.assign((size_t)(FW_NARR + 1) * Mpad, 0.f);   // + FW_P
   bw.assign((size_t)(BW_NARR + 1) * Mpad, 0.f);   // + BW_P
@@ -230,7 +230,7 @@ void build_tables(const HostHMM &h, int Q, std::vector<float> &fw, std::vector<f
   }
   // FW_P / BW_P: running products of the D->D coefficients inside each lane's block, in float32
   // like the kernels' own products (the in-lane carry of the D chain becomes one FMA per cell)
-  for (int lane = 0; lane < kWave; lane++) {
+  for (int lane = 0; lane < lanes; lane++) {
     float pf = 1.0f, pb = 1.0f;
     for (int q = 0; q < Q; q++) {
       pf *= fw[at(FW_D2, lane * Q + q)];

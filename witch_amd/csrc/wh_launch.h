@@ -98,6 +98,33 @@ size_t resolve_dcache_doubles();
 size_t resolve_tail_row_doubles();
 
 // models of any size (wh_generic.hip)
+// several wavefronts per pair (wh_score_wide.hip): models of 3 073 - 12 288 nodes
+struct WideArgs {
+  const DevHMM *hmms;
+  const float *tables;
+  const int32_t *hmm_list;     // model positions of this launch (all with the same wideW)
+  int n_list;
+  const uint8_t *residues;
+  const int64_t *offsets;
+  int64_t nq;
+  int *counter;
+  int Lcap, SP;
+  float *scratch;              // per-workgroup Forward slabs
+  size_t scratch_stride;       // floats per workgroup
+  int32_t *decibits;
+  uint8_t *flags;
+  float *fwd_bits;
+  wh_pair_detail *detail;
+  int H, K, Kp;
+  uint32_t degen[32];
+  ResolveRec *rrecs;
+  int *rcount;
+  int rcap;
+  const int32_t *qorder;
+};
+size_t wide_lds_bytes(int Lcap);
+hipError_t launch_score_wide(int Q, const WideArgs &a, int blocks, int waves, size_t lds, hipStream_t s);
+
 struct GenericArgs {
   const DevHMM *hmms;
   const double *gtab;

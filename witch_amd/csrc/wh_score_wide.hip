@@ -1,0 +1,665 @@
+// Scoring kernel for models of 3 073 - 12 288 nodes: SEVERAL wavefronts per (query, HMM) pair.
+//
+// `hmmbuild --symfrac 0.0` (witch_msa/gcmm/algorithm.py:463-470) makes every populated backbone column a node, so
+// the upper subsets of a large backbone (16S: 5-12 k columns) exceed what ONE wavefront holds in registers
+// (64 lanes x 48 cells).  Until round 3 such models ran through the float64 one-wave kernels of wh_generic.hip,
+// every DP row through memory, 30 x below the register kernels per cell.  Here a workgroup of W = 3..8 wavefronts
+// owns one pair: wave w, lane r holds the cells of nodes ((w*64 + r)*Q + q + 1), Q = 24, in registers, float32
+// probability space with exact power-of-two rescaling - the arithmetic of wh_score7.hip (same five sweeps, same
+// operation order inside a lane, HMMER's float32 score assembly).  What crosses a wavefront boundary goes through
+// LDS, twice per row and sweep:
+//   * the D->D chain: every wave scans its own lanes (DPP affine scan), publishes the value its last cell would
+//     have with a zero carry-in, and after the barrier folds the maps of the waves in front of it (A_wave is
+//     model-only, formed once per sweep) into its carry-in;
+//   * the row sum E(i) (Forward) / the B-state sum (Backward), the cells of the last lane that the next wave's
+//     first lane needs, formed in wave order so that the result does not depend on timing.
+// The model's tables do not fit in LDS (2 x 8 arrays x 12 288 nodes x 4 B): they are read from L2 on every use, in
+// the lane-blocked layout of wh_common.h over W*64 virtual lanes (a wave's access is one contiguous 1 KiB line);
+// all workgroups work on the same model at a time (model-major work items), so the reads hit L2.  The per-row
+// special states of the ONE pair a workgroup works on live in LDS.  Envelope Forward rows are spilled densely to
+// the workgroup's slab (no sparse spill, no node window: those are refinements of the one-wave kernel).
+// Pairs with a multidomain region are queued for resolve_kernel exactly as wh_score7.hip queues them.
+#include <hip/hip_runtime.h>
+
+#include "wh_device.h"
+#include "wh_launch.h"
+
+namespace wh {
+namespace wide {
+
+// per-wave exchange slot in LDS (floats)
+enum { X_BD = 0, X_ES, X_BM, X_BI, X_BDD, X_AT, X_T0, X_T1, X_N };
+
+__device__ __forceinline__ float flogsum0_w(float b) {
+  const float mx = b > 0.f ? b : 0.f, mn = b > 0.f ? 0.f : b;
+  if (mn == -INFINITY || (mx - mn) >= 15.7f) return mx;
+  const int idx = (int)((mx - mn) * 1000.0f);
+  return mx + (float)log(1.0 + exp((double)-idx / 1000.0));
+}
+
+// global-address-space views with WAVE-UNIFORM bases: a table access is then one scalar base + the lane's 32-bit offset +
+// an immediate (with flat per-lane pointers the compiler kept 60 64-bit addresses per row in scratch)
+typedef float wv4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) wv4 gf4;
+__device__ __forceinline__ const gf4 *uniform_global(const void *p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (const gf4 *)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ float4 ldg4(const gf4 *base, unsigned idx) { const wv4 v = base[idx]; return make_float4(v.x, v.y, v.z, v.w); }
+// element <elem> (wave-uniform) of virtual lane <vl>: the uniform part goes into the SCALAR base (two SALU adds), every access of
+// a lane shares ONE 32-bit VGPR offset.  <nl> is kept opaque per row (asm) by the callers: otherwise the compiler hoists the 60
+// loop-invariant addresses of a row out of the row loop as 64-bit VGPR pairs and spills them
+__device__ __forceinline__ float4 ldt(const gf4 *base, int elem, int nl, unsigned vl) {
+  const gf4 *p = base + (size_t)(unsigned)(elem * nl);
+  const wv4 v = p[vl];
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ int opaque_s(int v) { asm volatile("" : "+s"(v)); return v; }
+
+template <int NLT>
+struct WCtxT {
+  const gf4 *fw, *bw, *em;      // uniform bases of the three table groups: element (arr, q4) of virtual lane vl at [(arr*Q4 + q4) * NL + vl]
+  int vl;
+  float *spec;                  // LDS: SP_NARR-2 arrays of SP floats (N, B, E, J, C, S), one pair per workgroup
+  float *xch;                   // LDS: W slots of X_N floats
+  gf4 *Fs;                      // slab of the workgroup (uniform base): [row][2][Q4][NL]
+  int NLr, SP, w, W, lane, K, Kp;
+  // lanes over all waves of the workgroup: a compile-time constant in the production instantiations (table accesses then
+  // are one scalar base + immediate offsets; with a run-time value the compiler kept 60 offsets per row in scratch)
+  __device__ __forceinline__ int nl() const { return NLT > 0 ? NLT : NLr; }
+};
+
+__device__ __forceinline__ void wg_barrier() { __syncthreads(); }
+
+// inclusive product over lanes 0..lane of <a> (model-only; once per sweep)
+__device__ __forceinline__ float lane_prefix_product(float a, int lane) {
+  for (int d = 1; d < 64; d <<= 1) { const float o = __shfl_up(a, d); if (lane >= d) a *= o; }
+  return a;
+}
+
+// ------------------------------------------------------------------------------------------ Forward (P1 / P3)
+template <int Q, bool STORE, int NLT>
+__device__ __forceinline__ void forward_wide(const WCtxT<NLT> &c, const uint8_t *seq, int L, LenCfg cfg, float &xC_out, int &ef_out) {
+  constexpr int Q4 = Q / 4;
+  const int lane = c.lane, NL = c.nl(), SP = c.SP, w = c.w;
+  float *spec = c.spec, *xch = c.xch;
+  int nlv = NL;
+  auto T = [&](int a, int q4) -> float4 { return ldt(c.fw, a * Q4 + q4, nlv, (unsigned)c.vl); };
+  // model-only parts of the D scans
+  float A = 1.f;
+#pragma unroll
+  for (int q4 = 0; q4 < Q4; q4++) { const float4 d = T(FW_D2, q4); A *= d.x; A *= d.y; A *= d.z; A *= d.w; }
+  const ScanC sc = scan_prepare(A);
+  const float Aincl = lane_prefix_product(A, lane);
+  float Aexcl = __shfl_up(Aincl, 1);
+  if (lane == 0) Aexcl = 1.f;
+  if (lane == 63) xch[w * X_N + X_AT] = Aincl;
+  float Mp[Q], Ip[Q], Dp[Q];
+#pragma unroll
+  for (int q = 0; q < Q; q++) { Mp[q] = 0.f; Ip[q] = 0.f; Dp[q] = 0.f; }
+  float xN = 1.0f, xB = cfg.move, xJ = 0.f, xC = 0.f, xE = 0.f;
+  float bM = 0.f, bI = 0.f, bD = 0.f;          // row i-1 cells of the previous wave's last lane (lane 0 uses them)
+  int ef = 0;
+  if (w == 0 && lane == 0) {
+    spec[SP_N * SP] = xN; spec[SP_B * SP] = xB; spec[SP_E * SP] = 0.f; spec[SP_J * SP] = 0.f; spec[SP_C * SP] = 0.f;
+    reinterpret_cast<int *>(spec)[SP_S * SP] = 0;
+  }
+  wg_barrier();                                // X_AT of every wave is visible
+#pragma unroll 1
+  for (int i = 1; i <= L; i++) {
+    const int x = __builtin_amdgcn_readfirstlane((int)seq[i - 1]);
+    nlv = opaque_s(NL);
+    float mm1 = wave_shr1(Mp[Q - 1]), im1 = wave_shr1(Ip[Q - 1]), dm1 = wave_shr1(Dp[Q - 1]);
+    if (lane == 0) { mm1 = bM; im1 = bI; dm1 = bD; }
+#pragma unroll
+    for (int q4 = Q4 - 1; q4 >= 0; q4--) {
+      const float4 Aa = T(FW_A, q4), Bb = T(FW_B, q4), Cc = T(FW_C, q4), Ee = T(FW_E, q4);
+      const float4 MI = T(FW_MI, q4), II = T(FW_II, q4);
+      const float4 O = ldt(c.em, x * Q4 + q4, nlv, (unsigned)c.vl);
+#pragma unroll
+      for (int j = 3; j >= 0; j--) {
+        const int q = 4 * q4 + j;
+        const float pm = q > 0 ? Mp[q > 0 ? q - 1 : 0] : mm1;
+        const float pi = q > 0 ? Ip[q > 0 ? q - 1 : 0] : im1;
+        const float pd = q > 0 ? Dp[q > 0 ? q - 1 : 0] : dm1;
+        const float ni = fmaf(f4get(MI, j), Mp[q], f4get(II, j) * Ip[q]);
+        float acc = xB * f4get(Ee, j);
+        acc = fmaf(f4get(Aa, j), pm, acc);
+        acc = fmaf(f4get(Bb, j), pi, acc);
+        acc = fmaf(f4get(Cc, j), pd, acc);
+        Mp[q] = f4get(O, j) * acc;
+        Ip[q] = ni;
+      }
+    }
+    // D row: chains inside the lane, scan over the lanes of this wave, maps of the waves in front.  The first cell of a
+    // wave needs the NEW M of the cell in front of it (the last cell of the previous wave): one exchange of its own
+    if (lane == 63) xch[w * X_N + X_T0] = Mp[Q - 1];
+    wg_barrier();                                                               // #0
+    float mn1 = wave_shr1(Mp[Q - 1]);
+    if (lane == 0) mn1 = w > 0 ? xch[(w - 1) * X_N + X_T0] : 0.f;
+    float dprev = 0.f;
+#pragma unroll
+    for (int q4 = 0; q4 < Q4; q4++) {
+      const float4 D1 = T(FW_D1, q4), D2 = T(FW_D2, q4);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int q = 4 * q4 + j;
+        const float src = q > 0 ? Mp[q > 0 ? q - 1 : 0] : mn1;
+        dprev = fmaf(f4get(D2, j), dprev, f4get(D1, j) * src);
+        Dp[q] = dprev;
+      }
+    }
+    const float loc = scan_apply(sc, dprev);        // D of my last cell if nothing entered the wave from the front
+    if (lane == 63) xch[w * X_N + X_BD] = loc;
+    wg_barrier();                                                               // #1
+    // D of the last cell of the wave in front: D_last(v) = A_v * D_last(v-1) + B_v, folded in wave order
+    float cin = 0.f;
+    for (int v = 0; v < w; v++) cin = fmaf(xch[v * X_N + X_AT], cin, xch[v * X_N + X_BD]);
+    float carry = wave_shr1(loc);
+    carry = fmaf(Aexcl, cin, carry);
+    if (lane == 0) carry = cin;
+    float es = 0.f;
+#pragma unroll
+    for (int q4 = 0; q4 < Q4; q4++) {
+      const float4 D2 = T(FW_D2, q4);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int q = 4 * q4 + j;
+        carry *= f4get(D2, j);
+        Dp[q] += carry;
+        es += Mp[q] + Dp[q];
+      }
+    }
+    const float esw = wave_sum(es);
+    if (lane == 63) { xch[w * X_N + X_ES] = esw; xch[w * X_N + X_BM] = Mp[Q - 1]; xch[w * X_N + X_BI] = Ip[Q - 1]; xch[w * X_N + X_BDD] = Dp[Q - 1]; }
+    wg_barrier();                                                               // #2
+    xE = 0.f;
+    for (int v = 0; v < c.W; v++) xE += xch[v * X_N + X_ES];
+    if (w > 0) { bM = xch[(w - 1) * X_N + X_BM]; bI = xch[(w - 1) * X_N + X_BI]; bD = xch[(w - 1) * X_N + X_BDD]; }
+    xN = xN * cfg.loop;
+    xC = fmaf(xC, cfg.loop, xE * cfg.EC);
+    xJ = fmaf(xJ, cfg.loop, xE * cfg.EJ);
+    if (xE > kRescaleHi) {
+      const int e = f32_exponent(xE);
+      const float r = pow2f_int(-e);
+#pragma unroll
+      for (int q = 0; q < Q; q++) { Mp[q] *= r; Ip[q] *= r; Dp[q] *= r; }
+      xN *= r; xC *= r; xJ *= r; xE *= r;
+      bM *= r; bI *= r; bD *= r;
+      ef += e;
+    }
+    xB = (xJ + xN) * cfg.move;
+    if (w == 0 && lane == 0) {
+      spec[SP_N * SP + i] = xN; spec[SP_B * SP + i] = xB; spec[SP_E * SP + i] = xE;
+      spec[SP_J * SP + i] = xJ; spec[SP_C * SP + i] = xC;
+      reinterpret_cast<int *>(spec)[SP_S * SP + i] = ef;
+    }
+    if (STORE) {
+      gf4 *row = c.Fs + (size_t)i * (2 * Q4) * NL;
+#pragma unroll
+      for (int q4 = 0; q4 < Q4; q4++) {
+        const wv4 vm = {Mp[4 * q4], Mp[4 * q4 + 1], Mp[4 * q4 + 2], Mp[4 * q4 + 3]};
+        const wv4 vi = {Ip[4 * q4], Ip[4 * q4 + 1], Ip[4 * q4 + 2], Ip[4 * q4 + 3]};
+        row[(unsigned)(q4 * NL + c.vl)] = vm;
+        row[(unsigned)((Q4 + q4) * NL + c.vl)] = vi;
+      }
+    }
+  }
+  xC_out = xC;
+  ef_out = ef;
+  wg_barrier();
+}
+
+
+// ------------------------------------------------------------------------------------------ Backward rows
+// One Backward row for every wave of the workgroup (reversed node order: wave 0, lane 0 holds the LAST node).
+// On entry Mb / Ib hold row i+1 (zeros for i = L).  <emit>: multiply in the emission odds of residue x (row i < L) and
+// form the B-state sum over all waves; then the D chain with the carries of the waves in front, then M / I.
+template <int Q>
+struct BackState { float Mb[Q], Ib[Q]; };
+
+template <int Q, int NLT>
+__device__ __forceinline__ float backward_emit_wide(const WCtxT<NLT> &c, int x, float (&Mb)[Q], float &gfront) {
+  constexpr int Q4 = Q / 4;
+  const int NL = c.nl(), w = c.w, lane = c.lane;
+  float *xch = c.xch;
+  // reversed order: my reversed cells 4*p4 .. 4*p4+3 are the forward piece (Q4-1-p4) of the forward lane (NL-1-vl), components reversed
+  const int rv = NL - 1 - c.vl;              // the forward lane that holds my reversed cells
+  const int nlv = opaque_s(NL);
+  float part = 0.f;
+#pragma unroll
+  for (int p4 = 0; p4 < Q4; p4++) {
+    const float4 E = ldt(c.bw, BW_E * Q4 + p4, nlv, (unsigned)c.vl);
+    const float4 O = ldt(c.em, x * Q4 + (Q4 - 1 - p4), nlv, (unsigned)rv);
+    Mb[4 * p4 + 0] *= O.w; part = fmaf(E.x, Mb[4 * p4 + 0], part);
+    Mb[4 * p4 + 1] *= O.z; part = fmaf(E.y, Mb[4 * p4 + 1], part);
+    Mb[4 * p4 + 2] *= O.y; part = fmaf(E.z, Mb[4 * p4 + 2], part);
+    Mb[4 * p4 + 3] *= O.x; part = fmaf(E.w, Mb[4 * p4 + 3], part);
+  }
+  const float pw = wave_sum(part);
+  if (lane == 63) { xch[w * X_N + X_ES] = pw; xch[w * X_N + X_BM] = Mb[Q - 1]; }
+  wg_barrier();                                                                 // #A
+  float xB = 0.f;
+  for (int v = 0; v < c.W; v++) xB += xch[v * X_N + X_ES];
+  gfront = w > 0 ? xch[(w - 1) * X_N + X_BM] : 0.f;     // G of the cell in front of my first one
+  return xB;
+}
+
+template <int Q, int NLT>
+__device__ __forceinline__ void backward_cells_wide(const WCtxT<NLT> &c, const ScanC &sc, float Aexcl, float (&Mb)[Q], float (&Ib)[Q], float xE, float gfront) {
+  constexpr int Q4 = Q / 4;
+  const int NL = c.nl(), w = c.w, lane = c.lane;
+  float *xch = c.xch;
+  const int nlv = opaque_s(NL);
+  auto T = [&](int a, int q4) -> float4 { return ldt(c.bw, a * Q4 + q4, nlv, (unsigned)c.vl); };
+  float Dn[Q];
+  float gm1 = wave_shr1(Mb[Q - 1]);
+  if (lane == 0) gm1 = gfront;
+  float dprev = 0.f;
+#pragma unroll
+  for (int p4 = 0; p4 < Q4; p4++) {
+    const float4 DM = T(BW_DM, p4), DD = T(BW_DD, p4);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int p = 4 * p4 + j;
+      const float g = p > 0 ? Mb[p > 0 ? p - 1 : 0] : gm1;
+      dprev = fmaf(f4get(DD, j), dprev, fmaf(f4get(DM, j), g, xE));
+      Dn[p] = dprev;
+    }
+  }
+  const float loc = scan_apply(sc, dprev);
+  if (lane == 63) xch[w * X_N + X_BD] = loc;
+  wg_barrier();                                                                 // #B
+  float cin = 0.f;
+  for (int v = 0; v < w; v++) cin = fmaf(xch[v * X_N + X_AT], cin, xch[v * X_N + X_BD]);
+  float carry = wave_shr1(loc);
+  carry = fmaf(Aexcl, cin, carry);
+  if (lane == 0) carry = cin;
+  const float dfront = carry;                  // D of the cell in front of my first one (lane r: last cell of lane r-1)
+#pragma unroll
+  for (int p4 = 0; p4 < Q4; p4++) {
+    const float4 DD = T(BW_DD, p4);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int p = 4 * p4 + j;
+      carry *= f4get(DD, j);
+      Dn[p] += carry;
+    }
+  }
+#pragma unroll
+  for (int p4 = Q4 - 1; p4 >= 0; p4--) {
+    const float4 MM = T(BW_MM, p4), IM = T(BW_IM, p4), MI = T(BW_MI, p4), II = T(BW_II, p4);
+    const float4 MD = T(BW_MD, p4);
+#pragma unroll
+    for (int j = 3; j >= 0; j--) {
+      const int p = 4 * p4 + j;
+      const float g = p > 0 ? Mb[p > 0 ? p - 1 : 0] : gm1;
+      const float dn = p > 0 ? Dn[p > 0 ? p - 1 : 0] : dfront;
+      float nm = fmaf(f4get(MM, j), g, xE);
+      nm = fmaf(f4get(MI, j), Ib[p], nm);
+      nm = fmaf(f4get(MD, j), dn, nm);
+      const float ni = fmaf(f4get(IM, j), g, f4get(II, j) * Ib[p]);
+      Mb[p] = nm;
+      Ib[p] = ni;
+    }
+  }
+}
+
+// model-only parts of the Backward D scans of this sweep (X_AT published; the caller's first barrier makes it visible)
+template <int Q, int NLT>
+__device__ __forceinline__ void backward_prepare_wide(const WCtxT<NLT> &c, ScanC &sc, float &Aexcl) {
+  constexpr int Q4 = Q / 4;
+  float A = 1.f;
+#pragma unroll
+  for (int q4 = 0; q4 < Q4; q4++) { const float4 d = ldg4(c.bw, (unsigned)((BW_DD * Q4 + q4) * c.nl() + c.vl)); A *= d.x; A *= d.y; A *= d.z; A *= d.w; }
+  sc = scan_prepare(A);
+  const float Aincl = lane_prefix_product(A, c.lane);
+  Aexcl = __shfl_up(Aincl, 1);
+  if (c.lane == 0) Aexcl = 1.f;
+  if (c.lane == 63) c.xch[c.w * X_N + X_AT] = Aincl;
+  wg_barrier();
+}
+
+// ------------------------------------------------------------------------------------------ P2: multihit Backward + decoding
+template <int Q, int NLT>
+__device__ __forceinline__ void backward_decode_wide(const WCtxT<NLT> &c, const uint8_t *seq, int L, LenCfg cm, float invZ, int ef_L) {
+  const int SP = c.SP;
+  float *spec = c.spec;
+  ScanC sc;
+  float Aexcl;
+  backward_prepare_wide<Q, NLT>(c, sc, Aexcl);
+  float Mb[Q], Ib[Q];
+#pragma unroll
+  for (int p = 0; p < Q; p++) { Mb[p] = 0.f; Ib[p] = 0.f; }
+  float xC = cm.move, xJ = 0.f, xN = 0.f, xB = 0.f;
+  int eb = 0;
+#pragma unroll 1
+  for (int i = L; i >= 0; i--) {
+    float gfront = 0.f;
+    if (i < L) {
+      xB = backward_emit_wide<Q, NLT>(c, __builtin_amdgcn_readfirstlane((int)seq[i]), Mb, gfront);
+      xJ = fmaf(xJ, cm.loop, xB * cm.move);
+      xC = xC * cm.loop;
+      xN = fmaf(xN, cm.loop, xB * cm.move);
+    }
+    float xE = fmaf(xC, cm.EC, xJ * cm.EJ);
+    if (i >= 1) backward_cells_wide<Q, NLT>(c, sc, Aexcl, Mb, Ib, xE, gfront);
+    const float big = fmaxf(xB, xN);
+    if (big > kRescaleHi) {
+      const int e = f32_exponent(big);
+      const float r = pow2f_int(-e);
+#pragma unroll
+      for (int p = 0; p < Q; p++) { Mb[p] *= r; Ib[p] *= r; }
+      xB *= r; xJ *= r; xC *= r; xN *= r; xE *= r;
+      eb += e;
+    }
+    const float s_i = ldexpf(invZ, reinterpret_cast<const int *>(spec)[SP_S * SP + i] + eb - ef_L);
+    const float pe = spec[SP_E * SP + i] * xE * s_i;
+    const float pb = spec[SP_B * SP + i] * xB * s_i;
+    float njc = 0.f;
+    if (i >= 1) {
+      const float s_p = ldexpf(invZ, reinterpret_cast<const int *>(spec)[SP_S * SP + i - 1] + eb - ef_L);
+      njc = spec[SP_N * SP + i - 1] * xN;
+      njc = fmaf(spec[SP_J * SP + i - 1], xJ, njc);
+      njc = fmaf(spec[SP_C * SP + i - 1], xC, njc);
+      njc = njc * cm.loop * s_p;
+    }
+    // every wave holds the same values; the row's Forward states (read above by all) are overwritten by ONE lane after a
+    // barrier - the next row's barriers order the write before anybody reads row i-1's neighbours (rows are disjoint)
+    wg_barrier();
+    if (c.w == 0 && c.lane == 0) { spec[SP_E * SP + i] = pe; spec[SP_B * SP + i] = pb; spec[SP_N * SP + i] = njc; }
+  }
+  wg_barrier();
+}
+
+// ------------------------------------------------------------------------------------------ P4: unihit Backward + posteriors -> null2
+// Returns domcorr (every wave holds it).
+template <int Q, int NLT>
+__device__ __forceinline__ float backward_null2_wide(const WCtxT<NLT> &c, const uint8_t *eseq, int Ld, LenCfg cu, float invZe, float *n2tab, uint32_t degen) {
+  constexpr int Q4 = Q / 4;
+  const int SP = c.SP, NL = c.nl(), w = c.w, lane = c.lane;
+  const float *spec = c.spec;
+  float *xch = c.xch;
+  ScanC sc;
+  float Aexcl;
+  backward_prepare_wide<Q, NLT>(c, sc, Aexcl);
+  float Mb[Q], Ib[Q], fM[Q];
+#pragma unroll
+  for (int p = 0; p < Q; p++) { Mb[p] = 0.f; Ib[p] = 0.f; fM[p] = 0.f; }
+  float xC = cu.move, xJ = 0.f, xN = 0.f, xB = 0.f, xfac = 0.f, fIs = 0.f;
+  int S_next = 0;
+  // my reversed cells in the forward-ordered slab: forward lane NL-1-vl, piece Q4-1-p4, components reversed
+  const int rv = NL - 1 - c.vl;
+#pragma unroll 1
+  for (int i = Ld; i >= 1; i--) {
+    const int S_i = reinterpret_cast<const int *>(spec)[SP_S * SP + i];
+    const int dS = S_i - reinterpret_cast<const int *>(spec)[SP_S * SP + i - 1];
+    float gfront = 0.f;
+    if (i < Ld) {
+      mirror_scale<Q>(S_next - S_i, Mb, Ib, xJ, xC, xN);
+      xB = backward_emit_wide<Q, NLT>(c, __builtin_amdgcn_readfirstlane((int)eseq[i]), Mb, gfront);
+      xJ = fmaf(xJ, cu.loop, xB * cu.move);
+      xC = xC * cu.loop;
+      xN = fmaf(xN, cu.loop, xB * cu.move);
+    }
+    const float xE = fmaf(xC, cu.EC, xJ * cu.EJ);
+    backward_cells_wide<Q, NLT>(c, sc, Aexcl, Mb, Ib, xE, gfront);
+    clamp_backward<Q>(Mb, Ib, xB, xJ, xC, xN);
+    const float s_i = invZe;
+    const float s_p = ldexpf(invZe, -dS);
+    const gf4 *row = c.Fs + (size_t)i * (2 * Q4) * NL;
+    const int nlr = opaque_s(NL);
+    float idot = 0.f;
+#pragma unroll
+    for (int p4 = 0; p4 < Q4; p4++) {
+      const float4 fm = ldt(row, Q4 - 1 - p4, nlr, (unsigned)rv);
+      const float4 fi = ldt(row, Q4 + Q4 - 1 - p4, nlr, (unsigned)rv);
+      fM[4 * p4 + 0] = fmaf(fm.w * Mb[4 * p4 + 0], s_i, fM[4 * p4 + 0]);
+      fM[4 * p4 + 1] = fmaf(fm.z * Mb[4 * p4 + 1], s_i, fM[4 * p4 + 1]);
+      fM[4 * p4 + 2] = fmaf(fm.y * Mb[4 * p4 + 2], s_i, fM[4 * p4 + 2]);
+      fM[4 * p4 + 3] = fmaf(fm.x * Mb[4 * p4 + 3], s_i, fM[4 * p4 + 3]);
+      idot = fmaf(fi.w, Ib[4 * p4 + 0], idot); idot = fmaf(fi.z, Ib[4 * p4 + 1], idot);
+      idot = fmaf(fi.y, Ib[4 * p4 + 2], idot); idot = fmaf(fi.x, Ib[4 * p4 + 3], idot);
+    }
+    fIs = fmaf(idot, s_i, fIs);
+    float nj = spec[SP_N * SP + i - 1] * xN;
+    nj = fmaf(spec[SP_J * SP + i - 1], xJ, nj);
+    nj = fmaf(spec[SP_C * SP + i - 1], xC, nj);
+    S_next = S_i;
+    xfac = fmaf(nj * cu.loop, s_p, xfac);
+  }
+  // null2[a] = (sum_k fM_k o_k(a) + sum_k fI_k + f_NJC) / Ld over ALL waves, summed in wave order
+  const float siw = wave_sum(fIs);
+  wg_barrier();
+  if (lane == 0) xch[w * X_N + X_T1] = siw;
+  wg_barrier();
+  float si = 0.f;
+  for (int v = 0; v < c.W; v++) si += xch[v * X_N + X_T1];
+  const float norm = 1.0f / (float)Ld;
+  for (int x = 0; x < c.K; x++) {
+    float s = 0.f;
+#pragma unroll
+    for (int p4 = 0; p4 < Q4; p4++) {
+      const float4 O = ldg4(c.em, (unsigned)((x * Q4 + (Q4 - 1 - p4)) * NL + rv));
+      s = fmaf(fM[4 * p4 + 0], O.w, s); s = fmaf(fM[4 * p4 + 1], O.z, s);
+      s = fmaf(fM[4 * p4 + 2], O.y, s); s = fmaf(fM[4 * p4 + 3], O.x, s);
+    }
+    const float sw = wave_sum(s);
+    wg_barrier();
+    if (lane == 0) xch[w * X_N + X_T1] = sw;
+    wg_barrier();
+    float tot = 0.f;
+    for (int v = 0; v < c.W; v++) tot += xch[v * X_N + X_T1];
+    if (w == 0 && lane == 0) n2tab[x] = (tot + si) * norm + xfac * norm;
+  }
+  wg_barrier();
+  if (w == 0) {
+    float mine = 1.0f;
+    if (lane >= c.K && lane < c.Kp) {
+      float s = 0.f; int n = 0;
+      for (int x = 0; x < c.K; x++) if (degen & (1u << x)) { s += n2tab[x]; n++; }
+      mine = n > 0 ? s / (float)n : 1.0f;
+    } else if (lane < c.K) mine = n2tab[lane];
+    __builtin_amdgcn_wave_barrier();
+    if (lane < c.Kp) n2tab[lane] = logf(mine);
+    __builtin_amdgcn_wave_barrier();
+    float dc = 0.f;
+    for (int t = lane; t < Ld; t += kWave) dc += n2tab[eseq[t]];
+    const float domcorr = wave_sum(dc);
+    if (lane == 0) xch[X_T1] = domcorr;
+  }
+  wg_barrier();
+  const float out = xch[X_T1];
+  wg_barrier();
+  return out;
+}
+
+// ------------------------------------------------------------------------------------------ the kernel
+template <int Q, int NLT>
+__global__ __launch_bounds__(512) void score_wide_kernel(WideArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), W = blockDim.x >> 6;
+  const int NL = NLT > 0 ? NLT : W * 64, SP = a.SP, vl = w * 64 + lane;
+  constexpr int Q4 = Q / 4;
+  volatile int *s_item = reinterpret_cast<volatile int *>(smem);
+  float *spec = smem + 4;                               // 6 arrays of SP floats
+  float *xch = spec + 6 * SP;                           // W x X_N
+  float *n2tab = xch + 8 * X_N;
+  int *regs = reinterpret_cast<int *>(n2tab + 32);      // kRegsInts: regions, spare, envelope results
+  uint8_t *seq = reinterpret_cast<uint8_t *>(regs + kRegsInts);
+  const double LOG2 = 0.69314718055994529;
+  WCtxT<NLT> c;
+  c.spec = spec; c.xch = xch; c.NLr = NL; c.SP = SP; c.w = w; c.W = W; c.lane = lane; c.K = a.K; c.Kp = a.Kp;
+  c.Fs = const_cast<gf4 *>(uniform_global(a.scratch + (size_t)blockIdx.x * a.scratch_stride));
+  c.vl = vl;
+  uint32_t degen = 0;
+  for (int t = 0; t < 32; t++) if (t == lane) degen = a.degen[t];
+
+  for (;;) {
+    if (threadIdx.x == 0) *s_item = atomicAdd(a.counter, 1);
+    __syncthreads();
+    const long long item = *s_item;
+    __syncthreads();
+    if (item >= (long long)a.n_list * a.nq) break;
+    const int h = a.hmm_list[item / a.nq];
+    const int64_t qi = a.qorder ? (int64_t)a.qorder[item % a.nq] : item % a.nq;
+    const DevHMM *hm = a.hmms + h;
+    c.fw = uniform_global(a.tables + hm->wfw_off);
+    c.bw = uniform_global(a.tables + hm->wbw_off);
+    c.em = uniform_global(a.tables + hm->wem_off);
+    const int64_t off = a.offsets[qi];
+    const int L = (int)(a.offsets[qi + 1] - off);
+    const size_t out = (size_t)qi * a.H + h;
+    int flags = 0, decibits = 0;
+    float fwd_bits_out = -INFINITY;
+    wh_pair_detail *dp = (a.detail && threadIdx.x == 0) ? a.detail + out : nullptr;
+    if (dp) { dp->fwd_bits = -INFINITY; dp->seq_score = 0.f; dp->pre_score = 0.f; dp->seqbias_nats = 0.f; dp->nregions = 0; dp->nenv = 0; }
+    if (L > 0 && L <= a.Lcap) {
+      for (int t = threadIdx.x; t < L; t += blockDim.x) { const int r = a.residues[off + t]; seq[t] = (uint8_t)(r < a.Kp ? r : a.Kp - 1); }
+      __syncthreads();
+      // ---------------- P1
+      const LenCfg cm = len_config(L, true);
+      float xC1; int ef1;
+      forward_wide<Q, false, NLT>(c, seq, L, cm, xC1, ef1);
+      const double fwd_nats = (double)ef1 * LOG2 + log((double)(xC1 * cm.move));
+      const float fwdsc = (float)fwd_nats;
+      const float p1 = (float)L / (float)(L + 1);
+      const float nullsc = (float)((double)(float)L * log((double)p1) + log(1.0 - (double)p1));
+      fwd_bits_out = (float)((fwd_nats - (double)nullsc) / LOG2);
+      if (dp) dp->fwd_bits = fwd_bits_out;
+      if (xC1 > 0.f && isfinite(fwdsc)) {
+        // ---------------- P2 + region scan (wave 0; the others wait)
+        backward_decode_wide<Q, NLT>(c, seq, L, cm, 1.0f / (xC1 * cm.move), ef1);
+        if (w == 0) {
+          const float rt1 = 0.25f, rt2 = 0.10f, rt3 = 0.20f;
+          int nenv = 0, nreg = 0, fl = 0, i0 = -1;
+          float btot = 0.f, etot = 0.f;
+          bool trig = false;
+          if (lane == 0) { spec[SP_J * SP] = 0.f; spec[SP_C * SP] = 0.f; }
+          for (int j = 1; j <= L; j++) {
+            const float mocc = 1.0f - spec[SP_N * SP + j];
+            const float bold = btot, eold = etot;
+            btot += spec[SP_B * SP + j - 1];
+            etot += spec[SP_E * SP + j];
+            if (lane == 0) { spec[SP_J * SP + j] = btot; spec[SP_C * SP + j] = etot; }
+            if (!trig) {
+              if (mocc - (btot - bold) < rt2) i0 = j;
+              else if (i0 == -1) i0 = j;
+              if (mocc >= rt1) trig = true;
+            } else if (mocc - (etot - eold) < rt2) {
+              if (nenv < WH_MAX_ENVELOPES) { if (lane == 0) { regs[2 * nenv] = i0; regs[2 * nenv + 1] = j; } nenv++; }
+              else fl |= WH_FLAG_TRUNC;
+              nreg++; i0 = -1; trig = false;
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+          int multi_mask = 0;
+          for (int e = 0; e < nenv; e++) {
+            const int ri = regs[2 * e], rj = regs[2 * e + 1];
+            float mx = -1.0f;
+            const float e0 = spec[SP_C * SP + ri - 1], bj = spec[SP_J * SP + rj];
+            for (int z = ri + lane; z <= rj; z += kWave) {
+              const float u = spec[SP_C * SP + z] - e0, v = bj - spec[SP_J * SP + z - 1];
+              mx = fmaxf(mx, fminf(u, v));
+            }
+            mx = wave_max(mx);
+            if (mx >= rt3) { fl |= WH_FLAG_MULTI; multi_mask |= 1 << e; }
+          }
+          if (lane == 0) { regs[2 * WH_MAX_ENVELOPES] = nenv; regs[2 * WH_MAX_ENVELOPES + 1] = nreg; regs[2 * WH_MAX_ENVELOPES + 2] = fl; regs[2 * WH_MAX_ENVELOPES + 3] = multi_mask; }
+        }
+        __syncthreads();
+        const int nenv = regs[2 * WH_MAX_ENVELOPES], nreg = regs[2 * WH_MAX_ENVELOPES + 1], multi_mask = regs[2 * WH_MAX_ENVELOPES + 3];
+        flags |= regs[2 * WH_MAX_ENVELOPES + 2];
+        if (dp) { dp->nregions = nreg; dp->nenv = nenv; }
+        if (nenv > 0) {
+          const LenCfg cu = len_config(L, false);
+          float seqbias_sum = 0.f, sum_score = 0.f, sb2 = 0.f;
+          int Ld_tot = 0;
+          const bool queue_pair = multi_mask != 0 && a.rrecs != nullptr;
+          float *envres = reinterpret_cast<float *>(regs + 3 * WH_MAX_ENVELOPES);
+          for (int e = 0; e < nenv; e++) {
+            if (queue_pair && ((multi_mask >> e) & 1)) { if (threadIdx.x == 0) { envres[e] = 0.f; envres[WH_MAX_ENVELOPES + e] = 0.f; } continue; }
+            const int ri = regs[2 * e], rj = regs[2 * e + 1];
+            const int Ld = rj - ri + 1;
+            const uint8_t *eseq = seq + (ri - 1);
+            float xC3; int ef3;
+            forward_wide<Q, true, NLT>(c, eseq, Ld, cu, xC3, ef3);
+            __threadfence_block();
+            const float envsc = (float)((double)ef3 * LOG2 + log((double)(xC3 * cu.move)));
+            float domcorr = 0.f;
+            if (xC3 > 0.f) domcorr = backward_null2_wide<Q, NLT>(c, eseq, Ld, cu, 1.0f / (xC3 * cu.move), n2tab, degen);
+            seqbias_sum += domcorr;
+            if (envsc - domcorr > 0.0f) { sum_score += envsc; Ld_tot += Ld; sb2 += domcorr; }
+            if (dp) { dp->env_i[e] = ri; dp->env_j[e] = rj; dp->envsc[e] = envsc; dp->domcorr[e] = domcorr; }
+            if (queue_pair && threadIdx.x == 0) { envres[e] = envsc; envres[WH_MAX_ENVELOPES + e] = domcorr; }
+          }
+          if (queue_pair) {
+            __syncthreads();
+            if (threadIdx.x == 0) {
+              const int slot = atomicAdd(a.rcount, 1);
+              if (slot < a.rcap) {
+                ResolveRec *rr = a.rrecs + slot;
+                rr->q = qi; rr->h = h; rr->fwdsc = fwdsc; rr->fwd_bits = fwd_bits_out; rr->nreg = nreg; rr->nenv = nenv;
+                rr->multi_mask = multi_mask; rr->flags = flags;
+                for (int e = 0; e < nenv; e++) { rr->ri[e] = regs[2 * e]; rr->rj[e] = regs[2 * e + 1]; rr->envsc[e] = envres[e]; rr->domcorr[e] = envres[WH_MAX_ENVELOPES + e]; }
+              }
+            }
+          } else {
+            // ---------------- A.6 score assembly (float32 where HMMER is float32), as in wh_score7.hip
+            const float lomega = (float)log(1.0 / 256.0);
+            const float seqbias = flogsum0_w(lomega + seqbias_sum);
+            float pre_score = (float)(((double)fwdsc - (double)nullsc) / LOG2);
+            float seq_score = (float)(((double)fwdsc - (double)(nullsc + seqbias)) / LOG2);
+            sb2 = flogsum0_w(lomega + sb2);
+            sum_score += (float)((double)(L - Ld_tot) * log((double)((float)L / (float)(L + 3))));
+            const float pre2 = (float)(((double)sum_score - (double)nullsc) / LOG2);
+            sum_score = (float)(((double)sum_score - (double)(nullsc + sb2)) / LOG2);
+            if (Ld_tot > 0 && sum_score > seq_score) { seq_score = sum_score; pre_score = pre2; flags |= WH_FLAG_OVERRIDE; }
+            decibits = (int)rint((double)seq_score * 10.0);
+            flags |= WH_FLAG_REPORTED;
+            if (dp) { dp->seq_score = seq_score; dp->pre_score = pre_score; dp->seqbias_nats = seqbias; }
+          }
+        }
+      }
+    }
+    if (threadIdx.x == 0) {
+      a.decibits[out] = decibits;
+      a.flags[out] = (uint8_t)flags;
+      if (a.fwd_bits) a.fwd_bits[out] = fwd_bits_out;
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace wide
+
+size_t wide_lds_bytes(int Lcap) {
+  const int SP = (Lcap + 1 + 3) / 4 * 4;
+  return (size_t)(4 + 6 * SP + 8 * wide::X_N + 32 + kRegsInts) * sizeof(float) + (size_t)(Lcap + 16);
+}
+
+template <int Q, int NLT>
+static hipError_t launch_wide_t(const WideArgs &a, int blocks, int waves, size_t lds, hipStream_t s) {
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&wide::score_wide_kernel<Q, NLT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (err != hipSuccess) return err;
+  hipLaunchKernelGGL((wide::score_wide_kernel<Q, NLT>), dim3(blocks), dim3(waves * 64), lds, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_score_wide(int Q, const WideArgs &a, int blocks, int waves, size_t lds, hipStream_t s) {
+  if (waves < 1 || waves > kWideWavesMax) return hipErrorInvalidValue;
+  if (Q == 4) return launch_wide_t<4, 0>(a, blocks, waves, lds, s);       // test hook (WH_FORCE_WIDE=4): any workgroup size
+  if (Q != kWideQ) return hipErrorInvalidValue;
+  switch (waves) {
+    case 3: return launch_wide_t<kWideQ, 192>(a, blocks, waves, lds, s);
+    case 4: return launch_wide_t<kWideQ, 256>(a, blocks, waves, lds, s);
+    case 5: return launch_wide_t<kWideQ, 320>(a, blocks, waves, lds, s);
+    case 6: return launch_wide_t<kWideQ, 384>(a, blocks, waves, lds, s);
+    case 7: return launch_wide_t<kWideQ, 448>(a, blocks, waves, lds, s);
+    case 8: return launch_wide_t<kWideQ, 512>(a, blocks, waves, lds, s);
+    default: return launch_wide_t<kWideQ, 0>(a, blocks, waves, lds, s);   // 1, 2 waves: WH_FORCE_WIDE=24 on small models
+  }
+}
+
+}  // namespace wh

@@ -332,18 +332,21 @@ def main():
             # plain v_fma_f32 the sweeps use reaches the same SIMD throughput on gfx950).
             # the dominant kernel = the launch class with the largest measured share of the scoring time (a mixed eHMM has
             # several: one launch per cells-per-lane class); its cells = the local residues x the nodes of ITS models
-            fam_names = {0: "wh::k7::score_kernel7", 1: "wh::score_big_kernel", 2: "wh::generic_front_kernel"}
+            fam_names = {0: "wh::k7::score_kernel7", 1: "wh::score_big_kernel", 2: "wh::generic_front_kernel", 3: "wh::wide::score_wide_kernel"}
             def cls_of(m):      # cells-per-lane class of a model (witch_amd/csrc/wh_hmm.cpp choose_Q: next multiple of 4)
                 return max(4, (-(-int(m) // 64) + 3) // 4 * 4)
             if class_ms:
                 (dom_q, dom_kind), (dom_ms, dom_n) = max(class_ms.items(), key=lambda kv: kv[1][0])
                 if dom_kind == 2:
                     dom_M = M[M > 3072]
+                elif dom_kind == 3:         # several waves per pair: the class key is cells per lane x waves (24 x W)
+                    dom_M = M[np.array([m > 3072 and -(-int(m) // 1536) * 24 == dom_q for m in M])]
                 else:
                     dom_M = M[np.array([cls_of(m) == dom_q for m in M])]
                 score_launches, score_ms = max(dom_n, 1), dom_ms / max(dom_n, 1)
                 cells_launch = float(lens_local.sum() * dom_M.sum()) * args.steps / score_launches
-                dom_name = "%s<%d cells per lane>" % (fam_names.get(dom_kind, "?"), dom_q) if dom_kind != 2 else fam_names[2]
+                dom_name = (fam_names[2] if dom_kind == 2 else "%s<24 cells per lane, %d waves per pair>" % (fam_names[3], dom_q // 24) if dom_kind == 3
+                            else "%s<%d cells per lane>" % (fam_names.get(dom_kind, "?"), dom_q))
                 dom_share = dom_ms / max(kern_ms[0], 1e-9)
             else:
                 score_launches = max(kern_n[0], 1)

@@ -158,7 +158,8 @@ int wh_consensus_dev(wh_ehmm *e, const int64_t *d_offsets, int64_t nq, int32_t m
 int wh_last_kernel_ms(wh_ehmm *e, int which, double *ms, int *launches);
 /* Timing mode only: the scoring launches of the last wh_score[_dev] call, in launch order - the cells-per-lane class of the
  * launch's models (16 = models of 961..1024 nodes ...), the kernel family (0 phase-call wh::k7::score_kernel7, 1
- * pass-synchronous wh::score_big_kernel, 2 any-size wh::generic_front_kernel) and its HIP-event duration.  Returns the number
+ * pass-synchronous wh::score_big_kernel, 2 any-size wh::generic_front_kernel, 3 several-waves-per-pair wh::wide::score_wide_kernel with
+ * cells_per_lane = 24 x waves) and its HIP-event duration.  Returns the number
  * of launches (the first <cap> are written); bench.py names the measured dominant kernel from it. */
 int wh_last_score_launches(wh_ehmm *e, int32_t *cells_per_lane, int32_t *kind, double *ms, int cap);
 /* When enabled, every kernel launch is bracketed by HIP events (bench/roofline use). */

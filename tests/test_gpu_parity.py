@@ -1487,3 +1487,38 @@ def test_consensus_with_twenty_models_on_a_20000_column_backbone():
         n_span = max(n_span, mx - mn + 1)
     assert n_span > 3000          # the DP really ran over thousands of columns
     e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cells_per_lane", [4, 24])
+def test_several_waves_per_pair_kernel_on_the_golden_cases(cells_per_lane, orc):
+    """wh_score_wide.hip (models of 3 073 - 12 288 nodes in production: several wavefronts per pair, the D scan and the
+    row sums crossing the waves through LDS) forced onto the golden cases (WH_FORCE_WIDE, read at wh_ehmm_load): with
+    4 cells per lane a 1 211-node model runs on 5 waves, with 24 on one - every workgroup size from 1 to 5 against the
+    oracle, Forward log-odds, flags and deci-bit scores (multidomain pairs through the same resolver queue)."""
+    _need_gpu()
+    from tests.conftest import load_case
+    from witch_amd.ehmm import EHMM, pack_queries
+    old = os.environ.get("WH_FORCE_WIDE")
+    os.environ["WH_FORCE_WIDE"] = str(cells_per_lane)
+    try:
+        for name in ("dna_synth", "dna_hmmbuild", "amino_hmmbuild", "example_sub30"):
+            case = load_case(name)
+            e = EHMM(case.hmm_paths, hmm_index=case.hmm_index, nseq=case.nseq)
+            seqs = [e.digitize(s_) for s_ in case.qseqs]
+            res, offs = pack_queries(seqs)
+            deci, flags, fwd = e.score(res, offs, want_fwd=True)
+            e.close()
+            ohm = [orc.OracleHMM(p) for p in case.hmm_paths]
+            od, of, ofwd, osc = orc.score_batch(ohm, res, offs)
+            fin = np.isfinite(ofwd)
+            assert np.max(np.abs(fwd[fin] - ofwd[fin])) <= 1e-4, (name, float(np.max(np.abs(fwd[fin] - ofwd[fin]))))
+            assert np.array_equal(flags & 7, of & 7), name
+            multi = (of & 2) != 0
+            _check_decibits(np.where(multi, od, deci), od, osc, (of & 1) == 1, name)
+            _check_decibits(np.where(multi, deci, od), od, osc, (of & 1) == 1, name + " (multidomain)", LONG_EPS)
+    finally:
+        if old is None:
+            os.environ.pop("WH_FORCE_WIDE", None)
+        else:
+            os.environ["WH_FORCE_WIDE"] = old

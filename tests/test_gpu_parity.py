@@ -1495,7 +1495,9 @@ def test_several_waves_per_pair_kernel_on_the_golden_cases(cells_per_lane, orc):
     """wh_score_wide.hip (models of 3 073 - 12 288 nodes in production: several wavefronts per pair, the D scan and the
     row sums crossing the waves through LDS) forced onto the golden cases (WH_FORCE_WIDE, read at wh_ehmm_load): with
     4 cells per lane a 1 211-node model runs on 5 waves, with 24 on one - every workgroup size from 1 to 5 against the
-    oracle, Forward log-odds, flags and deci-bit scores (multidomain pairs through the same resolver queue)."""
+    oracle, Forward log-odds, flags and deci-bit scores (multidomain pairs through the same resolver queue), and the
+    aligned columns of the several-waves-per-pair alignment kernel (pairs that leave float32 range are handed to the
+    float64 kernel, as in production)."""
     _need_gpu()
     from tests.conftest import load_case
     from witch_amd.ehmm import EHMM, pack_queries
@@ -1508,8 +1510,15 @@ def test_several_waves_per_pair_kernel_on_the_golden_cases(cells_per_lane, orc):
             seqs = [e.digitize(s_) for s_ in case.qseqs]
             res, offs = pack_queries(seqs)
             deci, flags, fwd = e.score(res, offs, want_fwd=True)
+            # ... and the several-waves-per-pair ALIGNMENT kernel: every query against the first two models
+            pq = [q for q in range(len(seqs)) for _ in range(min(2, e.H))]
+            ph = [h for _ in range(len(seqs)) for h in range(min(2, e.H))]
+            cols, co = e.align(res, offs, pq, ph)
             e.close()
             ohm = [orc.OracleHMM(p) for p in case.hmm_paths]
+            for p_ in range(len(pq)):
+                want = ohm[ph[p_]].align(seqs[pq[p_]])
+                assert np.array_equal(cols[co[p_]:co[p_ + 1]], want), (name, "alignment", pq[p_], ph[p_])
             od, of, ofwd, osc = orc.score_batch(ohm, res, offs)
             fin = np.isfinite(ofwd)
             assert np.max(np.abs(fwd[fin] - ofwd[fin])) <= 1e-4, (name, float(np.max(np.abs(fwd[fin] - ofwd[fin]))))

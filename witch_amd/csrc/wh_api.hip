@@ -62,6 +62,7 @@ struct Knobs {
   int max_waves = 0;         // cap on waves per workgroup (0 = planner's choice)
   bool force_specg = false;  // force the HBM special-state mode
   bool no_logspace = false;  // skip the log-space alignment pass
+  bool no_wide_align = false; // models beyond 3 072 nodes are aligned by the float64 kernel only (A/B and debugging)
   bool no_window = false;    // envelope Backward sweeps run full width (no node window; A/B and debugging)
   bool no_resolve = false;   // multidomain regions stay ONE envelope (round-1 behaviour) instead of HMMER's stochastic resolver
   bool stats = false, trace = false;
@@ -320,6 +321,7 @@ int wh_set_option(wh_ehmm *e, const char *name, const char *value) {
   else if (!strcmp(name, "WH_NO_LOGSPACE")) k.no_logspace = on;
   else if (!strcmp(name, "WH_NO_RESOLVE")) k.no_resolve = on;
   else if (!strcmp(name, "WH_NO_WINDOW")) k.no_window = on;
+  else if (!strcmp(name, "WH_NO_WIDE_ALIGN")) k.no_wide_align = on;
   else if (!strcmp(name, "WH_STATS")) k.stats = on;
   else if (!strcmp(name, "WH_TRACE")) k.trace = on;
   else if (!strcmp(name, "WH_DBG")) k.dbg = atoi(v);
@@ -329,7 +331,7 @@ int wh_set_option(wh_ehmm *e, const char *name, const char *value) {
 }
 
 static void knobs_from_env(wh_ehmm *e) {
-  for (const char *name : {"WH_SCORE_KERNEL", "WH_KEEP_LOG2", "WH_MAX_WAVES", "WH_FORCE_SPECG", "WH_NO_LOGSPACE", "WH_NO_RESOLVE", "WH_NO_WINDOW", "WH_STATS", "WH_TRACE", "WH_DBG", "WH_RDBG"})
+  for (const char *name : {"WH_SCORE_KERNEL", "WH_KEEP_LOG2", "WH_MAX_WAVES", "WH_FORCE_SPECG", "WH_NO_LOGSPACE", "WH_NO_RESOLVE", "WH_NO_WINDOW", "WH_NO_WIDE_ALIGN", "WH_STATS", "WH_TRACE", "WH_DBG", "WH_RDBG"})
     if (const char *v = getenv(name)) (void)wh_set_option(e, name, v);
 }
 
@@ -1116,10 +1118,61 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
   e->last_align_redo = n_redo;
   e->last_align_unaligned = 0;
   e->last_unaligned_pairs.clear();
-  if (!e->generic.empty()) {
+  if (!e->generic.empty() || e->force_wide) {
     // pairs on models of more than 3072 nodes: the any-size float64 alignment kernel, one wavefront per pair
     std::vector<int32_t> gitems;
-    for (int64_t p = 0; p < npairs; p++) if (e->dev[(size_t)ph[(size_t)p]].Q > kMaxQ) gitems.push_back((int32_t)p);
+    const int Lc0 = std::max(max_len, 1);
+    // models of 3 073 - 12 288 nodes: the several-waves-per-pair alignment kernel (wh_score_wide.hip); pairs that leave
+    // float32 range there, longer queries and larger models go to the float64 kernel below
+    const size_t walds = wide_align_lds_bytes(Lc0);
+    const bool use_wide = walds <= kLdsBudget && !e->wide_by_w.empty() && !e->knobs.no_wide_align;
+    std::map<int, std::vector<int32_t>> witems;
+    for (int64_t p = 0; p < npairs; p++) {
+      const DevHMM &dm = e->dev[(size_t)ph[(size_t)p]];
+      if (use_wide && dm.wideW > 0 && (dm.Q > kMaxQ || e->force_wide)) witems[dm.wideW].push_back((int32_t)p);
+      else if (dm.Q > kMaxQ) gitems.push_back((int32_t)p);
+    }
+    if (!witems.empty()) {
+      if (e->d_recs.ensure(sizeof(int32_t) * ((size_t)npairs + 4))) return WH_ENOMEM;
+      HIPCHK(hipMemsetAsync(e->d_recs.p, 0, sizeof(int32_t) * (size_t)npairs, s));
+      size_t ooff = 0;
+      std::vector<int32_t> all;
+      for (auto &kv : witems) all.insert(all.end(), kv.second.begin(), kv.second.end());
+      if (e->d_order.ensure(sizeof(int32_t) * (all.size() + (size_t)npairs))) return WH_ENOMEM;
+      HIPCHK(hipMemcpyAsync(e->d_order.p, all.data(), sizeof(int32_t) * all.size(), hipMemcpyHostToDevice, s));
+      for (auto &kv : witems) {
+        const int W = kv.first;
+        WideAlignArgs wa;
+        memset(&wa, 0, sizeof wa);
+        wa.hmms = (const DevHMM *)e->d_hmms.p; wa.tables = (const float *)e->d_tables.p;
+        wa.residues = d_residues; wa.offsets = d_offsets;
+        wa.items = (const int32_t *)e->d_order.p + ooff; wa.n_items = (int)kv.second.size();
+        ooff += kv.second.size();
+        wa.pair_q = d_pair_q; wa.pair_h = d_pair_h; wa.col_off = d_col_offsets; wa.cols = d_cols;
+        wa.status = (int32_t *)e->d_recs.p;
+        wa.counter = (int *)e->d_counter.p + 80 + W;
+        wa.Lcap = Lc0; wa.SP = (Lc0 + 1 + 3) / 4 * 4;
+        wa.K = e->K; wa.Kp = e->Kp;
+        wa.scratch_stride = (size_t)(Lc0 + 1) * 5 * e->wide_q * W * kWave;
+        int blocks = (int)std::min<size_t>(kv.second.size(), (size_t)e->cu_count);
+        blocks = clamp_blocks(blocks, wa.scratch_stride * sizeof(float), e->d_wscratch);
+        if (e->d_wscratch.ensure((size_t)blocks * wa.scratch_stride * sizeof(float))) return WH_ENOMEM;
+        wa.scratch = (float *)e->d_wscratch.p;
+        HIPCHK(hipMemsetAsync(wa.counter, 0, sizeof(int), s));
+        if (e->knobs.trace) fprintf(stderr, "[wh] wide alignment: %zu pairs, %d waves per pair, %d workgroups, lds %zu, slab %zu MB per workgroup\n", kv.second.size(), W, blocks, walds, wa.scratch_stride * 4 >> 20);
+        hipError_t werr = launch_align_wide(e->wide_q, wa, blocks, W, walds, s);
+        if (werr != hipSuccess) { set_error("wide alignment kernel launch failed: %s", hipGetErrorString(werr)); return WH_EHIP; }
+        launches++;
+      }
+      std::vector<int32_t> wst((size_t)npairs);
+      HIPCHK(hipMemcpyAsync(wst.data(), e->d_recs.p, sizeof(int32_t) * wst.size(), hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
+      int n_hand = 0;
+      for (size_t p = 0; p < wst.size(); p++) if (wst[p] == 1) { gitems.push_back((int32_t)p); n_hand++; }
+      std::sort(gitems.begin(), gitems.end());
+      e->last_align_redo += n_hand;
+      if (e->knobs.trace && n_hand) fprintf(stderr, "[wh] wide alignment: %d pairs left float32 range, handed to the float64 kernel\n", n_hand);
+    }
     if (!gitems.empty()) {
       const int Lc = std::max(max_len, 1);
       GenericAlignArgs g;

@@ -122,6 +122,26 @@ struct WideArgs {
   int rcap;
   const int32_t *qorder;
 };
+struct WideAlignArgs {
+  const DevHMM *hmms;
+  const float *tables;
+  const uint8_t *residues;
+  const int64_t *offsets;
+  const int32_t *items;        // pair indices served by this launch (models with the same wideW)
+  int n_items;
+  const int64_t *pair_q;
+  const int32_t *pair_h;
+  const int64_t *col_off;
+  int32_t *cols;
+  int32_t *status;             // per pair: set to 1 when the pair left float32 range (the float64 kernel then redoes it)
+  int *counter;
+  int Lcap, SP;
+  float *scratch;              // per workgroup: Forward/posterior rows, then OA rows
+  size_t scratch_stride;       // floats per workgroup
+  int K, Kp;
+};
+size_t wide_align_lds_bytes(int Lcap);
+hipError_t launch_align_wide(int Q, const WideAlignArgs &a, int blocks, int waves, size_t lds, hipStream_t s);
 size_t wide_lds_bytes(int Lcap);
 hipError_t launch_score_wide(int Q, const WideArgs &a, int blocks, int waves, size_t lds, hipStream_t s);
 

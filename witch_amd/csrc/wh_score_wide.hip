@@ -632,7 +632,374 @@ __global__ __launch_bounds__(512) void score_wide_kernel(WideArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------ alignment (A.7)
+// "hmmalign" for the models this file serves: the chain of wh_align.hip (unihit Forward with dense rows -> Backward +
+// posterior decoding in place -> optimal-accuracy fill -> traceback with HMMER's candidate orders and striped E-state
+// scan) with the rows split over the workgroup's waves like the scoring sweeps above.  Pairs that leave float32 range
+// (clamp_backward fires: hmmalign itself switches to its log-space code there) are handed to the float64 any-size
+// kernel through <status>; so is nothing else - a pair either gets its columns here or is redone there.
+enum { WA_PN = 0, WA_B, WA_E, WA_PJ, WA_PC, WA_S, WA_ON, WA_OB, WA_OE, WA_OJ, WA_OC, WA_NARR };
+
+__device__ __forceinline__ float gate_w(float t, float v) { return t > 0.f ? v : 0.f; }
+__device__ __forceinline__ float scan_apply_max_w(const ScanC &c, float B) {
+  B = fmaxf(B, c.s[0] * dppf<0x111>(0.f, B));
+  B = fmaxf(B, c.s[1] * dppf<0x112>(0.f, B));
+  B = fmaxf(B, c.s[2] * dppf<0x114>(0.f, B));
+  B = fmaxf(B, c.s[3] * dppf<0x118>(0.f, B));
+  B = fmaxf(B, c.s[4] * dppf<0x142, 0xA>(0.f, B));
+  B = fmaxf(B, c.s[5] * dppf<0x143, 0xC>(0.f, B));
+  return B;
+}
+__device__ __forceinline__ int wave_max_i32_w(int x) { for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(x, m); x = o > x ? o : x; } return x; }
+
+template <int Q, int NLT>
+__global__ __launch_bounds__(512) void align_wide_kernel(WideAlignArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), W = blockDim.x >> 6;
+  const int NL = NLT > 0 ? NLT : W * 64, SP = a.SP, vl = w * 64 + lane;
+  constexpr int Q4 = Q / 4;
+  volatile int *s_item = reinterpret_cast<volatile int *>(smem);
+  float *spec = smem + 4;                               // WA_NARR arrays of SP floats
+  float *xch = spec + WA_NARR * SP;                     // W x X_N
+  uint8_t *seq = reinterpret_cast<uint8_t *>(xch + 8 * X_N);
+  WCtxT<NLT> c;
+  c.spec = spec; c.xch = xch; c.NLr = NL; c.SP = SP; c.w = w; c.W = W; c.lane = lane; c.K = a.K; c.Kp = a.Kp; c.vl = vl;
+  gf4 *slabA = const_cast<gf4 *>(uniform_global(a.scratch + (size_t)blockIdx.x * a.scratch_stride));      // F -> posteriors: [row][2][Q4][NL]
+  gf4 *slabB = slabA + (size_t)(a.Lcap + 1) * 2 * Q4 * NL;                                                 // OA rows: [row][3][Q4][NL]
+  c.Fs = slabA;
+  const int rv = NL - 1 - vl;
+
+  for (;;) {
+    if (threadIdx.x == 0) *s_item = atomicAdd(a.counter, 1);
+    __syncthreads();
+    const int item = *s_item;
+    __syncthreads();
+    if (item >= a.n_items) break;
+    const int pair = a.items[item];
+    const int h = a.pair_h[pair];
+    const int64_t qi = a.pair_q[pair];
+    const DevHMM *hm = a.hmms + h;
+    const int M = hm->M;
+    c.fw = uniform_global(a.tables + hm->wfw_off);
+    c.bw = uniform_global(a.tables + hm->wbw_off);
+    c.em = uniform_global(a.tables + hm->wem_off);
+    const float *fwG = a.tables + hm->wfw_off;
+    const int64_t off = a.offsets[qi];
+    const int L = (int)(a.offsets[qi + 1] - off);
+    int32_t *cols = a.cols + a.col_off[pair];
+    for (int t = threadIdx.x; t < L; t += blockDim.x) cols[t] = -1;
+    bool active = L > 0 && L <= a.Lcap;
+    for (int t = threadIdx.x; active && t < L; t += blockDim.x) { const int r = a.residues[off + t]; seq[t] = (uint8_t)(r < a.Kp ? r : a.Kp - 1); }
+    __syncthreads();
+    const LenCfg cu = len_config(L > 0 ? L : 1, false);
+    // ---------------- unihit Forward, rows to slab A (spec slots 0..5 = N, B, E, J, C, S)
+    float xC_L = 0.f; int ef_L = 0;
+    if (active) forward_wide<Q, true, NLT>(c, seq, L, cu, xC_L, ef_L);
+    __threadfence_block();
+    if (!(xC_L > 0.f)) active = false;
+    bool clamped = false;
+    // ---------------- Backward + posterior decoding, in place over slab A
+    if (active) {
+      const float invZ = 1.0f / (xC_L * cu.move);
+      ScanC sc;
+      float Aexcl;
+      backward_prepare_wide<Q, NLT>(c, sc, Aexcl);
+      float Mb[Q], Ib[Q];
+#pragma unroll
+      for (int p = 0; p < Q; p++) { Mb[p] = 0.f; Ib[p] = 0.f; }
+      float xC = cu.move, xJ = 0.f, xN = 0.f, xB = 0.f;
+#pragma unroll 1
+      for (int i = L; i >= 1; i--) {
+        gf4 *row = slabA + (size_t)i * (2 * Q4) * NL;
+        const int nlr = opaque_s(NL);
+        float4 fm4[Q4], fi4[Q4];
+#pragma unroll
+        for (int p4 = 0; p4 < Q4; p4++) { fm4[p4] = ldt(row, Q4 - 1 - p4, nlr, (unsigned)rv); fi4[p4] = ldt(row, Q4 + Q4 - 1 - p4, nlr, (unsigned)rv); }
+        float gfront = 0.f;
+        if (i < L) {
+          mirror_scale<Q>(reinterpret_cast<const int *>(spec)[WA_S * SP + i + 1] - reinterpret_cast<const int *>(spec)[WA_S * SP + i], Mb, Ib, xJ, xC, xN);
+          xB = backward_emit_wide<Q, NLT>(c, __builtin_amdgcn_readfirstlane((int)seq[i]), Mb, gfront);
+          xJ = fmaf(xJ, cu.loop, xB * cu.move);
+          xC = xC * cu.loop;
+          xN = fmaf(xN, cu.loop, xB * cu.move);
+        }
+        const float xE = fmaf(xC, cu.EC, xJ * cu.EJ);
+        backward_cells_wide<Q, NLT>(c, sc, Aexcl, Mb, Ib, xE, gfront);
+        clamped |= clamp_backward<Q>(Mb, Ib, xB, xJ, xC, xN);
+        const float s_i = invZ;
+        const float s_p = ldexpf(invZ, reinterpret_cast<const int *>(spec)[WA_S * SP + i - 1] - reinterpret_cast<const int *>(spec)[WA_S * SP + i]);
+#pragma unroll
+        for (int p4 = 0; p4 < Q4; p4++) {
+          // position 4*p4+j (reversed order) is component 3-j of the forward-ordered vector
+          const wv4 pm = {(fm4[p4].x * Mb[4 * p4 + 3]) * s_i, (fm4[p4].y * Mb[4 * p4 + 2]) * s_i, (fm4[p4].z * Mb[4 * p4 + 1]) * s_i, (fm4[p4].w * Mb[4 * p4 + 0]) * s_i};
+          const wv4 pi = {(fi4[p4].x * Ib[4 * p4 + 3]) * s_i, (fi4[p4].y * Ib[4 * p4 + 2]) * s_i, (fi4[p4].z * Ib[4 * p4 + 1]) * s_i, (fi4[p4].w * Ib[4 * p4 + 0]) * s_i};
+          row[(unsigned)((Q4 - 1 - p4) * NL + rv)] = pm;
+          row[(unsigned)((Q4 + Q4 - 1 - p4) * NL + rv)] = pi;
+        }
+        const float pn = spec[WA_PN * SP + i - 1] * xN * cu.loop * s_p;
+        const float pj = spec[WA_PJ * SP + i - 1] * xJ * cu.loop * s_p;
+        const float pc = spec[WA_PC * SP + i - 1] * xC * cu.loop * s_p;
+        if (w == 0 && lane == 0) { spec[WA_PN * SP + i] = pn; spec[WA_PJ * SP + i] = pj; spec[WA_PC * SP + i] = pc; }
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (clamped) active = false;                        // float32 range left: the float64 kernel redoes the pair
+    if (clamped && threadIdx.x == 0) a.status[pair] = 1;
+    // ---------------- optimal-accuracy fill, rows to slab B
+    const float tNl = cu.loop > 0.f ? 1.f : 0.f, tNm = cu.move > 0.f ? 1.f : 0.f;
+    const float tEJ = cu.EJ > 0.f ? 1.f : 0.f, tEC = cu.EC > 0.f ? 1.f : 0.f;
+    if (active) {
+      int nlv = NL;
+      auto T = [&](int arr, int q4) -> float4 { return ldt(c.fw, arr * Q4 + q4, nlv, (unsigned)vl); };
+      float allpass = 1.f;
+#pragma unroll
+      for (int q4 = 0; q4 < Q4; q4++) { const float4 d = T(FW_D2, q4); if (!(d.x > 0.f && d.y > 0.f && d.z > 0.f && d.w > 0.f)) allpass = 0.f; }
+      const ScanC sc = scan_prepare(allpass);
+      const float Gincl = lane_prefix_product(allpass, lane);
+      float Gexcl = __shfl_up(Gincl, 1);
+      if (lane == 0) Gexcl = 1.f;
+      if (lane == 63) xch[w * X_N + X_AT] = Gincl;
+      float Mp[Q], Ip[Q], Dp[Q];
+#pragma unroll
+      for (int q = 0; q < Q; q++) { Mp[q] = -INFINITY; Ip[q] = -INFINITY; Dp[q] = -INFINITY; }
+      float oN = 0.f, oB = 0.f, oJ = -INFINITY, oC = -INFINITY;
+      float bM = -INFINITY, bI = -INFINITY, bD = -INFINITY;     // previous row, last cell of the wave in front
+      if (w == 0 && lane == 0) {
+        spec[WA_ON * SP] = 0.f; spec[WA_OB * SP] = 0.f; spec[WA_OE * SP] = -INFINITY; spec[WA_OJ * SP] = -INFINITY; spec[WA_OC * SP] = -INFINITY;
+      }
+      __syncthreads();
+#pragma unroll 1
+      for (int i = 1; i <= L; i++) {
+        nlv = opaque_s(NL);
+        const gf4 *prow = slabA + (size_t)i * (2 * Q4) * NL;
+        float mm1 = wave_shr1(Mp[Q - 1]), im1 = wave_shr1(Ip[Q - 1]), dm1 = wave_shr1(Dp[Q - 1]);
+        // (wave_shr1 hands lane 0 a ZERO: the one-wave kernel's first lane sees 0 there too, not -inf)
+        if (lane == 0 && w > 0) { mm1 = bM; im1 = bI; dm1 = bD; }
+#pragma unroll
+        for (int q4 = Q4 - 1; q4 >= 0; q4--) {
+          const float4 A = T(FW_A, q4), B = T(FW_B, q4), C = T(FW_C, q4), E = T(FW_E, q4);
+          const float4 MI = T(FW_MI, q4), II = T(FW_II, q4);
+          const float4 pm4 = ldt(prow, q4, nlv, (unsigned)vl), pi4 = ldt(prow, Q4 + q4, nlv, (unsigned)vl);
+#pragma unroll
+          for (int j = 3; j >= 0; j--) {
+            const int q = 4 * q4 + j;
+            const float pm = q > 0 ? Mp[q > 0 ? q - 1 : 0] : mm1;
+            const float pi_ = q > 0 ? Ip[q > 0 ? q - 1 : 0] : im1;
+            const float pd = q > 0 ? Dp[q > 0 ? q - 1 : 0] : dm1;
+            float sv = gate_w(f4get(E, j), oB);
+            sv = fmaxf(sv, gate_w(f4get(A, j), pm));
+            sv = fmaxf(sv, gate_w(f4get(B, j), pi_));
+            sv = fmaxf(sv, gate_w(f4get(C, j), pd));
+            const float ni = fmaxf(gate_w(f4get(MI, j), Mp[q]), gate_w(f4get(II, j), Ip[q])) + f4get(pi4, j);
+            Mp[q] = sv + f4get(pm4, j);
+            Ip[q] = ni;
+          }
+        }
+        if (lane == 63) xch[w * X_N + X_T0] = Mp[Q - 1];
+        __syncthreads();                                                          // #0
+        float mn1 = wave_shr1(Mp[Q - 1]);
+        if (lane == 0 && w > 0) mn1 = xch[(w - 1) * X_N + X_T0];
+        float dprev = 0.f;
+#pragma unroll
+        for (int q4 = 0; q4 < Q4; q4++) {
+          const float4 D1 = T(FW_D1, q4), D2 = T(FW_D2, q4);
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const int q = 4 * q4 + j;
+            const float src = q > 0 ? Mp[q > 0 ? q - 1 : 0] : mn1;
+            dprev = fmaxf(gate_w(f4get(D1, j), src), gate_w(f4get(D2, j), dprev));
+            Dp[q] = dprev;
+          }
+        }
+        const float loc = scan_apply_max_w(sc, dprev);
+        if (lane == 63) xch[w * X_N + X_BD] = loc;
+        __syncthreads();                                                          // #1
+        float cin = 0.f;                               // D of the last cell in front of my wave (0 in front of the first wave, as wave_shr1 gives)
+        for (int v = 0; v < w; v++) cin = fmaxf(xch[v * X_N + X_BD], xch[v * X_N + X_AT] * cin);
+        float carry = wave_shr1(loc);
+        if (w > 0) carry = lane == 0 ? cin : fmaxf(carry, Gexcl * cin);
+        float rowmax = -INFINITY;
+#pragma unroll
+        for (int q4 = 0; q4 < Q4; q4++) {
+          const float4 D2 = T(FW_D2, q4);
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const int q = 4 * q4 + j;
+            carry = gate_w(f4get(D2, j), carry);
+            Dp[q] = fmaxf(Dp[q], carry);
+            if (vl * Q + q < M) rowmax = fmaxf(rowmax, fmaxf(Mp[q], Dp[q]));
+          }
+        }
+        const float rmw = wave_max(rowmax);
+        if (lane == 63) { xch[w * X_N + X_ES] = rmw; xch[w * X_N + X_BM] = Mp[Q - 1]; xch[w * X_N + X_BI] = Ip[Q - 1]; xch[w * X_N + X_BDD] = Dp[Q - 1]; }
+        __syncthreads();                                                          // #2
+        float xE = -INFINITY;
+        for (int v = 0; v < W; v++) xE = fmaxf(xE, xch[v * X_N + X_ES]);
+        if (w > 0) { bM = xch[(w - 1) * X_N + X_BM]; bI = xch[(w - 1) * X_N + X_BI]; bD = xch[(w - 1) * X_N + X_BDD]; }
+        {
+          const float a1 = tNl * (oJ + spec[WA_PJ * SP + i]), b1 = tEJ * xE;
+          oJ = a1 > b1 ? a1 : b1;
+          const float a2 = tNl * (oC + spec[WA_PC * SP + i]), b2 = tEC * xE;
+          oC = a2 > b2 ? a2 : b2;
+          oN = tNl * (oN + spec[WA_PN * SP + i]);
+          const float a3 = tNm * oN, b3 = tNm * oJ;
+          oB = a3 > b3 ? a3 : b3;
+        }
+        if (w == 0 && lane == 0) {
+          spec[WA_ON * SP + i] = oN; spec[WA_OB * SP + i] = oB; spec[WA_OE * SP + i] = xE; spec[WA_OJ * SP + i] = oJ; spec[WA_OC * SP + i] = oC;
+        }
+        gf4 *orow = slabB + (size_t)i * (3 * Q4) * NL;
+#pragma unroll
+        for (int q4 = 0; q4 < Q4; q4++) {
+          const wv4 vm = {Mp[4 * q4], Mp[4 * q4 + 1], Mp[4 * q4 + 2], Mp[4 * q4 + 3]};
+          const wv4 vi = {Ip[4 * q4], Ip[4 * q4 + 1], Ip[4 * q4 + 2], Ip[4 * q4 + 3]};
+          const wv4 vd = {Dp[4 * q4], Dp[4 * q4 + 1], Dp[4 * q4 + 2], Dp[4 * q4 + 3]};
+          orow[(unsigned)(q4 * NL + vl)] = vm;
+          orow[(unsigned)((Q4 + q4) * NL + vl)] = vi;
+          orow[(unsigned)((2 * Q4 + q4) * NL + vl)] = vd;
+        }
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---------------- traceback by the first wave: first maximum wins, candidate orders as in SURVEY.md A.7
+    if (active && w == 0) {
+      const float *sB = reinterpret_cast<const float *>((const void *)slabB);
+      auto cellB = [&](int row, int st, int k) -> float {      // OA cell (row, state, node k >= 1)
+        const int pos = k - 1, ln = pos / Q, q = pos % Q;
+        return __builtin_nontemporal_load(sB + (((size_t)(row * 3 + st) * Q4 + q / 4) * NL + ln) * 4 + (q % 4));
+      };
+      auto tabF = [&](int arr, int k) -> float {
+        const int pos = k - 1, ln = pos / Q, q = pos % Q;
+        return fwG[(((size_t)arr * Q4 + q / 4) * NL + ln) * 4 + (q % 4)];
+      };
+      enum { stS, stN, stB, stM, stI, stD, stE, stJ, stC };
+      int s0 = stC, s1 = stS, i = L, k = 0;
+      int guard = 4 * (L + M) + 16;
+      const int Qh = (M - 1) / 4 + 1 < 2 ? 2 : (M - 1) / 4 + 1;   // HMMER's SSE stripe count
+      while (s0 != stS && guard-- > 0) {
+        switch (s0) {
+          case stC: {
+            const float av = tNl * (spec[WA_OC * SP + i - 1] + spec[WA_PC * SP + i]), bv = tEC * spec[WA_OE * SP + i];
+            s1 = bv > av ? stE : stC;
+            break;
+          }
+          case stJ: {
+            const float av = tNl * (spec[WA_OJ * SP + i - 1] + spec[WA_PJ * SP + i]), bv = tEJ * spec[WA_OE * SP + i];
+            s1 = bv > av ? stE : stJ;
+            break;
+          }
+          case stE: {
+            // argmax over M (">=": the later cell in HMMER's striped scan wins) and D (">"), over the slices of all waves
+            const float vmax = spec[WA_OE * SP + i];        // the row maximum the fill recorded (same comparisons, same values)
+            int bestM = -1, bestD = -1;
+            for (int v = 0; v < W; v++) {
+              const gf4 *orow = slabB + (size_t)i * (3 * Q4) * NL;
+#pragma unroll
+              for (int q4 = 0; q4 < Q4; q4++) {
+                const float4 m4 = ldg4(orow, (unsigned)(q4 * NL + v * 64 + lane)), d4 = ldg4(orow, (unsigned)((2 * Q4 + q4) * NL + v * 64 + lane));
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                  const int kk = (v * 64 + lane) * Q + 4 * q4 + j + 1;
+                  if (kk <= M) {
+                    const int qh = (kk - 1) % Qh, rh = (kk - 1) / Qh;
+                    if (f4get(m4, j) == vmax) { const int pos = qh * 8 + rh; bestM = pos > bestM ? pos : bestM; }
+                    if (f4get(d4, j) == vmax) { const int pos = 0x3FFFFFFF - (qh * 8 + 4 + rh); bestD = pos > bestD ? pos : bestD; }
+                  }
+                }
+              }
+            }
+            bestM = wave_max_i32_w(bestM);
+            bestD = wave_max_i32_w(bestD);
+            int pos;
+            if (bestM >= 0) { pos = bestM; s1 = stM; }
+            else { pos = 0x3FFFFFFF - bestD; s1 = stD; }
+            k = (pos % 8 % 4) * Qh + pos / 8 + 1;
+            break;
+          }
+          case stM: {
+            float path[4];
+            path[0] = gate_w(tabF(FW_E, k), spec[WA_OB * SP + i - 1]);
+            if (i > 1 && k > 1) {
+              path[1] = gate_w(tabF(FW_A, k), cellB(i - 1, 0, k - 1));
+              path[2] = gate_w(tabF(FW_B, k), cellB(i - 1, 1, k - 1));
+              path[3] = gate_w(tabF(FW_C, k), cellB(i - 1, 2, k - 1));
+            } else if (k > 1) {
+              path[1] = gate_w(tabF(FW_A, k), -INFINITY);
+              path[2] = gate_w(tabF(FW_B, k), -INFINITY);
+              path[3] = gate_w(tabF(FW_C, k), -INFINITY);
+            } else { path[1] = 0.f; path[2] = 0.f; path[3] = 0.f; }
+            int best = 0;
+            if (path[1] > path[best]) best = 1;
+            if (path[2] > path[best]) best = 2;
+            if (path[3] > path[best]) best = 3;
+            s1 = best == 0 ? stB : best == 1 ? stM : best == 2 ? stI : stD;
+            if (lane == 0) cols[i - 1] = k - 1;
+            k--; i--;
+            break;
+          }
+          case stD: {
+            const float av = k > 1 ? gate_w(tabF(FW_D1, k), cellB(i, 0, k - 1)) : 0.f;
+            const float bv = k > 1 ? gate_w(tabF(FW_D2, k), cellB(i, 2, k - 1)) : 0.f;
+            s1 = bv > av ? stD : stM;
+            k--;
+            break;
+          }
+          case stI: {
+            const float pmv = i > 1 ? cellB(i - 1, 0, k) : -INFINITY;
+            const float piv = i > 1 ? cellB(i - 1, 1, k) : -INFINITY;
+            const float av = gate_w(tabF(FW_MI, k), pmv), bv = gate_w(tabF(FW_II, k), piv);
+            s1 = bv > av ? stI : stM;
+            i--;
+            break;
+          }
+          case stB: {
+            const float av = tNm * spec[WA_ON * SP + i], bv = tNm * spec[WA_OJ * SP + i];
+            s1 = bv > av ? stJ : stN;
+            break;
+          }
+          case stN: s1 = i == 0 ? stS : stN; break;
+          default: s1 = stS; break;
+        }
+        if ((s1 == stN || s1 == stJ || s1 == stC) && s1 == s0) i--;
+        if (i < 0 || k < 0 || (s1 == stM && (k < 1 || i < 1)) || ((s1 == stC || s1 == stJ) && i < 1)) break;   // defensive
+        s0 = s1;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace wide
+
+size_t wide_align_lds_bytes(int Lcap) {
+  const int SP = (Lcap + 1 + 3) / 4 * 4;
+  return (size_t)(4 + wide::WA_NARR * SP + 8 * wide::X_N) * sizeof(float) + (size_t)(Lcap + 16);
+}
+
+template <int Q, int NLT>
+static hipError_t launch_walign_t(const WideAlignArgs &a, int blocks, int waves, size_t lds, hipStream_t s) {
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&wide::align_wide_kernel<Q, NLT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (err != hipSuccess) return err;
+  hipLaunchKernelGGL((wide::align_wide_kernel<Q, NLT>), dim3(blocks), dim3(waves * 64), lds, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_align_wide(int Q, const WideAlignArgs &a, int blocks, int waves, size_t lds, hipStream_t s) {
+  if (waves < 1 || waves > kWideWavesMax) return hipErrorInvalidValue;
+  if (Q == 4) return launch_walign_t<4, 0>(a, blocks, waves, lds, s);
+  if (Q != kWideQ) return hipErrorInvalidValue;
+  switch (waves) {
+    case 3: return launch_walign_t<kWideQ, 192>(a, blocks, waves, lds, s);
+    case 4: return launch_walign_t<kWideQ, 256>(a, blocks, waves, lds, s);
+    case 5: return launch_walign_t<kWideQ, 320>(a, blocks, waves, lds, s);
+    case 6: return launch_walign_t<kWideQ, 384>(a, blocks, waves, lds, s);
+    case 7: return launch_walign_t<kWideQ, 448>(a, blocks, waves, lds, s);
+    case 8: return launch_walign_t<kWideQ, 512>(a, blocks, waves, lds, s);
+    default: return launch_walign_t<kWideQ, 0>(a, blocks, waves, lds, s);
+  }
+}
 
 size_t wide_lds_bytes(int Lcap) {
   const int SP = (Lcap + 1 + 3) / 4 * 4;

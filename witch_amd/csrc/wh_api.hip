@@ -780,6 +780,15 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       }
       const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)resolve_waves_per_cu(), kLdsBudget / rlds));
       int blocks = std::min(n_multi, e->cu_count * per_cu);
+      {
+        // Every resident wavefront brings a slab of tens of MB, and hipMalloc costs ~40 ms per GB: a queue of a few thousand
+        // pairs (the reference's example data: 8 412) spent 2.4 s allocating 55 GB for 0.12 s of work.  Unless the slabs exist
+        // already, a wave gets at least four pairs (the queue is handed out longest first, so the tail stays short).  (The cost is the
+        // driver scrubbing VRAM that another process used before: on a fresh device the same allocation takes milliseconds.)
+        const size_t have = std::min(e->d_rmx.cap / (r.mx_stride * sizeof(double)), e->d_rsegs.cap / std::max<size_t>(1, r.seg_stride * sizeof(int32_t)));
+        const int economy = std::max(256, n_multi / 4);
+        if ((size_t)blocks > have) blocks = std::max((int)std::min<size_t>(have, (size_t)blocks), std::min(blocks, economy));
+      }
       blocks = clamp_blocks(blocks, r.mx_stride * sizeof(double) + r.seg_stride * sizeof(int32_t), e->d_rmx);
       if (e->d_rmx.ensure((size_t)blocks * r.mx_stride * sizeof(double)) || e->d_rsegs.ensure((size_t)blocks * r.seg_stride * sizeof(int32_t)))
         return WH_ENOMEM;

@@ -664,6 +664,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       }
     }
     wide_done = wlds <= kLdsBudget;
+    if (!wide_done && e->force_wide) { set_error("WH_FORCE_WIDE: query length %d does not fit the wide kernel's LDS block", max_len); return WH_ERANGE; }
   }
   if (nq > 0 && (!e->generic_front.empty() || (!wide_done && !e->wide_by_w.empty() && !e->force_wide))) {
     // ---- models of more than 3072 nodes: the any-size float64 front end (wh_generic.hip), one wavefront per pair;

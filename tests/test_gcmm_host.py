@@ -312,3 +312,24 @@ def test_checkpoint_file_against_the_reference_writer_and_reader(tmp_path):
         t = next(iter(q))
         assert got[t][0] == q[t]
         assert got[t][1] == q._col_labels
+
+
+def test_engine_rejects_an_unknown_multidomain_policy():
+    """QueryAlignmentEngine.run validates multidomain_policy before any GPU work (a typo used to select the resolver)."""
+    with pytest.raises(ValueError, match="multidomain_policy"):
+        gcmm.QueryAlignmentEngine.run({}, [], 3, multidomain_policy="envelop")
+    with pytest.raises(ValueError, match="multidomain_policy"):
+        gcmm.QueryAlignmentEngine.run({}, [], 3, multidomain_policy="")
+
+
+def test_weights_reader_accepts_both_number_forms(tmp_path):
+    """weights.txt as numpy 1 wrote it (plain numbers) and as numpy 2 writes it (np.float64(...)), incl. a one-model tuple,
+    an empty tuple and a taxon with a colon in its name."""
+    p = tmp_path / "w.txt"
+    p.write_text("a:((3, 0.75), (1, 0.25))\n"
+                 "b:((7, np.float64(1.0)),)\n"
+                 "c:()\n"
+                 "ns:x:((2, np.float64(0.5)), (0, numpy.float64(0.5)))\n")
+    w = gcmm.readWeightsFromLocal(str(p))
+    assert w["a"] == ((3, 0.75), (1, 0.25)) and w["b"] == ((7, 1.0),) and w["c"] == () and w["ns:x"] == ((2, 0.5), (0, 0.5))
+    assert all(isinstance(x[1], np.float64) for v in w.values() for x in v)

@@ -50,6 +50,413 @@ __device__ __forceinline__ float tab_load(const float *tab, int arr, int k) {
 #define SPR(idx)  (SPECG ? __builtin_nontemporal_load(spec + (idx)) : spec[idx])
 #define SPRI(idx) (SPECG ? __builtin_nontemporal_load(reinterpret_cast<const int *>(spec) + (idx)) : reinterpret_cast<const int *>(spec)[idx])
 
+// ------------------------------------------------------------------ OA traceback
+// First maximum wins, candidate orders as in SURVEY.md A.7.  Shared by the full-width passes and the node window:
+// <oa(row, state, k)> reads an OA cell, <tab(arr, k)> a forward-orientation transition gate, <estate(i, s1, k)>
+// resolves the E state of row i (argmax over the row in HMMER's striped scan order).  PJ / PC: the special-state
+// arrays that hold the posteriors of J and C.
+// A path mostly runs along a diagonal (M -> M): lane t evaluates the choice at cell (i - t, k - t), a ballot finds
+// the first cell whose choice is not M, and the run up to it is consumed at once - one memory round trip per run
+// instead of one per residue.  Same comparisons in the same order: the path is the serial walk's.
+template <bool SPECG, int PJ, int PC, class OA, class TAB, class EST>
+__device__ __forceinline__ void oa_traceback(float *spec, int SP, int L, int M, int lane, int32_t *cols, float tNl, float tNm,
+                                             float tEJ, float tEC, OA oa, TAB tab, EST estate) {
+  enum { stS, stN, stB, stM, stI, stD, stE, stJ, stC };
+  int s0 = stC, s1 = stS, i = L, k = 0;
+  int guard = 4 * (L + M) + 16;
+  // row 0 of the OA matrix is -inf (never stored): handled by the i == 1 tests below
+  while (s0 != stS && guard-- > 0) {
+    switch (s0) {
+      case stC: {
+        const float av = tNl * (SPR(AL_OC * SP + i - 1) + SPR(PC * SP + i)), bv = tEC * SPR(AL_OE * SP + i);
+        s1 = bv > av ? stE : stC;
+        break;
+      }
+      case stJ: {
+        const float av = tNl * (SPR(AL_OJ * SP + i - 1) + SPR(PJ * SP + i)), bv = tEJ * SPR(AL_OE * SP + i);
+        s1 = bv > av ? stE : stJ;
+        break;
+      }
+      case stE: estate(i, s1, k); break;
+      case stM: {
+        const int it = i - lane, kt = k - lane;     // lane t: the cell t steps down the diagonal
+        const bool valid = it >= 1 && kt >= 1;
+        int best = 0;
+        if (valid) {
+          float path[4];
+          path[0] = gate(tab(FW_E, kt), SPR(AL_OB * SP + it - 1));
+          if (it > 1 && kt > 1) {
+            path[1] = gate(tab(FW_A, kt), oa(it - 1, 0, kt - 1));
+            path[2] = gate(tab(FW_B, kt), oa(it - 1, 1, kt - 1));
+            path[3] = gate(tab(FW_C, kt), oa(it - 1, 2, kt - 1));
+          } else if (kt > 1) {   // previous row is row 0: -inf behind an open gate, 0 behind a closed one
+            path[1] = gate(tab(FW_A, kt), -INFINITY);
+            path[2] = gate(tab(FW_B, kt), -INFINITY);
+            path[3] = gate(tab(FW_C, kt), -INFINITY);
+          } else { path[1] = 0.f; path[2] = 0.f; path[3] = 0.f; }
+          if (path[1] > path[best]) best = 1;
+          if (path[2] > path[best]) best = 2;
+          if (path[3] > path[best]) best = 3;
+        }
+        const unsigned long long stop = __ballot(!valid || best != 1);
+        const int t = stop ? __builtin_ctzll(stop) : kWave - 1;      // last cell of this run
+        if (valid && lane <= t) cols[it - 1] = kt - 1;
+        const int bt = __shfl(best, t);
+        s1 = stop == 0 ? stM : bt == 0 ? stB : bt == 1 ? stM : bt == 2 ? stI : stD;
+        k -= t + 1; i -= t + 1;
+        break;
+      }
+      case stD: {
+        const float av = k > 1 ? gate(tab(FW_D1, k), oa(i, 0, k - 1)) : 0.f;
+        const float bv = k > 1 ? gate(tab(FW_D2, k), oa(i, 2, k - 1)) : 0.f;
+        s1 = bv > av ? stD : stM;
+        k--;
+        break;
+      }
+      case stI: {
+        const float pmv = i > 1 ? oa(i - 1, 0, k) : -INFINITY;
+        const float piv = i > 1 ? oa(i - 1, 1, k) : -INFINITY;
+        const float av = gate(tab(FW_MI, k), pmv), bv = gate(tab(FW_II, k), piv);
+        s1 = bv > av ? stI : stM;
+        i--;
+        break;
+      }
+      case stB: {
+        const float av = tNm * SPR(AL_ON * SP + i), bv = tNm * SPR(AL_OJ * SP + i);
+        s1 = bv > av ? stJ : stN;
+        break;
+      }
+      case stN: s1 = i == 0 ? stS : stN; break;
+      default: s1 = stS; break;
+    }
+    if ((s1 == stN || s1 == stJ || s1 == stC) && s1 == s0) i--;
+    if (i < 0 || k < 0 || (s1 == stM && (k < 1 || i < 1)) || ((s1 == stC || s1 == stJ) && i < 1)) break;   // defensive
+    s0 = s1;
+  }
+}
+
+// argmax over the M (">=": the later cell in HMMER's striped scan wins) and D (">") cells of one OA row; this lane
+// holds the NQ cells of nodes node0 + 1 .. node0 + NQ.  A D cell wins only if it comes before every tied M cell AND
+// no tied M follows it; M uses ">=", so any tied M scanned after the D takes over: M wins whenever one exists.
+// Returns true for M; k = the node.
+template <int NQ>
+__device__ __forceinline__ bool estate_argmax(const float (&om)[NQ], const float (&odd)[NQ], int node0, int M, int &k) {
+  const int Qh = (M - 1) / 4 + 1 < 2 ? 2 : (M - 1) / 4 + 1;   // HMMER's SSE stripe count
+  float vmax = -INFINITY;
+#pragma unroll
+  for (int q = 0; q < NQ; q++)
+    if (node0 + q < M) vmax = fmaxf(vmax, fmaxf(om[q], odd[q]));
+  vmax = wave_max(vmax);
+  int bestM = -1, bestD = -1;
+#pragma unroll
+  for (int q = 0; q < NQ; q++) {
+    const int kk = node0 + q + 1;
+    if (kk <= M) {
+      const int qh = (kk - 1) % Qh, rh = (kk - 1) / Qh;
+      if (om[q] == vmax) { const int pos = qh * 8 + rh; bestM = pos > bestM ? pos : bestM; }
+      if (odd[q] == vmax) { const int pos = 0x3FFFFFFF - (qh * 8 + 4 + rh); bestD = pos > bestD ? pos : bestD; }
+    }
+  }
+  bestM = wave_max_i32(bestM);
+  bestD = wave_max_i32(bestD);
+  const int pos = bestM >= 0 ? bestM : 0x3FFFFFFF - bestD;
+  k = (pos % 8 % 4) * Qh + pos / 8 + 1;
+  return bestM >= 0;
+}
+
+// ------------------------------------------------------------------ alignment on a node window
+// A fragment query aligns to a stretch of the model: after the full-width Forward sweep (which records, in row 0 of
+// the two mask arrays, the lane blocks its dominant path runs through - wh_device.h) Backward, the posteriors, the
+// OA fill and the traceback run on the 64 * QB nodes around that stretch only (QB = 4 or 8 nodes per lane,
+// register-resident tables gathered once per pair, compact rows in slab B).  Paths that leave the window are
+// dropped, so every posterior is a lower bound and their total over the rows is L minus the dropped mass: the
+// window result is kept only when that total equals L within float32 noise (the rule of wh_score7.hip's envelope
+// sweep), otherwise the caller runs the full-width sweeps.  The Forward specials (AL_PN/PJ/PC) stay intact for
+// that case: the window posteriors of N/J/C go to AL_B/AL_E/AL_ML, which nothing reads after the Forward sweep.
+typedef __attribute__((address_space(3))) float awl_f;
+typedef __attribute__((address_space(3))) uint8_t awl_u8;
+typedef __attribute__((address_space(1))) float awg_f;
+
+struct AlnWinCtx {              // <= 16 dwords: passed in registers to the non-inlined sweep
+  awl_f *emL, *trL, *spec3;     // emission rows, both transition orientations, special-state rows (LDS)
+  awl_u8 *seq;
+  const awg_f *emG;             // all emission rows (L2)
+  awg_f *slabA, *specg;         // Forward rows of this wave; special-state rows in HBM (SPECG)
+  int SP, lane;
+};
+
+constexpr float kAlnWinTol = 3e-6f;
+enum { AW_PN = AL_B, AW_PJ = AL_E, AW_PC = AL_ML };
+
+// 1: columns written; 0: the window lost mass (or left float32 range), nothing was written
+template <int QB, int Q, bool SPECG>
+__device__ __noinline__ int align_window(const AlnWinCtx c, int32_t *cols, int L, int M, int m0, int Lcap, int Klds, LenCfg cu, float invZ, unsigned long long *wcyc) {
+  long long t_last = wcyc ? (long long)__builtin_readcyclecounter() : 0;
+#define AW_TICK(slot) do { if (wcyc) { const long long t_now = __builtin_readcyclecounter(); if (c.lane == 0) atomicAdd(wcyc + (slot), (unsigned long long)(t_now - t_last)); t_last = t_now; } } while (0)
+  static_assert(Q % QB == 0 && QB % 4 == 0, "a window lane must stay inside one forward lane block");
+  constexpr int Q4 = Q / 4, B4 = QB / 4, TBL = Q * kWave;
+  constexpr int R = 32 / QB;      // rows in flight (64 registers either way)
+  const int lane = c.lane, SP = c.SP;
+  float *spec = SPECG ? (float *)c.specg : (float *)c.spec3;
+  const uint8_t *seq = (const uint8_t *)c.seq;
+  const float *trF = (const float *)c.trL, *trB = trF + FW_NARR * TBL;
+  float4 *Wpp = reinterpret_cast<float4 *>((float *)c.slabA + (size_t)(Lcap + 1) * 2 * TBL);   // [row][M,I][B4][64]
+  float4 *Woa = Wpp + (size_t)(Lcap + 1) * 2 * B4 * kWave;                                      // [row][M,I,D][B4][64]
+  const int n0 = kWave * Q - m0 - kWave * QB;          // 0-based position of the window's first node
+
+  // ---------------- Backward + posteriors, reversed node order (lane 0 holds the window's last nodes)
+  {
+    int fwd[B4], out[B4];
+    TransTab<QB, true> T;
+    {
+      const float4 *bw4 = reinterpret_cast<const float4 *>(trB);
+#pragma unroll
+      for (int p4 = 0; p4 < B4; p4++) {
+        const int m4 = (m0 >> 2) + lane * B4 + p4;
+        const int rev = (m4 % Q4) * kWave + m4 / Q4;
+        const int jf = 16 * Q - 1 - m4;
+        fwd[p4] = (jf % Q4) * kWave + jf / Q4;
+        const int jw = 16 * QB - 1 - (lane * B4 + p4);
+        out[p4] = (jw % B4) * kWave + jw / B4;
+#pragma unroll
+        for (int a = 0; a < BW_NARR; a++) T.v[a][p4] = bw4[a * Q4 * kWave + rev];
+      }
+    }
+    const ScanC sc = scan_prepare(lane_product<QB, true>(T, BW_DD));
+    const float4 *em4L = reinterpret_cast<const float4 *>((const float *)c.emL);
+    const float4 *em4G = reinterpret_cast<const float4 *>((const float *)c.emG);
+    float Mb[QB], Ib[QB];
+#pragma unroll
+    for (int p = 0; p < QB; p++) { Mb[p] = 0.f; Ib[p] = 0.f; }
+    float xC = cu.move, xJ = 0.f, xN = 0.f, xB = 0.f, acc = 0.f, accs = 0.f;
+    bool clamped = false;
+    int S_next = 0;
+    // the stored Forward cells of a row are requested R rows ahead: at two waves per SIMD one HBM round trip takes
+    // as long as ~10 window rows of arithmetic
+    float4 ring[R][2 * B4];
+    auto request_row = [&](float4 (&slot)[2 * B4], int r) {
+      const float4 *row = reinterpret_cast<const float4 *>((const float *)c.slabA) + (size_t)r * (2 * Q4 * kWave);
+#pragma unroll
+      for (int p4 = 0; p4 < B4; p4++) { slot[p4] = nt_load4(row + fwd[p4]); slot[B4 + p4] = nt_load4(row + Q4 * kWave + fwd[p4]); }
+    };
+#pragma unroll
+    for (int r = 0; r < R; r++) if (L - r >= 1) request_row(ring[r], L - r);
+#pragma unroll 1
+    for (int ib = L; ib >= 1; ib -= R) {
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const int i = ib - r;
+      if (i < 1) break;
+      asm volatile("" ::: "memory");
+      float4 fm_c[B4], fi_c[B4];
+#pragma unroll
+      for (int p4 = 0; p4 < B4; p4++) { fm_c[p4] = ring[r][p4]; fi_c[p4] = ring[r][B4 + p4]; }
+      if (i - R >= 1) request_row(ring[r], i - R);
+      const int S_i = SPRI(AL_S * SP + i);
+      const int dS = S_i - SPRI(AL_S * SP + i - 1);
+      if (i < L) {
+        mirror_scale<QB>(S_next - S_i, Mb, Ib, xJ, xC, xN);
+        const int x = __builtin_amdgcn_readfirstlane((int)seq[i]);
+        float part = 0.f;
+#pragma unroll
+        for (int p4 = 0; p4 < B4; p4++) {
+          const float4 E = T.v[BW_E][p4];
+          const float4 O = x < Klds ? em4L[x * (Q * 16) + fwd[p4]] : em4G[(size_t)x * (Q * 16) + fwd[p4]];
+          Mb[4 * p4 + 0] *= O.w; part = fmaf(E.x, Mb[4 * p4 + 0], part);
+          Mb[4 * p4 + 1] *= O.z; part = fmaf(E.y, Mb[4 * p4 + 1], part);
+          Mb[4 * p4 + 2] *= O.y; part = fmaf(E.z, Mb[4 * p4 + 2], part);
+          Mb[4 * p4 + 3] *= O.x; part = fmaf(E.w, Mb[4 * p4 + 3], part);
+        }
+        xB = wave_sum(part);
+        xJ = fmaf(xJ, cu.loop, xB * cu.move);
+        xC = xC * cu.loop;
+        xN = fmaf(xN, cu.loop, xB * cu.move);
+      }
+      const float xE = fmaf(xC, cu.EC, xJ * cu.EJ);
+      backward_cells<QB, true, false>(T, sc, Mb, Ib, xE);
+      clamped |= clamp_backward<QB>(Mb, Ib, xB, xJ, xC, xN);
+      const float s_i = invZ;
+      const float s_p = ldexpf(invZ, -dS);
+      float4 *orow = Wpp + (size_t)i * (2 * B4 * kWave);
+#pragma unroll
+      for (int p4 = 0; p4 < B4; p4++) {
+        // position 4*p4+j (reversed order) is component 3-j of the forward-ordered vector
+        const float m0v = (fm_c[p4].x * Mb[4 * p4 + 3]) * s_i, m1v = (fm_c[p4].y * Mb[4 * p4 + 2]) * s_i;
+        const float m2v = (fm_c[p4].z * Mb[4 * p4 + 1]) * s_i, m3v = (fm_c[p4].w * Mb[4 * p4 + 0]) * s_i;
+        const float i0v = (fi_c[p4].x * Ib[4 * p4 + 3]) * s_i, i1v = (fi_c[p4].y * Ib[4 * p4 + 2]) * s_i;
+        const float i2v = (fi_c[p4].z * Ib[4 * p4 + 1]) * s_i, i3v = (fi_c[p4].w * Ib[4 * p4 + 0]) * s_i;
+        nt_store4(orow + out[p4], m0v, m1v, m2v, m3v);
+        nt_store4(orow + B4 * kWave + out[p4], i0v, i1v, i2v, i3v);
+        acc += (m0v + m1v) + (m2v + m3v);
+        acc += (i0v + i1v) + (i2v + i3v);
+      }
+      const float pn = SPR(AL_PN * SP + i - 1) * xN * cu.loop * s_p;
+      const float pj = SPR(AL_PJ * SP + i - 1) * xJ * cu.loop * s_p;
+      const float pc = SPR(AL_PC * SP + i - 1) * xC * cu.loop * s_p;
+      accs += pn + pj + pc;
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) { spec[AW_PN * SP + i] = pn; spec[AW_PJ * SP + i] = pj; spec[AW_PC * SP + i] = pc; }
+      __builtin_amdgcn_wave_barrier();
+      S_next = S_i;
+    }
+    }
+    const float mass = wave_sum(acc) + accs;
+    if (clamped || !(fabsf((float)L - mass) <= kAlnWinTol * (float)L)) return 0;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  AW_TICK(1);
+
+  // ---------------- optimal-accuracy fill on the window (forward node order)
+  const float tNl = cu.loop > 0.f ? 1.f : 0.f, tNm = cu.move > 0.f ? 1.f : 0.f;
+  const float tEJ = cu.EJ > 0.f ? 1.f : 0.f, tEC = cu.EC > 0.f ? 1.f : 0.f;
+  {
+    TransTab<QB, true> T;
+    {
+      const float4 *fw4 = reinterpret_cast<const float4 *>(trF);
+#pragma unroll
+      for (int g = 0; g < B4; g++) {
+        const int j = (n0 >> 2) + lane * B4 + g;
+        const int slot = (j % Q4) * kWave + j / Q4;
+#pragma unroll
+        for (int a = 0; a < FW_NARR; a++) T.v[a][g] = fw4[a * Q4 * kWave + slot];
+      }
+    }
+    float allpass = 1.f;
+#pragma unroll
+    for (int g = 0; g < B4; g++) {
+      const float4 d = T.v[FW_D2][g];
+      if (!(d.x > 0.f && d.y > 0.f && d.z > 0.f && d.w > 0.f)) allpass = 0.f;
+    }
+    const ScanC sc = scan_prepare(allpass);
+    float Mp[QB], Ip[QB], Dp[QB];
+#pragma unroll
+    for (int q = 0; q < QB; q++) { Mp[q] = -INFINITY; Ip[q] = -INFINITY; Dp[q] = -INFINITY; }
+    float oN = 0.f, oB = 0.f, oJ = -INFINITY, oC = -INFINITY;
+    if (lane == 0) {
+      spec[AL_ON * SP] = 0.f; spec[AL_OB * SP] = 0.f; spec[AL_OE * SP] = -INFINITY;
+      spec[AL_OJ * SP] = -INFINITY; spec[AL_OC * SP] = -INFINITY;
+    }
+    float4 ring[R][2 * B4];
+    auto request_pp = [&](float4 (&slot)[2 * B4], int r) {
+      const float4 *prow = Wpp + (size_t)r * (2 * B4 * kWave) + lane;
+#pragma unroll
+      for (int g = 0; g < B4; g++) { slot[g] = nt_load4(prow + g * kWave); slot[B4 + g] = nt_load4(prow + (B4 + g) * kWave); }
+    };
+#pragma unroll
+    for (int r = 0; r < R; r++) if (1 + r <= L) request_pp(ring[r], 1 + r);
+#pragma unroll 1
+    for (int ib = 1; ib <= L; ib += R) {
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+      const int i = ib + r;
+      if (i > L) break;
+      asm volatile("" ::: "memory");
+      float4 pm4[B4], pi4[B4];
+#pragma unroll
+      for (int g = 0; g < B4; g++) { pm4[g] = ring[r][g]; pi4[g] = ring[r][B4 + g]; }
+      if (i + R <= L) request_pp(ring[r], i + R);
+      const float mm1 = wave_shr1(Mp[QB - 1]), im1 = wave_shr1(Ip[QB - 1]), dm1 = wave_shr1(Dp[QB - 1]);
+#pragma unroll
+      for (int g = B4 - 1; g >= 0; g--) {
+        const float4 A = T.v[FW_A][g], B = T.v[FW_B][g], C = T.v[FW_C][g], E = T.v[FW_E][g];
+        const float4 MI = T.v[FW_MI][g], II = T.v[FW_II][g];
+#pragma unroll
+        for (int j = 3; j >= 0; j--) {
+          const int q = 4 * g + j;
+          const float pm = q > 0 ? Mp[q > 0 ? q - 1 : 0] : mm1;
+          const float pi_ = q > 0 ? Ip[q > 0 ? q - 1 : 0] : im1;
+          const float pd = q > 0 ? Dp[q > 0 ? q - 1 : 0] : dm1;
+          float sv = gate(f4get(E, j), oB);
+          sv = fmaxf(sv, gate(f4get(A, j), pm));
+          sv = fmaxf(sv, gate(f4get(B, j), pi_));
+          sv = fmaxf(sv, gate(f4get(C, j), pd));
+          const float ni = fmaxf(gate(f4get(MI, j), Mp[q]), gate(f4get(II, j), Ip[q])) + f4get(pi4[g], j);
+          Mp[q] = sv + f4get(pm4[g], j);
+          Ip[q] = ni;
+        }
+      }
+      const float mn1 = wave_shr1(Mp[QB - 1]);
+      float dprev = 0.f;
+#pragma unroll
+      for (int g = 0; g < B4; g++) {
+        const float4 D1 = T.v[FW_D1][g], D2 = T.v[FW_D2][g];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int q = 4 * g + j;
+          const float src = q > 0 ? Mp[q > 0 ? q - 1 : 0] : mn1;
+          dprev = fmaxf(gate(f4get(D1, j), src), gate(f4get(D2, j), dprev));
+          Dp[q] = dprev;
+        }
+      }
+      float carry = wave_shr1(scan_apply_max(sc, dprev));
+      float rowmax = -INFINITY;
+#pragma unroll
+      for (int g = 0; g < B4; g++) {
+        const float4 D2 = T.v[FW_D2][g];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int q = 4 * g + j;
+          carry = gate(f4get(D2, j), carry);
+          Dp[q] = fmaxf(Dp[q], carry);
+          if (n0 + lane * QB + q < M) rowmax = fmaxf(rowmax, fmaxf(Mp[q], Dp[q]));
+        }
+      }
+      const float xE = wave_max(rowmax);
+      {
+        const float a1 = tNl * (oJ + SPR(AW_PJ * SP + i)), b1 = tEJ * xE;
+        oJ = a1 > b1 ? a1 : b1;
+        const float a2 = tNl * (oC + SPR(AW_PC * SP + i)), b2 = tEC * xE;
+        oC = a2 > b2 ? a2 : b2;
+        oN = tNl * (oN + SPR(AW_PN * SP + i));
+        const float a3 = tNm * oN, b3 = tNm * oJ;
+        oB = a3 > b3 ? a3 : b3;
+      }
+      if (lane == 0) {
+        spec[AL_ON * SP + i] = oN; spec[AL_OB * SP + i] = oB; spec[AL_OE * SP + i] = xE;
+        spec[AL_OJ * SP + i] = oJ; spec[AL_OC * SP + i] = oC;
+      }
+      float4 *orow = Woa + (size_t)i * (3 * B4 * kWave) + lane;
+#pragma unroll
+      for (int g = 0; g < B4; g++) {
+        nt_store4(orow + g * kWave, Mp[4 * g], Mp[4 * g + 1], Mp[4 * g + 2], Mp[4 * g + 3]);
+        nt_store4(orow + (B4 + g) * kWave, Ip[4 * g], Ip[4 * g + 1], Ip[4 * g + 2], Ip[4 * g + 3]);
+        nt_store4(orow + (2 * B4 + g) * kWave, Dp[4 * g], Dp[4 * g + 1], Dp[4 * g + 2], Dp[4 * g + 3]);
+      }
+    }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  AW_TICK(2);
+
+  // ---------------- traceback on the compact rows (a cell in front of the window reads as 0, which is what the
+  // fill saw there)
+  {
+    const float *oaf = reinterpret_cast<const float *>(Woa);
+    auto oa = [&](int row, int st, int k) -> float {
+      const int pw = k - 1 - n0;
+      if (pw < 0 || pw >= kWave * QB) return 0.f;
+      const int ln = pw / QB, q = pw % QB;
+      return __builtin_nontemporal_load(oaf + ((size_t)(row * 3 + st) * B4 + q / 4) * (kWave * 4) + ln * 4 + (q % 4));
+    };
+    auto tab = [&](int arr, int k) -> float { return tab_load<Q>(trF, arr, k); };
+    auto estate = [&](int i, int &s1, int &k) {
+      const float4 *orow = Woa + (size_t)i * (3 * B4 * kWave) + lane;
+      float om[QB], odd[QB];
+#pragma unroll
+      for (int g = 0; g < B4; g++) {
+        const float4 m4 = nt_load4(orow + g * kWave), d4 = nt_load4(orow + (2 * B4 + g) * kWave);
+        om[4 * g] = m4.x; om[4 * g + 1] = m4.y; om[4 * g + 2] = m4.z; om[4 * g + 3] = m4.w;
+        odd[4 * g] = d4.x; odd[4 * g + 1] = d4.y; odd[4 * g + 2] = d4.z; odd[4 * g + 3] = d4.w;
+      }
+      s1 = estate_argmax<QB>(om, odd, n0 + lane * QB, M, k) ? 3 : 5;   // stM : stD
+    };
+    oa_traceback<SPECG, AW_PJ, AW_PC>(spec, SP, L, M, lane, cols, tNl, tNm, tEJ, tEC, oa, tab, estate);
+  }
+  AW_TICK(3);
+  return 1;
+}
+#undef AW_TICK
+
 // SWAP (long models, Q > 24): only ONE transition orientation is resident in LDS; the waves of a
 // workgroup run the three sweeps in lockstep and swap the tables between them (see wh_score_big.hip).
 // LOGSP: the fallback pass for pairs that left float32 range (wh_align_log.h).
@@ -130,6 +537,7 @@ __global__ __launch_bounds__(SWAP ? 256 : 512) void align_kernel(AlignArgs a) {
       }
       __builtin_amdgcn_wave_barrier();
       const LenCfg cu = len_config(L > 0 ? L : 1, false);
+      const long long t_pair = a.wstat ? (long long)__builtin_readcyclecounter() : 0;
 
       // ---------------- unihit Forward, rows spilled to slab A
       float xC_L = 0.f, lZ = -INFINITY; int ef_L = 0;
@@ -148,6 +556,35 @@ __global__ __launch_bounds__(SWAP ? 256 : 512) void align_kernel(AlignArgs a) {
       }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       if (!(xC_L > 0.f)) active = false;   // no alignment has non-zero probability: all residues stay -1
+
+      // ---------------- the three remaining passes on a node window, when the dominant path fits one
+      if constexpr (!SWAP && !LOGSP && !TREG && Q >= 8) {
+        if (active && !a.no_window) {
+          const unsigned long long um = ((unsigned long long)(unsigned)SPRI(AL_MH * SP) << 32) | (unsigned)SPRI(AL_ML * SP);
+          int done = 0, tried = 0;
+          if (um != 0) {
+            int lo = __builtin_ctzll(um), hi = 63 - __builtin_clzll(um);
+            lo = lo > 1 ? lo - 2 : 0; hi = hi < 63 ? hi + 1 : 63;
+            const int nodes = (hi - lo + 1) * Q;
+            AlnWinCtx c;
+            c.emL = (awl_f *)emL; c.trL = (awl_f *)trL; c.spec3 = SPECG ? nullptr : (awl_f *)spec; c.seq = (awl_u8 *)seq;
+            c.emG = (const awg_f *)emG; c.slabA = (awg_f *)slabA; c.specg = SPECG ? (awg_f *)spec : nullptr;
+            c.SP = SP; c.lane = lane;
+            const float invZ = 1.0f / (xC_L * cu.move);
+            unsigned long long *wcyc = a.wstat ? reinterpret_cast<unsigned long long *>(a.wstat + 4) : nullptr;
+            if (wcyc && lane == 0) atomicAdd(wcyc, (unsigned long long)(__builtin_readcyclecounter() - t_pair));
+            if (nodes <= 4 * kWave) {
+              tried = 1;
+              done = align_window<4, Q, SPECG>(c, cols, L, M, min((63 - hi) * Q, kWave * (Q - 4)), a.Lcap, Klds, cu, invZ, wcyc);
+            } else if (Q % 8 == 0 && Q > 8 && nodes <= 8 * kWave) {
+              tried = 1;
+              done = align_window<(Q % 8 == 0 ? 8 : 4), Q, SPECG>(c, cols, L, M, min((63 - hi) * Q, kWave * (Q - 8)), a.Lcap, Klds, cu, invZ, wcyc);
+            }
+          }
+          if (a.wstat && lane == 0) atomicAdd(a.wstat + (done ? 0 : tried ? 1 : 2), 1);
+          if (done) active = false;   // columns are written
+        }
+      }
 
       // ---------------- Backward + posterior decoding, in place over slab A
       orient(1);
@@ -329,109 +766,22 @@ __global__ __launch_bounds__(SWAP ? 256 : 512) void align_kernel(AlignArgs a) {
       }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 
-      // ---------------- traceback: first maximum wins, candidate orders as in SURVEY.md A.7
+      // ---------------- traceback
       if (active) {
-        enum { stS, stN, stB, stM, stI, stD, stE, stJ, stC };
-        int s0 = stC, s1 = stS, i = L, k = 0;
-        int guard = 4 * (L + M) + 16;
-        const int Qh = (M - 1) / 4 + 1 < 2 ? 2 : (M - 1) / 4 + 1;   // HMMER's SSE stripe count
-        // row 0 of the OA matrix is -inf (never stored): handled by the i == 1 tests below
-        while (s0 != stS && guard-- > 0) {
-          switch (s0) {
-            case stC: {
-              const float av = tNl * (SPR(AL_OC * SP + i - 1) + SPR(AL_PC * SP + i)), bv = tEC * SPR(AL_OE * SP + i);
-              s1 = bv > av ? stE : stC;
-              break;
-            }
-            case stJ: {
-              const float av = tNl * (SPR(AL_OJ * SP + i - 1) + SPR(AL_PJ * SP + i)), bv = tEJ * SPR(AL_OE * SP + i);
-              s1 = bv > av ? stE : stJ;
-              break;
-            }
-            case stE: {
-              // argmax over M (">=": the later cell in HMMER's striped scan wins) and D (">")
-              const float4 *orow = reinterpret_cast<const float4 *>(slabB) + (size_t)i * (3 * Q4 * kWave) + lane;
-              float vmax = -INFINITY;
-              float om[Q], odd[Q];
+        auto oa = [&](int row, int st, int k) -> float { return cell_load<Q>(slabB, row, 3, st, k); };
+        auto tab = [&](int arr, int k) -> float { return tab_load<Q>(fwG, arr, k); };
+        auto estate = [&](int i, int &s1, int &k) {
+          const float4 *orow = reinterpret_cast<const float4 *>(slabB) + (size_t)i * (3 * Q4 * kWave) + lane;
+          float om[Q], odd[Q];
 #pragma unroll
-              for (int q4 = 0; q4 < Q4; q4++) {
-                const float4 m4 = nt_load4(orow + q4 * kWave), d4 = nt_load4(orow + (2 * Q4 + q4) * kWave);
-                om[4 * q4] = m4.x; om[4 * q4 + 1] = m4.y; om[4 * q4 + 2] = m4.z; om[4 * q4 + 3] = m4.w;
-                odd[4 * q4] = d4.x; odd[4 * q4 + 1] = d4.y; odd[4 * q4 + 2] = d4.z; odd[4 * q4 + 3] = d4.w;
-              }
-#pragma unroll
-              for (int q = 0; q < Q; q++)
-                if (lane * Q + q < M) vmax = fmaxf(vmax, fmaxf(om[q], odd[q]));
-              vmax = wave_max(vmax);
-              int bestM = -1, bestD = -1;
-#pragma unroll
-              for (int q = 0; q < Q; q++) {
-                const int kk = lane * Q + q + 1;
-                if (kk <= M) {
-                  const int qh = (kk - 1) % Qh, rh = (kk - 1) / Qh;
-                  if (om[q] == vmax) { const int pos = qh * 8 + rh; bestM = pos > bestM ? pos : bestM; }
-                  if (odd[q] == vmax) { const int pos = 0x3FFFFFFF - (qh * 8 + 4 + rh); bestD = pos > bestD ? pos : bestD; }
-                }
-              }
-              bestM = wave_max_i32(bestM);
-              bestD = wave_max_i32(bestD);
-              // a D cell wins only if it comes before every tied M cell AND no tied M follows it;
-              // M uses ">=", so any tied M scanned after the D takes over: M wins whenever one exists
-              // after the first tied D, or when the first tied cell is an M.
-              int pos;
-              if (bestM >= 0) { pos = bestM; s1 = stM; }
-              else { pos = 0x3FFFFFFF - bestD; s1 = stD; }
-              k = (pos % 8 % 4) * Qh + pos / 8 + 1;
-              break;
-            }
-            case stM: {
-              float path[4];
-              path[0] = gate(tab_load<Q>(fwG, FW_E, k), SPR(AL_OB * SP + i - 1));
-              if (i > 1 && k > 1) {
-                path[1] = gate(tab_load<Q>(fwG, FW_A, k), cell_load<Q>(slabB, i - 1, 3, 0, k - 1));
-                path[2] = gate(tab_load<Q>(fwG, FW_B, k), cell_load<Q>(slabB, i - 1, 3, 1, k - 1));
-                path[3] = gate(tab_load<Q>(fwG, FW_C, k), cell_load<Q>(slabB, i - 1, 3, 2, k - 1));
-              } else if (k > 1) {   // previous row is row 0: -inf behind an open gate, 0 behind a closed one
-                path[1] = gate(tab_load<Q>(fwG, FW_A, k), -INFINITY);
-                path[2] = gate(tab_load<Q>(fwG, FW_B, k), -INFINITY);
-                path[3] = gate(tab_load<Q>(fwG, FW_C, k), -INFINITY);
-              } else { path[1] = 0.f; path[2] = 0.f; path[3] = 0.f; }
-              int best = 0;
-              if (path[1] > path[best]) best = 1;
-              if (path[2] > path[best]) best = 2;
-              if (path[3] > path[best]) best = 3;
-              s1 = best == 0 ? stB : best == 1 ? stM : best == 2 ? stI : stD;
-              if (lane == 0) cols[i - 1] = k - 1;
-              k--; i--;
-              break;
-            }
-            case stD: {
-              const float av = k > 1 ? gate(tab_load<Q>(fwG, FW_D1, k), cell_load<Q>(slabB, i, 3, 0, k - 1)) : 0.f;
-              const float bv = k > 1 ? gate(tab_load<Q>(fwG, FW_D2, k), cell_load<Q>(slabB, i, 3, 2, k - 1)) : 0.f;
-              s1 = bv > av ? stD : stM;
-              k--;
-              break;
-            }
-            case stI: {
-              const float pmv = i > 1 ? cell_load<Q>(slabB, i - 1, 3, 0, k) : -INFINITY;
-              const float piv = i > 1 ? cell_load<Q>(slabB, i - 1, 3, 1, k) : -INFINITY;
-              const float av = gate(tab_load<Q>(fwG, FW_MI, k), pmv), bv = gate(tab_load<Q>(fwG, FW_II, k), piv);
-              s1 = bv > av ? stI : stM;
-              i--;
-              break;
-            }
-            case stB: {
-              const float av = tNm * SPR(AL_ON * SP + i), bv = tNm * SPR(AL_OJ * SP + i);
-              s1 = bv > av ? stJ : stN;
-              break;
-            }
-            case stN: s1 = i == 0 ? stS : stN; break;
-            default: s1 = stS; break;
+          for (int q4 = 0; q4 < Q4; q4++) {
+            const float4 m4 = nt_load4(orow + q4 * kWave), d4 = nt_load4(orow + (2 * Q4 + q4) * kWave);
+            om[4 * q4] = m4.x; om[4 * q4 + 1] = m4.y; om[4 * q4 + 2] = m4.z; om[4 * q4 + 3] = m4.w;
+            odd[4 * q4] = d4.x; odd[4 * q4 + 1] = d4.y; odd[4 * q4 + 2] = d4.z; odd[4 * q4 + 3] = d4.w;
           }
-          if ((s1 == stN || s1 == stJ || s1 == stC) && s1 == s0) i--;
-          if (i < 0 || k < 0 || (s1 == stM && (k < 1 || i < 1)) || ((s1 == stC || s1 == stJ) && i < 1)) break;   // defensive
-          s0 = s1;
-        }
+          s1 = estate_argmax<Q>(om, odd, lane * Q, M, k) ? 3 : 5;   // stM : stD
+        };
+        oa_traceback<SPECG, AL_PJ, AL_PC>(spec, SP, L, M, lane, cols, tNl, tNm, tEJ, tEC, oa, tab, estate);
       }
     }
   }

@@ -1012,6 +1012,7 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
   int *d_redo_count = (int *)e->d_recs.p;
   int32_t *d_redo_list = (int32_t *)e->d_recs.p + 4;
   HIPCHK(hipMemsetAsync(d_redo_count, 0, sizeof(int), s));
+  HIPCHK(hipMemsetAsync((int *)e->d_counter.p + 96, 0, 12 * sizeof(int), s));
   if (timer_begin(e, 2, s)) return WH_EHIP;
   int launches = 0;
   // one pass = plan the launches of every model class for the pairs in <order> (grouped by model,
@@ -1083,6 +1084,8 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
     a.Lcap = std::max(max_len, 1); a.SP = plans[pl][4]; a.wave_lds = std::abs(plans[pl][5]);
     a.K = e->K; a.Kp = e->Kp; a.Klds = plans[pl][6] % 1000; a.swap = plans[pl][6] >= 1000 ? 1 : 0;
     a.logsp = logsp ? 1 : 0;
+    a.no_window = e->knobs.no_window ? 1 : 0;
+    a.wstat = (e->knobs.trace || e->knobs.stats) ? (int *)e->d_counter.p + 96 : nullptr;
     a.redo_count = (!logsp && want_redo) ? d_redo_count : nullptr;
     a.redo_list = (!logsp && want_redo) ? d_redo_list : nullptr;
     if (launches >= kMaxLaunches) { set_error("wh_align_dev: too many launches in one call"); return WH_ERANGE; }
@@ -1130,6 +1133,15 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
     if (e->knobs.trace) fprintf(stderr, "[wh] align: %d of %lld pairs left float32 range, redone in log space\n", n_redo, (long long)npairs);
     rc = run_pass(order2, cnt2, true);
     if (rc != WH_OK) return rc;
+  }
+  if (e->knobs.trace || e->knobs.stats) {
+    int ws[12] = {0};
+    HIPCHK(hipMemcpyAsync(ws, (int *)e->d_counter.p + 96, sizeof ws, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    unsigned long long cy[4];
+    memcpy(cy, ws + 4, sizeof cy);
+    fprintf(stderr, "[wh] align: %d pairs on a node window, %d windows rejected (full width), %d without a window; wave cycles of the window pairs: "
+            "Forward %.3g, Backward+posteriors %.3g, OA fill %.3g, traceback %.3g\n", ws[0], ws[1], ws[2], (double)cy[0], (double)cy[1], (double)cy[2], (double)cy[3]);
   }
   e->last_align_redo = n_redo;
   e->last_align_unaligned = 0;

@@ -248,6 +248,8 @@ struct AlignArgs {
   int32_t *redo_list;          // redo_list for the log-space pass (NULL in that pass)
   int logsp;                   // 1: this launch is the log-space pass
   int swap;                    // 1: pass-synchronous variant (one table orientation resident in LDS)
+  int no_window;               // 1: Backward / OA / traceback at full width only (WH_NO_WINDOW)
+  int *wstat;                  // NULL or 3 counters: pairs aligned on a window, window rejected, window not tried
 };
 hipError_t launch_align(int Q, const AlignArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
 

@@ -94,6 +94,8 @@ def hot_path_step(e, res_t, off_t, maxlen, k, gather_topk=None, keep_device=Fals
     hot_path_step.multidomain = int(((flags & 2) != 0).sum().item())
     hot_path_step.reported = int(((flags & 1) != 0).sum().item())
     hot_path_step.aligned_cells = float((lens.double() * torch.from_numpy(e.M.astype(np.float64)).to(ph.device)[ph.long()]).sum().item())
+    hot_path_step.aligned_residues = float(lens.double().sum().item())
+    hot_path_step.align_paths = e.last_align_paths()
     return out, int(pq.numel()), total_cols
 
 
@@ -374,13 +376,23 @@ def main():
                         "kernel_ms_avg": round(score_ms, 3), "launches": score_launches,
                         "peak_unpacked": 78.6, "frac_unpacked": round(s_tflops / 78.6, 4),
                         "algorithmic_hbm_bytes_per_launch": float(n_local * H * (L + 9.0)) * args.steps / score_launches}
-            # Alignment (HBM-bound by construction): 52 B/cell (Forward rows written + read 24, posteriors
-            # 16, OA rows 12) over the aligned pairs' L x M cells; the stage time spans the pass's launches
-            # (one per model size class, plus the log-space redo pass when pairs leave float32 range).
+            # Alignment.  Algorithmic bytes by sweep path (wh_last_align_paths): a pair aligned at full width moves
+            # 52 B per L x M cell (Forward rows written + read 24, posteriors 16, OA rows 12);
+            # a pair aligned on a node window moves 44 B per L x W cell, W = 256 or 512 nodes (its Forward cells
+            # written 8 and read 8, posteriors 16, OA rows 12) - the cells outside the window are computed by the
+            # Forward sweep but need not be stored.  Path shares are applied to the pass's totals (sum of L, sum of
+            # L x M over the aligned pairs).  The stage time spans the pass's launches (one per model size class,
+            # plus the log-space redo pass when pairs leave float32 range).
             align_ms = kern_ms[2] / args.steps
-            a_gbs = hot_path_step.aligned_cells * 52.0 / (align_ms * 1e-3) / 1e9 if align_ms > 0 else 0.0
+            ap = hot_path_step.align_paths
+            n_ap = max(1, sum(ap.values()))
+            f256, f512 = ap["window256"] / n_ap, ap["window512"] / n_ap
+            a_bytes = (hot_path_step.aligned_residues * 44.0 * (256 * f256 + 512 * f512)
+                       + hot_path_step.aligned_cells * 52.0 * (1.0 - f256 - f512)) if sum(ap.values()) else hot_path_step.aligned_cells * 52.0
+            a_gbs = a_bytes / (align_ms * 1e-3) / 1e9 if align_ms > 0 else 0.0
             roofline_align = {"bound": "hbm", "kernel": "wh::generic_align_kernel" if int(np.max(e.M)) > 3072 else "wh::align_kernel", "achieved": round(a_gbs, 1), "peak": 8000.0,
-                              "unit": "GB/s", "frac": round(a_gbs / 8000.0, 4), "bytes_per_cell": 52,
+                              "unit": "GB/s", "frac": round(a_gbs / 8000.0, 4), "algorithmic_bytes_per_step": a_bytes,
+                              "bytes_per_cell": {"full_width": 52, "window": 44}, "pairs_by_path": ap,
                               "cells_per_step": hot_path_step.aligned_cells, "stage_ms": round(align_ms, 3),
                               "launches_per_step": kern_n[2] / args.steps, "traffic": traffic_align, "traffic_source": traffic_src}
             t_s, t_a = kern_ms[0] / args.steps, align_ms

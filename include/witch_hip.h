@@ -132,6 +132,13 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
  * Callers must not feed such pairs into wh_consensus as if they were all-insertion alignments. */
 int wh_last_align_status(wh_ehmm *e, int64_t *n_logspace, int64_t *n_unaligned, int64_t *unaligned_pairs, int64_t cap);
 
+/* Which sweeps the register-kernel pairs (models of up to 3072 nodes) of the last wh_align / wh_align_dev call went
+ * through - same columns either way, the split only prices the call (bench.py):
+ * paths4[0] = Backward / posteriors / OA / traceback on a 256-node window around the dominant path, [3] = on a
+ * 512-node window, [1] = window result not accepted (mass certificate) and redone at full width, [2] = full width
+ * from the start (query too long for a window, no dominant path, models of fewer than 8 nodes per lane). */
+int wh_last_align_paths(wh_ehmm *e, int64_t *paths4);
+
 /* Weighted consensus of each query's per-HMM alignments (witch-ng merge DP; replaces the Python
  * loops of alignSubQueriesNew, witch_msa/gcmm/aligner.py:376-473).  Pairs are grouped by
  * query in top-k order: query q owns pairs qpair_off[q] .. qpair_off[q+1]; pair p aligned

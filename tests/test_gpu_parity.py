@@ -1531,3 +1531,42 @@ def test_several_waves_per_pair_kernel_on_the_golden_cases(cells_per_lane, orc):
             os.environ.pop("WH_FORCE_WIDE", None)
         else:
             os.environ["WH_FORCE_WIDE"] = old
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("alphabet,root_len,qlen", [("dna", 1000, 150), ("dna", 1500, (60, 420)), ("dna", 500, (30, 300)), ("amino", 700, (40, 260))])
+def test_alignment_on_a_node_window_equals_the_full_width_passes(alphabet, root_len, qlen, tmp_path):
+    """Fragment queries are aligned on the 256 / 512 nodes around the dominant Forward path (wh_align.hip:
+    align_window): every column must equal what the full-width sweeps (option WH_NO_WINDOW) produce, on family
+    fragments, on fragments with random flanks and on pure background sequences; and the window path must
+    actually have run (wh_last_align_paths)."""
+    _need_gpu()
+    from witch_amd import synth
+    from witch_amd.ehmm import EHMM, pack_queries
+    fam = synth.make_family(4242 + root_len, root_len, 16, alphabet, 0.04 if alphabet == "dna" else 0.03, 1e-4)
+    eh = synth.make_ehmm(fam, 6, str(tmp_path), witch_layout=False)
+    e = EHMM(eh.paths, hmm_index=eh.index, nseq=eh.nseq)
+    _, s1 = synth.make_queries(fam, 11, 300, qlen, 0.05)
+    _, s2 = synth.make_queries(fam, 12, 150, qlen, 0.15, flank_frac=0.4)
+    rng = np.random.default_rng(5)
+    K = 4 if alphabet == "dna" else 20
+    s3 = [rng.integers(0, K, size=int(rng.integers(20, 200))).astype(np.int8) for _ in range(50)]
+    seqs = [s.astype(np.uint8) for s in s1 + s2 + s3]
+    res, offs = pack_queries(seqs)
+    H = len(eh.paths)
+    pq = np.repeat(np.arange(len(seqs), dtype=np.int64), H)
+    ph = np.tile(np.arange(H, dtype=np.int32), len(seqs))
+    cw, co = e.align(res, offs, pq, ph)
+    paths = e.last_align_paths()
+    e.set_option("WH_NO_WINDOW", "1")
+    cf, co2 = e.align(res, offs, pq, ph)
+    paths_full = e.last_align_paths()
+    e.set_option("WH_NO_WINDOW", "")
+    e.close()
+    assert np.array_equal(co, co2)
+    bad = np.flatnonzero(cw != cf)
+    assert bad.size == 0, (bad[:10], cw[bad[:10]], cf[bad[:10]])
+    n = len(pq)
+    assert sum(paths.values()) == n and paths_full == {"window256": 0, "window512": 0, "window_rejected": 0, "full_width": n}
+    if int(e.M.max()) >= 512:       # 8 or more nodes per lane: fragments go through a window
+        assert paths["window256"] + paths["window512"] > n // 2, paths

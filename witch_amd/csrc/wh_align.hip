@@ -9,13 +9,16 @@
 //   F write 8 + read 8, posterior write 8 + read 8, OA write 12 bytes per DP cell.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "wh_device.h"
 #include "wh_align_log.h"
 #include "wh_launch.h"
 
 namespace wh {
 
-enum { AL_PN = 0, AL_B, AL_E, AL_PJ, AL_PC, AL_S, AL_ML, AL_MH, AL_ON, AL_OB, AL_OE, AL_OJ, AL_OC, AL_NARR };
+enum { AL_PN = 0, AL_B, AL_E, AL_PJ, AL_PC, AL_S, AL_ML, AL_MH, AL_ON, AL_OB, AL_OE, AL_OJ, AL_OC, AL_WPC, AL_NARR };
+static_assert(AL_NARR == kAlignSpecArrays, "wh_launch.h sizes the special-state rows");
 
 __device__ __forceinline__ float gate(float t, float v) { return t > 0.f ? v : 0.f; }
 
@@ -171,8 +174,11 @@ __device__ __forceinline__ bool estate_argmax(const float (&om)[NQ], const float
 // register-resident tables gathered once per pair, compact rows in slab B).  Paths that leave the window are
 // dropped, so every posterior is a lower bound and their total over the rows is L minus the dropped mass: the
 // window result is kept only when that total equals L within float32 noise (the rule of wh_score7.hip's envelope
-// sweep), otherwise the caller runs the full-width sweeps.  The Forward specials (AL_PN/PJ/PC) stay intact for
-// that case: the window posteriors of N/J/C go to AL_B/AL_E/AL_ML, which nothing reads after the Forward sweep.
+// sweep), otherwise the caller runs the full-width sweeps.  The window posteriors of N/J/C go to AL_B/AL_E (which
+// nothing reads after the Forward sweep) and AL_WPC.
+// For this attempt the Forward sweep spills its rows sparsely (a lane block is written only when one of its cells
+// exceeds 2^-24 of the row's E; the row's 64-bit mask of written blocks is in AL_ML/AL_MH): an unwritten block reads
+// as zero here, and what that drops is part of the mass the certificate measures.
 typedef __attribute__((address_space(3))) float awl_f;
 typedef __attribute__((address_space(3))) uint8_t awl_u8;
 typedef __attribute__((address_space(1))) float awg_f;
@@ -186,7 +192,8 @@ struct AlnWinCtx {              // <= 16 dwords: passed in registers to the non-
 };
 
 constexpr float kAlnWinTol = 3e-6f;
-enum { AW_PN = AL_B, AW_PJ = AL_E, AW_PC = AL_ML };
+constexpr float kAlnKeepScale = 5.9604645e-08f;   // 2^-24, as in wh_score7.hip
+enum { AW_PN = AL_B, AW_PJ = AL_E, AW_PC = AL_WPC };
 
 // 1: columns written; 0: the window lost mass (or left float32 range), nothing was written
 template <int QB, int Q, bool SPECG>
@@ -195,8 +202,10 @@ __device__ __noinline__ int align_window(const AlnWinCtx c, int32_t *cols, int L
 #define AW_TICK(slot) do { if (wcyc) { const long long t_now = __builtin_readcyclecounter(); if (c.lane == 0) atomicAdd(wcyc + (slot), (unsigned long long)(t_now - t_last)); t_last = t_now; } } while (0)
   static_assert(Q % QB == 0 && QB % 4 == 0, "a window lane must stay inside one forward lane block");
   constexpr int Q4 = Q / 4, B4 = QB / 4, TBL = Q * kWave;
-  constexpr int R = 32 / QB;      // rows in flight (64 registers either way)
-  const int lane = c.lane, SP = c.SP;
+  constexpr int R = QB == 4 ? 6 : 2;   // rows in flight (more spill registers inside the row loops)
+  L = __builtin_amdgcn_readfirstlane(L); M = __builtin_amdgcn_readfirstlane(M); m0 = __builtin_amdgcn_readfirstlane(m0);
+  Lcap = __builtin_amdgcn_readfirstlane(Lcap); Klds = __builtin_amdgcn_readfirstlane(Klds);
+  const int lane = c.lane, SP = __builtin_amdgcn_readfirstlane(c.SP);
   float *spec = SPECG ? (float *)c.specg : (float *)c.spec3;
   const uint8_t *seq = (const uint8_t *)c.seq;
   const float *trF = (const float *)c.trL, *trB = trF + FW_NARR * TBL;
@@ -223,7 +232,7 @@ __device__ __noinline__ int align_window(const AlnWinCtx c, int32_t *cols, int L
       }
     }
     const ScanC sc = scan_prepare(lane_product<QB, true>(T, BW_DD));
-    const float4 *em4L = reinterpret_cast<const float4 *>((const float *)c.emL);
+    const LdsF4 em4L((const float *)c.emL);
     const float4 *em4G = reinterpret_cast<const float4 *>((const float *)c.emG);
     float Mb[QB], Ib[QB];
 #pragma unroll
@@ -234,39 +243,49 @@ __device__ __noinline__ int align_window(const AlnWinCtx c, int32_t *cols, int L
     // the stored Forward cells of a row are requested R rows ahead: at two waves per SIMD one HBM round trip takes
     // as long as ~10 window rows of arithmetic
     float4 ring[R][2 * B4];
-    auto request_row = [&](float4 (&slot)[2 * B4], int r) {
+    unsigned havebits = 0;      // bit r: ring slot r holds a written lane block
+    const int lanef = (16 * Q - 1 - ((m0 >> 2) + lane * B4)) / Q4;     // forward lane block of my nodes
+    // every row issues the same memory operations (requests are never skipped: an unwritten block is loaded and
+    // discarded, a request past row 1 re-reads row 1), so the compiler's vmcnt bookkeeping is exact and a row waits
+    // for ITS cells only - with a conditional request the waits collapse to the last one issued
+    auto request_row = [&](float4 (&slot)[2 * B4], int rs, int r) {
+      const unsigned mword = (unsigned)(lanef < 32 ? SPRI(AL_ML * SP + r) : SPRI(AL_MH * SP + r));
+      const unsigned have = (mword >> (lanef & 31)) & 1u;
+      havebits = (havebits & ~(1u << rs)) | (have << rs);
       const float4 *row = reinterpret_cast<const float4 *>((const float *)c.slabA) + (size_t)r * (2 * Q4 * kWave);
 #pragma unroll
       for (int p4 = 0; p4 < B4; p4++) { slot[p4] = nt_load4(row + fwd[p4]); slot[B4 + p4] = nt_load4(row + Q4 * kWave + fwd[p4]); }
     };
-#pragma unroll
-    for (int r = 0; r < R; r++) if (L - r >= 1) request_row(ring[r], L - r);
-#pragma unroll 1
-    for (int ib = L; ib >= 1; ib -= R) {
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-      const int i = ib - r;
-      if (i < 1) break;
+    auto row2 = [&](int i, float4 (&slot)[2 * B4], int rs, auto more) {
       asm volatile("" ::: "memory");
       float4 fm_c[B4], fi_c[B4];
+      const bool have = (havebits >> rs) & 1u;
 #pragma unroll
-      for (int p4 = 0; p4 < B4; p4++) { fm_c[p4] = ring[r][p4]; fi_c[p4] = ring[r][B4 + p4]; }
-      if (i - R >= 1) request_row(ring[r], i - R);
+      for (int p4 = 0; p4 < B4; p4++) {
+        fm_c[p4] = have ? slot[p4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        fi_c[p4] = have ? slot[B4 + p4] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      if constexpr (decltype(more)::value) request_row(slot, rs, i - R >= 1 ? i - R : 1);
       const int S_i = SPRI(AL_S * SP + i);
       const int dS = S_i - SPRI(AL_S * SP + i - 1);
       if (i < L) {
         mirror_scale<QB>(S_next - S_i, Mb, Ib, xJ, xC, xN);
         const int x = __builtin_amdgcn_readfirstlane((int)seq[i]);
         float part = 0.f;
+        // the consumer sits inside each branch: a value live across the merge would be one flat load (wh_device.h)
+        auto emit = [&](auto em_ld) {
 #pragma unroll
-        for (int p4 = 0; p4 < B4; p4++) {
-          const float4 E = T.v[BW_E][p4];
-          const float4 O = x < Klds ? em4L[x * (Q * 16) + fwd[p4]] : em4G[(size_t)x * (Q * 16) + fwd[p4]];
-          Mb[4 * p4 + 0] *= O.w; part = fmaf(E.x, Mb[4 * p4 + 0], part);
-          Mb[4 * p4 + 1] *= O.z; part = fmaf(E.y, Mb[4 * p4 + 1], part);
-          Mb[4 * p4 + 2] *= O.y; part = fmaf(E.z, Mb[4 * p4 + 2], part);
-          Mb[4 * p4 + 3] *= O.x; part = fmaf(E.w, Mb[4 * p4 + 3], part);
-        }
+          for (int p4 = 0; p4 < B4; p4++) {
+            const float4 E = T.v[BW_E][p4];
+            const float4 O = em_ld(p4);
+            Mb[4 * p4 + 0] *= O.w; part = fmaf(E.x, Mb[4 * p4 + 0], part);
+            Mb[4 * p4 + 1] *= O.z; part = fmaf(E.y, Mb[4 * p4 + 1], part);
+            Mb[4 * p4 + 2] *= O.y; part = fmaf(E.z, Mb[4 * p4 + 2], part);
+            Mb[4 * p4 + 3] *= O.x; part = fmaf(E.w, Mb[4 * p4 + 3], part);
+          }
+        };
+        if (x < Klds) emit([&](int p4) { return em4L[x * (Q * 16) + fwd[p4]]; });
+        else emit([&](int p4) { return em4G[(size_t)x * (Q * 16) + fwd[p4]]; });
         xB = wave_sum(part);
         xJ = fmaf(xJ, cu.loop, xB * cu.move);
         xC = xC * cu.loop;
@@ -298,8 +317,17 @@ __device__ __noinline__ int align_window(const AlnWinCtx c, int32_t *cols, int L
       if (lane == 0) { spec[AW_PN * SP + i] = pn; spec[AW_PJ * SP + i] = pj; spec[AW_PC * SP + i] = pc; }
       __builtin_amdgcn_wave_barrier();
       S_next = S_i;
+    };
+#pragma unroll
+    for (int r = 0; r < R; r++) request_row(ring[r], r, L - r >= 1 ? L - r : 1);
+    int ib = L;
+#pragma unroll 1
+    for (; ib - (R - 1) >= 1; ib -= R) {
+#pragma unroll
+      for (int r = 0; r < R; r++) row2(ib - r, ring[r], r, std::true_type{});
     }
-    }
+#pragma unroll
+    for (int r = 0; r < R; r++) if (ib - r >= 1) row2(ib - r, ring[r], r, std::false_type{});
     const float mass = wave_sum(acc) + accs;
     if (clamped || !(fabsf((float)L - mass) <= kAlnWinTol * (float)L)) return 0;
   }
@@ -342,19 +370,12 @@ __device__ __noinline__ int align_window(const AlnWinCtx c, int32_t *cols, int L
 #pragma unroll
       for (int g = 0; g < B4; g++) { slot[g] = nt_load4(prow + g * kWave); slot[B4 + g] = nt_load4(prow + (B4 + g) * kWave); }
     };
-#pragma unroll
-    for (int r = 0; r < R; r++) if (1 + r <= L) request_pp(ring[r], 1 + r);
-#pragma unroll 1
-    for (int ib = 1; ib <= L; ib += R) {
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-      const int i = ib + r;
-      if (i > L) break;
+    auto row3 = [&](int i, float4 (&slot)[2 * B4], auto more) {
       asm volatile("" ::: "memory");
       float4 pm4[B4], pi4[B4];
 #pragma unroll
-      for (int g = 0; g < B4; g++) { pm4[g] = ring[r][g]; pi4[g] = ring[r][B4 + g]; }
-      if (i + R <= L) request_pp(ring[r], i + R);
+      for (int g = 0; g < B4; g++) { pm4[g] = slot[g]; pi4[g] = slot[B4 + g]; }
+      if constexpr (decltype(more)::value) request_pp(slot, i + R <= L ? i + R : L);   // same operations every row (see above)
       const float mm1 = wave_shr1(Mp[QB - 1]), im1 = wave_shr1(Ip[QB - 1]), dm1 = wave_shr1(Dp[QB - 1]);
 #pragma unroll
       for (int g = B4 - 1; g >= 0; g--) {
@@ -422,8 +443,17 @@ __device__ __noinline__ int align_window(const AlnWinCtx c, int32_t *cols, int L
         nt_store4(orow + (B4 + g) * kWave, Ip[4 * g], Ip[4 * g + 1], Ip[4 * g + 2], Ip[4 * g + 3]);
         nt_store4(orow + (2 * B4 + g) * kWave, Dp[4 * g], Dp[4 * g + 1], Dp[4 * g + 2], Dp[4 * g + 3]);
       }
+    };
+#pragma unroll
+    for (int r = 0; r < R; r++) request_pp(ring[r], 1 + r <= L ? 1 + r : L);
+    int ib = 1;
+#pragma unroll 1
+    for (; ib + (R - 1) <= L; ib += R) {
+#pragma unroll
+      for (int r = 0; r < R; r++) row3(ib + r, ring[r], std::true_type{});
     }
-    }
+#pragma unroll
+    for (int r = 0; r < R; r++) if (ib + r <= L) row3(ib + r, ring[r], std::false_type{});
   }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
   AW_TICK(2);
@@ -537,41 +567,48 @@ __global__ __launch_bounds__(SWAP ? 256 : 512) void align_kernel(AlignArgs a) {
       }
       __builtin_amdgcn_wave_barrier();
       const LenCfg cu = len_config(L > 0 ? L : 1, false);
-      const long long t_pair = a.wstat ? (long long)__builtin_readcyclecounter() : 0;
+      const long long t_pair = a.wcyc ? (long long)__builtin_readcyclecounter() : 0;
 
-      // ---------------- unihit Forward, rows spilled to slab A
+      // ---------------- unihit Forward, rows spilled to slab A: sparsely for the node-window attempt (a query short
+      // enough to fit one), at full width otherwise and when the window result was not accepted
       float xC_L = 0.f, lZ = -INFINITY; int ef_L = 0;
       orient(0);
-      if (active) {
-        TransTab<Q, TREG> T;
-        T.load(fwG, trF, lane);
-        if constexpr (LOGSP) {
-          lZ = forward_sweep_log<Q>(T, emL, emG, Klds, seq, L, cu, spec, SP, slabA, lane);
-          xC_L = lZ > -INFINITY ? 1.f : 0.f;
-        } else {
-          const ScanC sc = scan_prepare(lane_product<Q, TREG>(T, FW_D2));
-          // forward_sweep uses spec slots 0..5 = N,B,E,J,C,S with stride SP (AL_PN..AL_S coincide)
-          forward_sweep<Q, TREG, true>(T, sc, emL, emG, Klds, seq, L, cu, spec, SP, slabA, -1.0f, lane, xC_L, ef_L);   // dense
+      constexpr bool kWindows = !SWAP && !LOGSP && !TREG && Q >= 8;
+      const bool sparse = kWindows && !a.no_window && L <= kWave * (Q % 8 == 0 && Q > 8 ? 8 : 4);
+      if (!LOGSP && !sparse && active && a.wstat && lane == 0) atomicAdd(a.wstat + 2, 1);
+#pragma unroll 1
+      for (int attempt = sparse ? 0 : 1; attempt < 2 && active; attempt++) {
+        {
+          TransTab<Q, TREG> T;
+          T.load(fwG, trF, lane);
+          if constexpr (LOGSP) {
+            lZ = forward_sweep_log<Q>(T, emL, emG, Klds, seq, L, cu, spec, SP, slabA, lane);
+            xC_L = lZ > -INFINITY ? 1.f : 0.f;
+          } else {
+            const ScanC sc = scan_prepare(lane_product<Q, TREG>(T, FW_D2));
+            // forward_sweep uses spec slots 0..7 = N,B,E,J,C,S,ML,MH with stride SP (AL_PN..AL_MH coincide)
+            forward_sweep<Q, TREG, true>(T, sc, emL, emG, Klds, seq, L, cu, spec, SP, slabA, attempt == 0 ? kAlnKeepScale : -1.0f, lane, xC_L, ef_L);
+          }
         }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-      if (!(xC_L > 0.f)) active = false;   // no alignment has non-zero probability: all residues stay -1
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        if (!(xC_L > 0.f)) { active = false; break; }   // no alignment has non-zero probability: all residues stay -1
+        if (attempt == 1) break;
 
-      // ---------------- the three remaining passes on a node window, when the dominant path fits one
-      if constexpr (!SWAP && !LOGSP && !TREG && Q >= 8) {
-        if (active && !a.no_window) {
+        // ---------------- the three remaining passes on a node window, when the dominant path fits one
+        if constexpr (kWindows) {
           const unsigned long long um = ((unsigned long long)(unsigned)SPRI(AL_MH * SP) << 32) | (unsigned)SPRI(AL_ML * SP);
-          int done = 0, tried = 0;
+          int done = 0, tried = 0, nodes_w = 0;
           if (um != 0) {
             int lo = __builtin_ctzll(um), hi = 63 - __builtin_clzll(um);
             lo = lo > 1 ? lo - 2 : 0; hi = hi < 63 ? hi + 1 : 63;
             const int nodes = (hi - lo + 1) * Q;
+            nodes_w = nodes;
             AlnWinCtx c;
             c.emL = (awl_f *)emL; c.trL = (awl_f *)trL; c.spec3 = SPECG ? nullptr : (awl_f *)spec; c.seq = (awl_u8 *)seq;
             c.emG = (const awg_f *)emG; c.slabA = (awg_f *)slabA; c.specg = SPECG ? (awg_f *)spec : nullptr;
             c.SP = SP; c.lane = lane;
             const float invZ = 1.0f / (xC_L * cu.move);
-            unsigned long long *wcyc = a.wstat ? reinterpret_cast<unsigned long long *>(a.wstat + 4) : nullptr;
+            unsigned long long *wcyc = a.wcyc;
             if (wcyc && lane == 0) atomicAdd(wcyc, (unsigned long long)(__builtin_readcyclecounter() - t_pair));
             if (nodes <= 4 * kWave) {
               tried = 1;
@@ -581,7 +618,7 @@ __global__ __launch_bounds__(SWAP ? 256 : 512) void align_kernel(AlignArgs a) {
               done = align_window<(Q % 8 == 0 ? 8 : 4), Q, SPECG>(c, cols, L, M, min((63 - hi) * Q, kWave * (Q - 8)), a.Lcap, Klds, cu, invZ, wcyc);
             }
           }
-          if (a.wstat && lane == 0) atomicAdd(a.wstat + (done ? 0 : tried ? 1 : 2), 1);
+          if (a.wstat && lane == 0) atomicAdd(a.wstat + (done ? (nodes_w > 4 * kWave ? 3 : 0) : tried ? 1 : 2), 1);
           if (done) active = false;   // columns are written
         }
       }

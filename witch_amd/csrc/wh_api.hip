@@ -99,6 +99,7 @@ struct wh_ehmm {
   int max_Q = 4;                              // largest cells-per-lane of any model (sizes the float64 slabs)
   int last_align_redo = 0;          // pairs of the last wh_align call that went through the log-space pass
   int last_align_unaligned = 0;     // ... that the any-size kernel could not align (float64 range)
+  int64_t last_align_paths[4] = {0, 0, 0, 0};   // pairs of the last wh_align call: 256-node window, window rejected, no window, 512-node window
   std::vector<int64_t> last_unaligned_pairs;   // their pair numbers (wh_last_align_status)
   // timing only: one event in front of every scoring launch of the last call (+ one behind the last), its cells-per-lane class
   // and kernel family (0 phase-call, 1 pass-synchronous, 2 any-size front end): wh_last_score_launches
@@ -379,6 +380,12 @@ int wh_last_align_status(wh_ehmm *e, int64_t *n_logspace, int64_t *n_unaligned, 
   if (n_logspace) *n_logspace = e->last_align_redo;
   if (n_unaligned) *n_unaligned = (int64_t)e->last_unaligned_pairs.size();
   for (int64_t t = 0; t < cap && t < (int64_t)e->last_unaligned_pairs.size(); t++) unaligned_pairs[t] = e->last_unaligned_pairs[(size_t)t];
+  return WH_OK;
+}
+
+int wh_last_align_paths(wh_ehmm *e, int64_t *paths4) {
+  if (!e || !paths4) { set_error("wh_last_align_paths: bad argument"); return WH_EINVAL; }
+  for (int t = 0; t < 4; t++) paths4[t] = e->last_align_paths[t];
   return WH_OK;
 }
 
@@ -971,7 +978,7 @@ int wh_topk(wh_ehmm *e, const int32_t *decibits, const uint8_t *flags, int64_t n
 // ------------------------------------------------------------------------------------ align
 static int plan_align_block(int Q, int K, int Lcap, int *waves, int *SP, int *wave_lds, size_t *lds) {
   const int sp = (Lcap + 1 + 3) / 4 * 4;
-  const int wl = 13 * sp + (Lcap + 3) / 4 + 4;
+  const int wl = kAlignSpecArrays * sp + (Lcap + 3) / 4 + 4;
   const size_t table = (size_t)(K + 2 * FW_NARR) * Q * kWave * sizeof(float);
   int w = 8;
   while (w >= 1 && table + (size_t)w * wl * sizeof(float) > kLdsBudget) w--;
@@ -1085,13 +1092,14 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
     a.K = e->K; a.Kp = e->Kp; a.Klds = plans[pl][6] % 1000; a.swap = plans[pl][6] >= 1000 ? 1 : 0;
     a.logsp = logsp ? 1 : 0;
     a.no_window = e->knobs.no_window ? 1 : 0;
-    a.wstat = (e->knobs.trace || e->knobs.stats) ? (int *)e->d_counter.p + 96 : nullptr;
+    a.wstat = logsp ? nullptr : (int *)e->d_counter.p + 96;
+    a.wcyc = (!logsp && (e->knobs.trace || e->knobs.stats)) ? reinterpret_cast<unsigned long long *>((int *)e->d_counter.p + 100) : nullptr;
     a.redo_count = (!logsp && want_redo) ? d_redo_count : nullptr;
     a.redo_list = (!logsp && want_redo) ? d_redo_list : nullptr;
     if (launches >= kMaxLaunches) { set_error("wh_align_dev: too many launches in one call"); return WH_ERANGE; }
     int blocks = std::min(n, e->cu_count * std::max(1, 8 / waves));
     a.scratch_stride = (size_t)(a.Lcap + 1) * 5 * Q * kWave;
-    a.spec_stride = plans[pl][5] < 0 ? (size_t)13 * a.SP : 0;
+    a.spec_stride = plans[pl][5] < 0 ? (size_t)kAlignSpecArrays * a.SP : 0;
     blocks = clamp_blocks(blocks, (size_t)waves * (a.scratch_stride + a.spec_stride) * sizeof(float), e->d_ascratch);
     if (pass == 0) {
       need_scratch = std::max(need_scratch, (size_t)blocks * waves * a.scratch_stride * sizeof(float));
@@ -1134,14 +1142,17 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
     rc = run_pass(order2, cnt2, true);
     if (rc != WH_OK) return rc;
   }
-  if (e->knobs.trace || e->knobs.stats) {
+  {
     int ws[12] = {0};
     HIPCHK(hipMemcpyAsync(ws, (int *)e->d_counter.p + 96, sizeof ws, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    unsigned long long cy[4];
-    memcpy(cy, ws + 4, sizeof cy);
-    fprintf(stderr, "[wh] align: %d pairs on a node window, %d windows rejected (full width), %d without a window; wave cycles of the window pairs: "
-            "Forward %.3g, Backward+posteriors %.3g, OA fill %.3g, traceback %.3g\n", ws[0], ws[1], ws[2], (double)cy[0], (double)cy[1], (double)cy[2], (double)cy[3]);
+    for (int t = 0; t < 4; t++) e->last_align_paths[t] = ws[t];
+    if (e->knobs.trace || e->knobs.stats) {
+      unsigned long long cy[4];
+      memcpy(cy, ws + 4, sizeof cy);
+      fprintf(stderr, "[wh] align: %d + %d pairs on a 256- / 512-node window, %d windows rejected (full width), %d without a window; wave cycles of the window pairs: "
+              "Forward %.3g, Backward+posteriors %.3g, OA fill %.3g, traceback %.3g\n", ws[0], ws[3], ws[1], ws[2], (double)cy[0], (double)cy[1], (double)cy[2], (double)cy[3]);
+    }
   }
   e->last_align_redo = n_redo;
   e->last_align_unaligned = 0;

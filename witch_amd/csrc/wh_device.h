@@ -147,11 +147,22 @@ __device__ __forceinline__ float lane_product(const TransTab<Q, TREG> &T, int ar
 // Canonical residues come from the LDS copy of the table, degenerate codes (rare) from L2.
 // The two sources are kept in separate branches so that the LDS path compiles to ds_read_b128
 // (a pointer select between LDS and global would degrade both to flat loads).
+// The LDS branch reads through a pointer TYPED as LDS: with two generic pointers the compiler merges the branches
+// into one flat_load behind a pointer select - half the LDS rate, and a flat load counts on vmcnt AND lgkmcnt, so
+// every row waited for the row stores and row prefetches in flight (seen in the round-3 ISA of every sweep).
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) v4f_t lds_cv4_t;
+struct LdsF4 {      // float4 pieces of an LDS-resident array
+  lds_cv4_t *p;
+  __device__ __forceinline__ LdsF4(const float *base) : p((lds_cv4_t *)base) {}
+  __device__ __forceinline__ float4 operator[](int i) const { const v4f_t v = p[i]; return make_float4(v.x, v.y, v.z, v.w); }
+};
+
 template <int Q>
 __device__ __forceinline__ void load_em_fwd(float (&od)[Q], const float *emL, const float *emG, int x, int K,
                                             int lane) {
   if (x < K) {
-    const float4 *p = reinterpret_cast<const float4 *>(emL + (size_t)x * Q * kWave) + lane;
+    const LdsF4 p(emL + (size_t)x * Q * kWave + 4 * lane);
 #pragma unroll
     for (int q4 = 0; q4 < Q / 4; q4++) {
       float4 v = p[q4 * kWave];
@@ -172,7 +183,7 @@ template <int Q>
 __device__ __forceinline__ void load_em_rev(float (&od)[Q], const float *emL, const float *emG, int x, int K,
                                             int lane) {
   if (x < K) {
-    const float4 *p = reinterpret_cast<const float4 *>(emL + (size_t)x * Q * kWave) + (kWave - 1 - lane);
+    const LdsF4 p(emL + (size_t)x * Q * kWave + 4 * (kWave - 1 - lane));
 #pragma unroll
     for (int p4 = 0; p4 < Q / 4; p4++) {
       float4 v = p[(Q / 4 - 1 - p4) * kWave];
@@ -439,7 +450,7 @@ __device__ __forceinline__ float backward_emit(const TransTab<Q, TREG> &T, const
   };
   x = __builtin_amdgcn_readfirstlane(x);
   if (x < K) {
-    const float4 *ep = reinterpret_cast<const float4 *>(emL + (size_t)x * Q * kWave) + (kWave - 1 - lane);
+    const LdsF4 ep(emL + (size_t)x * Q * kWave + 4 * (kWave - 1 - lane));
     groups([&](int q4) { return ep[q4 * kWave]; });
   } else {
     const float4 *ep = reinterpret_cast<const float4 *>(emG + (size_t)x * Q * kWave) + (kWave - 1 - lane);

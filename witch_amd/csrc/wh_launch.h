@@ -223,6 +223,7 @@ struct TopkArgs {
 };
 hipError_t launch_topk(const TopkArgs &a, hipStream_t s);
 
+constexpr int kAlignSpecArrays = 14;   // special-state rows per wave of the alignment kernel (AL_NARR)
 struct AlignArgs {
   const DevHMM *hmms;
   const float *tables;
@@ -249,7 +250,8 @@ struct AlignArgs {
   int logsp;                   // 1: this launch is the log-space pass
   int swap;                    // 1: pass-synchronous variant (one table orientation resident in LDS)
   int no_window;               // 1: Backward / OA / traceback at full width only (WH_NO_WINDOW)
-  int *wstat;                  // NULL or 3 counters: pairs aligned on a window, window rejected, window not tried
+  int *wstat;                  // NULL or 4 counters: pairs aligned on a 256-node window, window rejected, window not tried, 512-node window
+  unsigned long long *wcyc;    // NULL or 4 wave-cycle sums of the window pairs: Forward, Backward + posteriors, OA fill, traceback
 };
 hipError_t launch_align(int Q, const AlignArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
 

@@ -331,7 +331,7 @@ __device__ __noinline__ P4Out sweep_backward_null2_win(const WaveCtx c, lds_u8 *
   }
   const int lanef = (16 * Q - 1 - ((m0 >> 2) + lane * B4)) / Q4;     // forward lane block of my nodes
   const ScanC sc = scan_prepare(lane_product<QB, true>(T, BW_DD));
-  const float4 *em4L = reinterpret_cast<const float4 *>((const float *)c.emL);
+  const LdsF4 em4L((const float *)c.emL);
   const float4 *em4G = reinterpret_cast<const float4 *>((const float *)c.emG);
   float Mb[QB], Ib[QB], fM[QB];
 #pragma unroll
@@ -366,15 +366,20 @@ __device__ __noinline__ P4Out sweep_backward_null2_win(const WaveCtx c, lds_u8 *
       mirror_scale<QB>(S_next - S_i, Mb, Ib, xJ, xC, xN);
       const int x = __builtin_amdgcn_readfirstlane((int)eseq[i]);
       float part = 0.f;
+      // the consumer sits inside each branch: a value live across the merge would be one flat load (wh_device.h)
+      auto emit = [&](auto em_ld) {
 #pragma unroll
-      for (int p4 = 0; p4 < B4; p4++) {
-        const float4 E = T.v[BW_E][p4];
-        const float4 O = x < Klds ? em4L[x * (Q * 16) + fwd[p4]] : em4G[(size_t)x * (Q * 16) + fwd[p4]];
-        Mb[4 * p4 + 0] *= O.w; part = fmaf(E.x, Mb[4 * p4 + 0], part);
-        Mb[4 * p4 + 1] *= O.z; part = fmaf(E.y, Mb[4 * p4 + 1], part);
-        Mb[4 * p4 + 2] *= O.y; part = fmaf(E.z, Mb[4 * p4 + 2], part);
-        Mb[4 * p4 + 3] *= O.x; part = fmaf(E.w, Mb[4 * p4 + 3], part);
-      }
+        for (int p4 = 0; p4 < B4; p4++) {
+          const float4 E = T.v[BW_E][p4];
+          const float4 O = em_ld(p4);
+          Mb[4 * p4 + 0] *= O.w; part = fmaf(E.x, Mb[4 * p4 + 0], part);
+          Mb[4 * p4 + 1] *= O.z; part = fmaf(E.y, Mb[4 * p4 + 1], part);
+          Mb[4 * p4 + 2] *= O.y; part = fmaf(E.z, Mb[4 * p4 + 2], part);
+          Mb[4 * p4 + 3] *= O.x; part = fmaf(E.w, Mb[4 * p4 + 3], part);
+        }
+      };
+      if (x < Klds) emit([&](int p4) { return em4L[x * (Q * 16) + fwd[p4]]; });
+      else emit([&](int p4) { return em4G[(size_t)x * (Q * 16) + fwd[p4]]; });
       xB = wave_sum(part);
       xJ = fmaf(xJ, cu.loop, xB * cu.move);
       xC = xC * cu.loop;
@@ -419,12 +424,16 @@ __device__ __noinline__ P4Out sweep_backward_null2_win(const WaveCtx c, lds_u8 *
   float mine = 1.0f;
   for (int x = 0; x < ctxK(c); x++) {
     float s = 0.f;
+    auto dot = [&](auto em_ld) {
 #pragma unroll
-    for (int p4 = 0; p4 < B4; p4++) {
-      const float4 O = x < Klds ? em4L[x * (Q * 16) + fwd[p4]] : em4G[(size_t)x * (Q * 16) + fwd[p4]];
-      s = fmaf(fM[4 * p4 + 0], O.w, s); s = fmaf(fM[4 * p4 + 1], O.z, s);
-      s = fmaf(fM[4 * p4 + 2], O.y, s); s = fmaf(fM[4 * p4 + 3], O.x, s);
-    }
+      for (int p4 = 0; p4 < B4; p4++) {
+        const float4 O = em_ld(p4);
+        s = fmaf(fM[4 * p4 + 0], O.w, s); s = fmaf(fM[4 * p4 + 1], O.z, s);
+        s = fmaf(fM[4 * p4 + 2], O.y, s); s = fmaf(fM[4 * p4 + 3], O.x, s);
+      }
+    };
+    if (x < Klds) dot([&](int p4) { return em4L[x * (Q * 16) + fwd[p4]]; });
+    else dot([&](int p4) { return em4G[(size_t)x * (Q * 16) + fwd[p4]]; });
     s = wave_sum(s);
     if (lane == x) mine = (s + si) * norm + xfac * norm;
   }

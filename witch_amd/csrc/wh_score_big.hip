@@ -146,7 +146,7 @@ __device__ __forceinline__ void forward_sweep_lean(const TransTab<Q, false> &T, 
         });
     // emission factor: canonical residues from the LDS copy of the table, degenerate codes (rare) from L2;
     // only this light pass is duplicated by the branch
-    auto emit = [&](const float4 *ep) WH_INL {
+    auto emit = [&](auto ep) WH_INL {
       pipe_groups<G, 1, 2>(up, [&](int g, float4 (&t)[1]) WH_INL { t[0] = ep[g * kWave]; },
                            [&](int g, const float4 (&t)[1]) WH_INL {
                              Mp[4 * g] *= t[0].x; Mp[4 * g + 1] *= t[0].y; Mp[4 * g + 2] *= t[0].z; Mp[4 * g + 3] *= t[0].w;
@@ -155,7 +155,7 @@ __device__ __forceinline__ void forward_sweep_lean(const TransTab<Q, false> &T, 
     };
     asm volatile("" ::: "memory");       // keeps the emission reads below the M/I pass (they would be hoisted
                                          // to the top of the row and held in 4*G registers across it)
-    if (x < K) emit(reinterpret_cast<const float4 *>(emL + (size_t)x * Q * kWave) + lane);
+    if (x < K) emit(LdsF4(emL + (size_t)x * Q * kWave + 4 * lane));
     else emit(reinterpret_cast<const float4 *>(emG + (size_t)x * Q * kWave) + lane);
     asm volatile("" ::: "memory");
     // D row: local chains, cross-lane scan, fix-up
@@ -235,7 +235,7 @@ __device__ __forceinline__ float backward_emit_lean(const TransTab<Q, false> &T,
   x = __builtin_amdgcn_readfirstlane(x);
   float part = 0.f;
   auto up = [](int s) WH_INL { return s; };
-  auto emit = [&](const float4 *ep) WH_INL {
+  auto emit = [&](auto ep) WH_INL {
     pipe_groups<G, 2, 2>(up, [&](int g, float4 (&t)[2]) WH_INL { t[0] = T.ld(BW_E, g); t[1] = ep[(G - 1 - g) * kWave]; },
                          [&](int g, const float4 (&t)[2]) WH_INL {
                            // forward-ordered emission piece: component 3-j is position 4*g+j
@@ -246,7 +246,7 @@ __device__ __forceinline__ float backward_emit_lean(const TransTab<Q, false> &T,
                            pin1(part);
                          });
   };
-  if (x < K) emit(reinterpret_cast<const float4 *>(emL + (size_t)x * Q * kWave) + (kWave - 1 - lane));
+  if (x < K) emit(LdsF4(emL + (size_t)x * Q * kWave + 4 * (kWave - 1 - lane)));
   else emit(reinterpret_cast<const float4 *>(emG + (size_t)x * Q * kWave) + (kWave - 1 - lane));
   return part;
 }

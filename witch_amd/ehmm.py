@@ -166,6 +166,13 @@ class EHMM:
             check(lib().wh_last_align_status(self._h, None, None, pairs.ctypes.data, nun.value), "wh_last_align_status")
         return int(nlog.value), pairs
 
+    def last_align_paths(self):
+        """Pairs of the last align call by sweep path: {"window256", "window512", "window_rejected", "full_width"}
+        (include/witch_hip.h: wh_last_align_paths)."""
+        p4 = np.zeros(4, dtype=np.int64)
+        check(lib().wh_last_align_paths(self._h, p4.ctypes.data), "wh_last_align_paths")
+        return {"window256": int(p4[0]), "window512": int(p4[3]), "window_rejected": int(p4[1]), "full_width": int(p4[2])}
+
     def consensus(self, offsets, qpair_off, pair_h, pair_w, col_offsets, cols, retained, nongaps, backbone_length):
         """Weighted consensus DP (wh_consensus).  retained / nongaps: one int array per model."""
         offsets = np.ascontiguousarray(offsets, dtype=np.int64)

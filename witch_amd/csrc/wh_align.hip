@@ -619,6 +619,10 @@ __global__ __launch_bounds__(SWAP ? 256 : 512) void align_kernel(AlignArgs a) {
             }
           }
           if (a.wstat && lane == 0) atomicAdd(a.wstat + (done ? (nodes_w > 4 * kWave ? 3 : 0) : tried ? 1 : 2), 1);
+          if (a.wcyc && tried && lane == 0) {      // slack histogram (blocks of Q nodes between the path's span and the window), WH_STATS
+            const int slack = ((nodes_w > 4 * kWave ? 8 : 4) * kWave - nodes_w) / Q;
+            atomicAdd(a.wstat + 12 + (done ? 0 : 8) + (slack > 7 ? 7 : slack), 1);
+          }
           if (done) active = false;   // columns are written
         }
       }

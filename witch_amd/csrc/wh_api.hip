@@ -1019,7 +1019,7 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
   int *d_redo_count = (int *)e->d_recs.p;
   int32_t *d_redo_list = (int32_t *)e->d_recs.p + 4;
   HIPCHK(hipMemsetAsync(d_redo_count, 0, sizeof(int), s));
-  HIPCHK(hipMemsetAsync((int *)e->d_counter.p + 96, 0, 12 * sizeof(int), s));
+  HIPCHK(hipMemsetAsync((int *)e->d_counter.p + 96, 0, 28 * sizeof(int), s));
   if (timer_begin(e, 2, s)) return WH_EHIP;
   int launches = 0;
   // one pass = plan the launches of every model class for the pairs in <order> (grouped by model,
@@ -1143,7 +1143,7 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
     if (rc != WH_OK) return rc;
   }
   {
-    int ws[12] = {0};
+    int ws[28] = {0};
     HIPCHK(hipMemcpyAsync(ws, (int *)e->d_counter.p + 96, sizeof ws, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     for (int t = 0; t < 4; t++) e->last_align_paths[t] = ws[t];
@@ -1152,6 +1152,11 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       memcpy(cy, ws + 4, sizeof cy);
       fprintf(stderr, "[wh] align: %d + %d pairs on a 256- / 512-node window, %d windows rejected (full width), %d without a window; wave cycles of the window pairs: "
               "Forward %.3g, Backward+posteriors %.3g, OA fill %.3g, traceback %.3g\n", ws[0], ws[3], ws[1], ws[2], (double)cy[0], (double)cy[1], (double)cy[2], (double)cy[3]);
+      fprintf(stderr, "[wh] align: window attempts by slack (lane blocks between the path's span with margins and the window, 0..7+): accepted");
+      for (int t = 0; t < 8; t++) fprintf(stderr, " %d", ws[12 + t]);
+      fprintf(stderr, "; rejected");
+      for (int t = 0; t < 8; t++) fprintf(stderr, " %d", ws[20 + t]);
+      fprintf(stderr, "\n");
     }
   }
   e->last_align_redo = n_redo;

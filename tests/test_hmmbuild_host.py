@@ -3,8 +3,10 @@
 The expected files were written by the reference's bundled hmmbuild with the reference's command line
 (witch_msa/gcmm/algorithm.py:463-470): the golden models of the scoring tests (tests/golden/make_golden*.py)
 and hand-shaped edge cases (tests/golden/make_golden_hmmbuild.py).  The bar is TEXT identity of every line
-except NAME, DATE, and the two things this build does not compute: the STATS lines (E-value calibration by
-simulation) and MAXL.  No GPU is needed: the builder is host code behind the C ABI.
+except NAME, DATE and MAXL (nucleotide models only; only nhmmer reads it; not computed here).  The three STATS LOCAL
+lines (E-value calibration by simulation, witch_amd/csrc/wh_calibrate.h) are optional in the C ABI
+(WH_BUILD_STATS) and, when asked for, text-identical too: their own tests below.  No GPU is needed: the builder
+is host code behind the C ABI.
 """
 import gzip
 import json
@@ -53,6 +55,10 @@ def family_rows(alphabet, seed, root_len, n_leaves, n_sub, sub_rate, indel_rate)
     return rows, synth.bfs_subsets(n_leaves, n_sub)
 
 
+def stats_lines(text):
+    return [l.rstrip() for l in text.splitlines() if l.startswith("STATS")]
+
+
 def assert_same(text, gold_text, what):
     a, b = body(text), body(gold_text)
     assert len(a) == len(b), (what, len(a), len(b))
@@ -75,6 +81,13 @@ def test_edge_cases_against_hmmbuild(case):
     text, M, neff = hmmbuild_text(rows, mol, case)
     assert_same(text, gold, case)
     assert "EFFN  %f" % neff in text and "LENG  %d" % M in text
+    assert not stats_lines(text)                       # not asked for: no calibration, no lines
+    # E-value calibration (MSV / Viterbi filter scores and Forward scores of 3 x 200 seeded random sequences):
+    # hmmbuild's printed digits, and nothing else in the file moves
+    text2, _, _ = hmmbuild_text(rows, mol, case, stats=True)
+    assert stats_lines(text2) == stats_lines(gold) and len(stats_lines(gold)) == 3, (case, stats_lines(text2), stats_lines(gold))
+    assert body(text2) == body(text)
+    assert text2.splitlines().index(stats_lines(text2)[0]) == [l.split()[0] for l in text2.splitlines()].index("CKSUM") + 1
 
 
 @pytest.mark.parametrize("case,args,mol", [
@@ -84,8 +97,10 @@ def test_edge_cases_against_hmmbuild(case):
 def test_golden_family_models(case, args, mol):
     rows, subs = family_rows(*args)
     for idx, (lo, hi) in enumerate(subs):
-        text, _, _ = hmmbuild_text(rows[lo:hi], mol, "sub")
-        assert_same(text, read(os.path.join(GOLD, case, "hmms", "A_0_%d.hmm" % idx)), (case, idx))
+        text, _, _ = hmmbuild_text(rows[lo:hi], mol, "sub", stats=True)
+        gold = read(os.path.join(GOLD, case, "hmms", "A_0_%d.hmm" % idx))
+        assert_same(text, gold, (case, idx))
+        assert stats_lines(text) == stats_lines(gold), (case, idx, stats_lines(text), stats_lines(gold))
 
 
 def test_example_backbone_models_and_column_tuples(tmp_path):
@@ -95,8 +110,14 @@ def test_example_backbone_models_and_column_tuples(tmp_path):
     subs = synth.bfs_subsets(len(rows), 15)
     gold = json.load(gzip.open(os.path.join(GOLD, "example_e2e", "golden.json.gz"), "rt"))
     for idx, (lo, hi) in enumerate(subs):
-        text, M, _ = hmmbuild_text([r.upper() for r in rows[lo:hi]], "dna", "sub")
-        assert_same(text, read(os.path.join(GOLD, "example_e2e", "hmms", "A_0_%d.hmm.gz" % idx)), idx)
+        # (calibration on the five smallest of these 1 278 .. 2 574-node models: ~0.6 s each; all 15 were checked once,
+        # tools/README.md)
+        want_stats = idx >= 10
+        text, M, _ = hmmbuild_text([r.upper() for r in rows[lo:hi]], "dna", "sub", stats=want_stats)
+        gold_text = read(os.path.join(GOLD, "example_e2e", "hmms", "A_0_%d.hmm.gz" % idx))
+        assert_same(text, gold_text, idx)
+        if want_stats:
+            assert stats_lines(text) == stats_lines(gold_text), (idx, stats_lines(text), stats_lines(gold_text))
     out = build_ehmm(names, rows, [("A_0_%d" % i, list(range(lo, hi))) for i, (lo, hi) in enumerate(subs)], "dna",
                      str(tmp_path), threads=4)
     for idx, (path, label, retained, nongaps) in enumerate(out):
@@ -196,9 +217,48 @@ def test_level0_hmmbuild_executable(tmp_path):
         cmd = [exe, "--cpu", "1", "--" + mol, "--ere", "0.59", "--symfrac", "0.0", "--informat", "afa", "-o", "/dev/null", str(out), afa]
         subprocess.run(cmd, check=True)
         text = out.read_text()
-        assert_same(text, read(os.path.join(GOLD, "hmmbuild_cases", case + ".hmm")), case)
+        gold = read(os.path.join(GOLD, "hmmbuild_cases", case + ".hmm"))
+        assert_same(text, gold, case)
         assert "NAME  %s\n" % case in text
+        assert stats_lines(text) == stats_lines(gold)        # like hmmbuild, the executable calibrates by default
+        subprocess.run(cmd[:1] + ["--nostats"] + cmd[1:], check=True)
+        assert not stats_lines(out.read_text()) and body(out.read_text()) == body(text)
     r = subprocess.run([exe, "--dna", "--wblosum", "x", "y"], capture_output=True, text=True)
     assert r.returncode != 0 and "not supported" in r.stderr
     r = subprocess.run([exe, "--ere", "0.59", str(tmp_path / "o"), os.path.join(GOLD, "hmmbuild_cases", "dna_single.afa")], capture_output=True, text=True)
     assert r.returncode != 0 and "required" in r.stderr
+
+
+HMMER_BIN = "/root/reference/witch_msa/tools/magus/tools/hmmer"
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(HMMER_BIN, "hmmsearch")), reason="the reference's bundled HMMER is not on this machine")
+def test_stock_hmmsearch_reads_the_calibrated_file(tmp_path):
+    """Interoperation with stock HMMER (a `-p <hmmdir>` rerun of the reference on an eHMM this build wrote,
+    witch_msa/gcmm/gcmm.py:163-171): the reference's bundled hmmsearch, with the reference's command line
+    (algorithm.py:526-532), prints the same report - scores AND E-values - for a model written by the level-0
+    hmmbuild executable as for hmmbuild's own file; without the STATS lines it reports no hit at all."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "witch_amd", "shim", "bin", "hmmbuild")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(root, "witch_amd", "shim"), "bin/hmmbuild"], check=True, stdout=subprocess.DEVNULL)
+    for case, mol in (("dna_conserved", "dna"), ("amino_mixed", "amino"), ("random_07_rna", "rna")):
+        afa = os.path.join(GOLD, "hmmbuild_cases", case + ".afa")
+        rows = [l.strip() for l in open(afa) if not l.startswith(">")]
+        fa = tmp_path / (case + ".fa")
+        fa.write_text("".join(">q%d\n%s\n" % (i, r.replace("-", "").replace(".", "")) for i, r in enumerate(rows[:6]) if len(r.replace("-", "").replace(".", "")) > 0))
+        reports = {}
+        for tag, extra in (("mine", []), ("nostats", ["--nostats"])):
+            model = tmp_path / ("%s.%s.hmm" % (case, tag))
+            subprocess.run([exe] + extra + ["--cpu", "1", "--" + mol, "--ere", "0.59", "--symfrac", "0.0", "--informat", "afa", "-o", "/dev/null", "-n", case,
+                                            str(model), afa], check=True)
+            reports[tag] = model
+        reports["gold"] = os.path.join(GOLD, "hmmbuild_cases", case + ".hmm")
+        out = {}
+        for tag, model in reports.items():
+            o = tmp_path / ("%s.%s.out" % (case, tag))
+            subprocess.run([os.path.join(HMMER_BIN, "hmmsearch"), "--cpu", "1", "--noali", "-E", "99999999", "-o", str(o), "--max", str(model), str(fa)], check=True)
+            out[tag] = [l for l in o.read_text().splitlines() if not l.startswith("#")]
+        assert out["mine"] == out["gold"], case
+        assert any("No hits detected" in l for l in out["nostats"]) and not any("No hits detected" in l for l in out["gold"]), case

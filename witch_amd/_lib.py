@@ -42,6 +42,8 @@ SYMBOLS = {
     "wh_ehmm_load": (_P, [C.POINTER(C.c_char_p), _P, _P, C.c_int]),
     "wh_hmmbuild": (C.c_int, [C.c_char_p, C.c_int32, C.c_int64, C.POINTER(C.c_char_p), C.c_char_p, C.c_double, C.c_double,
                             C.c_double, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
+    "wh_hmmbuild2": (C.c_int, [C.c_char_p, C.c_int32, C.c_int64, C.POINTER(C.c_char_p), C.c_char_p, C.c_double, C.c_double,
+                             C.c_double, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
     "wh_free_text": (None, [C.c_void_p]),
     "wh_merge_sharded": (C.c_int, [C.c_int, _P, _P, C.c_int64, _P, _P, _P, C.c_int32, C.c_int32, _P, _P, C.POINTER(C.c_void_p),
                                  C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

@@ -261,6 +261,8 @@ double mean_match_relent(const Model &h, const float *bg) {
   return KL / (double)h.M;
 }
 
+#include "wh_calibrate.h"
+
 void scale_model(Model &h, double scale) {
   const float s = (float)scale;
   for (float &v : h.t) v *= s;
@@ -289,6 +291,12 @@ void put_prob(std::string &s, float p) {
 extern "C" int wh_hmmbuild(const char *molecule, int32_t nseq, int64_t alen, const char *const *rows, const char *name,
                            double ere, double symfrac, double fragthresh, char **out_text, int64_t *out_len,
                            int32_t *out_M, double *out_neff) {
+  return wh_hmmbuild2(molecule, nseq, alen, rows, name, ere, symfrac, fragthresh, 0, out_text, out_len, out_M, out_neff);
+}
+
+extern "C" int wh_hmmbuild2(const char *molecule, int32_t nseq, int64_t alen, const char *const *rows, const char *name,
+                            double ere, double symfrac, double fragthresh, int32_t flags, char **out_text, int64_t *out_len,
+                            int32_t *out_M, double *out_neff) {
   if (!molecule || !rows || !out_text || !out_len || nseq < 1 || alen < 1) { wh::set_error("wh_hmmbuild: bad argument"); return WH_EINVAL; }
   Alphabet abc;
   if (!make_alphabet(molecule, abc)) { wh::set_error("wh_hmmbuild: unknown molecule '%s' (dna, rna, amino)", molecule); return WH_EINVAL; }
@@ -448,6 +456,17 @@ extern "C" int wh_hmmbuild(const char *molecule, int32_t nseq, int64_t alen, con
   append(s, "NSEQ  %d\n", nseq);
   append(s, "EFFN  %f\n", neff);
   append(s, "CKSUM %u\n", cksum);
+  if (flags & WH_BUILD_STATS) {
+    // E-value calibration (wh_calibrate.h): what stock HMMER needs to accept the file; this path never reads it
+    CalibModel cm;
+    cm.M = M; cm.K = K; cm.t = h.t.data(); cm.mat = h.mat.data(); cm.bg = abc.bg;
+    double ev[4];
+    calibrate_model(cm, mean_match_relent(h, abc.bg), ev);
+    // (the model keeps them as float32, and that is what hmmbuild prints)
+    append(s, "STATS LOCAL MSV      %8.4f %8.5f\n", (double)(float)ev[1], (double)(float)ev[0]);
+    append(s, "STATS LOCAL VITERBI  %8.4f %8.5f\n", (double)(float)ev[2], (double)(float)ev[0]);
+    append(s, "STATS LOCAL FORWARD  %8.4f %8.5f\n", (double)(float)ev[3], (double)(float)ev[0]);
+  }
   s += "HMM     ";
   for (int x = 0; x < K; x++) append(s, "     %c   ", abc.syms[x]);
   s += "\n";

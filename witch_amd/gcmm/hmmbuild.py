@@ -16,8 +16,10 @@ from .._lib import lib, check
 _MOLECULES = {"dna": b"dna", "rna": b"rna", "amino": b"amino"}
 
 
-def hmmbuild_text(rows, molecule="dna", name="sub", ere=0.59, symfrac=0.0, fragthresh=0.5):
-    """rows: aligned sequences (str or bytes, equal length).  Returns (HMMER3/f text, M, Neff)."""
+def hmmbuild_text(rows, molecule="dna", name="sub", ere=0.59, symfrac=0.0, fragthresh=0.5, stats=False):
+    """rows: aligned sequences (str or bytes, equal length).  Returns (HMMER3/f text, M, Neff).
+    stats=True adds hmmbuild's three STATS LOCAL lines (E-value calibration; include/witch_hip.h: WH_BUILD_STATS):
+    only stock HMMER needs them, this path never reads them."""
     if molecule not in _MOLECULES:
         raise ValueError("molecule must be dna, rna or amino")
     rows = [r.encode("ascii") if isinstance(r, str) else bytes(r) for r in rows]
@@ -28,8 +30,8 @@ def hmmbuild_text(rows, molecule="dna", name="sub", ere=0.59, symfrac=0.0, fragt
         raise ValueError("rows of an alignment must have equal length")
     arr = (C.c_char_p * len(rows))(*rows)
     text, n, M, neff = C.c_void_p(), C.c_int64(0), C.c_int32(0), C.c_double(0.0)
-    check(lib().wh_hmmbuild(_MOLECULES[molecule], len(rows), alen, arr, name.encode(), ere, symfrac, fragthresh,
-                            C.byref(text), C.byref(n), C.byref(M), C.byref(neff)), "wh_hmmbuild")
+    check(lib().wh_hmmbuild2(_MOLECULES[molecule], len(rows), alen, arr, name.encode(), ere, symfrac, fragthresh,
+                             1 if stats else 0, C.byref(text), C.byref(n), C.byref(M), C.byref(neff)), "wh_hmmbuild")
     try:
         out = C.string_at(text.value, n.value).decode("ascii")
     finally:

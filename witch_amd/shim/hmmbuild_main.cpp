@@ -37,6 +37,7 @@ static int fail(const char *fmt, ...) {
 int main(int argc, char **argv) {
   std::string mol, out_summary, name;
   double ere = -1.0, symfrac = 0.5;
+  bool stats = true;                               // like hmmbuild: the file carries its three STATS LOCAL lines
   std::vector<std::string> pos;
   for (int i = 1; i < argc; i++) {
     const std::string a = argv[i];
@@ -49,7 +50,8 @@ int main(int argc, char **argv) {
     else if (a == "-o") out_summary = need("-o");
     else if (a == "-n") name = need("-n");
     else if (a == "--fast" || a == "--wpb" || a == "--eent") continue;                   // HMMER's defaults, as implemented
-    else if (a == "-h") { printf("hmmbuild (witch_hip): hmmbuild [--cpu N] --dna|--rna|--amino [--ere X] [--symfrac X] --informat afa [-o FILE] [-n NAME] MODEL ALIGNMENT\n"); return 0; }
+    else if (a == "--nostats") stats = false;      // (extension) skip the E-value calibration: WITCH never reads the STATS lines
+    else if (a == "-h") { printf("hmmbuild (witch_hip): hmmbuild [--cpu N] --dna|--rna|--amino [--ere X] [--symfrac X] [--nostats] --informat afa [-o FILE] [-n NAME] MODEL ALIGNMENT\n"); return 0; }
     else if (!a.empty() && a[0] == '-' && a != "-") return fail("option %s is not supported by this build (it would change the model HMMER builds)", a.c_str());
     else pos.push_back(a);
   }
@@ -86,8 +88,8 @@ int main(int argc, char **argv) {
   int64_t n = 0;
   int32_t M = 0;
   double neff = 0.0;
-  const int rc = wh_hmmbuild(mol.c_str(), (int32_t)rows.size(), (int64_t)rows[0].size(), ptr.data(), name.c_str(), ere, symfrac, 0.5,
-                             &text, &n, &M, &neff);
+  const int rc = wh_hmmbuild2(mol.c_str(), (int32_t)rows.size(), (int64_t)rows[0].size(), ptr.data(), name.c_str(), ere, symfrac, 0.5,
+                              stats ? WH_BUILD_STATS : 0, &text, &n, &M, &neff);
   if (rc != 0) return fail("%s", wh::g_err);
   FILE *f = fopen(pos[0].c_str(), "w");
   if (!f) return fail("cannot write %s", pos[0].c_str());

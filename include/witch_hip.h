@@ -204,7 +204,7 @@ int wh_merge_sharded(int device, const uint8_t *q_text, const int64_t *q_off, in
  * (witch_msa/gcmm/algorithm.py:463-470).  rows: nseq aligned sequences of alen characters each (aligned
  * FASTA text, '-' '.' '_' gaps; no terminator needed), molecule "dna" | "rna" | "amino".  Writes the model as
  * HMMER3/f text (same probability fields, MAP / CONS annotation, COMPO, NSEQ / EFFN / CKSUM as hmmbuild
- * 3.1b2; no STATS lines - see wh_hmmbuild2 - and no MAXL line) into a malloc'ed buffer the caller releases with wh_free_text.  out_M /
+ * 3.1b2, MAXL included for nucleotide models; no STATS lines - see wh_hmmbuild2) into a malloc'ed buffer the caller releases with wh_free_text.  out_M /
  * out_neff (optional): model length and effective sequence number. */
 int  wh_hmmbuild(const char *molecule, int32_t nseq, int64_t alen, const char *const *rows, const char *name,
                  double ere, double symfrac, double fragthresh, char **out_text, int64_t *out_len,
@@ -214,7 +214,7 @@ int  wh_hmmbuild(const char *molecule, int32_t nseq, int64_t alen, const char *c
  * and Forward locations come out in hmmbuild's printed digits on all 47 golden model files; the reference's bundled
  * hmmsearch then prints the same report, E-values included, as for hmmbuild's own file).  WITCH never reads them
  * (hmmsearch -E 99999999, only bit scores are parsed); stock HMMER refuses a file without them.  Costs about 0.5 s
- * per 1 000-node model on one core, against 15 ms for the build itself.  No MAXL line (only nhmmer reads it). */
+ * per 1 000-node model on one core, against 15 ms for the build itself. */
 #define WH_BUILD_STATS 1
 int  wh_hmmbuild2(const char *molecule, int32_t nseq, int64_t alen, const char *const *rows, const char *name,
                   double ere, double symfrac, double fragthresh, int32_t flags, char **out_text, int64_t *out_len,

@@ -263,6 +263,43 @@ double mean_match_relent(const Model &h, const float *bg) {
 
 #include "wh_calibrate.h"
 
+// hmmbuild's MAXL line (p7_Builder_MaxLength at its default tail mass 1e-7): the length beyond which the core model,
+// entered at match state 1 and left at its end, emits a sequence with probability below 1e-7.  Restated from the
+// numbers: one unit of mass in M_1 at length 1; per step the delete states are closed over the current match masses,
+// the next match / insert masses are formed, and the first length whose successors hold less than 1e-7 in total is
+// the answer (+ 1).  This definition (among: uniform / unit starts over all match states, deletes counted as
+// length, thresholds on the exited mass) is the one that gives the MAXL of all 38 nucleotide golden files, models of
+// 13 .. 2 574 nodes (tests/test_hmmbuild_host.py).
+int max_length(const Model &h) {
+  const int M = h.M;
+  std::vector<double> Mc((size_t)M + 2, 0.0), Ic((size_t)M + 2, 0.0), D((size_t)M + 2, 0.0), nM((size_t)M + 2, 0.0), nI((size_t)M + 2, 0.0);
+  Mc[1] = 1.0;
+  const int bound = 100000;
+  for (int L = 1; L < bound; L++) {
+    D[1] = 0.0;
+    for (int k = 2; k <= M; k++) {
+      const float *tp = &h.t[(size_t)(k - 1) * 7];
+      D[(size_t)k] = Mc[(size_t)k - 1] * (double)tp[tMD] + D[(size_t)k - 1] * (double)tp[tDD];
+    }
+    double surv = 0.0;
+    nM[1] = 0.0;
+    for (int k = 2; k <= M; k++) {
+      const float *tp = &h.t[(size_t)(k - 1) * 7];
+      nM[(size_t)k] = Mc[(size_t)k - 1] * (double)tp[tMM] + Ic[(size_t)k - 1] * (double)tp[tIM] + D[(size_t)k - 1] * (double)tp[tDM];
+      surv += nM[(size_t)k];
+    }
+    for (int k = 1; k < M; k++) {
+      const float *tp = &h.t[(size_t)k * 7];
+      nI[(size_t)k] = Mc[(size_t)k] * (double)tp[tMI] + Ic[(size_t)k] * (double)tp[tII];
+      surv += nI[(size_t)k];
+    }
+    nI[(size_t)M] = 0.0;
+    if (surv < 1e-7) return L + 1;
+    Mc.swap(nM); Ic.swap(nI);
+  }
+  return bound;
+}
+
 void scale_model(Model &h, double scale) {
   const float s = (float)scale;
   for (float &v : h.t) v *= s;
@@ -451,6 +488,7 @@ extern "C" int wh_hmmbuild2(const char *molecule, int32_t nseq, int64_t alen, co
   s += "HMMER3/f [3.1b2 | February 2015]\n";
   append(s, "NAME  %s\n", name && *name ? name : "sub");
   append(s, "LENG  %d\n", M);
+  if (K == 4) append(s, "MAXL  %d\n", max_length(h));      // nucleotide models only, as hmmbuild
   append(s, "ALPH  %s\n", abc.name);
   s += "RF    no\nMM    no\nCONS  yes\nCS    no\nMAP   yes\n";
   append(s, "NSEQ  %d\n", nseq);

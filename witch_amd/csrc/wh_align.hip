@@ -5,8 +5,12 @@
 // residue sits in an insert state or in the N/C flanks.
 //
 // One wavefront per pair.  The Forward rows, then the posteriors (in place), then the
-// OA rows live in per-wave HBM slabs - this kernel is the HBM-bound one:
-//   F write 8 + read 8, posterior write 8 + read 8, OA write 12 bytes per DP cell.
+// OA rows live in per-wave HBM slabs:
+//   F write 8 + read 8, posterior write 8 + read 8, OA write 12 bytes per DP cell
+// at full width (HBM-bound).  A query short enough for it runs everything after the Forward sweep on the
+// 256 / 512 nodes around its dominant path instead (align_window below: sparse Forward spill, compact rows,
+// mass certificate, full-width fallback), and the traceback of both chains consumes whole M -> M runs per
+// memory round trip (oa_traceback).
 #include <hip/hip_runtime.h>
 
 #include <type_traits>

@@ -462,36 +462,11 @@ __device__ __noinline__ RegOut region_scan(lds_f *spec3, glb_f *specg, int SP, i
   float *spec = SG ? (float *)specg : (float *)spec3;
   auto ldf = [&](int idx) -> float { return SG ? __builtin_nontemporal_load(spec + idx) : spec[idx]; };
   int *regs = (int *)regs3;
-  const float rt1 = 0.25f, rt2 = 0.10f, rt3 = 0.20f;
+  const float rt3 = 0.20f;
   int nenv = 0, nreg = 0, flags = 0;
-  float btot = 0.f, etot = 0.f;
-  int i0 = -1;
-  bool trig = false;
-  if constexpr (SG) {
-    region_scan_global(spec, SP, L, regs, lane, nenv, nreg, flags);   // 64 rows per fetch (wh_device.h)
-  } else {
-    if (lane == 0) { spec[SP_J * SP] = 0.f; spec[SP_C * SP] = 0.f; }
-    for (int j = 1; j <= L; j++) {
-      const float mocc = 1.0f - ldf(SP_N * SP + j);
-      const float bold = btot, eold = etot;
-      btot += ldf(SP_B * SP + j - 1);
-      etot += ldf(SP_E * SP + j);
-      if (lane == 0) { spec[SP_J * SP + j] = btot; spec[SP_C * SP + j] = etot; }
-      if (!trig) {
-        if (mocc - (btot - bold) < rt2) i0 = j;
-        else if (i0 == -1) i0 = j;
-        if (mocc >= rt1) trig = true;
-      } else if (mocc - (etot - eold) < rt2) {
-        if (nenv < WH_MAX_ENVELOPES) {
-          if (lane == 0) { regs[2 * nenv] = i0; regs[2 * nenv + 1] = j; }
-          nenv++;
-        } else flags |= WH_FLAG_TRUNC;
-        nreg++;
-        i0 = -1;
-        trig = false;
-      }
-    }
-  }
+  // 64 rows per fetch, walked with v_readlane (wh_device.h): in HBM mode one round trip per 64 rows, in LDS mode no
+  // ds_read latency inside the serial recurrence; the sums are formed in the row-by-row order either way
+  region_scan_global(spec, SP, L, regs, lane, nenv, nreg, flags);
   __builtin_amdgcn_wave_barrier();
   if (SG) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
   // multidomain test: max_z min(etot[z]-etot[i-1], btot[j]-btot[z-1]) >= rt3

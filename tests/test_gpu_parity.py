@@ -1570,3 +1570,29 @@ def test_alignment_on_a_node_window_equals_the_full_width_passes(alphabet, root_
     assert sum(paths.values()) == n and paths_full == {"window256": 0, "window512": 0, "window_rejected": 0, "full_width": n}
     if int(e.M.max()) >= 512:       # 8 or more nodes per lane: fragments go through a window
         assert paths["window256"] + paths["window512"] > n // 2, paths
+
+
+@pytest.mark.gpu
+def test_forward_rows_that_underflow_to_zero_are_written(orc, tmp_path):
+    """A strong family window followed by a long random flank: after the hit the Forward sweep has rescaled by ~2^-300,
+    the flank's rows underflow to zero in every cell, and `0 > -0` must not keep them from being written - the
+    full-width Backward sweep reads rows without looking at the masks and used to see the previous pair's cells there
+    (found by tools/fuzz_align.py, seed 103; before the fix one of the three pairs below differed from the oracle in
+    every call that followed another pair in the same slab)."""
+    _need_gpu()
+    import importlib.util
+    from tests.conftest import ROOT
+    from witch_amd.ehmm import EHMM, pack_queries
+    spec = importlib.util.spec_from_file_location("fuzz_align", os.path.join(ROOT, "tools", "fuzz_align.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    alph, root, eh, seqs = fz.make_case(103, str(tmp_path))
+    e = EHMM(eh.paths, hmm_index=eh.index, nseq=eh.nseq)
+    res, offs = pack_queries(seqs)
+    ohm = [orc.OracleHMM(p) for p in eh.paths]
+    allp = [(q, h) for q in range(len(seqs)) for h in range(e.H)]
+    for sel in (allp, [(1, 0), (1, 1), (1, 2)], [(1, 0), (1, 1), (1, 2)], allp):
+        cols, co = e.align(res, offs, [q for q, _ in sel], [h for _, h in sel])
+        for p, (q, h) in enumerate(sel):
+            assert np.array_equal(cols[co[p]:co[p + 1]], ohm[h].align(seqs[q])), (q, h, len(seqs[q]))
+    e.close()

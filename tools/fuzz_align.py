@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Randomised alignment check on the GPU box: families of 300-1 600 nodes (DNA and protein), queries of 5-500
+residues - family windows with and without random flanks, unrelated sequences, degenerate residue codes - every
+(query, model) pair aligned in one batch and compared, column by column, with the float64 oracle.  Found the
+round-3 bug of the full-width passes (Forward rows that had underflowed to zero everywhere were not written, the
+Backward sweep then read the previous pair's cells: seed 103).  usage: tools/fuzz_align.py [first_seed] [n_seeds]"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from witch_amd import synth  # noqa: E402
+from witch_amd.ehmm import EHMM, pack_queries  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+
+def make_case(seed, workdir):
+    rng = np.random.default_rng(seed)
+    alph = "amino" if seed % 3 == 0 else "dna"
+    root = int(rng.integers(300, 1600))
+    fam = synth.make_family(2000 + seed, root, 8, alph, 0.05, 2e-3)
+    eh = synth.make_ehmm(fam, 3, workdir, witch_layout=False)
+    K = 20 if alph == "amino" else 4
+    Kp = 29 if alph == "amino" else 18
+    bg = synth.background(alph)
+    seqs = []
+    for t in range(12):
+        L = int(rng.choice([5, 25, 60, 150, 233, 333, 401, 500]))
+        if t % 4 == 0:
+            s_ = rng.choice(K, size=L, p=bg).astype(np.uint8)
+        else:
+            _, w = synth.make_queries(fam, seed * 100 + t, 1, min(L, root - 1), 0.05 + 0.1 * (t % 3), flank_frac=0.3 if t % 2 else 0.0)
+            s_ = w[0].astype(np.uint8)
+        if t % 5 == 1 and len(s_) > 4:
+            pos = rng.integers(0, len(s_), size=max(1, len(s_) // 10))
+            s_ = s_.copy()
+            s_[pos] = rng.integers(K, Kp - 3, size=len(pos)).astype(np.uint8)
+        seqs.append(s_)
+    return alph, root, eh, seqs
+
+
+if __name__ == "__main__":
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+    nbad = npairs = 0
+    paths = {}
+    for seed in range(first, first + n):
+        alph, root, eh, seqs = make_case(seed, tempfile.mkdtemp(prefix="fuzz_align_"))
+        e = EHMM(eh.paths, hmm_index=eh.index, nseq=eh.nseq)
+        res, offs = pack_queries(seqs)
+        pq = [q for q in range(len(seqs)) for _ in range(e.H)]
+        ph = [h for q in range(len(seqs)) for h in range(e.H)]
+        ohm = [orc.OracleHMM(p) for p in eh.paths]
+        want = [ohm[ph[p]].align(seqs[pq[p]]) for p in range(len(pq))]
+        # scores too: reported mask and multidomain flag equal, deci-bits within 1 of the oracle's (a difference of 1
+        # is the rounding boundary class of SURVEY 8.0; the parity tests apply the exact boundary rule)
+        deci, flags = e.score(res, offs)
+        od, of, _, _ = orc.score_batch(ohm, res, offs)
+        rep_ = (of & 1) == 1
+        sbad = int(np.sum((flags & 3) != (of & 3))) + int(np.sum(np.abs(deci[rep_].astype(np.int64) - od[rep_]) > 1))
+        if sbad:
+            nbad += sbad
+            print("SCORE MISMATCH seed", seed, "pairs", sbad, flush=True)
+        for rep in range(2):         # twice: the second call finds the first one's rows in the slabs
+            cols, co = e.align(res, offs, pq, ph)
+            for k_, v in e.last_align_paths().items():
+                paths[k_] = paths.get(k_, 0) + v
+            for p in range(len(pq)):
+                npairs += 1
+                if not np.array_equal(cols[co[p]:co[p + 1]], want[p]):
+                    nbad += 1
+                    print("MISMATCH seed", seed, "call", rep, "query", pq[p], "model", ph[p], "L", len(seqs[pq[p]]), "M", int(e.M[ph[p]]), flush=True)
+        e.close()
+        print("seed", seed, alph, "root", root, "mismatches so far:", nbad, "of", npairs, flush=True)
+    print("pairs by path", paths, "mismatches", nbad, "of", npairs)
+    sys.exit(1 if nbad else 0)

@@ -370,7 +370,9 @@ __device__ __forceinline__ void forward_sweep(const TransTab<Q, TREG> &T, const 
       float lmax = 0.f;
 #pragma unroll
       for (int q = 0; q < Q; q += 2) lmax = fmaxf(lmax, fmaxf(fmaxf(Mp[q], Mp[q + 1]), fmaxf(Ip[q], Ip[q + 1])));
-      const bool keep = lmax > keep_scale * xE;
+      // (keep_scale < 0 must store EVERY row: a row that has underflowed to zero everywhere gives 0 > -0 = false, and the
+      // full-width alignment passes, which read rows without looking at the masks, then saw the previous pair's cells)
+      const bool keep = keep_scale < 0.f || lmax > keep_scale * xE;
       const unsigned long long mask = __ballot(keep);
       umask |= __ballot(lmax > 0.5f * xE);
       if (lane == 0) {

@@ -3,7 +3,7 @@
 residues - family windows with and without random flanks, unrelated sequences, degenerate residue codes - every
 (query, model) pair aligned in one batch and compared, column by column, with the float64 oracle.  Found the
 round-3 bug of the full-width passes (Forward rows that had underflowed to zero everywhere were not written, the
-Backward sweep then read the previous pair's cells: seed 103).  usage: tools/fuzz_align.py [first_seed] [n_seeds]"""
+Backward sweep then read the previous pair's cells: seed 103).  usage: tools/fuzz_align.py [first_seed] [n_seeds] [min_nodes] [max_nodes] [length_scale]"""
 import os
 import sys
 import tempfile
@@ -17,10 +17,10 @@ from witch_amd.ehmm import EHMM, pack_queries  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 
 
-def make_case(seed, workdir):
+def make_case(seed, workdir, lo=300, hi=1600, lscale=1):
     rng = np.random.default_rng(seed)
     alph = "amino" if seed % 3 == 0 else "dna"
-    root = int(rng.integers(300, 1600))
+    root = int(rng.integers(lo, hi))
     fam = synth.make_family(2000 + seed, root, 8, alph, 0.05, 2e-3)
     eh = synth.make_ehmm(fam, 3, workdir, witch_layout=False)
     K = 20 if alph == "amino" else 4
@@ -28,7 +28,7 @@ def make_case(seed, workdir):
     bg = synth.background(alph)
     seqs = []
     for t in range(12):
-        L = int(rng.choice([5, 25, 60, 150, 233, 333, 401, 500]))
+        L = int(rng.choice([5, 25, 60, 150, 233, 333, 401, 500])) * lscale
         if t % 4 == 0:
             s_ = rng.choice(K, size=L, p=bg).astype(np.uint8)
         else:
@@ -45,10 +45,13 @@ def make_case(seed, workdir):
 if __name__ == "__main__":
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+    lo = int(sys.argv[3]) if len(sys.argv) > 3 else 300
+    hi = int(sys.argv[4]) if len(sys.argv) > 4 else 1600
+    lscale = int(sys.argv[5]) if len(sys.argv) > 5 else 1
     nbad = npairs = 0
     paths = {}
     for seed in range(first, first + n):
-        alph, root, eh, seqs = make_case(seed, tempfile.mkdtemp(prefix="fuzz_align_"))
+        alph, root, eh, seqs = make_case(seed, tempfile.mkdtemp(prefix="fuzz_align_"), lo, hi, lscale)
         e = EHMM(eh.paths, hmm_index=eh.index, nseq=eh.nseq)
         res, offs = pack_queries(seqs)
         pq = [q for q in range(len(seqs)) for _ in range(e.H)]

@@ -67,15 +67,24 @@ if __name__ == "__main__":
         if sbad:
             nbad += sbad
             print("SCORE MISMATCH seed", seed, "pairs", sbad, flush=True)
-        for rep in range(2):         # twice: the second call finds the first one's rows in the slabs
-            cols, co = e.align(res, offs, pq, ph)
+        # three calls in different pair orders: every call finds OTHER pairs' rows in the slabs it gets
+        prng = np.random.default_rng(seed + 7)
+        for rep in range(3):
+            order = np.arange(len(pq)) if rep == 0 else np.arange(len(pq))[::-1] if rep == 1 else prng.permutation(len(pq))
+            cols, co = e.align(res, offs, [pq[p] for p in order], [ph[p] for p in order])
             for k_, v in e.last_align_paths().items():
                 paths[k_] = paths.get(k_, 0) + v
-            for p in range(len(pq)):
+            for t, p in enumerate(order):
                 npairs += 1
-                if not np.array_equal(cols[co[p]:co[p + 1]], want[p]):
+                if not np.array_equal(cols[co[t]:co[t + 1]], want[p]):
                     nbad += 1
                     print("MISMATCH seed", seed, "call", rep, "query", pq[p], "model", ph[p], "L", len(seqs[pq[p]]), "M", int(e.M[ph[p]]), flush=True)
+        # scores of the queries in reversed order: the same numbers
+        rres, roffs = pack_queries(seqs[::-1])
+        rdeci, rflags = e.score(rres, roffs)
+        if not (np.array_equal(rdeci[::-1], deci) and np.array_equal(rflags[::-1], flags)):
+            nbad += 1
+            print("SCORE ORDER MISMATCH seed", seed, int(np.sum(rdeci[::-1] != deci)), "deci-bit values differ", flush=True)
         e.close()
         print("seed", seed, alph, "root", root, "mismatches so far:", nbad, "of", npairs, flush=True)
     print("pairs by path", paths, "mismatches", nbad, "of", npairs)

@@ -26,27 +26,41 @@ k = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 nbad = nq_tot = 0
 for seed in range(first, first + n):
     alph, root, eh, seqs = fuzz_align.make_case(seed, tempfile.mkdtemp(prefix="fuzz_l1_"))
+    fam = eh.family
     # text form, as the reference hands queries over: Easel's symbols, degenerate codes included
     sym = "ACDEFGHIKLMNPQRSTVWY-BJZOUX*~" if alph == "amino" else "ACGT-RYMKSWHBVDN*~"
-    texts = ["".join(sym[int(c)] for c in s) for s in seqs]
+    K = 20 if alph == "amino" else 4
+    texts = ["".join(sym[int(c) if int(c) != K else K + 1] for c in s) for s in seqs]     # (no gap symbol inside a query)
     names = ["q%02d" % i for i in range(len(seqs))]
     index_to_hmm = {i: _Sub(p, m) for i, p, m in zip(eh.index, eh.paths, eh.nseq)}
     retained = {i: (h.map_cols[1:] - 1).tolist() for i, h in zip(eh.index, eh.hmms)}
     nongaps = {i: h.nongaps.tolist() for i, h in zip(eh.index, eh.hmms)}
-    B = int(max(max(v) for v in retained.values())) + 1
+    B = int(fam.msa.shape[1])
     gcmm.install(gcmm.QueryAlignmentEngine.run(index_to_hmm, list(zip(names, texts)), k, subset_to_retained_columns=retained,
                                                subset_to_nongaps_per_column=nongaps, backbone_length=B))
     weights = gcmm.writeWeights(index_to_hmm, gcmm.rankBitscores(index_to_hmm, {}))
+    queries = []
     for q, (qn, qs) in enumerate(zip(names, texts)):
         if qn not in weights:
             continue
         nq_tot += 1
         query, _, _ = gcmm.alignSubQueriesNew("bb", B, index_to_hmm, None, 120, qn, qs, weights[qn], q)
+        queries.append(query)
         _, wmap, cols = gcmm.getBackbones(index_to_hmm, qn, q, qs, "p", weights[qn], ".", ".", use_gcm=False)
         codes, _ = ocons.consensus_trace(len(qs), list(cols.items()), wmap, retained, nongaps, B)
         if query[qn] != ocons.trace_to_string(qs, codes, B):
             nbad += 1
             print("MISMATCH seed", seed, "query", qn, "L", len(qs), flush=True)
+    # final merge: the device merge (wh_merge) and the host merger write the same two files
+    wd = tempfile.mkdtemp(prefix="fuzz_l1_out_")
+    bpath = os.path.join(wd, "backbone.fasta")
+    synth.write_msa_fasta(bpath, fam, 0, 8)
+    host = gcmm.mergeAlignmentsCollapsed(bpath, queries, {}, None, output_path=os.path.join(wd, "host.fasta"))
+    dev = gcmm.mergeAlignmentsDevice(bpath, {}, output_path=os.path.join(wd, "dev.fasta"), taxa=[t for t in names if t in weights])
+    for what, a_, b_ in zip(("full", "masked"), host, dev):
+        if open(a_, "rb").read() != open(b_, "rb").read():
+            nbad += 1
+            print("MERGE MISMATCH seed", seed, what, flush=True)
     print("seed", seed, alph, "root", root, "backbone", B, "mismatches so far:", nbad, "of", nq_tot, flush=True)
 print("mismatches", nbad, "of", nq_tot)
 sys.exit(1 if nbad else 0)

@@ -473,7 +473,7 @@ extern "C" int wh_hmmbuild2(const char *molecule, int32_t nseq, int64_t alen, co
   mocc[1] = h.t[tMI] + h.t[tMM];
   for (int k = 2; k <= M; k++) {
     const float *tp = &h.t[(size_t)(k - 1) * 7];
-    mocc[k] = mocc[k - 1] * (tp[tMM] + tp[tMI]) + (1.0f - mocc[k - 1]) * tp[tDM];
+    mocc[k] = (float)(mocc[k - 1] * (tp[tMM] + tp[tMI]) + (1.0 - mocc[k - 1]) * tp[tDM]);     // (HMMER's literal 1.0 is a double)
   }
   iocc[0] = h.t[tMI] / h.t[tIM];
   for (int k = 1; k <= M; k++) iocc[k] = mocc[k] * h.t[(size_t)k * 7 + tMI] / h.t[(size_t)k * 7 + tIM];

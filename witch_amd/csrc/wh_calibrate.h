@@ -75,7 +75,7 @@ inline void calib_profile(const CalibModel &h, CalibProfile &gm) {
   occ[1] = h.t[tMI] + h.t[tMM];
   for (int k = 2; k <= M; k++) {
     const float *tp = h.t + (size_t)(k - 1) * 7;
-    occ[k] = occ[k - 1] * (tp[tMM] + tp[tMI]) + (1.0f - occ[k - 1]) * tp[tDM];
+    occ[k] = (float)(occ[k - 1] * (tp[tMM] + tp[tMI]) + (1.0 - occ[k - 1]) * tp[tDM]);     // (HMMER's literal 1.0 is a double)
   }
   float Z = 0.f;
   for (int k = 1; k <= M; k++) Z += occ[k] * (float)(M - k + 1);

@@ -74,6 +74,7 @@ if __name__ == "__main__":
             cols, co = e.align(res, offs, [pq[p] for p in order], [ph[p] for p in order])
             for k_, v in e.last_align_paths().items():
                 paths[k_] = paths.get(k_, 0) + v
+            paths["log_space_redo"] = paths.get("log_space_redo", 0) + e.last_align_status()[0]
             for t, p in enumerate(order):
                 npairs += 1
                 if not np.array_equal(cols[co[t]:co[t + 1]], want[p]):

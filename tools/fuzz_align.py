@@ -48,7 +48,9 @@ if __name__ == "__main__":
     lo = int(sys.argv[3]) if len(sys.argv) > 3 else 300
     hi = int(sys.argv[4]) if len(sys.argv) > 4 else 1600
     lscale = int(sys.argv[5]) if len(sys.argv) > 5 else 1
-    nbad = npairs = 0
+    nbad = npairs = nboundary = 0
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_parity import _near_boundary_eps as near_boundary, BOUNDARY_EPS as boundary_eps   # the tests' rule
     paths = {}
     for seed in range(first, first + n):
         alph, root, eh, seqs = make_case(seed, tempfile.mkdtemp(prefix="fuzz_align_"), lo, hi, lscale)
@@ -61,9 +63,15 @@ if __name__ == "__main__":
         # scores too: reported mask and multidomain flag equal, deci-bits within 1 of the oracle's (a difference of 1
         # is the rounding boundary class of SURVEY 8.0; the parity tests apply the exact boundary rule)
         deci, flags = e.score(res, offs)
-        od, of, _, _ = orc.score_batch(ohm, res, offs)
+        od, of, _, osc = orc.score_batch(ohm, res, offs)
         rep_ = (of & 1) == 1
-        sbad = int(np.sum((flags & 3) != (of & 3))) + int(np.sum(np.abs(deci[rep_].astype(np.int64) - od[rep_]) > 1))
+        sbad = int(np.sum((flags & 7) != (of & 7)))
+        # the parity tests' rule: equal, or one unit apart with the oracle's float score at a "%6.1f" boundary
+        d1 = np.argwhere((deci != od) & rep_)
+        for qi_, hj_ in d1:
+            if abs(int(deci[qi_, hj_]) - int(od[qi_, hj_])) != 1 or not near_boundary(osc[qi_, hj_], boundary_eps):
+                sbad += 1
+        nboundary += len(d1)
         if sbad:
             nbad += sbad
             print("SCORE MISMATCH seed", seed, "pairs", sbad, flush=True)
@@ -88,5 +96,5 @@ if __name__ == "__main__":
             print("SCORE ORDER MISMATCH seed", seed, int(np.sum(rdeci[::-1] != deci)), "deci-bit values differ", flush=True)
         e.close()
         print("seed", seed, alph, "root", root, "mismatches so far:", nbad, "of", npairs, flush=True)
-    print("pairs by path", paths, "mismatches", nbad, "of", npairs)
+    print("pairs by path", paths, "deci-bit values one unit off at a rounding boundary:", nboundary, "mismatches", nbad, "of", npairs)
     sys.exit(1 if nbad else 0)

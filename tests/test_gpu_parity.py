@@ -1596,3 +1596,24 @@ def test_forward_rows_that_underflow_to_zero_are_written(orc, tmp_path):
         for p, (q, h) in enumerate(sel):
             assert np.array_equal(cols[co[p]:co[p + 1]], ohm[h].align(seqs[q])), (q, h, len(seqs[q]))
     e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tool,args", [
+    ("fuzz_align.py", ["100", "6"]),                       # 300-1 600-node families (seed 103: the round-3 spill bug)
+    ("fuzz_align.py", ["3000", "2", "1600", "3072"]),      # pass-synchronous kernels
+    ("fuzz_align.py", ["6000", "1", "3100", "6000"]),      # several-waves-per-pair kernels
+    ("fuzz_built_models.py", ["1", "10"]),                 # models written by wh_hmmbuild from random alignments
+    ("fuzz_level1.py", ["200", "4", "4"]),                 # consensus rows and merged files through the level-1 functions
+    ("fuzz_topk.py", ["1", "12"]),                         # weights / top-k / cut with engineered ties
+])
+def test_randomised_tools_find_no_difference(tool, args):
+    """A short run of each randomised check under tools/ (the campaigns of DESIGN section 9.2b use the same programs with
+    more seeds): scores under the exact boundary rule, flags, aligned columns in three pair orders, consensus rows,
+    merged files and top-k rows all equal to the oracle's."""
+    _need_gpu()
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool)] + args, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (tool, r.stdout[-1500:], r.stderr[-1500:])

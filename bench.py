@@ -220,6 +220,132 @@ def cpu_baseline(ehmm_paths, nseq, seqs, k, n_sample, threads):
     return len(sample) / dt, dt
 
 
+
+FAM_NAMES = {0: "wh::k7::score_kernel7", 1: "wh::score_big_kernel", 2: "wh::generic_front_kernel", 3: "wh::wide::score_wide_kernel"}
+
+
+def lib_sha16():
+    """First 16 hex digits of the sha256 of the loaded libwitch_hip.so: what a profile is stamped with."""
+    import hashlib
+    from witch_amd._lib import LIB_PATH
+    return hashlib.sha256(open(LIB_PATH, "rb").read()).hexdigest()[:16]
+
+
+def profile_stamp(workload, plain_run):
+    """profiles/traffic.json (tools/profile_round.sh + tools/prof_summary.py): PMC figures of an EARLIER run of this
+    command.  Used only when it was taken on this workload with THIS build of the library (sha256 stamp); a file from
+    another build is refused, so the line cannot carry a stale traffic figure."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if not (plain_run and os.path.exists(tpath)):
+        return None, "no stamped profile for this run"
+    try:
+        tj = json.load(open(tpath))
+    except Exception as ex:
+        return None, "profiles/traffic.json unreadable: %s" % ex
+    if tj.get("workload") != workload:
+        return None, "profiles/traffic.json is for workload %s" % tj.get("workload")
+    if tj.get("lib_sha16") != lib_sha16():
+        return None, "profiles/traffic.json was taken on another build (lib %s, this one %s): refused" % (tj.get("lib_sha16"), lib_sha16())
+    return tj, "profiles/traffic.json <- %s; counters of an earlier run of this command on this build (lib %s), NOT measured in this run" % (
+        str(tj.get("source", "?")).split(" ")[0], tj.get("lib_sha16"))
+
+
+def score_roofline(M, lens_local, class_ms, kern_ms0, kern_n0, steps, H, stamp, stamp_src):
+    """VALU roofline of the dominant scoring launch class.  Unit = one DP cell (residue x model
+    node): 32 flop/cell for the multihit Forward + Backward parsers + ~45 flop/cell for the envelope sweeps (unihit
+    Forward, Backward, decoding, null2) = 77 flop/cell over L x M cells per pair, ALGORITHMIC: the price of the work the
+    reference does, whatever the kernel executes for it.  Peak: 157.3 TFLOP/s fp32 vector (plain v_fma_f32 at two cycles
+    per wave64 instruction reaches it on gfx950).  The dominant kernel = the launch class with the largest measured share
+    of the scoring time (one launch per cells-per-lane class); its cells = the local residues x the nodes of ITS models."""
+    def cls_of(m):      # cells-per-lane class of a model (witch_amd/csrc/wh_hmm.cpp choose_Q: next multiple of 4)
+        return max(4, (-(-int(m) // 64) + 3) // 4 * 4)
+    if class_ms:
+        (dom_q, dom_kind), (dom_ms, dom_n) = max(class_ms.items(), key=lambda kv: kv[1][0])
+        if dom_kind == 2:
+            dom_M = M[M > 3072]
+        elif dom_kind == 3:         # several waves per pair: the class key is cells per lane x waves (24 x W)
+            dom_M = M[np.array([m > 3072 and -(-int(m) // 1536) * 24 == dom_q for m in M])]
+        else:
+            dom_M = M[np.array([cls_of(m) == dom_q for m in M])]
+        score_launches, score_ms = max(dom_n, 1), dom_ms / max(dom_n, 1)
+        cells_launch = float(lens_local.sum() * dom_M.sum()) * steps / score_launches
+        dom_name = (FAM_NAMES[2] if dom_kind == 2 else "%s<24 cells per lane, %d waves per pair>" % (FAM_NAMES[3], dom_q // 24) if dom_kind == 3
+                    else "%s<%d cells per lane>" % (FAM_NAMES.get(dom_kind, "?"), dom_q))
+        dom_share = dom_ms / max(kern_ms0, 1e-9)
+    else:
+        score_launches = max(kern_n0, 1)
+        score_ms = kern_ms0 / score_launches
+        cells_launch = float(lens_local.sum() * M.sum()) * steps / score_launches
+        dom_name, dom_share = "wh::k7::score_kernel7", 1.0
+    s_tflops = cells_launch * 77.0 / (score_ms * 1e-3) / 1e12 if score_ms > 0 else 0.0
+    L = float(np.mean(lens_local)) if len(lens_local) else 0.0
+    r = {"bound": "valu", "kernel": dom_name, "kernel_share_of_scoring_time": round(dom_share, 4),
+         "scoring_launch_classes": {"%s/%d" % (FAM_NAMES.get(kd, "?").split("::")[-1], qc): round(v[0] / steps, 3) for (qc, kd), v in sorted(class_ms.items())},
+         "achieved": round(s_tflops, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(s_tflops / 157.3, 4),
+         "traffic": stamp.get("score_kernel_hbm_bytes_per_launch") if stamp else None, "traffic_source": stamp_src,
+         "flop_per_cell": 77, "cells_per_launch": cells_launch, "cells_per_s": round(cells_launch / (score_ms * 1e-3), 1) if score_ms > 0 else 0.0,
+         "kernel_ms_avg": round(score_ms, 3), "launches": score_launches,
+         "algorithmic_hbm_bytes_per_launch": float(len(lens_local) * H * (L + 9.0)) * steps / score_launches}
+    if stamp and stamp.get("score_kernel_valu_insts_per_launch"):
+        # executed vector instructions x 64 lanes per cell (SQ_INSTS_VALU of the stamped profile), and the same in flop if
+        # every one were an FMA (2 flop) - the figure to hold against the algorithmic 77: their ratio is the instruction
+        # efficiency, frac / that ratio the share of cycles the vector ALUs issue
+        slots = float(stamp["score_kernel_valu_insts_per_launch"]) * 64.0 / float(stamp.get("score_kernel_cells_per_launch", cells_launch))
+        r["executed_valu_lane_ops_per_cell"] = round(slots, 2)
+        r["executed_flop_per_cell"] = round(2.0 * slots, 1)
+        r["instruction_efficiency"] = round(77.0 / (2.0 * slots), 3)
+        r["valu_issue_share"] = round((s_tflops / 157.3) / (77.0 / (2.0 * slots)), 3)
+    return r
+
+
+def also_block(name, steps, warmup, device):
+    """A second workload measured in the same run, reported beside <value> (never part of it): one-GPU hot-path rate
+    and the VALU roofline of its dominant launch class.  Used for SURVEY.md 8(d)'s own sketch of config 3
+    (dna_100k_x200_m1000: root 1000 nt, 0.2 % indels per branch; models of 996-2996 nodes in five size classes)."""
+    import torch
+    from witch_amd.ehmm import EHMM, pack_queries
+    wd = tempfile.mkdtemp(prefix="witch_bench_also_")
+    try:
+        fam, se, names, seqs, k = make_workload(name, wd)
+        e = EHMM(se.paths, hmm_index=se.index, nseq=se.nseq, device=device)
+        res, offs = pack_queries([s_.astype(np.uint8) for s_ in seqs])
+        maxlen = int(np.max(np.diff(offs)))
+        res_t, off_t = torch.from_numpy(res).cuda(), torch.from_numpy(offs).cuda()
+        for _ in range(warmup):
+            hot_path_step(e, res_t, off_t, maxlen, k)
+        e.set_timing(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        kern_ms, kern_n, class_ms = [0.0] * 5, [0] * 5, {}
+        for _ in range(steps):
+            hot_path_step(e, res_t, off_t, maxlen, k)
+            for which in (0, 1, 2, 4):
+                ms, n = e.last_kernel_ms(which)
+                kern_ms[which] += ms
+                kern_n[which] += n
+            for qc, kind, ms in e.last_score_launches():
+                c = class_ms.setdefault((qc, kind), [0.0, 0])
+                c[0] += ms
+                c[1] += 1
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        M = e.M.astype(np.float64)
+        lens = np.diff(offs).astype(np.float64)
+        out = {"workload": name, "value": round(len(seqs) * steps / dt, 2), "unit": "queries/s", "steps": steps, "warmup": warmup,
+               "ms_per_step": round(dt / steps * 1e3, 3), "n_queries": len(seqs), "n_hmms": e.H,
+               "model_len_min": int(M.min()), "model_len_max": int(M.max()), "model_len_mean": round(float(M.mean()), 1), "k": k,
+               "stage_ms_per_step": {"scoring_kernels": round(kern_ms[0] / steps, 3), "multidomain_resolver": round(kern_ms[4] / steps, 3),
+                                     "topk": round(kern_ms[1] / steps, 3), "align": round(kern_ms[2] / steps, 3)},
+               "cells_per_s_all_classes": round(float(lens.sum() * M.sum()) * steps / (kern_ms[0] * 1e-3), 1) if kern_ms[0] > 0 else 0.0,
+               "roofline": score_roofline(M, lens, class_ms, kern_ms[0], kern_n[0], steps, e.H, None, "not profiled"),
+               "pairs_multidomain": hot_path_step.multidomain,
+               "note": "SURVEY.md 8(d) config 3 as sketched there (root 1000 nt, 0.2 % indels per branch), same timed region as <value>, one GPU"}
+        e.close()
+        return out
+    finally:
+        shutil.rmtree(wd, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -230,6 +356,7 @@ def main():
     ap.add_argument("--nh", type=int, default=0, help="override the HMM count (development only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-level1", action="store_true", help="skip the level-1 end-to-end stage (reported beside the hot-path value)")
+    ap.add_argument("--no-also", action="store_true", help="skip the second workload reported beside the headline (dna_100k_x200_m1000)")
     args = ap.parse_args()
 
     import torch
@@ -273,10 +400,11 @@ def main():
         if use_dist:
             from witch_amd.distributed import gather_topk
             # the path's one exchange step: per-query top-k records to every rank over RCCL
-            gather = gather_topk
-            if rehearsal:
-                def gather(idx, w, nk, nu):       # gloo gathers host tensors
-                    return gather_topk(idx.cpu(), w.cpu(), nk.cpu(), nu.cpu())
+            # (ONE all_gather_into_tensor of packed 128-byte records; the shard sizes follow from shard_range)
+            def gather(idx, w, nk, nu):
+                if rehearsal:                     # gloo gathers host tensors
+                    idx, w, nk, nu = idx.cpu(), w.cpu(), nk.cpu(), nu.cpu()
+                return gather_topk(idx, w, nk, nu, n_total=nq_total)
 
         def barrier():
             torch.cuda.synchronize()
@@ -326,56 +454,12 @@ def main():
             L = float(np.mean(lens_local)) if hi > lo else 0.0
             qps = nq_total * args.steps / dt
             n_local = hi - lo
-            # ---- rooflines per SURVEY.md section 8(d).  Unit = one DP cell (residue x model node).
-            # Scoring (dominant kernel, VALU-bound by design): 32 flop/cell for the multihit Forward +
-            # Backward parsers + ~45 flop/cell for the envelope sweeps (unihit Forward, Backward, decoding,
-            # null2) over the envelope's cells; the envelope of a full-length hit is the whole query, so
-            # 77 flop/cell over L x M cells per pair.  Peak: 157.3 TFLOP/s fp32 vector (packed rate; the
-            # plain v_fma_f32 the sweeps use reaches the same SIMD throughput on gfx950).
-            # the dominant kernel = the launch class with the largest measured share of the scoring time (a mixed eHMM has
-            # several: one launch per cells-per-lane class); its cells = the local residues x the nodes of ITS models
-            fam_names = {0: "wh::k7::score_kernel7", 1: "wh::score_big_kernel", 2: "wh::generic_front_kernel", 3: "wh::wide::score_wide_kernel"}
-            def cls_of(m):      # cells-per-lane class of a model (witch_amd/csrc/wh_hmm.cpp choose_Q: next multiple of 4)
-                return max(4, (-(-int(m) // 64) + 3) // 4 * 4)
-            if class_ms:
-                (dom_q, dom_kind), (dom_ms, dom_n) = max(class_ms.items(), key=lambda kv: kv[1][0])
-                if dom_kind == 2:
-                    dom_M = M[M > 3072]
-                elif dom_kind == 3:         # several waves per pair: the class key is cells per lane x waves (24 x W)
-                    dom_M = M[np.array([m > 3072 and -(-int(m) // 1536) * 24 == dom_q for m in M])]
-                else:
-                    dom_M = M[np.array([cls_of(m) == dom_q for m in M])]
-                score_launches, score_ms = max(dom_n, 1), dom_ms / max(dom_n, 1)
-                cells_launch = float(lens_local.sum() * dom_M.sum()) * args.steps / score_launches
-                dom_name = (fam_names[2] if dom_kind == 2 else "%s<24 cells per lane, %d waves per pair>" % (fam_names[3], dom_q // 24) if dom_kind == 3
-                            else "%s<%d cells per lane>" % (fam_names.get(dom_kind, "?"), dom_q))
-                dom_share = dom_ms / max(kern_ms[0], 1e-9)
-            else:
-                score_launches = max(kern_n[0], 1)
-                score_ms = kern_ms[0] / score_launches
-                cells_launch = float(lens_local.sum() * M.sum()) * args.steps / score_launches
-                dom_name, dom_share = "wh::k7::score_kernel7", 1.0
+            # ---- rooflines per SURVEY.md section 8(d) (score_roofline above)
             cells_step = float(lens_local.sum() * M.sum())              # every local query x every model
-            s_tflops = cells_launch * 77.0 / (score_ms * 1e-3) / 1e12 if score_ms > 0 else 0.0
-            traffic, traffic_src, traffic_align = None, None, None
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):
-                try:
-                    tj = json.load(open(tpath))
-                    if tj.get("workload") == args.workload and not args.nq and not args.nh and world == 1:
-                        traffic = tj.get("score_kernel_hbm_bytes_per_launch")
-                        traffic_align = tj.get("align_kernel_hbm_bytes_per_launch")
-                        traffic_src = "profiles/traffic.json <- %s; counters of an earlier run of this command, NOT measured in this run" % tj.get("source", "?").split(" ")[0]
-                except Exception:
-                    traffic = None
-            roofline = {"bound": "valu", "kernel": dom_name, "kernel_share_of_scoring_time": round(dom_share, 4),
-                        "scoring_launch_classes": {"%s/%d" % (fam_names.get(kd, "?").split("::")[-1], qc): round(v[0] / args.steps, 3) for (qc, kd), v in sorted(class_ms.items())},
-                        "achieved": round(s_tflops, 2), "peak": 157.3,
-                        "unit": "TFLOP/s", "frac": round(s_tflops / 157.3, 4), "traffic": traffic, "traffic_source": traffic_src,
-                        "flop_per_cell": 77, "cells_per_launch": cells_launch,
-                        "kernel_ms_avg": round(score_ms, 3), "launches": score_launches,
-                        "peak_unpacked": 78.6, "frac_unpacked": round(s_tflops / 78.6, 4),
-                        "algorithmic_hbm_bytes_per_launch": float(n_local * H * (L + 9.0)) * args.steps / score_launches}
+            stamp, stamp_src = profile_stamp(args.workload, not args.nq and not args.nh and world == 1)
+            roofline = score_roofline(M, lens_local, class_ms, kern_ms[0], kern_n[0], args.steps, H, stamp, stamp_src)
+            traffic_align = stamp.get("align_kernel_hbm_bytes_per_launch") if stamp else None
+            traffic_src = stamp_src
             # Alignment.  Algorithmic bytes by sweep path (wh_last_align_paths): a pair aligned at full width moves
             # 52 B per L x M cell (Forward rows written + read 24, posteriors 16, OA rows 12);
             # a pair aligned on a node window moves 44 B per L x W cell, W = 256 or 512 nodes (its Forward cells
@@ -390,8 +474,15 @@ def main():
             a_bytes = (hot_path_step.aligned_residues * 44.0 * (256 * f256 + 512 * f512)
                        + hot_path_step.aligned_cells * 52.0 * (1.0 - f256 - f512)) if sum(ap.values()) else hot_path_step.aligned_cells * 52.0
             a_gbs = a_bytes / (align_ms * 1e-3) / 1e9 if align_ms > 0 else 0.0
+            # SURVEY 8(d) prices alignment at 52 B per L x M cell whatever the kernel stores; with the node window the kernel
+            # moves 3-4 x fewer bytes than that, so the survey's figure no longer describes it (it would read > 1 of the HBM
+            # peak) - printed beside the window-based figure that the roofline uses, not instead of it
+            s8d_bytes = hot_path_step.aligned_cells * 52.0
+            s8d_gbs = s8d_bytes / (align_ms * 1e-3) / 1e9 if align_ms > 0 else 0.0
             roofline_align = {"bound": "hbm", "kernel": "wh::generic_align_kernel" if int(np.max(e.M)) > 3072 else "wh::align_kernel", "achieved": round(a_gbs, 1), "peak": 8000.0,
                               "unit": "GB/s", "frac": round(a_gbs / 8000.0, 4), "algorithmic_bytes_per_step": a_bytes,
+                              "survey_8d": {"bytes_per_step": s8d_bytes, "bytes_per_cell": 52, "equivalent_GBps": round(s8d_gbs, 1), "frac_of_peak": round(s8d_gbs / 8000.0, 4),
+                                            "note": "52 B x L x M per aligned pair as SURVEY.md 8(d) prices it; the kernel does not move these bytes (node window), so this is a rate of algorithmic work, not of HBM traffic"},
                               "bytes_per_cell": {"full_width": 52, "window": 44}, "pairs_by_path": ap,
                               "cells_per_step": hot_path_step.aligned_cells, "stage_ms": round(align_ms, 3),
                               "launches_per_step": kern_n[2] / args.steps, "traffic": traffic_align, "traffic_source": traffic_src}
@@ -438,6 +529,11 @@ def main():
                     line["level1_e2e_queries_per_s"] = line["level1_e2e"]["queries_per_s"]
                 except Exception as ex:       # an extra stage must never take the bench line down
                     line["level1_e2e"] = {"failed": "%s: %s" % (type(ex).__name__, ex)}
+            if not args.no_also and world == 1 and args.workload == "dna_100k_x200" and not args.nq and not args.nh:
+                try:
+                    line["also"] = also_block("dna_100k_x200_m1000", 2, 1, local_rank)
+                except Exception as ex:       # an extra workload must never take the bench line down
+                    line["also"] = {"workload": "dna_100k_x200_m1000", "failed": "%s: %s" % (type(ex).__name__, ex)}
             if not args.no_cpu_baseline:
                 threads = min(os.cpu_count() or 1, 64)
                 # about 15 s of CPU work on 64 host threads: 384 queries of the headline (150 nt x 200 models of ~900

@@ -139,6 +139,21 @@ int wh_last_align_status(wh_ehmm *e, int64_t *n_logspace, int64_t *n_unaligned, 
  * from the start (query too long for a window, no dominant path, models of fewer than 8 nodes per lane). */
 int wh_last_align_paths(wh_ehmm *e, int64_t *paths4);
 
+/* How the envelope Backward sweeps (unihit Backward + posterior accumulation -> null2) of the last wh_score
+ * call ran, counted on the device by the one-wavefront-per-pair scoring kernels (models of up to 24 cells per lane;
+ * the pass-synchronous, several-waves-per-pair and any-size kernels have no window and are not counted):
+ * paths4[0] = envelopes whose sweep ran on a 256-node window around the dominant alignment and passed the mass
+ * certificate, [1] = the same on a 512-node window, [2] = windows that failed the certificate (each then ran again at
+ * full width), [3] = full-width sweeps (no window tried, a failed window, or the dense redo of a sparse spill).
+ * Waits for the device.  (What a window is: DESIGN.md section 4.1; WH_NO_WINDOW switches it off.) */
+int wh_last_score_paths(wh_ehmm *e, int64_t *paths4);
+
+/* Scoring passes the last wh_score call REPEATED (0 or 1).  The queue that hands pairs with a multidomain region to the
+ * resolver stage is sized by estimate (5 % of the pairs, or 1.25 x the largest share an earlier call on the handle
+ * queued); a call that needs more slots counts them, grows the queue and scores once more - same results, about twice
+ * the scoring time of that one call.  Negative: error. */
+int wh_last_queue_reruns(wh_ehmm *e);
+
 /* Weighted consensus of each query's per-HMM alignments (witch-ng merge DP; replaces the Python
  * loops of alignSubQueriesNew, witch_msa/gcmm/aligner.py:376-473).  Pairs are grouped by
  * query in top-k order: query q owns pairs qpair_off[q] .. qpair_off[q+1]; pair p aligned

@@ -82,7 +82,7 @@ def test_sweep_context_is_register_passed(tmp_path):
         pytest.skip("no hipcc")
     src = os.path.join(ROOT, "witch_amd", "csrc", "wh_score7.hip")
     out = tmp_path / "k7.s"
-    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize",
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-DWH_SLIM_SPEC",
                         "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "witch_amd", "csrc"),
                         "--cuda-device-only", "-S", "-o", str(out), src], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]

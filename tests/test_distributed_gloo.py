@@ -28,17 +28,20 @@ def _worker(rank, world, port, nq, k, outdir):
     nk = rng.integers(0, k + 1, size=nq).astype(np.int32)
     nu = np.minimum(nk, rng.integers(0, k + 1, size=nq)).astype(np.int32)
     lo, hi = shard_range(nq, rank, world)
-    got = gather_topk(torch.from_numpy(idx[lo:hi]), torch.from_numpy(w[lo:hi]), torch.from_numpy(nk[lo:hi]),
-                      torch.from_numpy(nu[lo:hi]))
-    ok = all(np.array_equal(g.numpy(), f) for g, f in zip(got, (idx, w, nk, nu)))
+    ok = True
+    for n_total in (nq, None):        # shard sizes from shard_range (one collective), or exchanged first
+        got = gather_topk(torch.from_numpy(idx[lo:hi]), torch.from_numpy(w[lo:hi]), torch.from_numpy(nk[lo:hi]),
+                          torch.from_numpy(nu[lo:hi]), n_total=n_total)
+        ok = ok and all(np.array_equal(g.numpy(), f) and g.dtype == torch.from_numpy(f).dtype for g, f in zip(got, (idx, w, nk, nu)))
     open(os.path.join(outdir, "rank%d" % rank), "w").write("ok" if ok else "bad")
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("nq", [101, 8])
-def test_sharded_topk_gather_world2(tmp_path, nq):
+@pytest.mark.parametrize("nq,world", [(101, 2), (8, 2), (103, 8), (5, 8)])
+def test_sharded_topk_gather(tmp_path, nq, world):
+    """world 2 and 8 (gloo): ragged shards, and at 8 ranks x 5 queries shards of zero rows"""
     import torch.multiprocessing as mp
-    world, port = 2, _free_port()
+    port = _free_port()
     mp.spawn(_worker, args=(world, port, nq, 10, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         assert open(tmp_path / ("rank%d" % r)).read() == "ok"

@@ -774,7 +774,7 @@ def test_ab_slot_kernel_agrees(golden_case):
     case = golden_case
     e, seqs, res, offs = _load(case)
     d0, f0 = e.score(res, offs)
-    for name, value in (("WH_SCORE_KERNEL", "8"), ("WH_MAX_WAVES", "4"), ("WH_FORCE_SPECG", "1")):
+    for name, value in (("WH_SCORE_KERNEL", "8"), ("WH_SCORE_KERNEL", "9"), ("WH_MAX_WAVES", "4"), ("WH_FORCE_SPECG", "1")):
         e.set_option(name, value)
         d1, f1 = e.score(res, offs)
         e.set_option(name, "")
@@ -782,6 +782,90 @@ def test_ab_slot_kernel_agrees(golden_case):
         assert np.array_equal(d0, d1), (case.name, name)
     with pytest.raises(Exception):
         e.set_option("WH_SCORE_KERNEL", "2")      # removed experiment kernels are refused, not ignored
+    e.close()
+
+
+def test_scoring_on_a_node_window_equals_the_full_width_sweeps(tmp_path):
+    """The envelope Backward sweep of the scoring kernel (unihit Backward + posterior accumulation -> null2) on a node
+    window against the same sweep at full width (WH_NO_WINDOW): 2 048 headline queries x 200 HMMs.  Flags identical;
+    deci-bits identical or one unit apart with the full-width float score at a "%6.1f" rounding boundary (SURVEY 8.0);
+    and the exported path counters prove that the window ran in one call and did not in the other."""
+    _need_gpu()
+    import bench
+    from witch_amd.ehmm import EHMM, pack_queries
+    fam, se, names, seqs, k = bench.make_workload("dna_100k_x200", str(tmp_path), 2048, None)
+    e = EHMM(se.paths, hmm_index=se.index, nseq=se.nseq)
+    res, offs = pack_queries([s_.astype(np.uint8) for s_ in seqs])
+    d_w, f_w, det_w = e.score(res, offs, want_detail=True)
+    p_w = e.last_score_paths()
+    e.set_option("WH_NO_WINDOW", "1")
+    d_f, f_f, det_f = e.score(res, offs, want_detail=True)
+    p_f = e.last_score_paths()
+    e.set_option("WH_NO_WINDOW", "")
+    # the window path ran: most envelopes of a 150-nt fragment fit 256 or 512 nodes.  Every envelope ends in one accepted
+    # sweep - a window, or a full-width sweep (directly, or after its window was rejected); a dense redo (rare) adds one
+    # more full-width sweep in either run
+    n_w = p_w["window256"] + p_w["window512"]
+    assert n_w > 0.8 * (n_w + p_w["full_width"]) and n_w > 300000, p_w
+    assert p_w["window_rejected"] < 0.01 * n_w, p_w
+    assert p_f["window256"] == 0 and p_f["window512"] == 0 and p_f["window_rejected"] == 0, p_f
+    assert abs(p_f["full_width"] - (n_w + p_w["full_width"])) <= 16, (p_w, p_f)      # the same envelopes in both runs
+    assert np.array_equal(f_w & 15, f_f & 15)
+    H = e.H
+    sc_f = np.array([d.seq_score for d in det_f], dtype=np.float64).reshape(len(seqs), H)
+    moved = _check_decibits(d_w, d_f, sc_f, (f_f & 1) == 1, "scoring window vs full width")
+    assert moved <= 8, moved                      # round 3 measured 2 of 1.6 million
+    # the Forward side is untouched by the window
+    assert all(a.fwd_bits == b.fwd_bits for a, b in zip(det_w[:4096], det_f[:4096]))
+    e.close()
+
+
+def test_two_queries_per_wave_kernel_equals_the_one_query_kernel(tmp_path):
+    """wh_score9.hip (two queries of one model per wavefront, option WH_SCORE_KERNEL=9) does per query what the
+    one-query sweeps do, operation by operation: scores, flags and Forward log-odds are identical BITWISE - on
+    equal-length queries, on queries of different lengths sharing a wave (odd counts included), and on a query set
+    with empty, multidomain and unrelated queries."""
+    _need_gpu()
+    import bench
+    from witch_amd import synth
+    from witch_amd.ehmm import EHMM, pack_queries
+    fam, se, names, seqs, k = bench.make_workload("dna_100k_x200", str(tmp_path), 1025, 12)
+    e = EHMM(se.paths, hmm_index=se.index, nseq=se.nseq)
+    rng = np.random.default_rng(5)
+    ragged = [s_.astype(np.uint8)[: int(rng.integers(20, 151))] for s_ in seqs[:301]]
+    junk = [rng.integers(0, 4, size=int(n)).astype(np.uint8) for n in rng.integers(1, 150, size=40)]
+    twice = [np.concatenate([s_[:70], s_[:70]]).astype(np.uint8) for s_ in seqs[:40]]       # two copies: multidomain candidates
+    for batch in ([s_.astype(np.uint8) for s_ in seqs], ragged, ragged[:7] + [np.zeros(0, dtype=np.uint8)] + junk + twice):
+        res, offs = pack_queries(batch)
+        d7, f7, w7 = e.score(res, offs, want_fwd=True)
+        p7 = e.last_score_paths()
+        e.set_option("WH_SCORE_KERNEL", "9")
+        d9, f9, w9 = e.score(res, offs, want_fwd=True)
+        p9 = e.last_score_paths()
+        e.set_option("WH_SCORE_KERNEL", "")
+        assert np.array_equal(f7, f9)
+        assert np.array_equal(d7, d9)
+        assert np.array_equal(w7.view(np.uint32), w9.view(np.uint32))
+        assert p7 == p9, (p7, p9)
+    e.close()
+
+
+def test_resolver_queue_overflow_repeats_the_scoring_pass(golden_case):
+    """The queue of pairs with a multidomain region is sized by estimate; a call that needs more slots than it got
+    counts them, grows the queue and scores again.  Forced here with a queue of 3 slots: same results as the
+    default sizing, and the re-run is reported."""
+    _need_gpu()
+    case = golden_case
+    e, seqs, res, offs = _load(case)
+    d0, f0 = e.score(res, offs)
+    n_multi = int(((f0 & 2) != 0).sum())
+    assert e.last_queue_reruns() == 0
+    e.set_option("WH_RQUEUE_CAP", "3")
+    d1, f1 = e.score(res, offs)
+    reruns = e.last_queue_reruns()
+    e.set_option("WH_RQUEUE_CAP", "")
+    assert np.array_equal(d0, d1) and np.array_equal(f0, f1), case.name
+    assert reruns == (1 if n_multi > 3 else 0), (case.name, n_multi, reruns)
     e.close()
 
 
@@ -1011,9 +1095,13 @@ def test_config5_shape_all_500_hmms(orc, tmp_path):
     e.close()
 
 
-def test_two_rank_rehearsal_equals_one_rank(tmp_path):
-    """BASELINE.json configs[3] rehearsed on one GPU: bench.py under torch.distributed.run with two ranks
-    (WITCH_BENCH_REHEARSAL=1: both on cuda:0, gloo gather) must gather exactly the 1-rank top-k table."""
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_multi_rank_rehearsal_equals_one_rank(tmp_path, ranks):
+    """BASELINE.json configs[3] rehearsed on one GPU: bench.py under torch.distributed.run with two and with four ranks
+    (WITCH_BENCH_REHEARSAL=1: all on cuda:0, gloo gather) must gather exactly the 1-rank top-k table.  Four is the
+    largest rank count a one-GPU box admits beside the test runner and the launcher (at most six processes may hold the
+    card: a six-rank attempt was killed by the box's process guard); the eight-way shard arithmetic and the packed
+    gather at world 8 run on the CPU (tests/test_distributed_gloo.py)."""
     _need_gpu()
     import json
     import os
@@ -1031,14 +1119,14 @@ def test_two_rank_rehearsal_equals_one_rank(tmp_path):
                         capture_output=True, text=True, timeout=900, env=env)
     assert r1.returncode == 0, r1.stderr[-2000:]
     env2 = dict(env, WITCH_BENCH_REHEARSAL="1")
-    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
                          "--master-addr", "127.0.0.1", "--master-port", str(port),
-                         os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common,
+                         os.path.join(ROOT, "bench.py"), "--gpus", str(ranks)] + common,
                         capture_output=True, text=True, timeout=900, env=env2)
     assert r2.returncode == 0, r2.stderr[-2000:]
     j1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][0])
     j2 = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][0])
-    assert j2["n_gpus"] == 2 and j2["config"]["sharding"] == "queries/2"
+    assert j2["n_gpus"] == ranks and j2["config"]["sharding"] == "queries/%d" % ranks
     assert j1["config"]["topk_crc32"] == j2["config"]["topk_crc32"]
     assert j1["distributions"]["n_used"] == j2["distributions"]["n_used"]
 
@@ -1163,9 +1251,13 @@ def test_end_to_end_example_against_the_reference_pipeline(tmp_path, ehmm_source
           % (n_pairs, multi, n_mask, n_score, d_set, d_order, d_w, d_str, len(case.qnames), same_full, same_masked))
     for qn, why in differing:
         print("   differs: %s (%s)" % (qn, why))
-    # observed on MI355X (rounds 2-3): 2 mask differences, 1 score, 4 queries with a different low-weight tail
-    assert n_mask <= 4 and n_score <= 4, (n_mask, n_score)
-    assert d_set + d_order + d_w <= 6, (d_set, d_order, d_w)
+    # observed on MI355X (rounds 2-4, both eHMM sources): 2 mask differences, 1 score, 4 queries with a different low-weight
+    # tail (HMMER's stochastic class, SURVEY finding 3) - and BOTH FINAL FILES IDENTICAL to the reference pipeline's.
+    # The gate is the observed state plus one; the north-star property itself is asserted unconditionally.
+    assert n_mask <= 3 and n_score <= 2, (n_mask, n_score)
+    assert d_set + d_order + d_w <= 5, (d_set, d_order, d_w)
+    assert d_str == 0, d_str
+    assert same_full and same_masked, (same_full, same_masked)
     assert (eng.flags & 8).sum() == 0 and not eng.truncated_pairs and not eng.unaligned_pairs
     # ---- a1 / f4 on the same run: the result files gcmm.search writes (the reference's chunk layout), weights.txt and
     # the checkpoint file, each read back; the merge fed from the checkpoint (the reference's resume path,
@@ -1342,8 +1434,9 @@ def test_device_merge_on_every_golden_case(golden_case, tmp_path):
 
 
 @pytest.mark.gpu
-def test_two_rank_level1_writes_the_reference_files(tmp_path):
-    """SURVEY 8e through the PRODUCT path, rehearsed with two ranks on one GPU (gloo):
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_multi_rank_level1_writes_the_reference_files(tmp_path, ranks):
+    """SURVEY 8e through the PRODUCT path, rehearsed with two and four ranks on one GPU (gloo):
     sharded engine -> gathered top-k -> mergeAlignmentsDevice with the all-reduced gap widths -> rank 0 writes.
     The two files must be the reference pipeline's (sha256 of the end-to-end golden), like the one-rank run."""
     _need_gpu()
@@ -1361,13 +1454,13 @@ def test_two_rank_level1_writes_the_reference_files(tmp_path):
     script = os.path.join(ROOT, "tools", "level1_ranks.py")
     r1 = subprocess.run([sys.executable, script, str(tmp_path / "one.fasta")], capture_output=True, text=True, timeout=600, env=env)
     assert r1.returncode == 0, r1.stderr[-2000:]
-    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                         "--master-addr", "127.0.0.1", "--master-port", str(port), script, str(tmp_path / "two.fasta")],
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
+                         "--master-addr", "127.0.0.1", "--master-port", str(port), script, str(tmp_path / "many.fasta")],
                         capture_output=True, text=True, timeout=600, env=env)
     assert r2.returncode == 0, r2.stderr[-2000:]
     j1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][0])
     j2 = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][0])
-    assert j2["world"] == 2 and j2["rows_local"] == [0, 250]
+    assert j2["world"] == ranks and j2["rows_local"] == [0, 500 // ranks]
     for j in (j1, j2):
         assert j["full"] == g["final_sha256"]["full"] and j["masked"] == g["final_sha256"]["masked"]
 

@@ -58,6 +58,20 @@ def main():
                   "read_bytes_per_launch": read_b, "write_bytes_per_launch": write_b,
                   "hbm_bytes_per_launch": read_b + write_b,
                   "note": "largest dispatch of the kernel in each pass; FETCH_SIZE doubled (gfx950 correction, MI355X_MICROARCH.md)"}
+    # SQ / GRBM pass: counters of the LARGEST dispatch of each kernel (summed over the XCDs / SEs as rocprofv3 reports them)
+    sq = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(float)))
+    for f in glob.glob(os.path.join(d, "pmc_SQ", "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            if k:
+                sq[k][r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"])
+    for k in sq:
+        big = max(sq[k].values(), key=lambda c: c.get("SQ_WAVE_CYCLES", 0.0))
+        out.setdefault(k, {})["sq"] = dict(big)
+    # stamp: the build these counters belong to (bench.py refuses a profile of another build)
+    import hashlib
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "witch_amd", "libwitch_hip.so")
+    out["lib_sha16"] = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16] if os.path.exists(lib) else None
     json.dump(out, open(os.path.join(d, "traffic.json"), "w"), indent=1)
     print(open(os.path.join(d, "kernel_stats.csv")).read() if stats else "no kernel stats")
     print(json.dumps(out, indent=1))

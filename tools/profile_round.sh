@@ -10,8 +10,11 @@ set -e
 tag=${1:-r02}; shift || true
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 out=gpurun_out/$tag; mkdir -p $out
-timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $out/trace -o trace --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-level1 "$@" > $out/trace.log 2>&1
+timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $out/trace -o trace --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-level1 --no-also "$@" > $out/trace.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 600 rocprofv3 --pmc $c -d $out/pmc_$c -o pmc --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-level1 "$@" > $out/pmc_$c.log 2>&1
+  timeout -k 10 600 rocprofv3 --pmc $c -d $out/pmc_$c -o pmc --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-level1 --no-also "$@" > $out/pmc_$c.log 2>&1
 done
+# 3. SQ / GRBM counters of the same command (own pass): executed vector instructions, LDS instructions, wave cycles and
+#    their waiting share, and GRBM_GUI_ACTIVE for the effective clock (sum over the 8 XCDs / 8 / kernel time)
+timeout -k 10 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE -d $out/pmc_SQ -o pmc --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-level1 --no-also "$@" > $out/pmc_SQ.log 2>&1 || echo "SQ pass failed" >> $out/fail.log
 python3 tools/prof_summary.py $out

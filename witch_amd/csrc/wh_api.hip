@@ -57,7 +57,8 @@ struct KernelTimer {
 // Development knobs.  Read from the environment ONCE, at wh_ehmm_load;
 // wh_set_option changes them on a live handle (tools/ab_score.py).  None is needed in production.
 struct Knobs {
-  int kernel = 7;            // 7 phase-call scoring kernel; 8 its second compilation (A/B slot)
+  int kernel = 7;            // 7 phase-call scoring kernel (one query per wavefront); 8 its second compilation (A/B slot);
+                             // 9 two queries per wavefront where a batch fits (wh_score9.hip; measured slower, kept for A/B: DESIGN.md)
   float keep_scale = 0.f;    // Forward-row spill threshold relative to E(row); 0 = the kernel's default
   int max_waves = 0;         // cap on waves per workgroup (0 = planner's choice)
   bool force_specg = false;  // force the HBM special-state mode
@@ -65,10 +66,12 @@ struct Knobs {
   bool no_wide_align = false; // models beyond 3 072 nodes are aligned by the float64 kernel only (A/B and debugging)
   bool no_window = false;    // envelope Backward sweeps run full width (no node window; A/B and debugging)
   bool no_resolve = false;   // multidomain regions stay ONE envelope (round-1 behaviour) instead of HMMER's stochastic resolver
+  int rqueue_cap = 0;        // test hook: size the resolver's queue for this many pairs instead of the estimate (forces the overflow re-run)
   bool stats = false, trace = false;
   int dbg = 0;
   int rdbg = 0;              // resolver: print the first <n> sampled segments and the cluster statistics of every region
 };
+static const int kScorePathSlot = 112;   // d_counter[112..119]: four 64-bit path counters of the last scoring call (wh_last_score_paths)
 static const int kMaxLaunches = 60;   // work-queue heads in d_counter (slot 63 belongs to the consensus kernel)
 
 struct wh_ehmm {
@@ -89,6 +92,10 @@ struct wh_ehmm {
   DevBuf d_ascratch;                        // per-wave slabs of the alignment kernels (allocated while the scoring kernels run)
   DevBuf d_gtab, d_rrecs, d_rmx, d_rsegs;   // multidomain resolver: float64 tables, pair queue, matrix slabs, segment arrays
   int last_resolved = 0;                    // pairs the resolver finished in the last wh_score call
+  int64_t rq_cap = 0;                       // records the queue of the current scoring call holds
+  double rq_rate = 0.0;                     // largest share of queued pairs any call on this handle has seen (sizes the next queue)
+  int64_t rq_floor = 0;                     // ... at least this many (set when a call overflowed its estimate; the call then runs again)
+  int last_queue_reruns = 0;                // scoring passes the last wh_score call repeated because its queue overflowed (0 or 1)
   // staging for the host-pointer entry points
   DevBuf s_res, s_off, s_deci, s_flags, s_fwd, s_det, s_idx, s_w, s_nk, s_nu, s_pq, s_ph, s_co, s_cols, s_pos;
   DevBuf d_rkeys, d_rorder, d_qorder, d_order, d_items, d_recs, d_spec, d_back, d_cwj, d_cwv, d_cwn, d_crow, c_buf[10];
@@ -320,7 +327,7 @@ int wh_set_option(wh_ehmm *e, const char *name, const char *value) {
   Knobs &k = e->knobs;
   if (!strcmp(name, "WH_SCORE_KERNEL")) {
     const int kv = *v ? atoi(v) : 7;
-    if (kv != 7 && kv != 8) { set_error("WH_SCORE_KERNEL=%s: this build has kernels 7 and 8", v); return WH_EINVAL; }
+    if (kv != 7 && kv != 8 && kv != 9) { set_error("WH_SCORE_KERNEL=%s: this build has kernels 7, 8 and 9", v); return WH_EINVAL; }
     k.kernel = kv;
   } else if (!strcmp(name, "WH_KEEP_LOG2")) k.keep_scale = *v ? ldexpf(1.0f, atoi(v)) : 0.f;
   else if (!strcmp(name, "WH_MAX_WAVES")) k.max_waves = *v ? std::max(1, std::min(16, atoi(v))) : 0;
@@ -328,6 +335,7 @@ int wh_set_option(wh_ehmm *e, const char *name, const char *value) {
   else if (!strcmp(name, "WH_NO_LOGSPACE")) k.no_logspace = on;
   else if (!strcmp(name, "WH_NO_RESOLVE")) k.no_resolve = on;
   else if (!strcmp(name, "WH_NO_WINDOW")) k.no_window = on;
+  else if (!strcmp(name, "WH_RQUEUE_CAP")) k.rqueue_cap = *v ? std::max(1, atoi(v)) : 0;
   else if (!strcmp(name, "WH_NO_WIDE_ALIGN")) k.no_wide_align = on;
   else if (!strcmp(name, "WH_STATS")) k.stats = on;
   else if (!strcmp(name, "WH_TRACE")) k.trace = on;
@@ -338,7 +346,7 @@ int wh_set_option(wh_ehmm *e, const char *name, const char *value) {
 }
 
 static void knobs_from_env(wh_ehmm *e) {
-  for (const char *name : {"WH_SCORE_KERNEL", "WH_KEEP_LOG2", "WH_MAX_WAVES", "WH_FORCE_SPECG", "WH_NO_LOGSPACE", "WH_NO_RESOLVE", "WH_NO_WINDOW", "WH_NO_WIDE_ALIGN", "WH_STATS", "WH_TRACE", "WH_DBG", "WH_RDBG"})
+  for (const char *name : {"WH_SCORE_KERNEL", "WH_KEEP_LOG2", "WH_MAX_WAVES", "WH_FORCE_SPECG", "WH_NO_LOGSPACE", "WH_NO_RESOLVE", "WH_NO_WINDOW", "WH_RQUEUE_CAP", "WH_NO_WIDE_ALIGN", "WH_STATS", "WH_TRACE", "WH_DBG", "WH_RDBG"})
     if (const char *v = getenv(name)) (void)wh_set_option(e, name, v);
 }
 
@@ -389,6 +397,22 @@ int wh_last_align_paths(wh_ehmm *e, int64_t *paths4) {
   return WH_OK;
 }
 
+int wh_last_score_paths(wh_ehmm *e, int64_t *paths4) {
+  if (!e || !paths4) { set_error("wh_last_score_paths: bad argument"); return WH_EINVAL; }
+  HIPCHK(hipSetDevice(e->device));
+  unsigned long long v[4] = {0, 0, 0, 0};
+  // (the counters stay on the device until the next scoring call resets them; this copy waits for the device)
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(v, (int *)e->d_counter.p + kScorePathSlot, sizeof v, hipMemcpyDeviceToHost));
+  for (int t = 0; t < 4; t++) paths4[t] = (int64_t)v[t];
+  return WH_OK;
+}
+
+int wh_last_queue_reruns(wh_ehmm *e) {
+  if (!e) { set_error("wh_last_queue_reruns: null handle"); return WH_EINVAL; }
+  return e->last_queue_reruns;
+}
+
 int wh_last_score_launches(wh_ehmm *e, int32_t *cells_per_lane, int32_t *kind, double *ms, int cap) {
   if (!e || cap < 0) { set_error("wh_last_score_launches: bad argument"); return WH_EINVAL; }
   const int n = e->cls_n > 0 ? e->cls_n - 1 : 0;
@@ -422,11 +446,14 @@ int wh_last_kernel_ms(wh_ehmm *e, int which, double *ms, int *launches) {
 static const size_t kLdsBudget = 160 * 1024 - 512;
 static const size_t kLdsHeader = 16;   // work-item slot in front of the tables (keeps them 16-byte aligned)
 
+// per-row special-state arrays of a wave's LDS block in the phase-call scoring kernel (wh_score7.hip is built with
+// WH_SLIM_SPEC: N, B, E, J, C, scale; an envelope's mask words share the B / E slots)
+static const int kScoreSpecArrays = 6;
 // LDS plan of the phase-call scoring kernel: tables (K emission rows + both transition
 // orientations) + per wave one block (special-state arrays, null2 table, region list, residues).
 static int plan_block1(const wh_ehmm *e, int Q, int K, int Lcap, int wmax, int *waves, int *SP, int *wave_lds, size_t *lds) {
   const int sp = (Lcap + 1 + 3) / 4 * 4;
-  const int wl = 8 * sp + 32 + kRegsInts + (Lcap + 3) / 4 + 4;
+  const int wl = kScoreSpecArrays * sp + 32 + kRegsInts + (Lcap + 3) / 4 + 4;
   const size_t table = (size_t)(K + 2 * FW_NARR) * Q * kWave * sizeof(float);
   int w = wmax;
   if (e->knobs.max_waves > 0) w = std::max(1, std::min(wmax, e->knobs.max_waves));
@@ -448,6 +475,10 @@ static int clamp_blocks(int blocks, size_t per_block, const DevBuf &have) {
   return (int)std::max<size_t>(1, std::min<size_t>((size_t)blocks, fit));
 }
 
+static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets, int64_t nq,
+                          int64_t total_residues, int32_t max_len, int32_t *d_decibits, uint8_t *d_flags,
+                          float *d_fwd_bits, wh_pair_detail *d_detail, void *stream, bool *overflow);
+
 int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets, int64_t nq,
                  int64_t total_residues, int32_t max_len, int32_t *d_decibits, uint8_t *d_flags,
                  float *d_fwd_bits, wh_pair_detail *d_detail, void *stream) {
@@ -455,6 +486,27 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
     set_error("wh_score_dev: bad argument");
     return WH_EINVAL;
   }
+  // The queue of pairs with a multidomain region is sized by ESTIMATE (a per-pair record is 168 bytes; the worst case,
+  // one record per pair, was 3.4 GB at the headline for a class that is 0.005 % of its pairs).  The kernels count every
+  // pair that wants a slot; when the count exceeds the capacity, the queue is grown to the count and the scoring pass
+  // runs once more (every pair is scored again, so the queue then holds exactly what the first pass counted).
+  e->last_queue_reruns = 0;
+  e->rq_floor = 0;
+  bool overflow = false;
+  int rc = score_dev_pass(e, d_residues, d_offsets, nq, total_residues, max_len, d_decibits, d_flags, d_fwd_bits, d_detail, stream, &overflow);
+  if (rc == WH_OK && overflow) {
+    e->last_queue_reruns = 1;
+    overflow = false;
+    rc = score_dev_pass(e, d_residues, d_offsets, nq, total_residues, max_len, d_decibits, d_flags, d_fwd_bits, d_detail, stream, &overflow);
+    if (rc == WH_OK && overflow) { set_error("wh_score_dev: the resolver's queue overflowed twice"); rc = WH_ERANGE; }
+  }
+  e->rq_floor = 0;
+  return rc;
+}
+
+static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets, int64_t nq,
+                          int64_t total_residues, int32_t max_len, int32_t *d_decibits, uint8_t *d_flags,
+                          float *d_fwd_bits, wh_pair_detail *d_detail, void *stream, bool *overflow) {
   hipStream_t s = (hipStream_t)stream;
   HIPCHK(hipSetDevice(e->device));
   if (timer_begin(e, 0, s)) return WH_EHIP;
@@ -476,9 +528,20 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
     int *d_rcount = (int *)e->d_counter.p + 64;      // [64] queue length, [65] work-queue head of the resolver
     e->last_resolved = 0;
     if (resolve) {
-      if (e->d_rrecs.ensure(sizeof(ResolveRec) * (size_t)npairs_all)) return WH_ENOMEM;
+      // estimate: 5 % of the pairs (at least 65 536) or 1.25 x the largest share an earlier call on this handle queued,
+      // plus every pair of the any-size float64 front end, which hands each pair with a region to the resolver; never
+      // more than one record per pair.  (Synthetic family fragments queue 0.005 % of their pairs, the reference's rRNA
+      // fragments 28 %: a first call on such data repeats its scoring pass once, later calls are sized by what it saw.)
+      int64_t cap = std::max<int64_t>(65536, std::max<int64_t>(npairs_all / 20, (int64_t)(1.25 * e->rq_rate * (double)npairs_all) + 1024)) +
+                    nq * (int64_t)e->generic_front.size();
+      cap = std::max<int64_t>(cap, (int64_t)(e->d_rrecs.cap / sizeof(ResolveRec)));   // what an earlier call allocated is free to use
+      if (kn.rqueue_cap > 0) cap = kn.rqueue_cap;                                      // test hook
+      cap = std::min<int64_t>(std::max(cap, e->rq_floor), npairs_all);
+      if (e->d_rrecs.ensure(sizeof(ResolveRec) * (size_t)cap)) return WH_ENOMEM;
+      e->rq_cap = cap;
       HIPCHK(hipMemsetAsync(d_rcount, 0, 2 * sizeof(int), s));
     }
+    HIPCHK(hipMemsetAsync((int *)e->d_counter.p + kScorePathSlot, 0, 4 * sizeof(unsigned long long), s));
     // Long models run four waves in lockstep per workgroup (wh_score_big.hip): hand them the queries in
     // descending length order, so that the waves of a workgroup finish their sweeps together and the longest
     // pairs start first.  (One D2H copy of the offsets and a host sort; only when such a class exists.)
@@ -531,7 +594,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       a.dbg = kn.dbg;
       a.no_window = kn.no_window ? 1 : 0;
       a.keep_scale = kn.keep_scale;
-      if (resolve) { a.rrecs = (ResolveRec *)e->d_rrecs.p; a.rcount = d_rcount; a.rcap = (int)npairs_all; }
+      if (resolve) { a.rrecs = (ResolveRec *)e->d_rrecs.p; a.rcount = d_rcount; a.rcap = (int)e->rq_cap; }
       memcpy(a.degen, e->degen, sizeof a.degen);
       int waves = 0, SP = 0, wave_lds = 0;
       size_t lds = 0;
@@ -540,9 +603,23 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       //  * the same kernel with the special-state rows in HBM ("SG"): long queries
       //  * pass-synchronous kernel (wh_score_big.hip): 28+ cells per lane, and 20/24-cell models whose
       //    emission rows do not fit in LDS beside both orientations (protein)
-      bool big = Q > kMaxQFast, specg = false;
-      if (!big) {
-        int rc_plan = plan_block1(e, Q, e->K, Lc, Q <= 16 ? 12 : 8, &waves, &SP, &wave_lds, &lds);
+      bool big = Q > kMaxQFast, specg = false, pairk = false;
+      if (!big && kn.kernel == 9 && !kn.force_specg && (Q == 8 || Q == 12 || Q == 16)) {
+        // two queries per wavefront (wh_score9.hip): eight waves, each with two blocks of per-row arrays
+        const int sp9 = (Lc + 1 + 3) / 4 * 4;
+        const int wl9 = 2 * score9_block_floats(sp9, Lc);
+        const size_t table = (size_t)(e->K + 2 * FW_NARR) * Q * kWave * sizeof(float);
+        int w9 = 8;
+        if (kn.max_waves > 0) w9 = std::max(1, std::min(8, kn.max_waves));
+        if (kLdsHeader + table + (size_t)w9 * wl9 * sizeof(float) <= kLdsBudget) {
+          pairk = true; waves = w9; SP = sp9; wave_lds = wl9;
+          lds = kLdsHeader + table + (size_t)w9 * wl9 * sizeof(float);
+        }
+      }
+      if (!big && !pairk) {
+        // (twelve waves = three per SIMD at 168 registers; 20-cell models keep that since the six-array block, 24-cell
+        // models get the nine or ten waves that fit beside their 120 KB of tables)
+        int rc_plan = plan_block1(e, Q, e->K, Lc, 12, &waves, &SP, &wave_lds, &lds);
         if (rc_plan != WH_OK || waves < 4 || kn.force_specg) {
           specg = true;
           SP = (Lc + 1 + 3) / 4 * 4;
@@ -571,20 +648,22 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
         SP = (Lc + 1 + 3) / 4 * 4;
         specg = true;
       }
-      a.SP = SP; a.wave_lds = wave_lds;
+      a.SP = SP; a.wave_lds = wave_lds; a.spec_arrays = kScoreSpecArrays;
+      a.paths = reinterpret_cast<unsigned long long *>((int *)e->d_counter.p + kScorePathSlot);
       a.qorder = (big || mixed) ? d_qorder : nullptr;
       a.QB = big ? waves * 2 : waves * 4;   // long models: a pair is milliseconds, smaller items shorten the tail of the launch
+      const int per_turn = pairk ? 2 : 1;   // queries a wave takes per turn
       // small batches (the reference's example as shipped: 500 fragments x 15 models): with the default item size there
       // are fewer than a handful of items per workgroup and the launch ends on its stragglers - one query per wave and
       // item then (the tables of a model are re-staged more often, which a small batch can afford)
       {
         const int max_blocks = big ? e->cu_count : e->cu_count * std::max(1, 8 / waves);
         const int64_t items_default = (int64_t)a.n_list * ((nq + a.QB - 1) / a.QB);
-        if (items_default < 4 * (int64_t)max_blocks) a.QB = waves;
+        if (items_default < 4 * (int64_t)max_blocks) a.QB = waves * per_turn;
       }
       a.n_qblocks = (int)((nq + a.QB - 1) / a.QB);
       a.n_items = a.n_list * a.n_qblocks;
-      a.scratch_stride = (size_t)(a.Lcap + 1) * 2 * Q * kWave;   // Forward slab per wave
+      a.scratch_stride = (size_t)per_turn * (size_t)(a.Lcap + 1) * 2 * Q * kWave;   // Forward slab(s) per wave
       a.spec_stride = specg ? (size_t)8 * a.SP : 0;
       int blocks = std::min(a.n_items, big ? e->cu_count : e->cu_count * std::max(1, 8 / waves));
       blocks = clamp_blocks(blocks, (size_t)waves * (a.scratch_stride + a.spec_stride) * sizeof(float), e->d_scratch);
@@ -606,10 +685,11 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
         a.stats = (unsigned long long *)e->d_recs.p;
       }
       if (kn.trace) fprintf(stderr, "[wh] score Q=%d kernel=%s specg=%d waves=%d blocks=%d lds=%zu SP=%d wave_lds=%d items=%d Lcap=%d\n", Q,
-                            big ? "pass-synchronous" : kn.kernel == 8 ? "phase-call(B)" : "phase-call", (int)specg, waves, blocks, lds, SP, wave_lds, a.n_items, a.Lcap);
+                            big ? "pass-synchronous" : pairk ? "two-queries-per-wave" : kn.kernel == 8 ? "phase-call(B)" : "phase-call", (int)specg, waves, blocks, lds, SP, wave_lds, a.n_items, a.Lcap);
       HIPCHK(hipMemsetAsync(a.counter, 0, sizeof(int), s));
       if (class_mark(e, s, Q, big ? 1 : 0)) return WH_EHIP;
       hipError_t err = big ? launch_score_big(Q, a, blocks, waves * kWave, lds, s)
+                       : pairk ? launch_score9(Q, a, blocks, waves * kWave, lds, s)
                        : kn.kernel == 8 ? launch_score7b(Q, a, blocks, waves * kWave, lds, s)
                                         : launch_score7(Q, a, blocks, waves * kWave, lds, s);
       if (err != hipSuccess) { set_error("score kernel launch (Q=%d) failed: %s", Q, hipGetErrorString(err)); return WH_EHIP; }
@@ -652,7 +732,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
         a.decibits = d_decibits; a.flags = d_flags; a.fwd_bits = d_fwd_bits; a.detail = d_detail;
         a.H = (int)e->hmms.size(); a.K = e->K; a.Kp = e->Kp;
         memcpy(a.degen, e->degen, sizeof a.degen);
-        if (resolve) { a.rrecs = (ResolveRec *)e->d_rrecs.p; a.rcount = (int *)e->d_counter.p + 64; a.rcap = (int)npairs_all; }
+        if (resolve) { a.rrecs = (ResolveRec *)e->d_rrecs.p; a.rcount = (int *)e->d_counter.p + 64; a.rcap = (int)e->rq_cap; }
         a.qorder = qorder_all;
         a.scratch_stride = (size_t)(Lc + 1) * 2 * e->wide_q * W * kWave;
         const int64_t n_items = nq * (int64_t)a.n_list;
@@ -696,7 +776,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
     g.decibits = d_decibits; g.flags = d_flags; g.fwd_bits = d_fwd_bits; g.detail = d_detail;
     g.H = (int)e->hmms.size(); g.K = e->K; g.Kp = e->Kp;
     memcpy(g.degen, e->degen, sizeof g.degen);
-    g.rrecs = (ResolveRec *)e->d_rrecs.p; g.rcount = (int *)e->d_counter.p + 64; g.rcap = (int)npairs_all;
+    g.rrecs = (ResolveRec *)e->d_rrecs.p; g.rcount = (int *)e->d_counter.p + 64; g.rcap = (int)e->rq_cap;
     const size_t glds = generic_lds_bytes(Lc);
     if (glds > kLdsBudget) { set_error("query length %d does not fit the any-size kernel's LDS", max_len); return WH_ERANGE; }
     const int64_t n_items = nq * (int64_t)n_gen;
@@ -733,6 +813,15 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
     if (rlds <= kLdsBudget && nq * (int64_t)e->hmms.size() < 0x7FFFFFFF) {
       HIPCHK(hipMemcpyAsync(&n_multi, d_rcount, sizeof(int), hipMemcpyDeviceToHost, s));
       HIPCHK(hipStreamSynchronize(s));
+      if (nq > 0) e->rq_rate = std::max(e->rq_rate, (double)n_multi / (double)(nq * (int64_t)e->hmms.size()));
+      if ((int64_t)n_multi > e->rq_cap) {
+        // more pairs asked for a slot than the estimate allowed: the caller repeats the scoring pass with room for all
+        if (e->knobs.trace) fprintf(stderr, "[wh] resolver queue: %d pairs for %lld slots, scoring pass repeated\n", n_multi, (long long)e->rq_cap);
+        e->rq_floor = n_multi;
+        *overflow = true;
+        if (timer_end(e, 4, s, 0)) return WH_EHIP;
+        return WH_OK;
+      }
     }
     if (n_multi > 0) {
       const int Qmax = e->max_Q;
@@ -740,7 +829,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       memset(&r, 0, sizeof r);
       r.hmms = (const DevHMM *)e->d_hmms.p; r.gtab = (const double *)e->d_gtab.p; r.ftab = (const float *)e->d_tables.p;
       r.residues = d_residues; r.offsets = d_offsets;
-      r.recs = (const ResolveRec *)e->d_rrecs.p; r.count = d_rcount; r.rec_cap = (int)(nq * (int64_t)e->hmms.size());
+      r.recs = (const ResolveRec *)e->d_rrecs.p; r.count = d_rcount; r.rec_cap = (int)e->rq_cap;
       r.counter = d_rwork;
       r.Lcap = Lc; r.Mmax = e->max_M;
       // a wave's slab: matrix rows | threshold-line cache of the walk | E-state row cache (at the end)

@@ -274,7 +274,9 @@ __device__ __forceinline__ void region_scan_global(float *spec, int SP, int L, i
 // keep_scale * E(row) (exec-masked stores: adjacent kept lanes still form contiguous segments);
 // the 64-bit mask of kept lanes goes to spec[SP_ML/SP_MH].  keep_scale < 0 stores everything.  Returns C(L) and its
 // scale exponent.
-template <int Q, bool TREG, bool STORE, bool USEP = false>
+// SLIM (with STORE): the per-row B and E arrays of an envelope sweep are never read again, so their slots hold the two
+// mask words instead (SP_B <- low word, SP_E <- high word) and a wave's block needs six arrays, not eight.
+template <int Q, bool TREG, bool STORE, bool USEP = false, bool SLIM = false>
 __device__ __forceinline__ void forward_sweep(const TransTab<Q, TREG> &T, const ScanC &sc, const float *emL,
                                               const float *emG, int K, const uint8_t *seq, int L, LenCfg cfg,
                                               float *spec, int SP, float *Fs, float keep_scale, int lane,
@@ -362,11 +364,13 @@ __device__ __forceinline__ void forward_sweep(const TransTab<Q, TREG> &T, const 
     }
     xB = (xJ + xN) * cfg.move;
     if (lane == 0) {
-      spec[SP_N * SP + i] = xN; spec[SP_B * SP + i] = xB; spec[SP_E * SP + i] = xE;
+      spec[SP_N * SP + i] = xN;
+      if (!(STORE && SLIM)) { spec[SP_B * SP + i] = xB; spec[SP_E * SP + i] = xE; }
       spec[SP_J * SP + i] = xJ; spec[SP_C * SP + i] = xC;
       reinterpret_cast<int *>(spec)[SP_S * SP + i] = ef;
     }
     if (STORE) {
+      constexpr int ML = SLIM ? SP_B : SP_ML, MH = SLIM ? SP_E : SP_MH;
       float lmax = 0.f;
 #pragma unroll
       for (int q = 0; q < Q; q += 2) lmax = fmaxf(lmax, fmaxf(fmaxf(Mp[q], Mp[q + 1]), fmaxf(Ip[q], Ip[q + 1])));
@@ -376,8 +380,8 @@ __device__ __forceinline__ void forward_sweep(const TransTab<Q, TREG> &T, const 
       const unsigned long long mask = __ballot(keep);
       umask |= __ballot(lmax > 0.5f * xE);
       if (lane == 0) {
-        reinterpret_cast<unsigned *>(spec)[SP_ML * SP + i] = (unsigned)(mask & 0xFFFFFFFFull);
-        reinterpret_cast<unsigned *>(spec)[SP_MH * SP + i] = (unsigned)(mask >> 32);
+        reinterpret_cast<unsigned *>(spec)[ML * SP + i] = (unsigned)(mask & 0xFFFFFFFFull);
+        reinterpret_cast<unsigned *>(spec)[MH * SP + i] = (unsigned)(mask >> 32);
       }
       if (keep) {
         float4 *row = reinterpret_cast<float4 *>(Fs) + (size_t)i * (2 * (Q / 4) * kWave) + lane;
@@ -392,8 +396,8 @@ __device__ __forceinline__ void forward_sweep(const TransTab<Q, TREG> &T, const 
   }
   if (STORE && lane == 0) {
     // row 0 of the two mask arrays is free (rows are 1..L): the dominant-path mask of the sweep
-    reinterpret_cast<unsigned *>(spec)[SP_ML * SP] = (unsigned)(umask & 0xFFFFFFFFull);
-    reinterpret_cast<unsigned *>(spec)[SP_MH * SP] = (unsigned)(umask >> 32);
+    reinterpret_cast<unsigned *>(spec)[(SLIM ? SP_B : SP_ML) * SP] = (unsigned)(umask & 0xFFFFFFFFull);
+    reinterpret_cast<unsigned *>(spec)[(SLIM ? SP_E : SP_MH) * SP] = (unsigned)(umask >> 32);
   }
   xC_out = xC;
   ef_out = ef;

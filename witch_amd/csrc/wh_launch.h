@@ -35,6 +35,7 @@ struct ScoreArgs {
   int Lcap;                    // longest query of the batch
   int SP;                      // stride of the per-row special-state arrays (>= Lcap+1)
   int wave_lds;                // floats of LDS per wave
+  int spec_arrays;             // per-row special-state arrays in that block the PLANNER assumed (the launcher refuses a mismatch with its build)
   float *scratch;              // per-wave Forward slabs
   size_t scratch_stride;       // floats per wave
   int32_t *decibits;
@@ -54,12 +55,17 @@ struct ScoreArgs {
   int *rcount;                 // queue length (device counter)
   int rcap;
   unsigned long long *stats;   // WH_STATS: [4..11] wave cycles per phase (or NULL)
+  unsigned long long *paths;   // 4 counters (always counted, one atomic per wave and counter at the end of the launch): envelope Backward
+                               // sweeps on a 256-node window, on a 512-node window, windows that failed the certificate, full-width sweeps
   const int32_t *qorder;       // long-model kernel: queries in descending length order (or NULL: input order)
 };
 
 hipError_t launch_score_big(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
 hipError_t launch_score7(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
 hipError_t launch_score7b(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);   // A/B slot
+// two queries per wavefront (wh_score9.hip): ScoreArgs::wave_lds = 2 x score9_block_floats(SP, Lcap), scratch_stride = two slabs
+hipError_t launch_score9(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
+int score9_block_floats(int SP, int Lcap);
 
 struct ResolveArgs {
   const DevHMM *hmms;

@@ -36,6 +36,15 @@ constexpr float kWinTol7 = 3e-6f;
 #define WH_K7_MAXQP 0
 #endif
 constexpr int kMaxQP = WH_K7_MAXQP;
+// WH_SLIM_SPEC (the two-queries-per-wave kernel, wh_score9.hip): six per-row arrays per query instead of eight - an
+// envelope's Forward sweep keeps its two mask words in the slots of the B and E rows, which nothing reads after it
+#ifdef WH_SLIM_SPEC
+constexpr bool kSlim = true;
+constexpr int kSpML = SP_B, kSpMH = SP_E, kSpArr = 6;
+#else
+constexpr bool kSlim = false;
+constexpr int kSpML = SP_ML, kSpMH = SP_MH, kSpArr = SP_NARR;
+#endif
 constexpr bool kMaskedAcc = true;   // P4: only lanes that own a stored Forward block accumulate
 
 __device__ __forceinline__ float flogsum0_v7(float b) {
@@ -90,7 +99,7 @@ __device__ __noinline__ FwdOut sweep_forward(const WaveCtx c, lds_u8 *seq3, int 
   T.load(nullptr, (const float *)c.fwL, c.lane);
   const ScanC sc = scan_prepare(lane_product<Q, false>(T, FW_D2));
   FwdOut o;
-  forward_sweep<Q, false, STORE, (Q <= kMaxQP)>(T, sc, (const float *)c.emL, (const float *)c.emG, ctxKlds(c), seq, L, cfg, SG ? (float *)c.specg : (float *)c.spec, c.SP, (float *)c.Fs, keep_scale, c.lane, o.xC, o.ef);
+  forward_sweep<Q, false, STORE, (Q <= kMaxQP), kSlim>(T, sc, (const float *)c.emL, (const float *)c.emG, ctxKlds(c), seq, L, cfg, SG ? (float *)c.specg : (float *)c.spec, c.SP, (float *)c.Fs, keep_scale, c.lane, o.xC, o.ef);
   if (SG) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // the rows were written by lane 0, every lane reads them next
   return o;
 }
@@ -181,7 +190,7 @@ __device__ __noinline__ P4Out sweep_backward_null2(const WaveCtx c, lds_u8 *eseq
     // across backward_cells); with two waves it is requested first.
     float4 fm4[Q / 4], fi4[Q / 4];
     auto request_row = [&]() {
-      const unsigned mword = src < 32 ? ldu(SP_ML * SP + i) : ldu(SP_MH * SP + i);
+      const unsigned mword = src < 32 ? ldu(kSpML * SP + i) : ldu(kSpMH * SP + i);
       const bool have = (mword >> (src & 31)) & 1u;
       const float4 *row = reinterpret_cast<const float4 *>((const float *)c.Fs) + (size_t)i * (2 * (Q / 4) * kWave) + src;
       if (have) {
@@ -214,7 +223,7 @@ __device__ __noinline__ P4Out sweep_backward_null2(const WaveCtx c, lds_u8 *eseq
     if (TH >= 768 && kMaskedAcc) {
       // only the lanes that own a stored block run the accumulation (the others would add zeros)
       asm volatile("" ::: "memory");
-      const unsigned mword = src < 32 ? ldu(SP_ML * SP + i) : ldu(SP_MH * SP + i);
+      const unsigned mword = src < 32 ? ldu(kSpML * SP + i) : ldu(kSpMH * SP + i);
       if ((mword >> (src & 31)) & 1u) {
         const float4 *row = reinterpret_cast<const float4 *>((const float *)c.Fs) + (size_t)i * (2 * (Q / 4) * kWave) + src;
         float idot = 0.f;
@@ -343,7 +352,7 @@ __device__ __noinline__ P4Out sweep_backward_null2_win(const WaveCtx c, lds_u8 *
   float4 fm_n[B4], fi_n[B4];
   bool have_n = false;
   auto request_row = [&](int r) {
-    const unsigned mword = lanef < 32 ? ldu(SP_ML * SP + r) : ldu(SP_MH * SP + r);
+    const unsigned mword = lanef < 32 ? ldu(kSpML * SP + r) : ldu(kSpMH * SP + r);
     have_n = (mword >> (lanef & 31)) & 1u;
     if (have_n) {
       const float4 *row = reinterpret_cast<const float4 *>((const float *)c.Fs) + (size_t)r * (2 * Q4 * kWave);
@@ -487,6 +496,7 @@ __device__ __noinline__ RegOut region_scan(lds_f *spec3, glb_f *specg, int SP, i
   return o;
 }
 
+#ifndef WH_SWEEPS_ONLY
 #define WH_TICK7(slot) do { if (a.stats) { const long long t_now = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(a.stats + (slot), (unsigned long long)(t_now - t_last)); t_last = t_now; } } while (0)
 
 template <int Q, int TH, bool SG>
@@ -503,17 +513,18 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
   const int SP = a.SP;
   WaveCtx c;
   c.emL = (lds_f *)emL; c.fwL = (lds_f *)trL; c.bwL = (lds_f *)(trL + NARR * TBL);
-  c.spec = (lds_f *)wbase; c.n2tab = (lds_f *)(wbase + (SG ? 0 : SP_NARR * SP));
+  c.spec = (lds_f *)wbase; c.n2tab = (lds_f *)(wbase + (SG ? 0 : kSpArr * SP));
   c.specg = SG ? (glb_f *)(a.spec_scratch + ((size_t)blockIdx.x * nwaves + wave) * a.spec_stride) : nullptr;
   c.degen = 0;
   for (int t = 0; t < 32; t++) if (t == lane) c.degen = a.degen[t];
   c.Fs = (glb_f *)(a.scratch + ((size_t)blockIdx.x * nwaves + wave) * a.scratch_stride);
   c.SP = SP; c.alpha = a.K | (a.Kp << 8) | (a.K << 16); c.lane = lane;
-  int *regs = reinterpret_cast<int *>(wbase + (SG ? 0 : SP_NARR * SP) + 32);
+  int *regs = reinterpret_cast<int *>(wbase + (SG ? 0 : kSpArr * SP) + 32);
   uint8_t *seq = reinterpret_cast<uint8_t *>(regs + kRegsInts);
   const double LOG2 = 0.69314718055994529;
   int cur_h = -1;
   const DevHMM *hm = nullptr;
+  unsigned n_w256 = 0, n_w512 = 0, n_wfail = 0, n_full = 0;   // this wave's envelope Backward sweeps by path (wh_last_score_paths)
 
   for (;;) {
     if (threadIdx.x == 0) *s_item_p = atomicAdd(a.counter, 1);
@@ -611,7 +622,7 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
                     // the node window around the lane blocks the dominant alignment runs through (two blocks in
                     // front: the envelope's first ~25 rows set no bit and lie that many nodes ahead; one block behind)
                     const unsigned *su = reinterpret_cast<const unsigned *>(SG ? (const float *)c.specg : (const float *)c.spec);
-                    const unsigned long long um = ((unsigned long long)su[SP_MH * SP] << 32) | su[SP_ML * SP];
+                    const unsigned long long um = ((unsigned long long)su[kSpMH * SP] << 32) | su[kSpML * SP];
                     if (um != 0) {
                       int lo = __builtin_ctzll(um), hi = 63 - __builtin_clzll(um);
                       lo = lo > 1 ? lo - 2 : 0; hi = hi < 63 ? hi + 1 : 63;
@@ -621,6 +632,7 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
                         const int m0 = min((63 - hi) * Q, kWave * (Q - 4));
                         p4 = sweep_backward_null2_win<4, Q, TH, SG>(c, (lds_u8 *)eseq, Ld, cu, 1.0f / (f3.xC * cu.move), kWinTol7, m0);
                         have4 = fabsf((float)Ld - p4.mass) <= kWinTol7 * (float)Ld;
+                        if (have4) n_w256++; else n_wfail++;
                         if (a.stats && lane == 0) {
                           atomicAdd(a.stats + (have4 ? 0 : 2), 1ull);
                           const float dev = fabsf((float)Ld - p4.mass) / (float)Ld;
@@ -630,6 +642,7 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
                         const int m0 = min((63 - hi) * Q, kWave * (Q - 8));
                         p4 = sweep_backward_null2_win<(Q % 8 == 0 ? 8 : 4), Q, TH, SG>(c, (lds_u8 *)eseq, Ld, cu, 1.0f / (f3.xC * cu.move), kWinTol7, m0);
                         have4 = fabsf((float)Ld - p4.mass) <= kWinTol7 * (float)Ld;
+                        if (have4) n_w512++; else n_wfail++;
                         if (a.stats && lane == 0) atomicAdd(a.stats + (have4 ? 1 : 2), 1ull);
                       }
                     }
@@ -637,6 +650,7 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
                 }
                 if (!have4) {
                   p4 = sweep_backward_null2<Q, TH, SG>(c, (lds_u8 *)eseq, Ld, cu, 1.0f / (f3.xC * cu.move), f3.ef, tol);
+                  n_full++;
                   if (a.stats && lane == 0) {
                     atomicAdd(a.stats + 3, 1ull);
                     const float dev = fabsf((float)Ld - p4.mass) / (float)Ld;
@@ -691,6 +705,12 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
       }
     }
   }
+  if (a.paths && lane == 0) {
+    if (n_w256) atomicAdd(a.paths + 0, (unsigned long long)n_w256);
+    if (n_w512) atomicAdd(a.paths + 1, (unsigned long long)n_w512);
+    if (n_wfail) atomicAdd(a.paths + 2, (unsigned long long)n_wfail);
+    if (n_full) atomicAdd(a.paths + 3, (unsigned long long)n_full);
+  }
 }
 
 template <int Q, int TH, bool SG>
@@ -723,13 +743,17 @@ static hipError_t launch7_q(int Q, const ScoreArgs &a, int blocks, int threads, 
   }
 }
 
+#endif  // WH_SWEEPS_ONLY
 }  // namespace WH_K7NS
 
+#ifndef WH_SWEEPS_ONLY
 hipError_t WH_K7LAUNCH(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
   using namespace WH_K7NS;
+  if (!a.spec_scratch && a.spec_arrays != kSpArr) return hipErrorInvalidValue;   // planner and kernel disagree about the LDS block
   if (threads <= 512) return launch7_q<512>(Q, a, blocks, threads, lds, s);
   if (threads <= 768) return launch7_q<768>(Q, a, blocks, threads, lds, s);
   return hipErrorInvalidValue;
 }
+#endif
 
 }  // namespace wh

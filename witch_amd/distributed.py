@@ -19,32 +19,43 @@ def shard_range(n: int, rank: int, world: int):
     return n * rank // world, n * (rank + 1) // world
 
 
-def gather_topk(idx, w, nk, nu, group=None):
-    """all-gather the ragged (per-rank row count) top-k tables; every rank gets the full
-    tables in query order.  Uses padded fixed-size all_gathers (ring collectives on xGMI are
-    per-link bound; four ~MB-sized messages are far below the latency/bandwidth knee)."""
+def gather_topk(idx, w, nk, nu, group=None, n_total=None):
+    """all-gather the per-rank top-k tables; every rank gets the full tables in query order.
+
+    ONE collective: a rank packs its rows into fixed-size byte records (w float64[k] | idx int32[k] | n_kept | n_used =
+    12k + 8 bytes, 128 B at k = 10), pads to the largest shard and calls all_gather_into_tensor once; the shard sizes
+    follow from shard_range(n_total, r, world), so nothing has to be exchanged about them and nothing is read back to
+    the host in between.  Without n_total (a caller that shards differently) the sizes are gathered first."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
     if world == 1 and not collectives_forced():
         return idx, w, nk, nu
-    n_local = torch.tensor([idx.shape[0]], device=idx.device, dtype=torch.int64)
-    sizes = [torch.zeros_like(n_local) for _ in range(world)]
-    dist.all_gather(sizes, n_local, group=group)
-    sizes = [int(s.item()) for s in sizes]
+    n_local, k = int(idx.shape[0]), int(idx.shape[1])
+    if n_total is not None:
+        sizes = [shard_range(int(n_total), r, world)[1] - shard_range(int(n_total), r, world)[0] for r in range(world)]
+        if sizes[dist.get_rank(group)] != n_local:
+            raise ValueError("gather_topk: %d local rows, but shard_range(%d, rank, %d) owns %d" % (n_local, n_total, world, sizes[dist.get_rank(group)]))
+    else:
+        mine = torch.tensor([n_local], device=idx.device, dtype=torch.int64)
+        got = torch.empty(world, device=idx.device, dtype=torch.int64)
+        dist.all_gather_into_tensor(got, mine, group=group)
+        sizes = [int(x) for x in got.tolist()]
     nmax = max(sizes)
-
-    def pad(t):
-        if t.shape[0] == nmax:
-            return t.contiguous()
-        p = torch.zeros((nmax,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        p[:t.shape[0]] = t
-        return p
-
-    outs = []
-    for t in (idx, w, nk, nu):
-        pt = pad(t)
-        buf = [torch.empty_like(pt) for _ in range(world)]
-        dist.all_gather(buf, pt, group=group)
-        outs.append(torch.cat([b[:s] for b, s in zip(buf, sizes)], 0))
-    return tuple(outs)
+    R = 12 * k + 8
+    rec = torch.zeros((nmax, R), dtype=torch.uint8, device=idx.device)
+    if n_local:
+        rec[:n_local, :8 * k] = w.contiguous().view(torch.uint8).reshape(n_local, 8 * k)
+        rec[:n_local, 8 * k:12 * k] = idx.contiguous().view(torch.uint8).reshape(n_local, 4 * k)
+        rec[:n_local, 12 * k:12 * k + 4] = nk.contiguous().view(torch.uint8).reshape(n_local, 4)
+        rec[:n_local, 12 * k + 4:] = nu.contiguous().view(torch.uint8).reshape(n_local, 4)
+    flat = torch.empty((world * nmax, R), dtype=torch.uint8, device=idx.device)    # rank r's records at rows [r * nmax, (r + 1) * nmax)
+    dist.all_gather_into_tensor(flat, rec, group=group)
+    out = flat.reshape(world, nmax, R)
+    allrec = torch.cat([out[r, :sizes[r]] for r in range(world)], 0) if len(set(sizes)) > 1 else flat
+    n = allrec.shape[0]
+    g_w = allrec[:, :8 * k].contiguous().view(w.dtype).reshape(n, k)
+    g_idx = allrec[:, 8 * k:12 * k].contiguous().view(idx.dtype).reshape(n, k)
+    g_nk = allrec[:, 12 * k:12 * k + 4].contiguous().view(nk.dtype).reshape(n)
+    g_nu = allrec[:, 12 * k + 4:].contiguous().view(nu.dtype).reshape(n)
+    return g_idx, g_w, g_nk, g_nu

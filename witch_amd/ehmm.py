@@ -110,6 +110,19 @@ class EHMM:
         return [(int(q[t]), int(kind[t]), float(ms[t])) for t in range(min(n, 64))]
 
     # ------------------------------------------------------------------ host (numpy) operators
+    def last_score_paths(self):
+        """Envelope Backward sweeps of the last score call by path: {"window256", "window512", "window_rejected",
+        "full_width"} (include/witch_hip.h: wh_last_score_paths)."""
+        p4 = np.zeros(4, dtype=np.int64)
+        check(lib().wh_last_score_paths(self._h, p4.ctypes.data), "wh_last_score_paths")
+        return {"window256": int(p4[0]), "window512": int(p4[1]), "window_rejected": int(p4[2]), "full_width": int(p4[3])}
+
+    def last_queue_reruns(self) -> int:
+        """Scoring passes the last score call repeated because the resolver's queue overflowed its estimate (0 or 1)."""
+        n = lib().wh_last_queue_reruns(self._h)
+        check(min(n, 0), "wh_last_queue_reruns")
+        return int(n)
+
     def score(self, residues, offsets, want_fwd=False, want_detail=False):
         residues = np.ascontiguousarray(residues, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.int64)

@@ -183,7 +183,7 @@ class QueryAlignmentEngine:
         dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
         t0 = __import__("time").time()
         parts = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (self.topk_idx, self.topk_w, self.n_kept, self.n_used)]
-        idx, w, nk, nu = gather_topk(*parts, group=group)
+        idx, w, nk, nu = gather_topk(*parts, group=group, n_total=len(self.taxa))
         self.topk_idx, self.topk_w, self.n_kept, self.n_used = [t.cpu().numpy() for t in (idx, w, nk, nu)]
         assert self.topk_idx.shape[0] == len(self.taxa), "ranks were given different query lists"
         self.topk_rows = (0, len(self.taxa))

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cmath>
 #include <thread>
 #include <array>
 #include <cstdio>
@@ -98,7 +99,7 @@ struct wh_ehmm {
   int last_queue_reruns = 0;                // scoring passes the last wh_score call repeated because its queue overflowed (0 or 1)
   // staging for the host-pointer entry points
   DevBuf s_res, s_off, s_deci, s_flags, s_fwd, s_det, s_idx, s_w, s_nk, s_nu, s_pq, s_ph, s_co, s_cols, s_pos;
-  DevBuf d_rkeys, d_rorder, d_qorder, d_order, d_items, d_recs, d_spec, d_back, d_cwj, d_cwv, d_cwn, d_crow, c_buf[10];
+  DevBuf d_rkeys, d_rorder, d_rchunks, d_qorder, d_order, d_items, d_recs, d_spec, d_back, d_cwj, d_cwv, d_cwn, d_crow, c_buf[10];
   uint32_t degen[32];
   bool timing = false;
   KernelTimer timers[5];
@@ -163,7 +164,7 @@ void wh_ehmm_free(wh_ehmm *e) {
   if (!e) return;
   for (DevBuf *b : {&e->d_gtab, &e->d_rrecs, &e->d_rmx, &e->d_rsegs, &e->d_hmms, &e->d_tables, &e->d_nseq, &e->d_index, &e->d_lists, &e->d_counter, &e->d_scratch, &e->d_ascratch, &e->d_wscratch,
                     &e->s_res, &e->s_off, &e->s_deci, &e->s_flags, &e->s_fwd, &e->s_det, &e->s_idx, &e->s_w,
-                    &e->s_nk, &e->s_nu, &e->s_pq, &e->s_ph, &e->s_co, &e->s_cols, &e->s_pos, &e->d_rkeys, &e->d_rorder, &e->d_qorder, &e->d_order, &e->d_items, &e->d_recs, &e->d_spec, &e->d_back, &e->d_cwj, &e->d_cwv, &e->d_cwn, &e->d_crow,
+                    &e->s_nk, &e->s_nu, &e->s_pq, &e->s_ph, &e->s_co, &e->s_cols, &e->s_pos, &e->d_rkeys, &e->d_rorder, &e->d_rchunks, &e->d_qorder, &e->d_order, &e->d_items, &e->d_recs, &e->d_spec, &e->d_back, &e->d_cwj, &e->d_cwv, &e->d_cwn, &e->d_crow,
                     &e->c_buf[0], &e->c_buf[1], &e->c_buf[2], &e->c_buf[3], &e->c_buf[4], &e->c_buf[5], &e->c_buf[6],
                     &e->c_buf[7], &e->c_buf[8], &e->c_buf[9]})
     b->release();
@@ -843,18 +844,34 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
       memcpy(r.degen, e->degen, sizeof r.degen);
       r.dbg = e->knobs.rdbg;
       if (e->knobs.stats) {
-        if (e->d_recs.ensure(128)) return WH_ENOMEM;
-        HIPCHK(hipMemsetAsync(e->d_recs.p, 0, 128, s));
+        if (e->d_recs.ensure(256)) return WH_ENOMEM;
+        HIPCHK(hipMemsetAsync(e->d_recs.p, 0, 256, s));
+        { unsigned long long bigv = ~0ull; HIPCHK(hipMemcpyAsync((char *)e->d_recs.p + 16 * 8, &bigv, 8, hipMemcpyHostToDevice, s)); HIPCHK(hipStreamSynchronize(s)); }
         r.stats = (unsigned long long *)e->d_recs.p;
       }
-      // The order of the queue.  Few pairs per wave (8 412 pairs over 2 048 waves on the reference's example data,
-      // costs several-fold apart): longest first, the order decides the tail of the launch.  Many pairs per wave:
-      // model by model (longest first inside a model) - the float64 tables of a model are 9 doubles per node and
-      // every wave streams its model's tables once per ROW of its Forward sweeps; with the pairs in arrival order
-      // hundreds of models were in flight and those reads missed L2.
-      r.order = nullptr;
-      if (n_multi > 1) {
-        if (e->d_rkeys.ensure(2 * sizeof(float) * (size_t)n_multi) || e->d_rorder.ensure(sizeof(int32_t) * (size_t)n_multi)) return WH_ENOMEM;
+      // ---- launch geometry: ONE workgroup of up to eight waves per CU.  Models of up to 16 cells per lane get their
+      // eight float64 transition arrays staged in the workgroup's LDS (49 KB at 12 cells per lane) when that fits beside
+      // the waves' blocks; the Forward sweeps of their pairs then read one array per cell from L2 instead of nine.
+      int Qt = 0;
+      for (auto &kv : e->by_q) if (kv.first <= 16 && (kv.first == 4 || kv.first == 8 || kv.first == 12 || kv.first == 16)) Qt = std::max(Qt, kv.first);
+      if (getenv("WH_RES_NO_LDS_TABLES")) Qt = 0;
+      int waves = std::min<int>(resolve_waves_per_cu(), 8);
+      if (Qt > 0 && resolve_lds_header_bytes(Qt) + (size_t)waves * rlds > kLdsBudget) {
+        // fewer waves WITH the tables only while at least six fit; otherwise the tables stay in L2
+        int w2 = waves;
+        while (w2 > 0 && resolve_lds_header_bytes(Qt) + (size_t)w2 * rlds > kLdsBudget) w2--;
+        if (w2 >= 6) waves = w2; else Qt = 0;
+      }
+      while (waves > 1 && resolve_lds_header_bytes(Qt) + (size_t)waves * rlds > kLdsBudget) waves--;
+      const size_t lds_total = resolve_lds_header_bytes(Qt) + (size_t)waves * rlds;
+      r.lds_tables = Qt;
+      r.wave_lds_ints = (int)(rlds / 4);
+      // ---- the order of the queue.  Pairs are grouped model by model (longest pair first inside a model): the waves of a
+      // workgroup work on ONE model at a time, so they share the staged tables and, for the models whose tables stay in
+      // L2, stream the same arrays (wh_resolve.hip: slots and segments).
+      if (e->d_rkeys.ensure(2 * sizeof(float) * (size_t)n_multi) || e->d_rorder.ensure(sizeof(int32_t) * (size_t)n_multi)) return WH_ENOMEM;
+      std::vector<int32_t> chunk_list;
+      {
         int32_t *d_models = (int32_t *)e->d_rkeys.p + n_multi;
         hipError_t kerr = launch_resolve_keys(r.recs, n_multi, r.hmms, (float *)e->d_rkeys.p, d_models, s);
         if (kerr != hipSuccess) { set_error("resolve key kernel launch failed: %s", hipGetErrorString(kerr)); return WH_EHIP; }
@@ -865,38 +882,79 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
         HIPCHK(hipStreamSynchronize(s));
         std::vector<int32_t> ord((size_t)n_multi);
         for (int t = 0; t < n_multi; t++) ord[(size_t)t] = t;
-        if (n_multi < 32 * e->cu_count * resolve_waves_per_cu())
-          std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) { return keys[(size_t)x] > keys[(size_t)y]; });
-        else
-          std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) {
-            return models[(size_t)x] != models[(size_t)y] ? models[(size_t)x] < models[(size_t)y] : keys[(size_t)x] > keys[(size_t)y];
-          });
+        std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) {
+          return models[(size_t)x] != models[(size_t)y] ? models[(size_t)x] < models[(size_t)y] : keys[(size_t)x] > keys[(size_t)y];
+        });
+        // one segment per model; slots in proportion to the segments' cost (four per workgroup in all, at least one per model)
+        struct Seg { int start, count, h; double cost; };
+        std::vector<Seg> segs;
+        double total_cost = 0.0;
+        for (int t = 0; t < n_multi;) {
+          const int h = models[(size_t)ord[(size_t)t]];
+          int u = t;
+          double cost = 0.0;
+          while (u < n_multi && models[(size_t)ord[(size_t)u]] == h) { cost += std::max(1.0f, keys[(size_t)ord[(size_t)u]]); u++; }
+          segs.push_back({t, u - t, h, cost});
+          total_cost += cost;
+          t = u;
+        }
+        std::vector<int> order_s(segs.size());
+        for (size_t t = 0; t < segs.size(); t++) order_s[t] = (int)t;
+        std::stable_sort(order_s.begin(), order_s.end(), [&](int x, int y) { return segs[(size_t)x].cost > segs[(size_t)y].cost; });
+        const double per_slot = total_cost / (4.0 * (double)e->cu_count);
+        std::vector<int32_t> slot_list;
+        for (int sidx : order_s) {
+          const Seg &g = segs[(size_t)sidx];
+          int ns = (int)std::ceil(g.cost / std::max(per_slot, 1.0));
+          ns = std::max(1, std::min(ns, std::max(1, (g.count + 7) / 8)));       // never more slots than groups of eight pairs
+          for (int v = 0; v < ns; v++) slot_list.push_back(sidx);
+        }
+        chunk_list.reserve(segs.size() * 4);
+        for (const Seg &g : segs) { chunk_list.push_back(g.start); chunk_list.push_back(g.count); chunk_list.push_back(g.h); chunk_list.push_back(e->dev[(size_t)g.h].Q); }
+        // one buffer: segments | slots | cursors
+        const size_t n_seg = segs.size(), n_slot = slot_list.size();
+        if (e->d_rchunks.ensure(sizeof(int32_t) * (4 * n_seg + n_slot + n_seg))) return WH_ENOMEM;
+        int32_t *d_chunks = (int32_t *)e->d_rchunks.p, *d_slots = d_chunks + 4 * n_seg, *d_cursors = d_slots + n_slot;
         HIPCHK(hipMemcpyAsync(e->d_rorder.p, ord.data(), sizeof(int32_t) * ord.size(), hipMemcpyHostToDevice, s));
-        HIPCHK(hipStreamSynchronize(s));     // ord is a local
+        HIPCHK(hipMemcpyAsync(d_chunks, chunk_list.data(), sizeof(int32_t) * chunk_list.size(), hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(d_slots, slot_list.data(), sizeof(int32_t) * slot_list.size(), hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemsetAsync(d_cursors, 0, sizeof(int32_t) * n_seg, s));
+        HIPCHK(hipStreamSynchronize(s));     // ord, chunk_list and slot_list are locals
+        r.chunks = d_chunks; r.n_chunks = (int)n_seg;
+        r.slots = d_slots; r.n_slots = (int)n_slot;
+        r.cursors = d_cursors;
         r.order = (const int32_t *)e->d_rorder.p;
+        r.chunks = (const int32_t *)e->d_rchunks.p;
+        r.n_chunks = (int)(chunk_list.size() / 4);
       }
-      const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)resolve_waves_per_cu(), kLdsBudget / rlds));
-      int blocks = std::min(n_multi, e->cu_count * per_cu);
+      int blocks = std::min(r.n_slots, e->cu_count);
       {
         // Every resident wavefront brings a slab of tens of MB, and hipMalloc costs ~40 ms per GB: a queue of a few thousand
         // pairs (the reference's example data: 8 412) spent 2.4 s allocating 55 GB for 0.12 s of work.  Unless the slabs exist
-        // already, a wave gets at least four pairs (the queue is handed out longest first, so the tail stays short).  (The cost is the
-        // driver scrubbing VRAM that another process used before: on a fresh device the same allocation takes milliseconds.)
-        const size_t have = std::min(e->d_rmx.cap / (r.mx_stride * sizeof(double)), e->d_rsegs.cap / std::max<size_t>(1, r.seg_stride * sizeof(int32_t)));
-        const int economy = std::max(256, n_multi / 4);
+        // already, a wave gets at least four pairs.  (The cost is the driver scrubbing VRAM that another process used
+        // before: on a fresh device the same allocation takes milliseconds.)
+        const size_t have = std::min(e->d_rmx.cap / (r.mx_stride * sizeof(double)), e->d_rsegs.cap / std::max<size_t>(1, r.seg_stride * sizeof(int32_t))) / (size_t)waves;
+        const int economy = std::max(32, n_multi / (4 * waves));
         if ((size_t)blocks > have) blocks = std::max((int)std::min<size_t>(have, (size_t)blocks), std::min(blocks, economy));
       }
-      blocks = clamp_blocks(blocks, r.mx_stride * sizeof(double) + r.seg_stride * sizeof(int32_t), e->d_rmx);
-      if (e->d_rmx.ensure((size_t)blocks * r.mx_stride * sizeof(double)) || e->d_rsegs.ensure((size_t)blocks * r.seg_stride * sizeof(int32_t)))
+      blocks = clamp_blocks(blocks, (size_t)waves * (r.mx_stride * sizeof(double) + r.seg_stride * sizeof(int32_t)), e->d_rmx);
+      if (e->d_rmx.ensure((size_t)blocks * waves * r.mx_stride * sizeof(double)) || e->d_rsegs.ensure((size_t)blocks * waves * r.seg_stride * sizeof(int32_t)))
         return WH_ENOMEM;
       r.mx = (double *)e->d_rmx.p; r.segs = (int32_t *)e->d_rsegs.p;
-      if (e->knobs.trace) fprintf(stderr, "[wh] resolve: %d pairs with a multidomain region, %d wavefronts, lds %zu, slab %zu MB per wave\n", n_multi, blocks, rlds, r.mx_stride * 8 >> 20);
-      hipError_t err = launch_resolve(r, blocks, rlds, s);
+      if (e->knobs.trace) fprintf(stderr, "[wh] resolve: %d pairs with a multidomain region on %d models, %d workgroups of %d waves, lds %zu (float64 tables of up to %d cells per lane staged: %s), slab %zu MB per wave\n",
+                                  n_multi, r.n_chunks, blocks, waves, lds_total, Qt, Qt ? "yes" : "no", r.mx_stride * 8 >> 20);
+      const auto t_rl0 = std::chrono::steady_clock::now();
+      hipError_t err = launch_resolve(r, blocks, waves, lds_total, s);
       if (err != hipSuccess) { set_error("resolve kernel launch failed: %s", hipGetErrorString(err)); return WH_EHIP; }
+      if (e->knobs.trace) {
+        HIPCHK(hipStreamSynchronize(s));
+        fprintf(stderr, "[wh] resolve kernel alone: %.1f ms (host clock around launch + synchronize)\n",
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_rl0).count());
+      }
       rlaunches++;
       e->last_resolved = n_multi;
       if (r.stats) {
-        unsigned long long st[13];
+        unsigned long long st[20];
         HIPCHK(hipMemcpyAsync(st, r.stats, sizeof st, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         const double tot = (double)(st[0] + st[1] + st[2] + st[3] + st[4]);
@@ -908,6 +966,9 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
                 st[8] / (200.0 * n_multi), st[9] / (200.0 * n_multi), st[10] / (200.0 * n_multi), st[11] / (200.0 * n_multi),
                 (double)st[5] / (double)std::max<unsigned long long>(1, st[8] + st[9] + st[10]));
         fprintf(stderr, "[wh]   threshold-line cache: %.1f%% of the fetches hit\n", 100.0 * st[12] / (double)std::max<unsigned long long>(1, st[8] + st[9] + st[10]));
+        fprintf(stderr, "[wh]   shader clock while a pair is resolved: %.2f GHz (cycle counter / 100 MHz real-time counter); pair cycles %.3g\n", st[15] ? 0.1 * (double)st[14] / (double)st[15] : 0.0, (double)st[14]);
+        fprintf(stderr, "[wh]   wave lifetimes: %llu waves, mean %.1f ms, longest %.1f ms (a wave leaves when no slot is left)\n", st[19], st[19] ? 1e-5 * (double)st[17] / (double)st[19] : 0.0, 1e-5 * (double)st[18]);
+        fprintf(stderr, "[wh]   waiting at the workgroup's slot barriers: %.1f%% on top of the pair cycles (%d slots on %d models, %d workgroups of %d waves)\n", 100.0 * st[13] / tot, r.n_slots, r.n_chunks, blocks, waves);
       }
     }
   }

@@ -118,6 +118,15 @@ __device__ __forceinline__ gdbl *as_global(const double *p) {
   return (gdbl *)(((unsigned long long)hi << 32) | lo);
 }
 __device__ __forceinline__ d2_t ldg_d2(const gdbl *p) { return *reinterpret_cast<const gd2_t *>(p); }
+// the same for a model's transition arrays staged in LDS (resolve_kernel: one copy per workgroup)
+typedef __attribute__((address_space(3))) double ldbl;
+typedef __attribute__((address_space(3))) d2_t ld2_t;
+__device__ __forceinline__ d2_t ldl_d2(const ldbl *p) { return *reinterpret_cast<const ld2_t *>(p); }
+__device__ __forceinline__ const ldbl *as_lds(const ldbl *p) {
+  typedef __attribute__((address_space(3))) char lds_c;
+  const int v = __builtin_amdgcn_readfirstlane((int)(size_t)(const lds_c *)p);
+  return (const ldbl *)(const lds_c *)(size_t)(unsigned)v;
+}
 __device__ __forceinline__ void stg_d2(gdbl *p, double a, double b) { d2_t v = {a, b}; *reinterpret_cast<gd2_t *>(p) = v; }
 
 template <bool STORE>
@@ -246,9 +255,12 @@ __device__ double gforward(const GModel &m, const uint8_t *seq, int L, GLen c, c
 // memory round trips per row, ~29 000 cycles per row on the protein workload with 2 048 waves in flight - here
 // the only loads are the model's tables (independent of the recurrence), rows are written out and never read
 // back, and the neighbour lane's last node arrives by shuffle.  Same operations in the same order as gforward.
-template <int QC>
+// TL: the eight transition arrays come from the workgroup's LDS copy <tl_> (same layout as tf_), the emission row of the
+// residue from L2 as before.  The sweep was bound by its table reads - nine float64 arrays per cell, 72 B, from L2 once
+// per row and wave; the LDS copy leaves one (the emission row) on that path.
+template <int QC, bool TL = false>
 __device__ __attribute__((noinline)) double gforward_reg(const double *tf_, const double *te_, int Q_, const uint8_t *seq, int L_, GLen c,
-                                                         double *slab_, size_t rowlen, int lane, bool store_) {
+                                                         double *slab_, size_t rowlen, int lane, bool store_, const ldbl *tl_ = nullptr) {
   // (a called function receives its arguments in vector registers: what is wave-uniform is said again, and the
   // table / slab pointers are given their address space back, or every access becomes a flat_ instruction with a
   // per-lane address and every guard a divergent branch.  Inlined at its eight call sites the function cost the
@@ -260,8 +272,10 @@ __device__ __attribute__((noinline)) double gforward_reg(const double *tf_, cons
   const int L = __builtin_amdgcn_readfirstlane(L_);
   const bool store = __builtin_amdgcn_readfirstlane((int)store_) != 0;
   const gdbl *tf = as_global(tf_), *te = as_global(te_);
+  const ldbl *tl = TL ? as_lds(tl_) : nullptr;
   gdbl *slab = as_global(slab_);
   const size_t SQ = (size_t)Q * 64;
+  auto tab2 = [&](int arr, size_t o) -> d2_t { if constexpr (TL) return ldl_d2(tl + (size_t)arr * SQ + o); else return ldg_d2(tf + (size_t)arr * SQ + o); };
   double M[QC], I[QC], D[QC], PQ[QC];
 #pragma unroll
   for (int q = 0; q < QC; q++) { M[q] = 0.0; I[q] = 0.0; D[q] = 0.0; PQ[q] = 1.0; }
@@ -273,9 +287,12 @@ __device__ __attribute__((noinline)) double gforward_reg(const double *tf_, cons
   }
   double pN = 1.0, pB = c.move, pJ = 0.0, pC = 0.0;
   double Alane = 1.0;
-  for (int q = 0; q < Q; q++) Alane *= tf[(size_t)gD2 * SQ + ofs2(q, lane)];
+  for (int q = 0; q < Q; q += 2) { const d2_t v = tab2(gD2, ofs2(q, lane)); Alane *= v.x; Alane *= v.y; }
   double lastM = 0.0, lastI = 0.0, lastD = 0.0;     // node Q of this lane in the previous row
   for (int i = 1; i <= L; i++) {
+    // (nothing in the loop stores to LDS, so the compiler would hoist the 8 x QC table reads of the LDS variant out of it -
+    // 192 registers at 12 cells per lane, reloaded from scratch 44 times per row: measured 20 % SLOWER than the L2 reads)
+    if (TL) asm volatile("" ::: "memory");
     gdbl *cr = slab + (size_t)i * rowlen;
     const gdbl *od = te + (size_t)seq[i - 1] * SQ;
     const double um = shfl_up_d(lastM, 1), ui = shfl_up_d(lastI, 1), ud = shfl_up_d(lastD, 1);
@@ -288,8 +305,8 @@ __device__ __attribute__((noinline)) double gforward_reg(const double *tf_, cons
 #pragma unroll
         for (int u2 = 0; u2 < 2; u2++) {
           const size_t o = ofs2(q0 + 2 * u2, lane);
-          const d2_t vA = ldg_d2(tf + gA * SQ + o), vB = ldg_d2(tf + gB * SQ + o), vC = ldg_d2(tf + gC * SQ + o), vE = ldg_d2(tf + gE * SQ + o);
-          const d2_t vMI = ldg_d2(tf + gMI * SQ + o), vII = ldg_d2(tf + gII * SQ + o), vD1 = ldg_d2(tf + gD1 * SQ + o), vD2 = ldg_d2(tf + gD2 * SQ + o);
+          const d2_t vA = tab2(gA, o), vB = tab2(gB, o), vC = tab2(gC, o), vE = tab2(gE, o);
+          const d2_t vMI = tab2(gMI, o), vII = tab2(gII, o), vD1 = tab2(gD1, o), vD2 = tab2(gD2, o);
           const d2_t vem = ldg_d2(od + o);
           tA[2 * u2] = vA.x; tA[2 * u2 + 1] = vA.y; tB[2 * u2] = vB.x; tB[2 * u2 + 1] = vB.y; tC[2 * u2] = vC.x; tC[2 * u2 + 1] = vC.y;
           tE[2 * u2] = vE.x; tE[2 * u2 + 1] = vE.y; tMI[2 * u2] = vMI.x; tMI[2 * u2 + 1] = vMI.y; tII[2 * u2] = vII.x; tII[2 * u2 + 1] = vII.y;
@@ -352,8 +369,18 @@ __device__ __attribute__((noinline)) double gforward_reg(const double *tf_, cons
   return ls + log(pC * c.move);
 }
 
+// tl != NULL: the model's eight transition arrays are staged in the workgroup's LDS at <tl> (models of up to 16 cells per lane)
 template <bool STORE>
-__device__ __forceinline__ double gforward_any(const GModel &m, const uint8_t *seq, int L, GLen c, const GMx &mx, int lane) {
+__device__ __forceinline__ double gforward_any(const GModel &m, const uint8_t *seq, int L, GLen c, const GMx &mx, int lane, const ldbl *tl = nullptr) {
+  if (tl) {
+    switch (m.Q) {
+      case 4: return gforward_reg<4, true>(m.tf, m.te, m.Q, seq, L, c, mx.p, mx.rowlen, lane, STORE, tl);
+      case 8: return gforward_reg<8, true>(m.tf, m.te, m.Q, seq, L, c, mx.p, mx.rowlen, lane, STORE, tl);
+      case 12: return gforward_reg<12, true>(m.tf, m.te, m.Q, seq, L, c, mx.p, mx.rowlen, lane, STORE, tl);
+      case 16: return gforward_reg<16, true>(m.tf, m.te, m.Q, seq, L, c, mx.p, mx.rowlen, lane, STORE, tl);
+      default: break;
+    }
+  }
   switch (m.Q) {
     case 4: return gforward_reg<4>(m.tf, m.te, m.Q, seq, L, c, mx.p, mx.rowlen, lane, STORE);
     case 8: return gforward_reg<8>(m.tf, m.te, m.Q, seq, L, c, mx.p, mx.rowlen, lane, STORE);

@@ -74,10 +74,17 @@ struct ResolveArgs {
   const uint8_t *residues;
   const int64_t *offsets;
   const ResolveRec *recs;
-  const int32_t *order;        // queue positions in processing order (longest pairs first / model by model), or NULL
+  const int32_t *order;        // queue positions in processing order (model by model, longest pairs first inside a model), or NULL
+  const int32_t *chunks;       // the queue's segments, one per model: (first entry of <order>, entries, model position, cells per lane) x n_chunks
+  int n_chunks;
+  const int32_t *slots;        // what a workgroup draws: segment numbers, a model's in proportion to its share of the work
+  int n_slots;
+  int *cursors;                // per segment: next entry to hand out (zeroed before the launch)
+  int lds_tables;              // > 0: a chunk's model of up to this many cells per lane has its float64 transition arrays staged in LDS
+  int wave_lds_ints;           // 4-byte units of LDS per wave
   const int *count;            // number of queued pairs (device)
   int rec_cap;
-  int *counter;                // work-queue head
+  int *counter;                // work-queue head (chunks)
   int Lcap, Mmax;
   double *mx;                  // per-wave matrix slabs
   size_t mx_stride;            // doubles per wave
@@ -93,7 +100,8 @@ struct ResolveArgs {
   unsigned long long *stats;   // WH_STATS: wave cycles per phase [0] region Forward [1] traces [2] clustering [3] cluster statistics [4] envelope Forward
   int dbg;                     // WH_RDBG > 0: print the first <dbg> sampled segments and the cluster statistics of every region
 };
-hipError_t launch_resolve(const ResolveArgs &a, int blocks, size_t lds, hipStream_t s);
+hipError_t launch_resolve(const ResolveArgs &a, int blocks, int waves, size_t lds, hipStream_t s);
+size_t resolve_lds_header_bytes(int Qt);
 // cost estimate of every queued pair (cells of its multidomain regions) for the longest-first order
 hipError_t launch_resolve_keys(const ResolveRec *recs, int n, const DevHMM *hmms, float *keys, int32_t *models, hipStream_t s);
 size_t resolve_lds_bytes(int Lcap, int Mmax);

@@ -78,20 +78,28 @@ __device__ __forceinline__ bool seg_linked(int i1, int j1, int k1, int m1, int i
 
 }  // namespace
 
-// LDS per wave (ints unless noted): see resolve_lds_bytes()
-// LDS per wave (4-byte units): residues, the domains of the
-// current trace and their null2 vectors, the emitting state per residue (int16), Easel's two vertex
-// stacks (uint16).  The end-point histograms of the cluster statistics live in the wave's HBM slab.
+// LDS per wave (4-byte units).  What the traces use - the domains of the current trace, their null2 vectors, the emitting
+// state per residue (int16) - and what the clustering uses afterwards - Easel's two vertex stacks (uint16) - are never
+// alive together and share one block (round 4: 19 -> 11 KB per wave at 2 000-residue queries, which makes room for a
+// model's float64 transition arrays beside eight waves).  The end-point histograms of the cluster statistics live in the
+// wave's HBM slab.
+__host__ __device__ inline size_t resolve_uni_ints(int Lcap) {
+  const int Lp = (Lcap + 4) & ~1;
+  const size_t traces = (size_t)kDomMax * (4 + 32) + Lp / 2 + 2, clustering = kSegCap;
+  return ((traces > clustering ? traces : clustering) + 1) & ~(size_t)1;
+}
 __host__ __device__ inline size_t resolve_lds_ints(int Lcap, int Mmax) {
   (void)Mmax;
-  const int Lp = (Lcap + 4) & ~1;
-  return (size_t)(Lcap + 8) / 4 + 2 /*seq*/ + kDomMax * (4 + 32) + Lp / 2 + 2 /*stk*/ + kSegCap /*two uint16 stacks*/ + 7 * kEnvMax + 16;
+  return (((size_t)(Lcap + 8) / 4 + 2 + 1) & ~(size_t)1) /*seq*/ + resolve_uni_ints(Lcap) + 128 /*64 float64 bins of the E-state row pass*/ + 7 * kEnvMax + 16;
 }
 // waves per SIMD the kernel is compiled for (registers per lane = 512 / WH_RES_OCC)
 #ifndef WH_RES_OCC
 #define WH_RES_OCC 2
 #endif
-size_t resolve_lds_bytes(int Lcap, int Mmax) { return resolve_lds_ints(Lcap, Mmax) * 4 + 16; }
+size_t resolve_lds_bytes(int Lcap, int Mmax) { return resolve_lds_ints(Lcap, Mmax) * 4; }       // per WAVE
+// per workgroup in front of the wave blocks: a 16-byte header (chunk number, chunk cursor) and, when the launch stages
+// them, the eight float64 transition arrays of ONE model of up to <Qt> cells per lane
+size_t resolve_lds_header_bytes(int Qt) { return 16 + (size_t)gNARR * Qt * 64 * sizeof(double); }
 // per wave in HBM: the segment arrays, the end-point histogram, and the two per-residue float arrays (null2 scores of
 // the pair, accumulators of the region): in LDS they cost 8 bytes per residue of the LONGEST query of the batch and
 // halved the resident waves for 2 000-residue proteins
@@ -105,24 +113,39 @@ size_t resolve_tail_row_doubles() { return kTailRow; }
 size_t resolve_dcache_doubles() { return (size_t)129 * (1 << kDcBits); }
 typedef unsigned u4_t __attribute__((ext_vector_type(4)));
 int resolve_waves_per_cu() { return 4 * WH_RES_OCC; }
+constexpr int kResMaxWaves = 8;       // waves per workgroup the kernel is compiled for (512 threads, 256 registers)
 
 #define RTICK(slot) do { if (a.stats) { const long long t_now = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(a.stats + (slot), (unsigned long long)(t_now - tk0)); tk0 = t_now; } } while (0)
 
-__global__ __launch_bounds__(64, WH_RES_OCC) void resolve_kernel(ResolveArgs a) {
-  extern __shared__ __attribute__((aligned(16))) int lds_raw[];
-  const int lane = threadIdx.x;
+// Workgroups of <W> waves (one per CU).  The queue is ordered model by model; a workgroup draws SLOTS - each the right to
+// work on one model's segment - and its waves then pull that segment's pairs one by one from a cursor in global memory,
+// together with the waves of every other workgroup that holds a slot of the same model (a model gets slots in
+// proportion to its share of the work, so its segment drains from several CUs at once and the only idle time is a
+// wave's wait for its neighbours' last pair when the segment runs out).  Per segment the model's eight float64
+// transition arrays are staged in LDS once for all waves (models of up to 16 cells per lane; a.lds_tables), which is
+// what the two Forward sweeps of a pair read from: they were 34-45 % of the kernel and bound by streaming those arrays
+// from L2 once per row and wave.
+__global__ __launch_bounds__(64 * kResMaxWaves) void resolve_kernel(ResolveArgs a) {
+  extern __shared__ __attribute__((aligned(16))) int lds_all[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwaves = blockDim.x >> 6;
+  volatile int *s_hdr = lds_all;                                  // [0] chunk of the workgroup, [1] cursor inside it
+  double *tabL = reinterpret_cast<double *>(lds_all + 4);         // staged transition arrays (a.lds_tables > 0)
+  int *lds_raw = lds_all + 4 + (a.lds_tables > 0 ? gNARR * a.lds_tables * 64 * 2 : 0) + (size_t)wave * a.wave_lds_ints;
   const int Lp = (a.Lcap + 4) & ~1;
   uint8_t *seq = reinterpret_cast<uint8_t *>(lds_raw);
-  int *dom = lds_raw + (a.Lcap + 8) / 4 + 2;           // kDomMax x (sqfrom, sqto, hmmfrom, hmmto)
+  int *uni = lds_raw + ((((a.Lcap + 8) / 4 + 2) + 1) & ~1);
+  int *dom = uni;                                                 // traces: kDomMax x (sqfrom, sqto, hmmfrom, hmmto)
   float *dnull = reinterpret_cast<float *>(dom + 4 * kDomMax);   // kDomMax x 32
   short *stk = reinterpret_cast<short *>(dnull + 32 * kDomMax);  // emitting state of each residue: +k match, -k insert
   const int SEGCAP = a.seg_cap;
-  unsigned short *s_a = reinterpret_cast<unsigned short *>(stk + Lp + 4);   // Easel's vertex stacks of the clustering
+  unsigned short *s_a = reinterpret_cast<unsigned short *>(uni); // clustering (after the traces): Easel's vertex stacks, same block
   unsigned short *s_b = s_a + SEGCAP;
-  int *misc = reinterpret_cast<int *>(s_b + SEGCAP);             // 7 x kEnvMax ints: envelope and cluster lists of the pair
-  // 64 float64 bins of the E-state row pass, over the (then idle) clustering stacks, 8-byte aligned
-  double *bins = reinterpret_cast<double *>(lds_raw) + ((reinterpret_cast<char *>(s_a) - reinterpret_cast<char *>(lds_raw)) + 7) / 8;
-  int32_t *sg = a.segs + (size_t)blockIdx.x * a.seg_stride;      // per wave in HBM: 6 arrays of SEGCAP ints + the histogram
+  double *bins = reinterpret_cast<double *>(uni + resolve_uni_ints(a.Lcap));   // 64 float64 bins of the E-state row pass (8-byte aligned)
+  int *misc = reinterpret_cast<int *>(bins + 64);                // 7 x kEnvMax ints: envelope and cluster lists of the pair
+  (void)Lp;
+  const size_t wslot = (size_t)blockIdx.x * nwaves + wave;        // this wave's slab / segment arrays
+  int32_t *sg = a.segs + wslot * a.seg_stride;      // per wave in HBM: 6 arrays of SEGCAP ints + the histogram
   int32_t *s_idx = sg, *s_i = sg + SEGCAP, *s_j = sg + 2 * SEGCAP, *s_k = sg + 3 * SEGCAP, *s_m = sg + 4 * SEGCAP;
   int32_t *s_as = sg + 5 * SEGCAP;
   int32_t *epc = sg + 6 * SEGCAP;                                // end-point histogram of one cluster
@@ -140,17 +163,63 @@ __global__ __launch_bounds__(64, WH_RES_OCC) void resolve_kernel(ResolveArgs a) 
     return sum;
   };
   const double LOG2 = 0.69314718055994529;
-  const int n_items = *a.count < a.rec_cap ? *a.count : a.rec_cap;
+  int cur_h = -1;
+  bool use_tl = false;
+  if (a.stats && threadIdx.x == 0) atomicMin(a.stats + 16, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 
   for (;;) {
+    // ---- next slot of the workgroup: the right to work on one model's segment of the queue
+    const long long t_idle0 = a.stats ? __builtin_readcyclecounter() : 0;
+    __syncthreads();                                   // every wave is done with the previous segment (and its tables)
+    if (wave == 0) {
+      // wave 0 picks the segment: the next slot while there are slots; afterwards ANY segment that still has pairs (the
+      // workgroup joins whoever is still working - without this the launch ended on the last slots' workgroups alone:
+      // mean wave lifetime 714 ms of a 919 ms launch), -1 when every segment is drained
+      int seg_pick = -1;
+      int slot = 0;
+      if (lane == 0) slot = atomicAdd(a.counter, 1);
+      slot = __shfl(slot, 0);
+      if (slot < a.n_slots) seg_pick = a.slots[slot];
+      else {
+        for (int base = 0; base < a.n_chunks && seg_pick < 0; base += 64) {
+          const int sgi = (int)((blockIdx.x * 7u + (unsigned)(base + lane)) % (unsigned)a.n_chunks);
+          const bool in = base + lane < a.n_chunks;
+          const int left = in ? a.chunks[4 * sgi + 1] - __hip_atomic_load(a.cursors + sgi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+          const unsigned long long have = __ballot(left > 0);
+          if (have) seg_pick = __shfl(sgi, __ffsll((long long)have) - 1);
+        }
+      }
+      if (lane == 0) s_hdr[0] = seg_pick;
+    }
+    __syncthreads();
+    if (a.stats && lane == 0) atomicAdd(a.stats + 13, (unsigned long long)(__builtin_readcyclecounter() - t_idle0));
+    const int seg = __builtin_amdgcn_readfirstlane(s_hdr[0]);
+    if (seg < 0) break;                                // the same for every wave of the workgroup
+    const int c_start = a.chunks[4 * seg], c_count = a.chunks[4 * seg + 1], c_h = a.chunks[4 * seg + 2], c_Q = a.chunks[4 * seg + 3];
+    // (a segment that other workgroups have drained already costs this one a table staging and one atomic per wave)
+    if (c_h != cur_h) {
+      use_tl = a.lds_tables > 0 && c_Q <= a.lds_tables && (c_Q == 4 || c_Q == 8 || c_Q == 12 || c_Q == 16);
+      if (use_tl) {
+        const d2_t *src = reinterpret_cast<const d2_t *>(a.gtab + a.hmms[c_h].gfw_off);
+        d2_t *dst = reinterpret_cast<d2_t *>(tabL);
+        for (int t = threadIdx.x; t < gNARR * c_Q * 32; t += blockDim.x) dst[t] = src[t];
+      }
+      cur_h = c_h;
+      __syncthreads();
+    }
+  for (;;) {
+    // the segment's next pair, for whichever wave of whichever workgroup asks first (pairs are in descending cost)
     int item = 0;
-    if (lane == 0) item = atomicAdd(a.counter, 1);
+    if (lane == 0) item = atomicAdd(a.cursors + seg, 1);
     item = __shfl(item, 0);
-    if (item >= n_items) break;
+    if (item >= c_count) break;
     // By value: with a reference into the queue AND the LDS lists below, this toolchain produced a kernel that
     // read a garbage record (out-of-slab writes); either alone was fine.  Record fields are range-checked below
     // and the sampling loop is bounded, so a bad record can no longer run the wave out of its slab.
-    const ResolveRec rec = a.recs[a.order ? a.order[item] : item];
+    const long long t_pair0 = a.stats ? __builtin_readcyclecounter() : 0;
+    const unsigned long long r_pair0 = a.stats ? __builtin_amdgcn_s_memrealtime() : 0;
+    const ResolveRec rec = a.recs[a.order ? a.order[c_start + item] : c_start + item];
+    if (rec.h != c_h) continue;                        // never true for a well-formed chunk list (the staged tables are c_h's)
     const DevHMM hm = a.hmms[rec.h];
     GModel m;
     m.tf = a.gtab + hm.gfw_off; m.te = a.gtab + hm.gem_off;
@@ -158,7 +227,7 @@ __global__ __launch_bounds__(64, WH_RES_OCC) void resolve_kernel(ResolveArgs a) 
     m.Q = __builtin_amdgcn_readfirstlane(hm.Q); m.M = __builtin_amdgcn_readfirstlane(hm.M);
     GMx mx;
     mx.Q = m.Q; mx.rowlen = (size_t)3 * m.Q * 64 + xNSPEC;
-    mx.p = a.mx + (size_t)blockIdx.x * a.mx_stride;
+    mx.p = a.mx + wslot * a.mx_stride;
     const int64_t off = a.offsets[rec.q];
     const int L = (int)(a.offsets[rec.q + 1] - off);
     const size_t out = (size_t)rec.q * a.H + rec.h;
@@ -189,7 +258,7 @@ __global__ __launch_bounds__(64, WH_RES_OCC) void resolve_kernel(ResolveArgs a) 
       // ---------------- A.4b
       const uint8_t *rs = seq + (ireg - 1);       // rs[pos-1] = residue at region position pos
       long long tk0 = a.stats ? __builtin_readcyclecounter() : 0;
-      const double regfwd = gforward_any<true>(m, rs, Lr, cm, mx, lane);
+      const double regfwd = gforward_any<true>(m, rs, Lr, cm, mx, lane, use_tl ? (const ldbl *)tabL : nullptr);
       RTICK(0);
 #ifdef WH_RESOLVE_DEBUG
       if (a.dbg && lane == 0) printf("[resolve] region forward %.12f\n", regfwd);
@@ -719,7 +788,7 @@ __global__ __launch_bounds__(64, WH_RES_OCC) void resolve_kernel(ResolveArgs a) 
       for (int d = 0; d < nsig; d++) {
         if (dominated & (1u << d)) continue;
         const int i2 = g_i[d], j2 = g_j[d], Ld = j2 - i2 + 1;
-        const double envsc = gforward_any<false>(m, seq + (i2 - 1), Ld, cu, mx, lane);
+        const double envsc = gforward_any<false>(m, seq + (i2 - 1), Ld, cu, mx, lane, use_tl ? (const ldbl *)tabL : nullptr);
         const float dc = n2sum(i2, j2);
         if (nenv < kEnvMax) { env_i[nenv] = i2; env_j[nenv] = j2; env_sc[nenv] = (float)envsc; env_dc[nenv] = dc; nenv++; }
         else flags |= WH_FLAG_TRUNC;
@@ -762,6 +831,15 @@ __global__ __launch_bounds__(64, WH_RES_OCC) void resolve_kernel(ResolveArgs a) 
       for (int e = 0; e < dp->nenv; e++) { dp->env_i[e] = env_i[e]; dp->env_j[e] = env_j[e]; dp->envsc[e] = env_sc[e]; dp->domcorr[e] = env_dc[e]; }
     }
     if (lane == 0) { a.decibits[out] = decibits; a.flags[out] = (uint8_t)flags; }
+    if (a.stats && lane == 0) {      // shader cycles and 100 MHz ticks of this pair: their ratio is the clock the kernel ran at
+      atomicAdd(a.stats + 14, (unsigned long long)(__builtin_readcyclecounter() - t_pair0));
+      atomicAdd(a.stats + 15, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - r_pair0));
+    }
+  }
+  }
+  if (a.stats && lane == 0) {        // this wave's lifetime since the first workgroup started (100 MHz ticks): sum, maximum, count
+    const unsigned long long life = __builtin_amdgcn_s_memrealtime() - *(volatile unsigned long long *)(a.stats + 16);
+    atomicAdd(a.stats + 17, life); atomicMax(a.stats + 18, life); atomicAdd(a.stats + 19, 1ull);
   }
 }
 
@@ -784,10 +862,11 @@ hipError_t launch_resolve_keys(const ResolveRec *recs, int n, const DevHMM *hmms
   return hipGetLastError();
 }
 
-hipError_t launch_resolve(const ResolveArgs &a, int blocks, size_t lds, hipStream_t s) {
+hipError_t launch_resolve(const ResolveArgs &a, int blocks, int waves, size_t lds, hipStream_t s) {
+  if (waves < 1 || waves > kResMaxWaves) return hipErrorInvalidValue;
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&resolve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (err != hipSuccess) return err;
-  hipLaunchKernelGGL(resolve_kernel, dim3(blocks), dim3(64), lds, s, a);
+  hipLaunchKernelGGL(resolve_kernel, dim3(blocks), dim3(64 * waves), lds, s, a);
   return hipGetLastError();
 }
 

@@ -139,14 +139,17 @@ int wh_last_align_status(wh_ehmm *e, int64_t *n_logspace, int64_t *n_unaligned, 
  * from the start (query too long for a window, no dominant path, models of fewer than 8 nodes per lane). */
 int wh_last_align_paths(wh_ehmm *e, int64_t *paths4);
 
-/* How the envelope Backward sweeps (unihit Backward + posterior accumulation -> null2) of the last wh_score
- * call ran, counted on the device by the one-wavefront-per-pair scoring kernels (models of up to 24 cells per lane;
- * the pass-synchronous, several-waves-per-pair and any-size kernels have no window and are not counted):
- * paths4[0] = envelopes whose sweep ran on a 256-node window around the dominant alignment and passed the mass
+/* How the Backward sweeps of the last wh_score call ran, counted on the device by the one-wavefront-per-pair scoring
+ * kernels (models of up to 24 cells per lane; the pass-synchronous, several-waves-per-pair and any-size kernels have no
+ * window and are not counted).  Envelope sweeps (unihit Backward + posterior accumulation -> null2):
+ * paths6[0] = envelopes whose sweep ran on a 256-node window around the dominant alignment and passed the mass
  * certificate, [1] = the same on a 512-node window, [2] = windows that failed the certificate (each then ran again at
  * full width), [3] = full-width sweeps (no window tried, a failed window, or the dense redo of a sparse spill).
- * Waits for the device.  (What a window is: DESIGN.md section 4.1; WH_NO_WINDOW switches it off.) */
-int wh_last_score_paths(wh_ehmm *e, int64_t *paths4);
+ * Multihit sweeps (Backward + domain decoding): [4] = pairs whose regions come from a sweep on a node
+ * window (every threshold decision of the region scan beyond the window's slack), [5] = pairs whose window left a
+ * decision in doubt and whose sweep ran again at full width (pairs that never tried a window are in neither).
+ * Waits for the device.  (What a window is: DESIGN.md section 4.1; WH_NO_WINDOW switches both off.) */
+int wh_last_score_paths(wh_ehmm *e, int64_t *paths6);
 
 /* Scoring passes the last wh_score call REPEATED (0 or 1).  The queue that hands pairs with a multidomain region to the
  * resolver stage is sized by estimate (5 % of the pairs, or 1.25 x the largest share an earlier call on the handle

@@ -56,6 +56,7 @@ def main():
                 dt = (time.perf_counter() - t0) * 1e3
                 ms, n = e.last_kernel_ms(0)
                 rms, _ = e.last_kernel_ms(4)
+                paths = e.last_score_paths()
                 d = deci.cpu().numpy()
                 f = flags.cpu().numpy()
                 if ref is None:
@@ -63,8 +64,8 @@ def main():
                 nd = int((d != ref[0]).sum())
                 nf = int(((f & 7) != (ref[1] & 7)).sum())
                 mx = int(np.abs(d.astype(np.int64) - ref[0]).max())
-                print("rep %d  %-44s kernel %9.3f ms (wall %9.3f)  %.3g cells/s  resolver %9.3f ms for %d multidomain pairs  decibit diffs vs first: %d (max %d)  flag diffs: %d  dense redos: %d"
-                      % (rep, v or "(default)", ms, dt, cells / (ms * 1e-3), rms, int(((f & 2) != 0).sum()), nd, mx, nf, int(((f & 16) != 0).sum())), flush=True)
+                print("rep %d  %-44s kernel %9.3f ms (wall %9.3f)  %.3g cells/s  resolver %9.3f ms for %d multidomain pairs  decibit diffs vs first: %d (max %d)  flag diffs: %d  dense redos: %d  paths %s"
+                      % (rep, v or "(default)", ms, dt, cells / (ms * 1e-3), rms, int(((f & 2) != 0).sum()), nd, mx, nf, int(((f & 16) != 0).sum()), paths), flush=True)
     finally:
         shutil.rmtree(wd, ignore_errors=True)
 

@@ -66,13 +66,14 @@ struct Knobs {
   bool no_logspace = false;  // skip the log-space alignment pass
   bool no_wide_align = false; // models beyond 3 072 nodes are aligned by the float64 kernel only (A/B and debugging)
   bool no_window = false;    // envelope Backward sweeps run full width (no node window; A/B and debugging)
+  bool no_p2win = false;     // the multihit Backward sweep runs full width only (A/B and debugging)
   bool no_resolve = false;   // multidomain regions stay ONE envelope (round-1 behaviour) instead of HMMER's stochastic resolver
   int rqueue_cap = 0;        // test hook: size the resolver's queue for this many pairs instead of the estimate (forces the overflow re-run)
   bool stats = false, trace = false;
   int dbg = 0;
   int rdbg = 0;              // resolver: print the first <n> sampled segments and the cluster statistics of every region
 };
-static const int kScorePathSlot = 112;   // d_counter[112..119]: four 64-bit path counters of the last scoring call (wh_last_score_paths)
+static const int kScorePathSlot = 112;   // d_counter[112..123]: six 64-bit path counters of the last scoring call (wh_last_score_paths)
 static const int kMaxLaunches = 60;   // work-queue heads in d_counter (slot 63 belongs to the consensus kernel)
 
 struct wh_ehmm {
@@ -336,6 +337,7 @@ int wh_set_option(wh_ehmm *e, const char *name, const char *value) {
   else if (!strcmp(name, "WH_NO_LOGSPACE")) k.no_logspace = on;
   else if (!strcmp(name, "WH_NO_RESOLVE")) k.no_resolve = on;
   else if (!strcmp(name, "WH_NO_WINDOW")) k.no_window = on;
+  else if (!strcmp(name, "WH_NO_P2WIN")) k.no_p2win = on;
   else if (!strcmp(name, "WH_RQUEUE_CAP")) k.rqueue_cap = *v ? std::max(1, atoi(v)) : 0;
   else if (!strcmp(name, "WH_NO_WIDE_ALIGN")) k.no_wide_align = on;
   else if (!strcmp(name, "WH_STATS")) k.stats = on;
@@ -347,7 +349,7 @@ int wh_set_option(wh_ehmm *e, const char *name, const char *value) {
 }
 
 static void knobs_from_env(wh_ehmm *e) {
-  for (const char *name : {"WH_SCORE_KERNEL", "WH_KEEP_LOG2", "WH_MAX_WAVES", "WH_FORCE_SPECG", "WH_NO_LOGSPACE", "WH_NO_RESOLVE", "WH_NO_WINDOW", "WH_RQUEUE_CAP", "WH_NO_WIDE_ALIGN", "WH_STATS", "WH_TRACE", "WH_DBG", "WH_RDBG"})
+  for (const char *name : {"WH_SCORE_KERNEL", "WH_KEEP_LOG2", "WH_MAX_WAVES", "WH_FORCE_SPECG", "WH_NO_LOGSPACE", "WH_NO_RESOLVE", "WH_NO_WINDOW", "WH_NO_P2WIN", "WH_RQUEUE_CAP", "WH_NO_WIDE_ALIGN", "WH_STATS", "WH_TRACE", "WH_DBG", "WH_RDBG"})
     if (const char *v = getenv(name)) (void)wh_set_option(e, name, v);
 }
 
@@ -398,14 +400,15 @@ int wh_last_align_paths(wh_ehmm *e, int64_t *paths4) {
   return WH_OK;
 }
 
-int wh_last_score_paths(wh_ehmm *e, int64_t *paths4) {
+int wh_last_score_paths(wh_ehmm *e, int64_t *paths6) {
+  int64_t *paths4 = paths6;
   if (!e || !paths4) { set_error("wh_last_score_paths: bad argument"); return WH_EINVAL; }
   HIPCHK(hipSetDevice(e->device));
-  unsigned long long v[4] = {0, 0, 0, 0};
+  unsigned long long v[6] = {0, 0, 0, 0, 0, 0};
   // (the counters stay on the device until the next scoring call resets them; this copy waits for the device)
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(v, (int *)e->d_counter.p + kScorePathSlot, sizeof v, hipMemcpyDeviceToHost));
-  for (int t = 0; t < 4; t++) paths4[t] = (int64_t)v[t];
+  for (int t = 0; t < 6; t++) paths4[t] = (int64_t)v[t];
   return WH_OK;
 }
 
@@ -452,9 +455,9 @@ static const size_t kLdsHeader = 16;   // work-item slot in front of the tables 
 static const int kScoreSpecArrays = 6;
 // LDS plan of the phase-call scoring kernel: tables (K emission rows + both transition
 // orientations) + per wave one block (special-state arrays, null2 table, region list, residues).
-static int plan_block1(const wh_ehmm *e, int Q, int K, int Lcap, int wmax, int *waves, int *SP, int *wave_lds, size_t *lds) {
+static int plan_block1(const wh_ehmm *e, int Q, int K, int Lcap, int wmax, int *waves, int *SP, int *wave_lds, size_t *lds, int extra_arrays = 0) {
   const int sp = (Lcap + 1 + 3) / 4 * 4;
-  const int wl = kScoreSpecArrays * sp + 32 + kRegsInts + (Lcap + 3) / 4 + 4;
+  const int wl = (kScoreSpecArrays + extra_arrays) * sp + 32 + kRegsInts + (Lcap + 3) / 4 + 4;
   const size_t table = (size_t)(K + 2 * FW_NARR) * Q * kWave * sizeof(float);
   int w = wmax;
   if (e->knobs.max_waves > 0) w = std::max(1, std::min(wmax, e->knobs.max_waves));
@@ -542,7 +545,7 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
       e->rq_cap = cap;
       HIPCHK(hipMemsetAsync(d_rcount, 0, 2 * sizeof(int), s));
     }
-    HIPCHK(hipMemsetAsync((int *)e->d_counter.p + kScorePathSlot, 0, 4 * sizeof(unsigned long long), s));
+    HIPCHK(hipMemsetAsync((int *)e->d_counter.p + kScorePathSlot, 0, 6 * sizeof(unsigned long long), s));
     // Long models run four waves in lockstep per workgroup (wh_score_big.hip): hand them the queries in
     // descending length order, so that the waves of a workgroup finish their sweeps together and the longest
     // pairs start first.  (One D2H copy of the offsets and a host sort; only when such a class exists.)
@@ -604,7 +607,7 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
       //  * the same kernel with the special-state rows in HBM ("SG"): long queries
       //  * pass-synchronous kernel (wh_score_big.hip): 28+ cells per lane, and 20/24-cell models whose
       //    emission rows do not fit in LDS beside both orientations (protein)
-      bool big = Q > kMaxQFast, specg = false, pairk = false;
+      bool big = Q > kMaxQFast, specg = false, pairk = false, p2win = false;
       if (!big && kn.kernel == 9 && !kn.force_specg && (Q == 8 || Q == 12 || Q == 16)) {
         // two queries per wavefront (wh_score9.hip): eight waves, each with two blocks of per-row arrays
         const int sp9 = (Lc + 1 + 3) / 4 * 4;
@@ -621,6 +624,13 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
         // (twelve waves = three per SIMD at 168 registers; 20-cell models keep that since the six-array block, 24-cell
         // models get the nine or ten waves that fit beside their 120 KB of tables)
         int rc_plan = plan_block1(e, Q, e->K, Lc, 12, &waves, &SP, &wave_lds, &lds);
+        // ... and, where the waves still fit with them, three more per-row arrays per wave: the multihit Backward sweep then
+        // tries a node window first (wh_score7.hip, "P2 on a node window")
+        if (rc_plan == WH_OK && waves >= 4 && !kn.force_specg && !kn.no_window && !kn.no_p2win && Q >= 8) {
+          int w2 = 0, sp2 = 0, wl2 = 0;
+          size_t lds2 = 0;
+          if (plan_block1(e, Q, e->K, Lc, 12, &w2, &sp2, &wl2, &lds2, 3) == WH_OK && w2 >= waves) { p2win = true; waves = w2; SP = sp2; wave_lds = wl2; lds = lds2; }
+        }
         if (rc_plan != WH_OK || waves < 4 || kn.force_specg) {
           specg = true;
           SP = (Lc + 1 + 3) / 4 * 4;
@@ -651,6 +661,7 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
       }
       a.SP = SP; a.wave_lds = wave_lds; a.spec_arrays = kScoreSpecArrays;
       a.paths = reinterpret_cast<unsigned long long *>((int *)e->d_counter.p + kScorePathSlot);
+      a.p2win = (p2win && !specg && !big && !pairk) ? 1 : 0;
       a.qorder = (big || mixed) ? d_qorder : nullptr;
       a.QB = big ? waves * 2 : waves * 4;   // long models: a pair is milliseconds, smaller items shorten the tail of the launch
       const int per_turn = pairk ? 2 : 1;   // queries a wave takes per turn
@@ -680,8 +691,8 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
       a.scratch = (float *)e->d_scratch.p;
       if (specg) a.spec_scratch = (float *)e->d_spec.p;
       if (kn.stats) {
-        if (e->d_recs.ensure(256)) return WH_ENOMEM;
-        HIPCHK(hipMemsetAsync(e->d_recs.p, 0, 256, s));
+        if (e->d_recs.ensure(320)) return WH_ENOMEM;
+        HIPCHK(hipMemsetAsync(e->d_recs.p, 0, 320, s));
         { unsigned long long bigv = ~0ull; HIPCHK(hipMemcpyAsync((char *)e->d_recs.p + 13 * 8, &bigv, 8, hipMemcpyHostToDevice, s)); }
         a.stats = (unsigned long long *)e->d_recs.p;
       }
@@ -696,13 +707,15 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
       if (err != hipSuccess) { set_error("score kernel launch (Q=%d) failed: %s", Q, hipGetErrorString(err)); return WH_EHIP; }
       launches++;
       if (a.stats) {
-        unsigned long long st[32];
+        unsigned long long st[40];
         HIPCHK(hipMemcpyAsync(st, a.stats, sizeof st, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         const double tot = (double)(st[4] + st[5] + st[6] + st[7] + st[8] + st[9] + st[10] + st[11]);
         fprintf(stderr, "[wh] Q=%d wave cycles: P1 %.1f%%  P2 %.1f%%  regions %.1f%%  P3 %.1f%%  P4 %.1f%%  null2 %.1f%%  swaps+barriers %.1f%%  other %.1f%%  (total %.3g ticks)\n", Q, 100.0 * st[4] / tot,
                 100.0 * st[5] / tot, 100.0 * st[6] / tot, 100.0 * st[7] / tot, 100.0 * st[8] / tot, 100.0 * st[9] / tot, 100.0 * st[10] / tot, 100.0 * st[11] / tot, tot);
         fprintf(stderr, "[wh] Q=%d envelope Backward sweeps: %llu on a 256-node window, %llu on a 512-node window, %llu windows failed the mass certificate, %llu full width; union of the stored lane blocks: span %.1f blocks (with margin), %.1f blocks set, of %llu envelopes\n", Q, st[0], st[1], st[2], st[3], (double)st[12] / (double)std::max(1ull, st[14]), (double)st[15] / (double)std::max(1ull, st[14]), st[14]);
+        fprintf(stderr, "[wh] Q=%d multihit Backward on a window: %llu scans, of them in doubt at a threshold %llu, at the multidomain bound %llu; window loss out of range %llu; mean eps %.3g\n", Q,
+                st[35], st[32], st[33], st[36], st[35] ? 1e-9 * (double)st[34] / (double)st[35] : 0.0);
         fprintf(stderr, "[wh] Q=%d |Ld - mass| / Ld  (<3e-7, <1e-6, <3e-6, <1e-5, <2e-5, more): window sweeps %llu %llu %llu %llu %llu %llu; full-width sweeps %llu %llu %llu %llu %llu %llu\n", Q,
                 st[16], st[17], st[18], st[19], st[20], st[21], st[22], st[23], st[24], st[25], st[26], st[27]);
       }
@@ -854,8 +867,10 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
       // the waves' blocks; the Forward sweeps of their pairs then read one array per cell from L2 instead of nine.
       int Qt = 0;
       for (auto &kv : e->by_q) if (kv.first <= 16 && (kv.first == 4 || kv.first == 8 || kv.first == 12 || kv.first == 16)) Qt = std::max(Qt, kv.first);
-      if (getenv("WH_RES_NO_LDS_TABLES")) Qt = 0;
+      const bool small_queue = n_multi < 64 * e->cu_count;        // fewer than eight pairs per wave (see below)
+      if (getenv("WH_RES_NO_LDS_TABLES") || small_queue) Qt = 0;
       int waves = std::min<int>(resolve_waves_per_cu(), 8);
+      if (const char *wv = getenv("WH_RES_WAVES")) waves = std::max(1, std::min(8, atoi(wv)));      // experiments: waves per workgroup (= per CU)
       if (Qt > 0 && resolve_lds_header_bytes(Qt) + (size_t)waves * rlds > kLdsBudget) {
         // fewer waves WITH the tables only while at least six fit; otherwise the tables stay in L2
         int w2 = waves;
@@ -882,14 +897,21 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
         HIPCHK(hipStreamSynchronize(s));
         std::vector<int32_t> ord((size_t)n_multi);
         for (int t = 0; t < n_multi; t++) ord[(size_t)t] = t;
-        std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) {
-          return models[(size_t)x] != models[(size_t)y] ? models[(size_t)x] < models[(size_t)y] : keys[(size_t)x] > keys[(size_t)y];
-        });
+        // A small queue (fewer than eight pairs per wave: the reference's example data as shipped, 2 103 pairs) is ONE
+        // segment in descending cost, models mixed, tables from L2: there the order decides the tail of the launch and
+        // nothing else matters.  Otherwise: model by model.
+        if (small_queue)
+          std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) { return keys[(size_t)x] > keys[(size_t)y]; });
+        else
+          std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) {
+            return models[(size_t)x] != models[(size_t)y] ? models[(size_t)x] < models[(size_t)y] : keys[(size_t)x] > keys[(size_t)y];
+          });
         // one segment per model; slots in proportion to the segments' cost (four per workgroup in all, at least one per model)
         struct Seg { int start, count, h; double cost; };
         std::vector<Seg> segs;
         double total_cost = 0.0;
-        for (int t = 0; t < n_multi;) {
+        if (small_queue) { segs.push_back({0, n_multi, -1, 1.0}); total_cost = 1.0; }
+        for (int t = small_queue ? n_multi : 0; t < n_multi;) {
           const int h = models[(size_t)ord[(size_t)t]];
           int u = t;
           double cost = 0.0;
@@ -905,12 +927,13 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
         std::vector<int32_t> slot_list;
         for (int sidx : order_s) {
           const Seg &g = segs[(size_t)sidx];
-          int ns = (int)std::ceil(g.cost / std::max(per_slot, 1.0));
+          int ns = (int)std::ceil(g.cost / std::max(per_slot, 1e-30));
           ns = std::max(1, std::min(ns, std::max(1, (g.count + 7) / 8)));       // never more slots than groups of eight pairs
+          if (small_queue) ns = std::max(1, std::min(e->cu_count, (g.count + waves - 1) / waves));
           for (int v = 0; v < ns; v++) slot_list.push_back(sidx);
         }
         chunk_list.reserve(segs.size() * 4);
-        for (const Seg &g : segs) { chunk_list.push_back(g.start); chunk_list.push_back(g.count); chunk_list.push_back(g.h); chunk_list.push_back(e->dev[(size_t)g.h].Q); }
+        for (const Seg &g : segs) { chunk_list.push_back(g.start); chunk_list.push_back(g.count); chunk_list.push_back(g.h); chunk_list.push_back(g.h >= 0 ? e->dev[(size_t)g.h].Q : 0); }
         // one buffer: segments | slots | cursors
         const size_t n_seg = segs.size(), n_slot = slot_list.size();
         if (e->d_rchunks.ensure(sizeof(int32_t) * (4 * n_seg + n_slot + n_seg))) return WH_ENOMEM;

@@ -276,11 +276,13 @@ __device__ __forceinline__ void region_scan_global(float *spec, int SP, int L, i
 // scale exponent.
 // SLIM (with STORE): the per-row B and E arrays of an envelope sweep are never read again, so their slots hold the two
 // mask words instead (SP_B <- low word, SP_E <- high word) and a wave's block needs six arrays, not eight.
-template <int Q, bool TREG, bool STORE, bool USEP = false, bool SLIM = false>
+// UM (without STORE): the dominant-path mask alone - the union over every EIGHTH row of the lane blocks that hold a cell
+// above E(row)/2 - written to um_out[0..1]; the multihit sweep uses it to place the node window of its Backward sweep.
+template <int Q, bool TREG, bool STORE, bool USEP = false, bool SLIM = false, bool UM = false>
 __device__ __forceinline__ void forward_sweep(const TransTab<Q, TREG> &T, const ScanC &sc, const float *emL,
                                               const float *emG, int K, const uint8_t *seq, int L, LenCfg cfg,
                                               float *spec, int SP, float *Fs, float keep_scale, int lane,
-                                              float &xC_out, int &ef_out) {
+                                              float &xC_out, int &ef_out, unsigned *um_out = nullptr) {
   float Mp[Q], Ip[Q], Dp[Q];
 #pragma unroll
   for (int q = 0; q < Q; q++) { Mp[q] = 0.f; Ip[q] = 0.f; Dp[q] = 0.f; }
@@ -369,6 +371,14 @@ __device__ __forceinline__ void forward_sweep(const TransTab<Q, TREG> &T, const 
       spec[SP_J * SP + i] = xJ; spec[SP_C * SP + i] = xC;
       reinterpret_cast<int *>(spec)[SP_S * SP + i] = ef;
     }
+    if (UM && !STORE) {
+      if ((i & 7) == 0) {
+        float lmax = 0.f;
+#pragma unroll
+        for (int q = 0; q < Q; q += 2) lmax = fmaxf(lmax, fmaxf(fmaxf(Mp[q], Mp[q + 1]), fmaxf(Ip[q], Ip[q + 1])));
+        umask |= __ballot(lmax > 0.5f * xE);
+      }
+    }
     if (STORE) {
       constexpr int ML = SLIM ? SP_B : SP_ML, MH = SLIM ? SP_E : SP_MH;
       float lmax = 0.f;
@@ -399,6 +409,7 @@ __device__ __forceinline__ void forward_sweep(const TransTab<Q, TREG> &T, const 
     reinterpret_cast<unsigned *>(spec)[(SLIM ? SP_B : SP_ML) * SP] = (unsigned)(umask & 0xFFFFFFFFull);
     reinterpret_cast<unsigned *>(spec)[(SLIM ? SP_E : SP_MH) * SP] = (unsigned)(umask >> 32);
   }
+  if (UM && !STORE && lane == 0) { um_out[0] = (unsigned)(umask & 0xFFFFFFFFull); um_out[1] = (unsigned)(umask >> 32); }
   xC_out = xC;
   ef_out = ef;
 }

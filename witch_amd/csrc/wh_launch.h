@@ -49,14 +49,16 @@ struct ScoreArgs {
   uint32_t degen[32];
   int Klds;                    // emission rows staged in LDS (= K, or 0: read from L2)
   int no_window;               // 1: envelope Backward sweeps at full width only (WH_NO_WINDOW)
+  int p2win;                   // 1: the wave blocks hold three more per-row arrays and the multihit Backward sweep tries a node window first
   int dbg;                     // timing experiments only: 1 = skip Forward-row stores, 2 = skip Forward-row loads
   float keep_scale;            // Forward-row spill threshold relative to E(row); 0 = the kernel's default (2^-24)
   ResolveRec *rrecs;           // queue of pairs with a multidomain region (NULL: such regions become one envelope)
   int *rcount;                 // queue length (device counter)
   int rcap;
   unsigned long long *stats;   // WH_STATS: [4..11] wave cycles per phase (or NULL)
-  unsigned long long *paths;   // 4 counters (always counted, one atomic per wave and counter at the end of the launch): envelope Backward
-                               // sweeps on a 256-node window, on a 512-node window, windows that failed the certificate, full-width sweeps
+  unsigned long long *paths;   // 6 counters (always counted, one atomic per wave and counter at the end of the launch): envelope Backward
+                               // sweeps on a 256-node window, on a 512-node window, windows that failed the certificate, full-width sweeps;
+                               // multihit Backward sweeps kept from a node window, windows whose region scan was in doubt (redone at full width)
   const int32_t *qorder;       // long-model kernel: queries in descending length order (or NULL: input order)
 };
 

@@ -198,7 +198,8 @@ __global__ __launch_bounds__(64 * kResMaxWaves) void resolve_kernel(ResolveArgs 
     const int c_start = a.chunks[4 * seg], c_count = a.chunks[4 * seg + 1], c_h = a.chunks[4 * seg + 2], c_Q = a.chunks[4 * seg + 3];
     // (a segment that other workgroups have drained already costs this one a table staging and one atomic per wave)
     if (c_h != cur_h) {
-      use_tl = a.lds_tables > 0 && c_Q <= a.lds_tables && (c_Q == 4 || c_Q == 8 || c_Q == 12 || c_Q == 16);
+      // (c_h < 0: a segment of mixed models - the whole of a small queue in descending cost - reads its tables from L2)
+      use_tl = c_h >= 0 && a.lds_tables > 0 && c_Q <= a.lds_tables && (c_Q == 4 || c_Q == 8 || c_Q == 12 || c_Q == 16);
       if (use_tl) {
         const d2_t *src = reinterpret_cast<const d2_t *>(a.gtab + a.hmms[c_h].gfw_off);
         d2_t *dst = reinterpret_cast<d2_t *>(tabL);
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(64 * kResMaxWaves) void resolve_kernel(ResolveArgs 
     const long long t_pair0 = a.stats ? __builtin_readcyclecounter() : 0;
     const unsigned long long r_pair0 = a.stats ? __builtin_amdgcn_s_memrealtime() : 0;
     const ResolveRec rec = a.recs[a.order ? a.order[c_start + item] : c_start + item];
-    if (rec.h != c_h) continue;                        // never true for a well-formed chunk list (the staged tables are c_h's)
+    if (c_h >= 0 && rec.h != c_h) continue;            // never true for a well-formed segment list (the staged tables are c_h's)
     const DevHMM hm = a.hmms[rec.h];
     GModel m;
     m.tf = a.gtab + hm.gfw_off; m.te = a.gtab + hm.gem_off;

@@ -92,6 +92,8 @@ struct RegOut { int nenv, nreg, flags; };   // flags: WH_FLAG_* | multidomain ma
 struct FwdOut { float xC; int ef; };
 
 // ---------------------------------------------------------------- P1 / P3
+// (the sweep without STORE is the multihit one, P1: it also leaves the dominant-path mask in n2tab[30..31] for P2's window)
+constexpr int kUmSlot = 30;
 template <int Q, bool STORE, int TH, bool SG>
 __device__ __noinline__ FwdOut sweep_forward(const WaveCtx c, lds_u8 *seq3, int L, LenCfg cfg, float keep_scale) {
   const uint8_t *seq = (const uint8_t *)seq3;
@@ -99,7 +101,9 @@ __device__ __noinline__ FwdOut sweep_forward(const WaveCtx c, lds_u8 *seq3, int 
   T.load(nullptr, (const float *)c.fwL, c.lane);
   const ScanC sc = scan_prepare(lane_product<Q, false>(T, FW_D2));
   FwdOut o;
-  forward_sweep<Q, false, STORE, (Q <= kMaxQP), kSlim>(T, sc, (const float *)c.emL, (const float *)c.emG, ctxKlds(c), seq, L, cfg, SG ? (float *)c.specg : (float *)c.spec, c.SP, (float *)c.Fs, keep_scale, c.lane, o.xC, o.ef);
+  constexpr bool UM = !STORE && !SG && Q >= 8;
+  forward_sweep<Q, false, STORE, (Q <= kMaxQP), kSlim, UM>(T, sc, (const float *)c.emL, (const float *)c.emG, ctxKlds(c), seq, L, cfg, SG ? (float *)c.specg : (float *)c.spec, c.SP, (float *)c.Fs, keep_scale, c.lane, o.xC, o.ef,
+                                                           reinterpret_cast<unsigned *>((float *)c.n2tab) + kUmSlot);
   if (SG) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // the rows were written by lane 0, every lane reads them next
   return o;
 }
@@ -465,6 +469,187 @@ __device__ __noinline__ P4Out sweep_backward_null2_win(const WaveCtx c, lds_u8 *
   return o;
 }
 
+// ---------------------------------------------------------------- P2 on a node window (round 4)
+// The multihit Backward sweep exists for per-ROW numbers only: the posterior of a domain beginning / ending at each row
+// and of the row's residue being emitted by a flank state, which the region scan compares with 0.25 / 0.10 / 0.20.
+// Restricted to the window of 64*QB nodes around the dominant alignment (placed by P1's mask) it costs a third - and
+// its answers are LOWER BOUNDS with a known slack: the Forward side is the full-width sweep's, so a windowed posterior
+// is the probability of its event AND of the rest of the path staying inside the window; what is missing is at most
+// eps = 1 - Z_window / Z, the probability that a path leaves the window at all, and the sweep measures exactly that at
+// row 0.  (eps is ~7e-4 on the headline workload: a junk second mini-domain anywhere in the model.)  The region scan
+// below therefore takes every threshold decision with that slack and reports whether all of them were beyond doubt;
+// only then are its regions used - they are then the regions of the full-width sweep, decision by decision - otherwise
+// P2 runs at full width as before.  The windowed posteriors go to three arrays of their own (tmp = spec + kSpArr * SP):
+// the Forward rows of P1 stay intact for the full-width sweep.
+struct WinDec { float eps; };
+template <int QB, int Q, int TH>
+__device__ __noinline__ WinDec sweep_backward_decode_win(const WaveCtx c, lds_u8 *seq3, int L, LenCfg cm, float invZ, int ef_L, int m0) {
+  static_assert(Q % QB == 0 && QB % 4 == 0, "a window lane must stay inside one forward lane block");
+  constexpr int Q4 = Q / 4, B4 = QB / 4;
+  const uint8_t *seq = (const uint8_t *)seq3;
+  const int lane = c.lane, SP = c.SP, Klds = ctxKlds(c);
+  const float *spec = (const float *)c.spec;
+  float *tmp = (float *)c.spec + kSpArr * SP;          // [0] pe, [1] pb, [2] njc rows of the window sweep
+  const int *speci = reinterpret_cast<const int *>(spec);
+  int fwd[B4];
+  TransTab<QB, true> T;
+  {
+    const float4 *bw4 = reinterpret_cast<const float4 *>((const float *)c.bwL);
+#pragma unroll
+    for (int p4 = 0; p4 < B4; p4++) {
+      const int m4 = (m0 >> 2) + lane * B4 + p4;
+      const int rev = (m4 % Q4) * kWave + m4 / Q4;
+      const int jf = 16 * Q - 1 - m4;
+      fwd[p4] = (jf % Q4) * kWave + jf / Q4;
+#pragma unroll
+      for (int a = 0; a < BW_NARR; a++) T.v[a][p4] = bw4[a * Q4 * kWave + rev];
+    }
+  }
+  const ScanC sc = scan_prepare(lane_product<QB, true>(T, BW_DD));
+  const LdsF4 em4L((const float *)c.emL);
+  const float4 *em4G = reinterpret_cast<const float4 *>((const float *)c.emG);
+  float Mb[QB], Ib[QB];
+#pragma unroll
+  for (int p = 0; p < QB; p++) { Mb[p] = 0.f; Ib[p] = 0.f; }
+  float xC = cm.move, xJ = 0.f, xN = 0.f, xB = 0.f;
+  int eb = 0;
+  float ratio = 0.f;
+#pragma unroll 1
+  for (int i = L; i >= 0; i--) {
+    asm volatile("" ::: "memory");
+    if (i < L) {
+      const int x = __builtin_amdgcn_readfirstlane((int)seq[i]);
+      float part = 0.f;
+      auto emit = [&](auto em_ld) {
+#pragma unroll
+        for (int p4 = 0; p4 < B4; p4++) {
+          const float4 E = T.v[BW_E][p4];
+          const float4 O = em_ld(p4);
+          Mb[4 * p4 + 0] *= O.w; part = fmaf(E.x, Mb[4 * p4 + 0], part);
+          Mb[4 * p4 + 1] *= O.z; part = fmaf(E.y, Mb[4 * p4 + 1], part);
+          Mb[4 * p4 + 2] *= O.y; part = fmaf(E.z, Mb[4 * p4 + 2], part);
+          Mb[4 * p4 + 3] *= O.x; part = fmaf(E.w, Mb[4 * p4 + 3], part);
+        }
+      };
+      if (x < Klds) emit([&](int p4) { return em4L[x * (Q * 16) + fwd[p4]]; });
+      else emit([&](int p4) { return em4G[(size_t)x * (Q * 16) + fwd[p4]]; });
+      xB = wave_sum(part);
+      xJ = fmaf(xJ, cm.loop, xB * cm.move);
+      xC = xC * cm.loop;
+      xN = fmaf(xN, cm.loop, xB * cm.move);
+    }
+    float xE = fmaf(xC, cm.EC, xJ * cm.EJ);
+    if (i >= 1) backward_cells<QB, true, false>(T, sc, Mb, Ib, xE);
+    const float big = fmaxf(xB, xN);
+    if (big > kRescaleHi) {
+      const int e = f32_exponent(big);
+      const float r = pow2f_int(-e);
+#pragma unroll
+      for (int p = 0; p < QB; p++) { Mb[p] *= r; Ib[p] *= r; }
+      xB *= r; xJ *= r; xC *= r; xN *= r; xE *= r;
+      eb += e;
+    }
+    const float s_i = ldexpf(invZ, speci[SP_S * SP + i] + eb - ef_L);
+    const float pe = spec[SP_E * SP + i] * xE * s_i;
+    const float pb = spec[SP_B * SP + i] * xB * s_i;
+    float njc = 0.f;
+    if (i >= 1) {
+      const float s_p = ldexpf(invZ, speci[SP_S * SP + i - 1] + eb - ef_L);
+      njc = spec[SP_N * SP + i - 1] * xN;
+      njc = fmaf(spec[SP_J * SP + i - 1], xJ, njc);
+      njc = fmaf(spec[SP_C * SP + i - 1], xC, njc);
+      njc = njc * cm.loop * s_p;
+    } else {
+      ratio = spec[SP_N * SP] * xN * s_i;               // N_F(0) N_B(0) / Z: the share of the paths that stay inside the window
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) { tmp[i] = pe; tmp[SP + i] = pb; tmp[2 * SP + i] = njc; }
+    __builtin_amdgcn_wave_barrier();
+  }
+  WinDec o;
+  o.eps = 1.0f - ratio;
+  return o;
+}
+
+// The region scan (region_scan_global + the multidomain test) over the windowed posteriors, every decision taken with
+// the slack of the window (header above): a windowed posterior p_w stands for a true value in [p_w, p_w + eps].
+// Returns the regions and, in bit 24 of flags, whether any decision was in doubt (the caller then discards the result).
+// The cumulative sums go back into the pe row (etot) and the njc row (btot): both are read at the row they are written.
+template <int TH>
+__device__ __noinline__ RegOut region_scan_cert(lds_f *spec3, int SP, int L, lds_i *regs3, int lane, float eps) {
+  float *tmp = (float *)spec3 + kSpArr * SP;
+  float *tE = tmp, *tB = tmp + SP, *tN = tmp + 2 * SP;
+  int *regs = (int *)regs3;
+  const float rt1 = 0.25f, rt2 = 0.10f, rt3 = 0.20f;
+  const float slack = 2e-5f;                // float32 rounding of the sums, on top of eps
+  const float e1 = eps + slack, e2 = 2.0f * eps + slack;
+  int nenv = 0, nreg = 0, flags = 0, doubt = 0, doubt_md = 0;
+  float btot = 0.f, etot = 0.f;
+  int i0 = -1;
+  bool trig = false;
+  const float pb0 = tB[0];
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) { tE[0] = 0.f; tN[0] = 0.f; }
+  for (int j0 = 1; j0 <= L; j0 += kWave) {
+    const int jj = j0 + lane;
+    const bool valid = jj <= L;
+    const float nv = valid ? tN[jj] : 0.f;
+    const float bv = valid ? (jj - 1 == 0 ? pb0 : tB[jj - 1]) : 0.f;
+    const float ev = valid ? tE[jj] : 0.f;
+    float jout = 0.f, cout = 0.f;
+    const int cnt = L - j0 + 1 < kWave ? L - j0 + 1 : kWave;
+    for (int t = 0; t < cnt; t++) {
+      const int j = j0 + t;
+      const float mocc = 1.0f - readlane_f(nv, t);          // true value in [mocc - eps, mocc]
+      const float bold = btot, eold = etot;
+      btot += readlane_f(bv, t);
+      etot += readlane_f(ev, t);
+      if (lane == t) { jout = btot; cout = etot; }
+      if (!trig) {
+        const float d = mocc - (btot - bold);               // true value in [d - 2 eps, d]
+        if (d >= rt2 - slack && d < rt2 + e2) doubt = 1;
+        if (d < rt2) i0 = j;
+        else if (i0 == -1) i0 = j;
+        if (mocc >= rt1 - slack && mocc < rt1 + e1) doubt = 1;
+        if (mocc >= rt1) trig = true;
+      } else {
+        const float d = mocc - (etot - eold);
+        if (d >= rt2 - slack && d < rt2 + e2) doubt = 1;
+        if (d < rt2) {
+          if (nenv < WH_MAX_ENVELOPES) {
+            if (lane == 0) { regs[2 * nenv] = i0; regs[2 * nenv + 1] = j; }
+            nenv++;
+          } else flags |= WH_FLAG_TRUNC;
+          nreg++;
+          i0 = -1;
+          trig = false;
+        }
+      }
+    }
+    if (valid) { tN[jj] = jout; tE[jj] = cout; }
+  }
+  __builtin_amdgcn_wave_barrier();
+  // multidomain test: max_z min(etot[z]-etot[i-1], btot[j]-btot[z-1]) >= rt3; each sum of windowed posteriors over the
+  // region's rows falls short of the true one by at most (rows) x eps
+  int multi_mask = 0;
+  for (int e = 0; e < nenv; e++) {
+    const int ri = regs[2 * e], rj = regs[2 * e + 1];
+    float mx = -1.0f;
+    const float e0 = tE[ri - 1], bj = tN[rj];
+    for (int z = ri + lane; z <= rj; z += kWave) {
+      const float u = tE[z] - e0, v = bj - tN[z - 1];
+      mx = fmaxf(mx, fminf(u, v));
+    }
+    mx = wave_max(mx);
+    const float up = mx + (float)(rj - ri + 1) * eps + slack;
+    if (mx >= rt3) { flags |= WH_FLAG_MULTI; multi_mask |= 1 << e; if (mx < rt3 + slack) doubt_md = 1; }
+    else if (up >= rt3) doubt_md = 1;
+  }
+  RegOut o;
+  o.nenv = nenv; o.nreg = nreg; o.flags = flags | (multi_mask << 8) | (doubt << 24) | (doubt_md << 25);
+  return o;
+}
+
 // ---------------------------------------------------------------- region scan (A.4)
 template <int TH, bool SG>
 __device__ __noinline__ RegOut region_scan(lds_f *spec3, glb_f *specg, int SP, int L, lds_i *regs3, int lane) {
@@ -513,18 +698,20 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
   const int SP = a.SP;
   WaveCtx c;
   c.emL = (lds_f *)emL; c.fwL = (lds_f *)trL; c.bwL = (lds_f *)(trL + NARR * TBL);
-  c.spec = (lds_f *)wbase; c.n2tab = (lds_f *)(wbase + (SG ? 0 : kSpArr * SP));
+  const int spArrAll = kSpArr + (a.p2win ? 3 : 0);          // + the three rows of the windowed P2 (ScoreArgs::p2win)
+  c.spec = (lds_f *)wbase; c.n2tab = (lds_f *)(wbase + (SG ? 0 : spArrAll * SP));
   c.specg = SG ? (glb_f *)(a.spec_scratch + ((size_t)blockIdx.x * nwaves + wave) * a.spec_stride) : nullptr;
   c.degen = 0;
   for (int t = 0; t < 32; t++) if (t == lane) c.degen = a.degen[t];
   c.Fs = (glb_f *)(a.scratch + ((size_t)blockIdx.x * nwaves + wave) * a.scratch_stride);
   c.SP = SP; c.alpha = a.K | (a.Kp << 8) | (a.K << 16); c.lane = lane;
-  int *regs = reinterpret_cast<int *>(wbase + (SG ? 0 : kSpArr * SP) + 32);
+  int *regs = reinterpret_cast<int *>(wbase + (SG ? 0 : spArrAll * SP) + 32);
   uint8_t *seq = reinterpret_cast<uint8_t *>(regs + kRegsInts);
   const double LOG2 = 0.69314718055994529;
   int cur_h = -1;
   const DevHMM *hm = nullptr;
   unsigned n_w256 = 0, n_w512 = 0, n_wfail = 0, n_full = 0;   // this wave's envelope Backward sweeps by path (wh_last_score_paths)
+  unsigned n_p2w = 0, n_p2rej = 0;                            // multihit Backward sweeps kept from a window / windows in doubt (redone at full width)
 
   for (;;) {
     if (threadIdx.x == 0) *s_item_p = atomicAdd(a.counter, 1);
@@ -581,10 +768,41 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
         if (dp) dp->fwd_bits = fwd_bits_out;
         if (f1.xC > 0.f && isfinite(fwdsc)) {
           WH_TICK7(4);
-          // ---------------- P2 + region scan
-          sweep_backward_decode<Q, TH, SG>(c, (lds_u8 *)seq, L, cm, 1.0f / (f1.xC * cm.move), f1.ef);
-          WH_TICK7(5);
-          const RegOut ro = region_scan<TH, SG>(c.spec, c.specg, SP, L, (lds_i *)regs, lane);
+          // ---------------- P2 + region scan: on a node window when every decision of the scan is then beyond doubt
+          RegOut ro;
+          bool have_ro = false;
+          if constexpr (Q >= 8 && !SG) {
+            if (a.p2win && !a.no_window) {
+              const unsigned *su = reinterpret_cast<const unsigned *>((const float *)c.n2tab) + kUmSlot;
+              const unsigned long long um = ((unsigned long long)su[1] << 32) | su[0];
+              if (um != 0) {
+                int lo = __builtin_ctzll(um), hi = 63 - __builtin_clzll(um);
+                lo = lo > 1 ? lo - 2 : 0; hi = hi < 63 ? hi + 1 : 63;
+                const int nodes = (hi - lo + 1) * Q;
+                WinDec wd;
+                wd.eps = 1.0f;
+                if (nodes <= 4 * kWave) wd = sweep_backward_decode_win<4, Q, TH>(c, (lds_u8 *)seq, L, cm, 1.0f / (f1.xC * cm.move), f1.ef, min((63 - hi) * Q, kWave * (Q - 4)));
+                else if (Q % 8 == 0 && Q > 8 && nodes <= 8 * kWave) wd = sweep_backward_decode_win<(Q % 8 == 0 ? 8 : 4), Q, TH>(c, (lds_u8 *)seq, L, cm, 1.0f / (f1.xC * cm.move), f1.ef, min((63 - hi) * Q, kWave * (Q - 8)));
+                if (wd.eps > -1e-4f && wd.eps < 0.01f) {
+                  ro = region_scan_cert<TH>(c.spec, SP, L, (lds_i *)regs, lane, fmaxf(wd.eps, 0.f));
+                  have_ro = ((ro.flags >> 24) & 3) == 0;
+                  if (a.stats && lane == 0) {
+                    if ((ro.flags >> 24) & 1) atomicAdd(a.stats + 32, 1ull);
+                    if ((ro.flags >> 25) & 1) atomicAdd(a.stats + 33, 1ull);
+                    atomicAdd(a.stats + 34, (unsigned long long)(wd.eps * 1e9f));
+                    atomicAdd(a.stats + 35, 1ull);
+                  }
+                  ro.flags &= 0xFFFFFF;
+                } else if (a.stats && lane == 0) atomicAdd(a.stats + 36, 1ull);
+                if (have_ro) n_p2w++; else n_p2rej++;
+              }
+            }
+          }
+          if (!have_ro) {
+            sweep_backward_decode<Q, TH, SG>(c, (lds_u8 *)seq, L, cm, 1.0f / (f1.xC * cm.move), f1.ef);
+            WH_TICK7(5);
+            ro = region_scan<TH, SG>(c.spec, c.specg, SP, L, (lds_i *)regs, lane);
+          } else WH_TICK7(5);
           const int nenv = ro.nenv, nreg = ro.nreg, multi_mask = ro.flags >> 8;
           flags |= ro.flags & 0xFF;
           if (dp) { dp->nregions = nreg; dp->nenv = nenv; }
@@ -710,6 +928,8 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
     if (n_w512) atomicAdd(a.paths + 1, (unsigned long long)n_w512);
     if (n_wfail) atomicAdd(a.paths + 2, (unsigned long long)n_wfail);
     if (n_full) atomicAdd(a.paths + 3, (unsigned long long)n_full);
+    if (n_p2w) atomicAdd(a.paths + 4, (unsigned long long)n_p2w);
+    if (n_p2rej) atomicAdd(a.paths + 5, (unsigned long long)n_p2rej);
   }
 }
 

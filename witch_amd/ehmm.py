@@ -111,11 +111,12 @@ class EHMM:
 
     # ------------------------------------------------------------------ host (numpy) operators
     def last_score_paths(self):
-        """Envelope Backward sweeps of the last score call by path: {"window256", "window512", "window_rejected",
-        "full_width"} (include/witch_hip.h: wh_last_score_paths)."""
-        p4 = np.zeros(4, dtype=np.int64)
-        check(lib().wh_last_score_paths(self._h, p4.ctypes.data), "wh_last_score_paths")
-        return {"window256": int(p4[0]), "window512": int(p4[1]), "window_rejected": int(p4[2]), "full_width": int(p4[3])}
+        """Backward sweeps of the last score call by path: envelope sweeps {"window256", "window512", "window_rejected",
+        "full_width"}, multihit sweeps {"p2_window", "p2_window_in_doubt"} (include/witch_hip.h: wh_last_score_paths)."""
+        p6 = np.zeros(6, dtype=np.int64)
+        check(lib().wh_last_score_paths(self._h, p6.ctypes.data), "wh_last_score_paths")
+        return {"window256": int(p6[0]), "window512": int(p6[1]), "window_rejected": int(p6[2]), "full_width": int(p6[3]),
+                "p2_window": int(p6[4]), "p2_window_in_doubt": int(p6[5])}
 
     def last_queue_reruns(self) -> int:
         """Scoring passes the last score call repeated because the resolver's queue overflowed its estimate (0 or 1)."""

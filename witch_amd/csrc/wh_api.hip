@@ -629,7 +629,7 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
         if (rc_plan == WH_OK && waves >= 4 && !kn.force_specg && !kn.no_window && !kn.no_p2win && Q >= 8) {
           int w2 = 0, sp2 = 0, wl2 = 0;
           size_t lds2 = 0;
-          if (plan_block1(e, Q, e->K, Lc, 12, &w2, &sp2, &wl2, &lds2, 3) == WH_OK && w2 >= waves) { p2win = true; waves = w2; SP = sp2; wave_lds = wl2; lds = lds2; }
+          if (plan_block1(e, Q, e->K, Lc, 12, &w2, &sp2, &wl2, &lds2, 3) == WH_OK && (w2 >= waves || (getenv("WH_P2WIN_FORCE") && w2 >= 8))) { p2win = true; waves = w2; SP = sp2; wave_lds = wl2; lds = lds2; }
         }
         if (rc_plan != WH_OK || waves < 4 || kn.force_specg) {
           specg = true;

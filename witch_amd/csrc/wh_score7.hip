@@ -712,6 +712,8 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
   const DevHMM *hm = nullptr;
   unsigned n_w256 = 0, n_w512 = 0, n_wfail = 0, n_full = 0;   // this wave's envelope Backward sweeps by path (wh_last_score_paths)
   unsigned n_p2w = 0, n_p2rej = 0;                            // multihit Backward sweeps kept from a window / windows in doubt (redone at full width)
+  float eps_prev = 0.f, eps_prev2 = 0.f;                      // slack of the last two windows tried on the current model
+  unsigned n_pairs_h = 0;                                     // pairs of the current model this wave has scored
 
   for (;;) {
     if (threadIdx.x == 0) *s_item_p = atomicAdd(a.counter, 1);
@@ -732,6 +734,7 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
       float4 *d1 = reinterpret_cast<float4 *>(trL);
       for (int t = threadIdx.x; t < NARR * TBL / 4; t += blockDim.x) { d1[t] = s1[t]; d1[NARR * TBL / 4 + t] = s2[t]; }
       cur_h = h;
+      eps_prev = 0.f; eps_prev2 = 0.f; n_pairs_h = 0;
       __syncthreads();
     }
     c.emG = (const glb_f *)(a.tables + hm->em_off);
@@ -772,7 +775,13 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
           RegOut ro;
           bool have_ro = false;
           if constexpr (Q >= 8 && !SG) {
-            if (a.p2win && !a.no_window) {
+            // (the slack of a window is mostly the model's: a junk mini-domain costs what its weakest nodes allow.  Rows x
+            // slack must stay below the 0.20 of the multidomain test for a single-domain region to be certified, so a wave
+            // that has measured a slack too large for this query length TWICE in a row skips the window on the model's next
+            // pairs and probes again every sixteenth)
+            const bool try_win = fminf(eps_prev, eps_prev2) * (float)L < 0.17f || (n_pairs_h & 15) == 0;
+            n_pairs_h++;
+            if (a.p2win && !a.no_window && try_win) {
               const unsigned *su = reinterpret_cast<const unsigned *>((const float *)c.n2tab) + kUmSlot;
               const unsigned long long um = ((unsigned long long)su[1] << 32) | su[0];
               if (um != 0) {
@@ -783,6 +792,7 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
                 wd.eps = 1.0f;
                 if (nodes <= 4 * kWave) wd = sweep_backward_decode_win<4, Q, TH>(c, (lds_u8 *)seq, L, cm, 1.0f / (f1.xC * cm.move), f1.ef, min((63 - hi) * Q, kWave * (Q - 4)));
                 else if (Q % 8 == 0 && Q > 8 && nodes <= 8 * kWave) wd = sweep_backward_decode_win<(Q % 8 == 0 ? 8 : 4), Q, TH>(c, (lds_u8 *)seq, L, cm, 1.0f / (f1.xC * cm.move), f1.ef, min((63 - hi) * Q, kWave * (Q - 8)));
+                eps_prev2 = eps_prev; eps_prev = fabsf(wd.eps);
                 if (wd.eps > -1e-4f && wd.eps < 0.01f) {
                   ro = region_scan_cert<TH>(c.spec, SP, L, (lds_i *)regs, lane, fmaxf(wd.eps, 0.f));
                   have_ro = ((ro.flags >> 24) & 3) == 0;

@@ -58,7 +58,7 @@ extern "C" {
 #define WH_FLAG_TRUNC     8   /* more envelopes than WH_MAX_ENVELOPES; extra ones dropped */
 #define WH_FLAG_EXACT    16   /* an envelope failed the sparse-spill certificate and was redone dense */
 
-#define WH_MAX_ENVELOPES 8
+#define WH_MAX_ENVELOPES 16
 
 typedef struct wh_ehmm wh_ehmm;
 

@@ -856,6 +856,43 @@ def test_multihit_backward_on_a_node_window_gives_the_full_width_regions(tmp_pat
         e.close()
 
 
+def test_queries_with_more_than_eight_regions_lose_none(orc, tmp_path):
+    """HMMER has no limit on the domains of a sequence; this library keeps up to 16 regions per pair (as does the oracle)
+    and flags what it drops (WH_FLAG_TRUNC).  Queries of ten to fourteen copies of a family fragment, random sequence
+    between them: every region is found and scored, nothing is flagged, scores and envelopes equal the oracle's - on a
+    small model (one-query kernel) and through the pass-synchronous kernel (1 900 nodes)."""
+    _need_gpu()
+    from witch_amd import synth
+    from witch_amd.ehmm import EHMM, pack_queries
+    rng = np.random.default_rng(77)
+    for root_len in (180, 1900):
+        fam = synth.make_family(3100 + root_len, root_len, 16, "dna", 0.03, 1e-4)
+        eh = synth.make_ehmm(fam, 2, str(tmp_path / str(root_len)), witch_layout=False)
+        e = EHMM(eh.paths, hmm_index=eh.index, nseq=eh.nseq)
+        _, frags = synth.make_queries(fam, 5, 14, 60)
+        seqs = []
+        for copies in (10, 12, 14):
+            parts = []
+            for c in range(copies):
+                parts.append(frags[c % len(frags)].astype(np.uint8))
+                parts.append(rng.integers(0, 4, size=int(rng.integers(25, 40))).astype(np.uint8))
+            seqs.append(np.concatenate(parts))
+        res, offs = pack_queries(seqs)
+        deci, flags, det = e.score(res, offs, want_detail=True)
+        ohm = [orc.OracleHMM(p) for p in eh.paths]
+        od, of, ofwd, osc = orc.score_batch(ohm, res, offs)
+        assert (flags & 8).sum() == 0, "an envelope was dropped"
+        assert max(d.nregions for d in det) > 8, [d.nregions for d in det]       # the case this test is about
+        assert np.array_equal(flags & 3, of & 3)
+        _check_decibits(deci, od, osc, (of & 1) == 1, ("many regions", root_len), LONG_EPS)
+        for q in range(len(seqs)):
+            for h in range(e.H):
+                r = ohm[h].score(seqs[q])
+                d = det[q * e.H + h]
+                assert d.nregions == r.nregions, (root_len, q, h, d.nregions, r.nregions)
+        e.close()
+
+
 def test_two_queries_per_wave_kernel_equals_the_one_query_kernel(tmp_path):
     """wh_score9.hip (two queries of one model per wavefront, option WH_SCORE_KERNEL=9) does per query what the
     one-query sweeps do, operation by operation: scores, flags and Forward log-odds are identical BITWISE - on

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwitch_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
-WH_MAX_ENVELOPES = 8
+WH_MAX_ENVELOPES = 16
 FLAG_REPORTED, FLAG_MULTI, FLAG_OVERRIDE, FLAG_TRUNC, FLAG_EXACT = 1, 2, 4, 8, 16
 ALPH_DNA, ALPH_RNA, ALPH_AMINO = 0, 1, 2
 

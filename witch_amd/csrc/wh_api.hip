@@ -869,8 +869,8 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
       for (auto &kv : e->by_q) if (kv.first <= 16 && (kv.first == 4 || kv.first == 8 || kv.first == 12 || kv.first == 16)) Qt = std::max(Qt, kv.first);
       const bool small_queue = n_multi < 64 * e->cu_count;        // fewer than eight pairs per wave (see below)
       if (getenv("WH_RES_NO_LDS_TABLES") || small_queue) Qt = 0;
-      int waves = std::min<int>(resolve_waves_per_cu(), 8);
-      if (const char *wv = getenv("WH_RES_WAVES")) waves = std::max(1, std::min(8, atoi(wv)));      // experiments: waves per workgroup (= per CU)
+      int waves = resolve_waves_per_cu();
+      if (const char *wv = getenv("WH_RES_WAVES")) waves = std::max(1, std::min(resolve_waves_per_cu(), atoi(wv)));      // experiments: waves per workgroup (= per CU)
       if (Qt > 0 && resolve_lds_header_bytes(Qt) + (size_t)waves * rlds > kLdsBudget) {
         // fewer waves WITH the tables only while at least six fit; otherwise the tables stay in L2
         int w2 = waves;

@@ -113,7 +113,7 @@ size_t resolve_tail_row_doubles() { return kTailRow; }
 size_t resolve_dcache_doubles() { return (size_t)129 * (1 << kDcBits); }
 typedef unsigned u4_t __attribute__((ext_vector_type(4)));
 int resolve_waves_per_cu() { return 4 * WH_RES_OCC; }
-constexpr int kResMaxWaves = 8;       // waves per workgroup the kernel is compiled for (512 threads, 256 registers)
+constexpr int kResMaxWaves = 4 * WH_RES_OCC;       // waves per workgroup the kernel is compiled for (512 threads, 256 registers at WH_RES_OCC = 2)
 
 #define RTICK(slot) do { if (a.stats) { const long long t_now = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(a.stats + (slot), (unsigned long long)(t_now - tk0)); tk0 = t_now; } } while (0)
 

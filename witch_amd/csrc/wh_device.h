@@ -59,6 +59,29 @@ __device__ __forceinline__ float wave_max(float x) {
   return fmaxf(fmaxf(readlane_f(x, 0), readlane_f(x, 16)), fmaxf(readlane_f(x, 32), readlane_f(x, 48)));
 }
 
+// ------------------------------------------------------------------ per-row arrays in HBM, walked downwards
+// The sweeps of long queries keep their per-row special states in a per-wave HBM region (SG sweeps).  Read one value
+// at a time, every row paid a dependent HBM round trip per array; here 64 rows of each array arrive with ONE coalesced
+// load (lane t holds row top - t, shifted by the array's <shift>) and a row's value is a v_readlane into a scalar
+// register.  <off[n]> is the float offset of array n's row 0, <shift[n]> is 0 or -1 (the sweep reads row i - 1).
+template <int N>
+struct RowsDown {
+  unsigned v[N];
+  int top;
+  __device__ __forceinline__ void load(const float *spec, const int (&off)[N], const int (&shift)[N], int i, int lane) {
+    top = i;
+#pragma unroll
+    for (int n = 0; n < N; n++) {
+      const int r = i - lane + shift[n];
+      v[n] = r >= 0 ? __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(spec) + off[n] + r) : 0u;
+    }
+  }
+  __device__ __forceinline__ bool spent(int i) const { return top - i >= kWave; }
+  __device__ __forceinline__ unsigned u(int n, int i) const { return (unsigned)__builtin_amdgcn_readlane((int)v[n], top - i); }
+  __device__ __forceinline__ int s(int n, int i) const { return __builtin_amdgcn_readlane((int)v[n], top - i); }
+  __device__ __forceinline__ float f(int n, int i) const { return __builtin_bit_cast(float, __builtin_amdgcn_readlane((int)v[n], top - i)); }
+};
+
 // ------------------------------------------------------------------ affine prefix scan
 // Inclusive scan over lanes of maps D -> A_r * D + B_r.  The A-part is model-only, so the
 // six per-step multipliers are computed once (scan_prepare) and each row costs 6 x (DPP + FMA).

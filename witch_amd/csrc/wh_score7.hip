@@ -127,9 +127,24 @@ __device__ __noinline__ void sweep_backward_decode(const WaveCtx c, lds_u8 *seq3
   for (int p = 0; p < Q; p++) { Mb[p] = 0.f; Ib[p] = 0.f; }
   float xC = cm.move, xJ = 0.f, xN = 0.f, xB = 0.f;
   int eb = 0;
+  // long-query mode: the Forward rows are read 64 at a time (RowsDown), the posteriors leave 64 at a time
+  RowsDown<7> R;
+  const int r_off[7] = {SP_S * SP, SP_S * SP, SP_E * SP, SP_B * SP, SP_N * SP, SP_J * SP, SP_C * SP};
+  const int r_sh[7] = {0, -1, 0, 0, -1, -1, -1};
+  float wE = 0.f, wB = 0.f, wN = 0.f;
+  auto flush = [&](int lo) {                   // rows R.top - lane down to <lo>
+    const int r = R.top - lane;
+    if (r >= lo) {
+      __builtin_nontemporal_store(wE, spec + SP_E * SP + r);
+      __builtin_nontemporal_store(wB, spec + SP_B * SP + r);
+      __builtin_nontemporal_store(wN, spec + SP_N * SP + r);
+    }
+  };
+  if (SG) R.load(spec, r_off, r_sh, L, lane);
 #pragma unroll 1
   for (int i = L; i >= 0; i--) {
     asm volatile("" ::: "memory");
+    if (SG && R.spent(i)) { flush(i + 1); R.load(spec, r_off, r_sh, i, lane); }
     if (i < L) {
       xB = wave_sum(backward_emit<Q, false>(T, emL, (const float *)c.emG, seq[i], ctxKlds(c), lane, Mb));
       xJ = fmaf(xJ, cm.loop, xB * cm.move);
@@ -147,22 +162,26 @@ __device__ __noinline__ void sweep_backward_decode(const WaveCtx c, lds_u8 *seq3
       xB *= r; xJ *= r; xC *= r; xN *= r; xE *= r;
       eb += e;
     }
-    const float s_i = ldexpf(invZ, ldi(SP_S * SP + i) + eb - ef_L);
-    const float pe = ldf(SP_E * SP + i) * xE * s_i;
-    const float pb = ldf(SP_B * SP + i) * xB * s_i;
+    const float s_i = ldexpf(invZ, (SG ? R.s(0, i) : ldi(SP_S * SP + i)) + eb - ef_L);
+    const float pe = (SG ? R.f(2, i) : ldf(SP_E * SP + i)) * xE * s_i;
+    const float pb = (SG ? R.f(3, i) : ldf(SP_B * SP + i)) * xB * s_i;
     float njc = 0.f;
     if (i >= 1) {
-      const float s_p = ldexpf(invZ, ldi(SP_S * SP + i - 1) + eb - ef_L);
-      njc = ldf(SP_N * SP + i - 1) * xN;
-      njc = fmaf(ldf(SP_J * SP + i - 1), xJ, njc);
-      njc = fmaf(ldf(SP_C * SP + i - 1), xC, njc);
+      const float s_p = ldexpf(invZ, (SG ? R.s(1, i) : ldi(SP_S * SP + i - 1)) + eb - ef_L);
+      njc = (SG ? R.f(4, i) : ldf(SP_N * SP + i - 1)) * xN;
+      njc = fmaf(SG ? R.f(5, i) : ldf(SP_J * SP + i - 1), xJ, njc);
+      njc = fmaf(SG ? R.f(6, i) : ldf(SP_C * SP + i - 1), xC, njc);
       njc = njc * cm.loop * s_p;
     }
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0) { spec[SP_E * SP + i] = pe; spec[SP_B * SP + i] = pb; spec[SP_N * SP + i] = njc; }
-    __builtin_amdgcn_wave_barrier();
+    if (SG) {
+      if (lane == R.top - i) { wE = pe; wB = pb; wN = njc; }
+    } else {
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) { spec[SP_E * SP + i] = pe; spec[SP_B * SP + i] = pb; spec[SP_N * SP + i] = njc; }
+      __builtin_amdgcn_wave_barrier();
+    }
   }
-  if (SG) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  if (SG) { flush(0); __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 }
 
 // ---------------------------------------------------------------- P4: unihit Backward + posterior -> null2
@@ -186,15 +205,21 @@ __device__ __noinline__ P4Out sweep_backward_null2(const WaveCtx c, lds_u8 *eseq
   float xC = cu.move, xJ = 0.f, xN = 0.f, xB = 0.f, xfac = 0.f, fIs = 0.f;
   const int src = kWave - 1 - lane;   // the forward-order lane that owns my (reversed) cells
   int S_next = 0;                     // S(i+1), carried so that every row reads its exponent once
+  RowsDown<7> R;                      // long-query mode: 64 rows of the per-row arrays per coalesced load
+  const int r_off[7] = {kSpML * SP, kSpMH * SP, SP_S * SP, SP_S * SP, SP_N * SP, SP_J * SP, SP_C * SP};
+  const int r_sh[7] = {0, 0, 0, -1, -1, -1, -1};
+  if (SG) R.load(spec, r_off, r_sh, Ld, lane);
 #pragma unroll 1
   for (int i = Ld; i >= 1; i--) {
     asm volatile("" ::: "memory");
+    if (SG && R.spent(i)) R.load(spec, r_off, r_sh, i, lane);
+    auto mask_word = [&]() -> unsigned { return SG ? (src < 32 ? R.u(0, i) : R.u(1, i)) : (src < 32 ? ldu(kSpML * SP + i) : ldu(kSpMH * SP + i)); };
     // Forward row i: with three or more waves per SIMD the other waves cover the HBM latency,
     // so the row is requested only after the cell update (TH >= 768; saves 2*Q registers
     // across backward_cells); with two waves it is requested first.
     float4 fm4[Q / 4], fi4[Q / 4];
     auto request_row = [&]() {
-      const unsigned mword = src < 32 ? ldu(kSpML * SP + i) : ldu(kSpMH * SP + i);
+      const unsigned mword = mask_word();
       const bool have = (mword >> (src & 31)) & 1u;
       const float4 *row = reinterpret_cast<const float4 *>((const float *)c.Fs) + (size_t)i * (2 * (Q / 4) * kWave) + src;
       if (have) {
@@ -210,8 +235,8 @@ __device__ __noinline__ P4Out sweep_backward_null2(const WaveCtx c, lds_u8 *eseq
     };
     if (TH < 768) request_row();
     // mirrored scaling (wh_device.h, "envelope Backward scaling")
-    const int S_i = ldi(SP_S * SP + i);
-    const int dS = S_i - ldi(SP_S * SP + i - 1);      // Forward rescale at row i (>= 0)
+    const int S_i = SG ? R.s(2, i) : ldi(SP_S * SP + i);
+    const int dS = S_i - (SG ? R.s(3, i) : ldi(SP_S * SP + i - 1));      // Forward rescale at row i (>= 0)
     if (i < Ld) {
       mirror_scale<Q>(S_next - S_i, Mb, Ib, xJ, xC, xN);
       xB = wave_sum(backward_emit<Q, false>(T, emL, (const float *)c.emG, eseq[i], ctxKlds(c), lane, Mb));
@@ -227,7 +252,7 @@ __device__ __noinline__ P4Out sweep_backward_null2(const WaveCtx c, lds_u8 *eseq
     if (TH >= 768 && kMaskedAcc) {
       // only the lanes that own a stored block run the accumulation (the others would add zeros)
       asm volatile("" ::: "memory");
-      const unsigned mword = src < 32 ? ldu(kSpML * SP + i) : ldu(kSpMH * SP + i);
+      const unsigned mword = mask_word();
       if ((mword >> (src & 31)) & 1u) {
         const float4 *row = reinterpret_cast<const float4 *>((const float *)c.Fs) + (size_t)i * (2 * (Q / 4) * kWave) + src;
         float idot = 0.f;
@@ -259,9 +284,9 @@ __device__ __noinline__ P4Out sweep_backward_null2(const WaveCtx c, lds_u8 *eseq
       }
       fIs = fmaf(idot, s_i, fIs);
     }
-    float nj = ldf(SP_N * SP + i - 1) * xN;
-    nj = fmaf(ldf(SP_J * SP + i - 1), xJ, nj);
-    nj = fmaf(ldf(SP_C * SP + i - 1), xC, nj);
+    float nj = (SG ? R.f(4, i) : ldf(SP_N * SP + i - 1)) * xN;
+    nj = fmaf(SG ? R.f(5, i) : ldf(SP_J * SP + i - 1), xJ, nj);
+    nj = fmaf(SG ? R.f(6, i) : ldf(SP_C * SP + i - 1), xC, nj);
     S_next = S_i;
     xfac = fmaf(nj * cu.loop, s_p, xfac);
   }
@@ -355,8 +380,15 @@ __device__ __noinline__ P4Out sweep_backward_null2_win(const WaveCtx c, lds_u8 *
   // width), so their HBM round trip runs beside a whole row of arithmetic
   float4 fm_n[B4], fi_n[B4];
   bool have_n = false;
-  auto request_row = [&](int r) {
-    const unsigned mword = lanef < 32 ? ldu(kSpML * SP + r) : ldu(kSpMH * SP + r);
+  // long-query mode: 64 rows of the per-row arrays per coalesced load; the masks are read a row ahead, so their
+  // chunk is reloaded one row early (arrays 0 / 1 hold rows top - 1 - t)
+  RowsDown<7> R;
+  const int r_off[7] = {kSpML * SP, kSpMH * SP, SP_S * SP, SP_S * SP, SP_N * SP, SP_J * SP, SP_C * SP};
+  const int r_sh[7] = {-1, -1, 0, -1, -1, -1, -1};
+  if (SG) R.load(spec, r_off, r_sh, Ld, lane);
+  auto request_row = [&](int r, bool first) {
+    const unsigned mword = SG ? (first ? (lanef < 32 ? ldu(kSpML * SP + r) : ldu(kSpMH * SP + r)) : (lanef < 32 ? R.u(0, r + 1) : R.u(1, r + 1)))
+                              : (lanef < 32 ? ldu(kSpML * SP + r) : ldu(kSpMH * SP + r));
     have_n = (mword >> (lanef & 31)) & 1u;
     if (have_n) {
       const float4 *row = reinterpret_cast<const float4 *>((const float *)c.Fs) + (size_t)r * (2 * Q4 * kWave);
@@ -364,17 +396,18 @@ __device__ __noinline__ P4Out sweep_backward_null2_win(const WaveCtx c, lds_u8 *
       for (int p4 = 0; p4 < B4; p4++) { fm_n[p4] = nt_load4(row + fwd[p4]); fi_n[p4] = nt_load4(row + Q4 * kWave + fwd[p4]); }
     }
   };
-  request_row(Ld);
+  request_row(Ld, true);
 #pragma unroll 1
   for (int i = Ld; i >= 1; i--) {
     asm volatile("" ::: "memory");
+    if (SG && R.spent(i)) R.load(spec, r_off, r_sh, i, lane);
     float4 fm_c[B4], fi_c[B4];
 #pragma unroll
     for (int p4 = 0; p4 < B4; p4++) { fm_c[p4] = fm_n[p4]; fi_c[p4] = fi_n[p4]; }
     const bool have = have_n;
-    if (i > 1) request_row(i - 1);
-    const int S_i = ldi(SP_S * SP + i);
-    const int dS = S_i - ldi(SP_S * SP + i - 1);
+    if (i > 1) request_row(i - 1, false);
+    const int S_i = SG ? R.s(2, i) : ldi(SP_S * SP + i);
+    const int dS = S_i - (SG ? R.s(3, i) : ldi(SP_S * SP + i - 1));
     if (i < Ld) {
       mirror_scale<QB>(S_next - S_i, Mb, Ib, xJ, xC, xN);
       const int x = __builtin_amdgcn_readfirstlane((int)eseq[i]);
@@ -418,9 +451,9 @@ __device__ __noinline__ P4Out sweep_backward_null2_win(const WaveCtx c, lds_u8 *
       }
       fIs = fmaf(idot, s_i, fIs);
     }
-    float nj = ldf(SP_N * SP + i - 1) * xN;
-    nj = fmaf(ldf(SP_J * SP + i - 1), xJ, nj);
-    nj = fmaf(ldf(SP_C * SP + i - 1), xC, nj);
+    float nj = (SG ? R.f(4, i) : ldf(SP_N * SP + i - 1)) * xN;
+    nj = fmaf(SG ? R.f(5, i) : ldf(SP_J * SP + i - 1), xJ, nj);
+    nj = fmaf(SG ? R.f(6, i) : ldf(SP_C * SP + i - 1), xC, nj);
     S_next = S_i;
     xfac = fmaf(nj * cu.loop, s_p, xfac);
   }

@@ -86,8 +86,8 @@ struct wh_ehmm {
   std::map<int, std::vector<int32_t>> by_q;   // Q class -> model positions
   std::vector<int32_t> generic;               // models beyond the register-resident classes (wh_generic.hip)
   std::vector<int32_t> generic_front;         // ... of them, those SCORED by the float64 front end (the others: wide_by_w)
-  std::map<int, std::vector<int32_t>> wide_by_w;   // waves per pair -> models scored by wh_score_wide.hip (3 073 - 12 288 nodes)
-  int wide_q = 0;                             // cells per lane of the wide tables (kWideQ; 4 with WH_FORCE_WIDE=4: tests)
+  std::map<int, std::vector<int32_t>> wide_by_w;   // cells per lane * 16 + waves per pair -> models scored by wh_score_wide.hip (3 073 - 12 288 nodes)
+  int force_wide_q = 0;                       // WH_FORCE_WIDE=<4|12|24>: cells per lane of every model's wide tables (tests)
   bool force_wide = false;                    // WH_FORCE_WIDE: EVERY model is scored by the wide kernel (test hook)
   DevBuf d_wscratch;                          // Forward slabs of the wide kernel's workgroups
   DevBuf d_hmms, d_tables, d_nseq, d_index, d_lists, d_counter, d_scratch;
@@ -197,10 +197,11 @@ wh_ehmm *wh_ehmm_load(const char *const *hmm_paths, const int32_t *hmm_index, co
   // WH_FORCE_WIDE=<4|24>: every model that fits 8 waves of that many cells per lane ALSO gets wide tables and is scored by the
   // several-waves-per-pair kernel (tests run the golden cases through it; production: models beyond 3 072 nodes only)
   const int force_wide_q = getenv("WH_FORCE_WIDE") ? atoi(getenv("WH_FORCE_WIDE")) : 0;
-  e->force_wide = force_wide_q == 4 || force_wide_q == kWideQ;
-  e->wide_q = e->force_wide ? force_wide_q : kWideQ;
-  const int wide_q = e->wide_q;
+  e->force_wide = force_wide_q == 4 || force_wide_q == kWideQ || force_wide_q == kWideQReg;
+  e->force_wide_q = e->force_wide ? force_wide_q : 0;
   const bool force_wide = e->force_wide;
+  // cells per lane of a model's wide tables: 12 (transition tables in registers) up to 6 144 nodes, 24 beyond
+  auto wide_q_of = [force_wide, force_wide_q](int M) { return force_wide ? force_wide_q : (M <= kWideQReg * kWave * kWideWavesMax ? kWideQReg : kWideQ); };
   std::vector<Built> built((size_t)n);
   {
     std::atomic<int> next{0};
@@ -217,6 +218,7 @@ wh_ehmm *wh_ehmm_load(const char *const *hmm_paths, const int32_t *hmm_index, co
         if (b.Q < 0) continue;
         if (b.Q <= kMaxQ) build_tables(h, b.Q, b.fw, b.bw, b.em);     // (the any-size kernels read the float64 tables only)
         if (b.Q > kMaxQ || force_wide) {
+          const int wide_q = wide_q_of(h.M);
           const int ww = (h.M + kWave * wide_q - 1) / (kWave * wide_q);
           if (ww <= kWideWavesMax) { b.wideW = ww; build_tables(h, wide_q, b.wfw, b.wbw, b.wem, ww * kWave); }
         }
@@ -260,11 +262,11 @@ wh_ehmm *wh_ehmm_load(const char *const *hmm_paths, const int32_t *hmm_index, co
     d.wideQ = 0; d.wideW = 0;
     if (b.wideW > 0) {
       tables.resize((tables.size() + 3) / 4 * 4, 0.f);
-      d.wideQ = wide_q; d.wideW = b.wideW;
+      d.wideQ = wide_q_of(h.M); d.wideW = b.wideW;
       d.wfw_off = (int64_t)tables.size(); tables.insert(tables.end(), b.wfw.begin(), b.wfw.end());
       d.wbw_off = (int64_t)tables.size(); tables.insert(tables.end(), b.wbw.begin(), b.wbw.end());
       d.wem_off = (int64_t)tables.size(); tables.insert(tables.end(), b.wem.begin(), b.wem.end());
-      e->wide_by_w[b.wideW].push_back(i);
+      e->wide_by_w[d.wideQ * 16 + b.wideW].push_back(i);
     }
     d.gfw_off = (int64_t)gtab.size(); gtab.insert(gtab.end(), b.gfw.begin(), b.gfw.end());
     d.gem_off = (int64_t)gtab.size(); gtab.insert(gtab.end(), b.gem.begin(), b.gem.end());
@@ -726,29 +728,36 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
     // ---- models of 3 073 - 12 288 nodes: several wavefronts per pair, float32 (wh_score_wide.hip); one launch per
     // waves-per-pair class.  A query batch too long for the kernel's LDS block falls back to the float64 front end below.
     const int Lc = std::max(max_len, 1);
-    const size_t wlds = wide_lds_bytes(Lc);
+    const size_t wlds0 = wide_lds_bytes(Lc);
     const int64_t npairs_all = nq * (int64_t)e->hmms.size();
     const bool resolve = !e->knobs.no_resolve && resolve_lds_bytes(Lc, e->max_M) <= kLdsBudget && npairs_all < 0x7FFFFFFF;
-    if (wlds <= kLdsBudget) {
+    if (wlds0 <= kLdsBudget) {
       size_t woff = 0;            // (the queue of the resolver was sized and reset with the one-wave launches above)
       for (auto &kv : e->by_q) woff += kv.second.size();
       woff += e->generic_front.size();
+      int wclass = 0;
       for (auto &kv : e->wide_by_w) {
-        const int W = kv.first;
+        const int W = kv.first & 15, wq = kv.first >> 4;
+        // 12-cell classes: the emission rows of the canonical residues go to LDS where they fit behind the block
+        const size_t em_floats = (size_t)e->K * wq * W * kWave;
+        const bool em_lds = wq == kWideQReg && !getenv("WH_WIDE_NO_EM_LDS") && wide_lds_bytes(Lc, em_floats) <= kLdsBudget;
+        const size_t wlds = em_lds ? wide_lds_bytes(Lc, em_floats) : wlds0;
         WideArgs a;
         memset(&a, 0, sizeof a);
         a.hmms = (const DevHMM *)e->d_hmms.p; a.tables = (const float *)e->d_tables.p;
         a.hmm_list = (const int32_t *)e->d_lists.p + woff; a.n_list = (int)kv.second.size();
         woff += kv.second.size();
         a.residues = d_residues; a.offsets = d_offsets; a.nq = nq;
-        a.counter = (int *)e->d_counter.p + 68 + W;
+        if (wclass > 8) { set_error("too many classes of long models"); return WH_ERANGE; }
+        a.counter = (int *)e->d_counter.p + 68 + wclass++;
+        a.em_lds = em_lds ? 1 : 0;
         a.Lcap = Lc; a.SP = (Lc + 1 + 3) / 4 * 4;
         a.decibits = d_decibits; a.flags = d_flags; a.fwd_bits = d_fwd_bits; a.detail = d_detail;
         a.H = (int)e->hmms.size(); a.K = e->K; a.Kp = e->Kp;
         memcpy(a.degen, e->degen, sizeof a.degen);
         if (resolve) { a.rrecs = (ResolveRec *)e->d_rrecs.p; a.rcount = (int *)e->d_counter.p + 64; a.rcap = (int)e->rq_cap; }
         a.qorder = qorder_all;
-        a.scratch_stride = (size_t)(Lc + 1) * 2 * e->wide_q * W * kWave;
+        a.scratch_stride = (size_t)(Lc + 1) * 2 * wq * W * kWave;
         const int64_t n_items = nq * (int64_t)a.n_list;
         const int per_cu = (W <= 4 && 2 * wlds <= kLdsBudget) ? 2 : 1;
         int blocks = (int)std::min<int64_t>(n_items, (int64_t)e->cu_count * per_cu);
@@ -757,14 +766,14 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
         a.scratch = (float *)e->d_wscratch.p;
         HIPCHK(hipMemsetAsync(a.counter, 0, sizeof(int), s));
         if (e->knobs.trace) fprintf(stderr, "[wh] wide scoring: %lld pairs on %d models, %d waves per pair x %d cells per lane, %d workgroups, lds %zu, slab %zu MB per workgroup\n",
-                                    (long long)n_items, a.n_list, W, e->wide_q, blocks, wlds, a.scratch_stride * 4 >> 20);
-        if (class_mark(e, s, e->wide_q * W, 3)) return WH_EHIP;
-        hipError_t werr = launch_score_wide(e->wide_q, a, blocks, W, wlds, s);
+                                    (long long)n_items, a.n_list, W, wq, blocks, wlds, a.scratch_stride * 4 >> 20);
+        if (class_mark(e, s, wq * W, 3)) return WH_EHIP;
+        hipError_t werr = launch_score_wide(wq, a, blocks, W, wlds, s);
         if (werr != hipSuccess) { set_error("wide score kernel launch failed: %s", hipGetErrorString(werr)); return WH_EHIP; }
         launches++;
       }
     }
-    wide_done = wlds <= kLdsBudget;
+    wide_done = wlds0 <= kLdsBudget;
     if (!wide_done && e->force_wide) { set_error("WH_FORCE_WIDE: query length %d does not fit the wide kernel's LDS block", max_len); return WH_ERANGE; }
   }
   if (nq > 0 && (!e->generic_front.empty() || (!wide_done && !e->wide_by_w.empty() && !e->force_wide))) {
@@ -1346,7 +1355,7 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
     std::map<int, std::vector<int32_t>> witems;
     for (int64_t p = 0; p < npairs; p++) {
       const DevHMM &dm = e->dev[(size_t)ph[(size_t)p]];
-      if (use_wide && dm.wideW > 0 && (dm.Q > kMaxQ || e->force_wide)) witems[dm.wideW].push_back((int32_t)p);
+      if (use_wide && dm.wideW > 0 && (dm.Q > kMaxQ || e->force_wide)) witems[dm.wideQ * 16 + dm.wideW].push_back((int32_t)p);
       else if (dm.Q > kMaxQ) gitems.push_back((int32_t)p);
     }
     if (!witems.empty()) {
@@ -1357,8 +1366,9 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       for (auto &kv : witems) all.insert(all.end(), kv.second.begin(), kv.second.end());
       if (e->d_order.ensure(sizeof(int32_t) * (all.size() + (size_t)npairs))) return WH_ENOMEM;
       HIPCHK(hipMemcpyAsync(e->d_order.p, all.data(), sizeof(int32_t) * all.size(), hipMemcpyHostToDevice, s));
+      int wclass = 0;
       for (auto &kv : witems) {
-        const int W = kv.first;
+        const int W = kv.first & 15, wq = kv.first >> 4;
         WideAlignArgs wa;
         memset(&wa, 0, sizeof wa);
         wa.hmms = (const DevHMM *)e->d_hmms.p; wa.tables = (const float *)e->d_tables.p;
@@ -1367,17 +1377,18 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
         ooff += kv.second.size();
         wa.pair_q = d_pair_q; wa.pair_h = d_pair_h; wa.col_off = d_col_offsets; wa.cols = d_cols;
         wa.status = (int32_t *)e->d_recs.p;
-        wa.counter = (int *)e->d_counter.p + 80 + W;
+        if (wclass > 8) { set_error("too many classes of long models"); return WH_ERANGE; }
+        wa.counter = (int *)e->d_counter.p + 80 + wclass++;
         wa.Lcap = Lc0; wa.SP = (Lc0 + 1 + 3) / 4 * 4;
         wa.K = e->K; wa.Kp = e->Kp;
-        wa.scratch_stride = (size_t)(Lc0 + 1) * 5 * e->wide_q * W * kWave;
+        wa.scratch_stride = (size_t)(Lc0 + 1) * 5 * wq * W * kWave;
         int blocks = (int)std::min<size_t>(kv.second.size(), (size_t)e->cu_count);
         blocks = clamp_blocks(blocks, wa.scratch_stride * sizeof(float), e->d_wscratch);
         if (e->d_wscratch.ensure((size_t)blocks * wa.scratch_stride * sizeof(float))) return WH_ENOMEM;
         wa.scratch = (float *)e->d_wscratch.p;
         HIPCHK(hipMemsetAsync(wa.counter, 0, sizeof(int), s));
         if (e->knobs.trace) fprintf(stderr, "[wh] wide alignment: %zu pairs, %d waves per pair, %d workgroups, lds %zu, slab %zu MB per workgroup\n", kv.second.size(), W, blocks, walds, wa.scratch_stride * 4 >> 20);
-        hipError_t werr = launch_align_wide(e->wide_q, wa, blocks, W, walds, s);
+        hipError_t werr = launch_align_wide(wq, wa, blocks, W, walds, s);
         if (werr != hipSuccess) { set_error("wide alignment kernel launch failed: %s", hipGetErrorString(werr)); return WH_EHIP; }
         launches++;
       }

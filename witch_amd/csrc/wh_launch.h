@@ -137,6 +137,7 @@ struct WideArgs {
   int *rcount;
   int rcap;
   const int32_t *qorder;
+  int em_lds;                  // 12-cell kernels: the emission rows of the canonical residues are staged in LDS (behind the block)
 };
 struct WideAlignArgs {
   const DevHMM *hmms;
@@ -158,7 +159,7 @@ struct WideAlignArgs {
 };
 size_t wide_align_lds_bytes(int Lcap);
 hipError_t launch_align_wide(int Q, const WideAlignArgs &a, int blocks, int waves, size_t lds, hipStream_t s);
-size_t wide_lds_bytes(int Lcap);
+size_t wide_lds_bytes(int Lcap, size_t em_floats = 0);
 hipError_t launch_score_wide(int Q, const WideArgs &a, int blocks, int waves, size_t lds, hipStream_t s);
 
 struct GenericArgs {

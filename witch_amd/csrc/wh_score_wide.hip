@@ -25,6 +25,14 @@
 #include "wh_launch.h"
 
 namespace wh {
+
+// floats in front of the LDS emission copy of the TR scoring kernels (= the whole block of the others), 16-byte aligned
+__host__ __device__ inline int wide_em_lds_offset_floats(int Lcap) {
+  const int SP = (Lcap + 1 + 3) / 4 * 4;
+  const int fl = 4 + 6 * SP + 8 * 8 + 32 + kRegsInts + (Lcap + 16 + 3) / 4;
+  return (fl + 3) / 4 * 4;
+}
+
 namespace wide {
 
 // per-wave exchange slot in LDS (floats)
@@ -57,9 +65,11 @@ __device__ __forceinline__ float4 ldt(const gf4 *base, int elem, int nl, unsigne
 }
 __device__ __forceinline__ int opaque_s(int v) { asm volatile("" : "+s"(v)); return v; }
 
+typedef __attribute__((address_space(3))) wv4 lf4;
 template <int NLT>
 struct WCtxT {
   const gf4 *fw, *bw, *em;      // uniform bases of the three table groups: element (arr, q4) of virtual lane vl at [(arr*Q4 + q4) * NL + vl]
+  const lf4 *emL;               // TR kernels: the emission rows of the canonical residues in LDS (same layout), or null
   int vl;
   float *spec;                  // LDS: SP_NARR-2 arrays of SP floats (N, B, E, J, C, S), one pair per workgroup
   float *xch;                   // LDS: W slots of X_N floats
@@ -79,13 +89,30 @@ __device__ __forceinline__ float lane_prefix_product(float a, int lane) {
 }
 
 // ------------------------------------------------------------------------------------------ Forward (P1 / P3)
-template <int Q, bool STORE, int NLT>
+// TR: the eight transition arrays of the sweep live in REGISTERS (8 x Q floats per lane: 12-cell lanes), loaded once per sweep,
+// and the emission rows of the canonical residues are read from LDS - a row then issues no table load at all.  Without TR
+// (24-cell lanes: the tables would need 192 registers) every use is an L2 read.
+template <int Q>
+__device__ __forceinline__ float4 emission_piece(const gf4 *emG, const lf4 *emL, int K, int x, int q4, int nlv, unsigned vl) {
+  constexpr int Q4 = Q / 4;
+  if (emL != nullptr && x < K) { const wv4 v = emL[(unsigned)((x * Q4 + q4) * nlv) + vl]; return make_float4(v.x, v.y, v.z, v.w); }
+  return ldt(emG, x * Q4 + q4, nlv, vl);
+}
+
+template <int Q, bool STORE, int NLT, bool TR = false>
 __device__ __forceinline__ void forward_wide(const WCtxT<NLT> &c, const uint8_t *seq, int L, LenCfg cfg, float &xC_out, int &ef_out) {
   constexpr int Q4 = Q / 4;
   const int lane = c.lane, NL = c.nl(), SP = c.SP, w = c.w;
   float *spec = c.spec, *xch = c.xch;
   int nlv = NL;
-  auto T = [&](int a, int q4) -> float4 { return ldt(c.fw, a * Q4 + q4, nlv, (unsigned)c.vl); };
+  float4 tf[TR ? FW_NARR : 1][TR ? Q4 : 1];
+  if (TR) {
+#pragma unroll
+    for (int a = 0; a < FW_NARR; a++)
+#pragma unroll
+      for (int q4 = 0; q4 < Q4; q4++) tf[TR ? a : 0][TR ? q4 : 0] = ldg4(c.fw, (unsigned)((a * Q4 + q4) * NL + c.vl));
+  }
+  auto T = [&](int a, int q4) -> float4 { if constexpr (TR) return tf[a][q4]; else return ldt(c.fw, a * Q4 + q4, nlv, (unsigned)c.vl); };
   // model-only parts of the D scans
   float A = 1.f;
 #pragma unroll
@@ -116,7 +143,7 @@ __device__ __forceinline__ void forward_wide(const WCtxT<NLT> &c, const uint8_t 
     for (int q4 = Q4 - 1; q4 >= 0; q4--) {
       const float4 Aa = T(FW_A, q4), Bb = T(FW_B, q4), Cc = T(FW_C, q4), Ee = T(FW_E, q4);
       const float4 MI = T(FW_MI, q4), II = T(FW_II, q4);
-      const float4 O = ldt(c.em, x * Q4 + q4, nlv, (unsigned)c.vl);
+      const float4 O = TR ? emission_piece<Q>(c.em, c.emL, c.K, x, q4, nlv, (unsigned)c.vl) : ldt(c.em, x * Q4 + q4, nlv, (unsigned)c.vl);
 #pragma unroll
       for (int j = 3; j >= 0; j--) {
         const int q = 4 * q4 + j;
@@ -219,8 +246,23 @@ __device__ __forceinline__ void forward_wide(const WCtxT<NLT> &c, const uint8_t 
 template <int Q>
 struct BackState { float Mb[Q], Ib[Q]; };
 
-template <int Q, int NLT>
-__device__ __forceinline__ float backward_emit_wide(const WCtxT<NLT> &c, int x, float (&Mb)[Q], float &gfront) {
+// the Backward sweep's eight transition arrays in registers (TR) - or nothing, and every use is an L2 read
+template <int Q, bool TR>
+struct BackTab {
+  float4 v[TR ? BW_NARR : 1][TR ? Q / 4 : 1];
+  template <int NLT>
+  __device__ __forceinline__ void load(const WCtxT<NLT> &c) {
+    if (TR) {
+#pragma unroll
+      for (int a = 0; a < BW_NARR; a++)
+#pragma unroll
+        for (int q4 = 0; q4 < Q / 4; q4++) v[TR ? a : 0][TR ? q4 : 0] = ldg4(c.bw, (unsigned)((a * (Q / 4) + q4) * c.nl() + c.vl));
+    }
+  }
+};
+
+template <int Q, int NLT, bool TR = false>
+__device__ __forceinline__ float backward_emit_wide(const WCtxT<NLT> &c, const BackTab<Q, TR> &tb, int x, float (&Mb)[Q], float &gfront) {
   constexpr int Q4 = Q / 4;
   const int NL = c.nl(), w = c.w, lane = c.lane;
   float *xch = c.xch;
@@ -230,8 +272,9 @@ __device__ __forceinline__ float backward_emit_wide(const WCtxT<NLT> &c, int x, 
   float part = 0.f;
 #pragma unroll
   for (int p4 = 0; p4 < Q4; p4++) {
-    const float4 E = ldt(c.bw, BW_E * Q4 + p4, nlv, (unsigned)c.vl);
-    const float4 O = ldt(c.em, x * Q4 + (Q4 - 1 - p4), nlv, (unsigned)rv);
+    float4 E, O;
+    if constexpr (TR) { E = tb.v[BW_E][p4]; O = emission_piece<Q>(c.em, c.emL, c.K, x, Q4 - 1 - p4, nlv, (unsigned)rv); }
+    else { E = ldt(c.bw, BW_E * Q4 + p4, nlv, (unsigned)c.vl); O = ldt(c.em, x * Q4 + (Q4 - 1 - p4), nlv, (unsigned)rv); }
     Mb[4 * p4 + 0] *= O.w; part = fmaf(E.x, Mb[4 * p4 + 0], part);
     Mb[4 * p4 + 1] *= O.z; part = fmaf(E.y, Mb[4 * p4 + 1], part);
     Mb[4 * p4 + 2] *= O.y; part = fmaf(E.z, Mb[4 * p4 + 2], part);
@@ -246,13 +289,13 @@ __device__ __forceinline__ float backward_emit_wide(const WCtxT<NLT> &c, int x, 
   return xB;
 }
 
-template <int Q, int NLT>
-__device__ __forceinline__ void backward_cells_wide(const WCtxT<NLT> &c, const ScanC &sc, float Aexcl, float (&Mb)[Q], float (&Ib)[Q], float xE, float gfront) {
+template <int Q, int NLT, bool TR = false>
+__device__ __forceinline__ void backward_cells_wide(const WCtxT<NLT> &c, const BackTab<Q, TR> &tb, const ScanC &sc, float Aexcl, float (&Mb)[Q], float (&Ib)[Q], float xE, float gfront) {
   constexpr int Q4 = Q / 4;
   const int NL = c.nl(), w = c.w, lane = c.lane;
   float *xch = c.xch;
   const int nlv = opaque_s(NL);
-  auto T = [&](int a, int q4) -> float4 { return ldt(c.bw, a * Q4 + q4, nlv, (unsigned)c.vl); };
+  auto T = [&](int a, int q4) -> float4 { if constexpr (TR) return tb.v[a][q4]; else return ldt(c.bw, a * Q4 + q4, nlv, (unsigned)c.vl); };
   float Dn[Q];
   float gm1 = wave_shr1(Mb[Q - 1]);
   if (lane == 0) gm1 = gfront;
@@ -322,13 +365,15 @@ __device__ __forceinline__ void backward_prepare_wide(const WCtxT<NLT> &c, ScanC
 }
 
 // ------------------------------------------------------------------------------------------ P2: multihit Backward + decoding
-template <int Q, int NLT>
+template <int Q, int NLT, bool TR = false>
 __device__ __forceinline__ void backward_decode_wide(const WCtxT<NLT> &c, const uint8_t *seq, int L, LenCfg cm, float invZ, int ef_L) {
   const int SP = c.SP;
   float *spec = c.spec;
   ScanC sc;
   float Aexcl;
   backward_prepare_wide<Q, NLT>(c, sc, Aexcl);
+  BackTab<Q, TR> tb;
+  tb.load(c);
   float Mb[Q], Ib[Q];
 #pragma unroll
   for (int p = 0; p < Q; p++) { Mb[p] = 0.f; Ib[p] = 0.f; }
@@ -338,13 +383,13 @@ __device__ __forceinline__ void backward_decode_wide(const WCtxT<NLT> &c, const 
   for (int i = L; i >= 0; i--) {
     float gfront = 0.f;
     if (i < L) {
-      xB = backward_emit_wide<Q, NLT>(c, __builtin_amdgcn_readfirstlane((int)seq[i]), Mb, gfront);
+      xB = backward_emit_wide<Q, NLT, TR>(c, tb, __builtin_amdgcn_readfirstlane((int)seq[i]), Mb, gfront);
       xJ = fmaf(xJ, cm.loop, xB * cm.move);
       xC = xC * cm.loop;
       xN = fmaf(xN, cm.loop, xB * cm.move);
     }
     float xE = fmaf(xC, cm.EC, xJ * cm.EJ);
-    if (i >= 1) backward_cells_wide<Q, NLT>(c, sc, Aexcl, Mb, Ib, xE, gfront);
+    if (i >= 1) backward_cells_wide<Q, NLT, TR>(c, tb, sc, Aexcl, Mb, Ib, xE, gfront);
     const float big = fmaxf(xB, xN);
     if (big > kRescaleHi) {
       const int e = f32_exponent(big);
@@ -375,7 +420,7 @@ __device__ __forceinline__ void backward_decode_wide(const WCtxT<NLT> &c, const 
 
 // ------------------------------------------------------------------------------------------ P4: unihit Backward + posteriors -> null2
 // Returns domcorr (every wave holds it).
-template <int Q, int NLT>
+template <int Q, int NLT, bool TR = false>
 __device__ __forceinline__ float backward_null2_wide(const WCtxT<NLT> &c, const uint8_t *eseq, int Ld, LenCfg cu, float invZe, float *n2tab, uint32_t degen) {
   constexpr int Q4 = Q / 4;
   const int SP = c.SP, NL = c.nl(), w = c.w, lane = c.lane;
@@ -384,6 +429,8 @@ __device__ __forceinline__ float backward_null2_wide(const WCtxT<NLT> &c, const 
   ScanC sc;
   float Aexcl;
   backward_prepare_wide<Q, NLT>(c, sc, Aexcl);
+  BackTab<Q, TR> tb;
+  tb.load(c);
   float Mb[Q], Ib[Q], fM[Q];
 #pragma unroll
   for (int p = 0; p < Q; p++) { Mb[p] = 0.f; Ib[p] = 0.f; fM[p] = 0.f; }
@@ -398,13 +445,13 @@ __device__ __forceinline__ float backward_null2_wide(const WCtxT<NLT> &c, const 
     float gfront = 0.f;
     if (i < Ld) {
       mirror_scale<Q>(S_next - S_i, Mb, Ib, xJ, xC, xN);
-      xB = backward_emit_wide<Q, NLT>(c, __builtin_amdgcn_readfirstlane((int)eseq[i]), Mb, gfront);
+      xB = backward_emit_wide<Q, NLT, TR>(c, tb, __builtin_amdgcn_readfirstlane((int)eseq[i]), Mb, gfront);
       xJ = fmaf(xJ, cu.loop, xB * cu.move);
       xC = xC * cu.loop;
       xN = fmaf(xN, cu.loop, xB * cu.move);
     }
     const float xE = fmaf(xC, cu.EC, xJ * cu.EJ);
-    backward_cells_wide<Q, NLT>(c, sc, Aexcl, Mb, Ib, xE, gfront);
+    backward_cells_wide<Q, NLT, TR>(c, tb, sc, Aexcl, Mb, Ib, xE, gfront);
     clamp_backward<Q>(Mb, Ib, xB, xJ, xC, xN);
     const float s_i = invZe;
     const float s_p = ldexpf(invZe, -dS);
@@ -476,7 +523,7 @@ __device__ __forceinline__ float backward_null2_wide(const WCtxT<NLT> &c, const 
 }
 
 // ------------------------------------------------------------------------------------------ the kernel
-template <int Q, int NLT>
+template <int Q, int NLT, bool TR>
 __global__ __launch_bounds__(512) void score_wide_kernel(WideArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), W = blockDim.x >> 6;
@@ -488,9 +535,13 @@ __global__ __launch_bounds__(512) void score_wide_kernel(WideArgs a) {
   float *n2tab = xch + 8 * X_N;
   int *regs = reinterpret_cast<int *>(n2tab + 32);      // kRegsInts: regions, spare, envelope results
   uint8_t *seq = reinterpret_cast<uint8_t *>(regs + kRegsInts);
+  // TR: behind the residues (16-byte aligned), the emission rows of the canonical residues of the CURRENT model
+  wv4 *emL = reinterpret_cast<wv4 *>(smem + wide_em_lds_offset_floats(a.Lcap));
+  int em_h = -1;
   const double LOG2 = 0.69314718055994529;
   WCtxT<NLT> c;
   c.spec = spec; c.xch = xch; c.NLr = NL; c.SP = SP; c.w = w; c.W = W; c.lane = lane; c.K = a.K; c.Kp = a.Kp;
+  c.emL = (TR && a.em_lds) ? (const lf4 *)emL : nullptr;
   c.Fs = const_cast<gf4 *>(uniform_global(a.scratch + (size_t)blockIdx.x * a.scratch_stride));
   c.vl = vl;
   uint32_t degen = 0;
@@ -508,6 +559,12 @@ __global__ __launch_bounds__(512) void score_wide_kernel(WideArgs a) {
     c.fw = uniform_global(a.tables + hm->wfw_off);
     c.bw = uniform_global(a.tables + hm->wbw_off);
     c.em = uniform_global(a.tables + hm->wem_off);
+    if (TR && a.em_lds && h != em_h) {                  // (work items are model-major: once per model and workgroup)
+      const gf4 *src = c.em;
+      for (int t = threadIdx.x; t < a.K * Q4 * NL; t += blockDim.x) emL[t] = src[t];
+      em_h = h;
+      __syncthreads();
+    }
     const int64_t off = a.offsets[qi];
     const int L = (int)(a.offsets[qi + 1] - off);
     const size_t out = (size_t)qi * a.H + h;
@@ -521,7 +578,7 @@ __global__ __launch_bounds__(512) void score_wide_kernel(WideArgs a) {
       // ---------------- P1
       const LenCfg cm = len_config(L, true);
       float xC1; int ef1;
-      forward_wide<Q, false, NLT>(c, seq, L, cm, xC1, ef1);
+      forward_wide<Q, false, NLT, TR>(c, seq, L, cm, xC1, ef1);
       const double fwd_nats = (double)ef1 * LOG2 + log((double)(xC1 * cm.move));
       const float fwdsc = (float)fwd_nats;
       const float p1 = (float)L / (float)(L + 1);
@@ -530,7 +587,7 @@ __global__ __launch_bounds__(512) void score_wide_kernel(WideArgs a) {
       if (dp) dp->fwd_bits = fwd_bits_out;
       if (xC1 > 0.f && isfinite(fwdsc)) {
         // ---------------- P2 + region scan (wave 0; the others wait)
-        backward_decode_wide<Q, NLT>(c, seq, L, cm, 1.0f / (xC1 * cm.move), ef1);
+        backward_decode_wide<Q, NLT, TR>(c, seq, L, cm, 1.0f / (xC1 * cm.move), ef1);
         if (w == 0) {
           const float rt1 = 0.25f, rt2 = 0.10f, rt3 = 0.20f;
           int nenv = 0, nreg = 0, fl = 0, i0 = -1;
@@ -584,11 +641,11 @@ __global__ __launch_bounds__(512) void score_wide_kernel(WideArgs a) {
             const int Ld = rj - ri + 1;
             const uint8_t *eseq = seq + (ri - 1);
             float xC3; int ef3;
-            forward_wide<Q, true, NLT>(c, eseq, Ld, cu, xC3, ef3);
+            forward_wide<Q, true, NLT, TR>(c, eseq, Ld, cu, xC3, ef3);
             __threadfence_block();
             const float envsc = (float)((double)ef3 * LOG2 + log((double)(xC3 * cu.move)));
             float domcorr = 0.f;
-            if (xC3 > 0.f) domcorr = backward_null2_wide<Q, NLT>(c, eseq, Ld, cu, 1.0f / (xC3 * cu.move), n2tab, degen);
+            if (xC3 > 0.f) domcorr = backward_null2_wide<Q, NLT, TR>(c, eseq, Ld, cu, 1.0f / (xC3 * cu.move), n2tab, degen);
             seqbias_sum += domcorr;
             if (envsc - domcorr > 0.0f) { sum_score += envsc; Ld_tot += Ld; sb2 += domcorr; }
             if (dp) { dp->env_i[e] = ri; dp->env_j[e] = rj; dp->envsc[e] = envsc; dp->domcorr[e] = domcorr; }
@@ -664,6 +721,8 @@ __global__ __launch_bounds__(512) void align_wide_kernel(WideAlignArgs a) {
   uint8_t *seq = reinterpret_cast<uint8_t *>(xch + 8 * X_N);
   WCtxT<NLT> c;
   c.spec = spec; c.xch = xch; c.NLr = NL; c.SP = SP; c.w = w; c.W = W; c.lane = lane; c.K = a.K; c.Kp = a.Kp; c.vl = vl;
+  c.emL = nullptr;
+  const BackTab<Q, false> tb0{};
   gf4 *slabA = const_cast<gf4 *>(uniform_global(a.scratch + (size_t)blockIdx.x * a.scratch_stride));      // F -> posteriors: [row][2][Q4][NL]
   gf4 *slabB = slabA + (size_t)(a.Lcap + 1) * 2 * Q4 * NL;                                                 // OA rows: [row][3][Q4][NL]
   c.Fs = slabA;
@@ -718,13 +777,13 @@ __global__ __launch_bounds__(512) void align_wide_kernel(WideAlignArgs a) {
         float gfront = 0.f;
         if (i < L) {
           mirror_scale<Q>(reinterpret_cast<const int *>(spec)[WA_S * SP + i + 1] - reinterpret_cast<const int *>(spec)[WA_S * SP + i], Mb, Ib, xJ, xC, xN);
-          xB = backward_emit_wide<Q, NLT>(c, __builtin_amdgcn_readfirstlane((int)seq[i]), Mb, gfront);
+          xB = backward_emit_wide<Q, NLT>(c, tb0, __builtin_amdgcn_readfirstlane((int)seq[i]), Mb, gfront);
           xJ = fmaf(xJ, cu.loop, xB * cu.move);
           xC = xC * cu.loop;
           xN = fmaf(xN, cu.loop, xB * cu.move);
         }
         const float xE = fmaf(xC, cu.EC, xJ * cu.EJ);
-        backward_cells_wide<Q, NLT>(c, sc, Aexcl, Mb, Ib, xE, gfront);
+        backward_cells_wide<Q, NLT>(c, tb0, sc, Aexcl, Mb, Ib, xE, gfront);
         clamped |= clamp_backward<Q>(Mb, Ib, xB, xJ, xC, xN);
         const float s_i = invZ;
         const float s_p = ldexpf(invZ, reinterpret_cast<const int *>(spec)[WA_S * SP + i - 1] - reinterpret_cast<const int *>(spec)[WA_S * SP + i]);
@@ -989,6 +1048,15 @@ static hipError_t launch_walign_t(const WideAlignArgs &a, int blocks, int waves,
 hipError_t launch_align_wide(int Q, const WideAlignArgs &a, int blocks, int waves, size_t lds, hipStream_t s) {
   if (waves < 1 || waves > kWideWavesMax) return hipErrorInvalidValue;
   if (Q == 4) return launch_walign_t<4, 0>(a, blocks, waves, lds, s);
+  if (Q == kWideQReg) {
+    switch (waves) {
+      case 5: return launch_walign_t<kWideQReg, 320>(a, blocks, waves, lds, s);
+      case 6: return launch_walign_t<kWideQReg, 384>(a, blocks, waves, lds, s);
+      case 7: return launch_walign_t<kWideQReg, 448>(a, blocks, waves, lds, s);
+      case 8: return launch_walign_t<kWideQReg, 512>(a, blocks, waves, lds, s);
+      default: return launch_walign_t<kWideQReg, 0>(a, blocks, waves, lds, s);
+    }
+  }
   if (Q != kWideQ) return hipErrorInvalidValue;
   switch (waves) {
     case 3: return launch_walign_t<kWideQ, 192>(a, blocks, waves, lds, s);
@@ -1001,31 +1069,40 @@ hipError_t launch_align_wide(int Q, const WideAlignArgs &a, int blocks, int wave
   }
 }
 
-size_t wide_lds_bytes(int Lcap) {
-  const int SP = (Lcap + 1 + 3) / 4 * 4;
-  return (size_t)(4 + 6 * SP + 8 * wide::X_N + 32 + kRegsInts) * sizeof(float) + (size_t)(Lcap + 16);
+size_t wide_lds_bytes(int Lcap, size_t em_floats) {
+  return (size_t)wide_em_lds_offset_floats(Lcap) * sizeof(float) + em_floats * sizeof(float);
 }
 
-template <int Q, int NLT>
+template <int Q, int NLT, bool TR>
 static hipError_t launch_wide_t(const WideArgs &a, int blocks, int waves, size_t lds, hipStream_t s) {
-  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&wide::score_wide_kernel<Q, NLT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&wide::score_wide_kernel<Q, NLT, TR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (err != hipSuccess) return err;
-  hipLaunchKernelGGL((wide::score_wide_kernel<Q, NLT>), dim3(blocks), dim3(waves * 64), lds, s, a);
+  hipLaunchKernelGGL((wide::score_wide_kernel<Q, NLT, TR>), dim3(blocks), dim3(waves * 64), lds, s, a);
   return hipGetLastError();
 }
 
 hipError_t launch_score_wide(int Q, const WideArgs &a, int blocks, int waves, size_t lds, hipStream_t s) {
   if (waves < 1 || waves > kWideWavesMax) return hipErrorInvalidValue;
-  if (Q == 4) return launch_wide_t<4, 0>(a, blocks, waves, lds, s);       // test hook (WH_FORCE_WIDE=4): any workgroup size
-  if (Q != kWideQ) return hipErrorInvalidValue;
+  if (Q == 4) return launch_wide_t<4, 0, false>(a, blocks, waves, lds, s);       // test hook (WH_FORCE_WIDE=4): any workgroup size
+  if (Q == kWideQReg) {
+    // 12 cells per lane, transition tables in registers: models of 3 073 - 6 144 nodes (five to eight waves)
+    switch (waves) {
+      case 5: return launch_wide_t<kWideQReg, 320, true>(a, blocks, waves, lds, s);
+      case 6: return launch_wide_t<kWideQReg, 384, true>(a, blocks, waves, lds, s);
+      case 7: return launch_wide_t<kWideQReg, 448, true>(a, blocks, waves, lds, s);
+      case 8: return launch_wide_t<kWideQReg, 512, true>(a, blocks, waves, lds, s);
+      default: return launch_wide_t<kWideQReg, 0, true>(a, blocks, waves, lds, s);   // 1 - 4 waves: WH_FORCE_WIDE=12 on small models
+    }
+  }
+  if (Q != kWideQ || a.em_lds) return hipErrorInvalidValue;
   switch (waves) {
-    case 3: return launch_wide_t<kWideQ, 192>(a, blocks, waves, lds, s);
-    case 4: return launch_wide_t<kWideQ, 256>(a, blocks, waves, lds, s);
-    case 5: return launch_wide_t<kWideQ, 320>(a, blocks, waves, lds, s);
-    case 6: return launch_wide_t<kWideQ, 384>(a, blocks, waves, lds, s);
-    case 7: return launch_wide_t<kWideQ, 448>(a, blocks, waves, lds, s);
-    case 8: return launch_wide_t<kWideQ, 512>(a, blocks, waves, lds, s);
-    default: return launch_wide_t<kWideQ, 0>(a, blocks, waves, lds, s);   // 1, 2 waves: WH_FORCE_WIDE=24 on small models
+    case 3: return launch_wide_t<kWideQ, 192, false>(a, blocks, waves, lds, s);
+    case 4: return launch_wide_t<kWideQ, 256, false>(a, blocks, waves, lds, s);
+    case 5: return launch_wide_t<kWideQ, 320, false>(a, blocks, waves, lds, s);
+    case 6: return launch_wide_t<kWideQ, 384, false>(a, blocks, waves, lds, s);
+    case 7: return launch_wide_t<kWideQ, 448, false>(a, blocks, waves, lds, s);
+    case 8: return launch_wide_t<kWideQ, 512, false>(a, blocks, waves, lds, s);
+    default: return launch_wide_t<kWideQ, 0, false>(a, blocks, waves, lds, s);   // 1, 2 waves: WH_FORCE_WIDE=24 on small models
   }
 }
 

@@ -757,7 +757,9 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
         memcpy(a.degen, e->degen, sizeof a.degen);
         if (resolve) { a.rrecs = (ResolveRec *)e->d_rrecs.p; a.rcount = (int *)e->d_counter.p + 64; a.rcap = (int)e->rq_cap; }
         a.qorder = qorder_all;
-        a.scratch_stride = (size_t)(Lc + 1) * 2 * wq * W * kWave;
+        a.sparse = getenv("WH_WIDE_DENSE") ? 0 : 1;
+        a.scratch_stride = (size_t)(Lc + 1) * 2 * wq * W * kWave + (a.sparse ? (size_t)(Lc + 1) * W * 2 + 4 : 0);
+        a.scratch_stride = (a.scratch_stride + 3) & ~(size_t)3;
         const int64_t n_items = nq * (int64_t)a.n_list;
         const int per_cu = (W <= 4 && 2 * wlds <= kLdsBudget) ? 2 : 1;
         int blocks = (int)std::min<int64_t>(n_items, (int64_t)e->cu_count * per_cu);
@@ -768,8 +770,21 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
         if (e->knobs.trace) fprintf(stderr, "[wh] wide scoring: %lld pairs on %d models, %d waves per pair x %d cells per lane, %d workgroups, lds %zu, slab %zu MB per workgroup\n",
                                     (long long)n_items, a.n_list, W, wq, blocks, wlds, a.scratch_stride * 4 >> 20);
         if (class_mark(e, s, wq * W, 3)) return WH_EHIP;
+        if (e->knobs.stats) {
+          if (e->d_recs.ensure(320)) return WH_ENOMEM;
+          HIPCHK(hipMemsetAsync(e->d_recs.p, 0, 64, s));
+          a.stats = (unsigned long long *)e->d_recs.p;
+        }
         hipError_t werr = launch_score_wide(wq, a, blocks, W, wlds, s);
         if (werr != hipSuccess) { set_error("wide score kernel launch failed: %s", hipGetErrorString(werr)); return WH_EHIP; }
+        if (a.stats) {
+          unsigned long long st[6];
+          HIPCHK(hipMemcpyAsync(st, a.stats, sizeof st, hipMemcpyDeviceToHost, s));
+          HIPCHK(hipStreamSynchronize(s));
+          const double tot = (double)st[5] > 0 ? (double)st[5] : 1.0;
+          fprintf(stderr, "[wh] wide %d x %d cells per lane, cycles of the first wave: P1 %.1f%%  P2 %.1f%%  regions %.1f%%  P3 %.1f%%  P4 %.1f%%  (of %.3g)\n", W, wq,
+                  100.0 * st[0] / tot, 100.0 * st[1] / tot, 100.0 * st[2] / tot, 100.0 * st[3] / tot, 100.0 * st[4] / tot, tot);
+        }
         launches++;
       }
     }

@@ -138,6 +138,8 @@ struct WideArgs {
   int rcap;
   const int32_t *qorder;
   int em_lds;                  // 12-cell kernels: the emission rows of the canonical residues are staged in LDS (behind the block)
+  unsigned long long *stats;   // WH_STATS: [0..4] cycles of the first wave in P1, P2, region scan, P3, P4; [5] whole items (or NULL)
+  int sparse;                  // envelope Forward rows: only the lanes above 2^-24 of the row's E are stored (+ masks behind the slab)
 };
 struct WideAlignArgs {
   const DevHMM *hmms;

@@ -35,6 +35,9 @@ __host__ __device__ inline int wide_em_lds_offset_floats(int Lcap) {
 
 namespace wide {
 
+constexpr float kWideKeepScale = 5.9604645e-08f;   // 2^-24 of the row's E, as in wh_score7.hip
+constexpr float kWideMassTol = 2e-5f;
+
 // per-wave exchange slot in LDS (floats)
 enum { X_BD = 0, X_ES, X_BM, X_BI, X_BDD, X_AT, X_T0, X_T1, X_N };
 
@@ -74,6 +77,7 @@ struct WCtxT {
   float *spec;                  // LDS: SP_NARR-2 arrays of SP floats (N, B, E, J, C, S), one pair per workgroup
   float *xch;                   // LDS: W slots of X_N floats
   gf4 *Fs;                      // slab of the workgroup (uniform base): [row][2][Q4][NL]
+  unsigned long long *masks;    // sparse spill (scoring): [row][W] the lanes of each wave that stored their cells of the row; or null
   int NLr, SP, w, W, lane, K, Kp;
   // lanes over all waves of the workgroup: a compile-time constant in the production instantiations (table accesses then
   // are one scalar base + immediate offsets; with a run-time value the compiler kept 60 offsets per row in scratch)
@@ -99,8 +103,12 @@ __device__ __forceinline__ float4 emission_piece(const gf4 *emG, const lf4 *emL,
   return ldt(emG, x * Q4 + q4, nlv, vl);
 }
 
+// STORE: the M and I rows go to the slab.  With c.masks a lane's cells are written only when one of them exceeds
+// keep_scale * E(row) (the sparse spill of wh_device.h: a read of 800 residues walks an eighth of a 6 000-node model, and the
+// dense rows made P3 / P4 HBM-bound: 49 KB per row and workgroup), the kept lanes of every wave are recorded per row, and the
+// envelope's posterior mass certifies the result (backward_null2_wide); keep_scale < 0 stores everything.
 template <int Q, bool STORE, int NLT, bool TR = false>
-__device__ __forceinline__ void forward_wide(const WCtxT<NLT> &c, const uint8_t *seq, int L, LenCfg cfg, float &xC_out, int &ef_out) {
+__device__ __forceinline__ void forward_wide(const WCtxT<NLT> &c, const uint8_t *seq, int L, LenCfg cfg, float &xC_out, int &ef_out, float keep_scale = -1.0f) {
   constexpr int Q4 = Q / 4;
   const int lane = c.lane, NL = c.nl(), SP = c.SP, w = c.w;
   float *spec = c.spec, *xch = c.xch;
@@ -223,13 +231,24 @@ __device__ __forceinline__ void forward_wide(const WCtxT<NLT> &c, const uint8_t 
       reinterpret_cast<int *>(spec)[SP_S * SP + i] = ef;
     }
     if (STORE) {
-      gf4 *row = c.Fs + (size_t)i * (2 * Q4) * NL;
+      bool keep = true;
+      if (c.masks != nullptr) {
+        float lmax = 0.f;
 #pragma unroll
-      for (int q4 = 0; q4 < Q4; q4++) {
-        const wv4 vm = {Mp[4 * q4], Mp[4 * q4 + 1], Mp[4 * q4 + 2], Mp[4 * q4 + 3]};
-        const wv4 vi = {Ip[4 * q4], Ip[4 * q4 + 1], Ip[4 * q4 + 2], Ip[4 * q4 + 3]};
-        row[(unsigned)(q4 * NL + c.vl)] = vm;
-        row[(unsigned)((Q4 + q4) * NL + c.vl)] = vi;
+        for (int q = 0; q < Q; q += 2) lmax = fmaxf(lmax, fmaxf(fmaxf(Mp[q], Mp[q + 1]), fmaxf(Ip[q], Ip[q + 1])));
+        keep = keep_scale < 0.f || lmax > keep_scale * xE;
+        const unsigned long long mask = __ballot(keep);
+        if (lane == 0) __builtin_nontemporal_store(mask, c.masks + (size_t)i * c.W + w);
+      }
+      if (keep) {
+        gf4 *row = c.Fs + (size_t)i * (2 * Q4) * NL;
+#pragma unroll
+        for (int q4 = 0; q4 < Q4; q4++) {
+          const wv4 vm = {Mp[4 * q4], Mp[4 * q4 + 1], Mp[4 * q4 + 2], Mp[4 * q4 + 3]};
+          const wv4 vi = {Ip[4 * q4], Ip[4 * q4 + 1], Ip[4 * q4 + 2], Ip[4 * q4 + 3]};
+          row[(unsigned)(q4 * NL + c.vl)] = vm;
+          row[(unsigned)((Q4 + q4) * NL + c.vl)] = vi;
+        }
       }
     }
   }
@@ -419,9 +438,11 @@ __device__ __forceinline__ void backward_decode_wide(const WCtxT<NLT> &c, const 
 }
 
 // ------------------------------------------------------------------------------------------ P4: unihit Backward + posteriors -> null2
-// Returns domcorr (every wave holds it).
+// Returns domcorr (every wave holds it) and, in <mass_out>, the posterior mass that reached the accumulators: with the sparse
+// spill it certifies the result (it must reach Ld (1 - tol), wh_score7.hip); when it does not, the function returns early
+// and the caller repeats the envelope with every row stored.
 template <int Q, int NLT, bool TR = false>
-__device__ __forceinline__ float backward_null2_wide(const WCtxT<NLT> &c, const uint8_t *eseq, int Ld, LenCfg cu, float invZe, float *n2tab, uint32_t degen) {
+__device__ __forceinline__ float backward_null2_wide(const WCtxT<NLT> &c, const uint8_t *eseq, int Ld, LenCfg cu, float invZe, float *n2tab, uint32_t degen, float mass_tol, float &mass_out) {
   constexpr int Q4 = Q / 4;
   const int SP = c.SP, NL = c.nl(), w = c.w, lane = c.lane;
   const float *spec = c.spec;
@@ -438,10 +459,37 @@ __device__ __forceinline__ float backward_null2_wide(const WCtxT<NLT> &c, const 
   int S_next = 0;
   // my reversed cells in the forward-ordered slab: forward lane NL-1-vl, piece Q4-1-p4, components reversed
   const int rv = NL - 1 - c.vl;
+  // sparse spill: the word of the forward wave that holds my reversed cells (W-1-w), my cells are bit 63-lane; lane t < W
+  // reads the word of wave t ONE ROW AHEAD (a per-lane address: a vector load, coherent with the stores of this workgroup)
+  const bool sparse = c.masks != nullptr;
+  unsigned long long mv_next = 0;
+  if (sparse && lane < c.W) mv_next = __builtin_nontemporal_load(c.masks + (size_t)Ld * c.W + lane);
 #pragma unroll 1
   for (int i = Ld; i >= 1; i--) {
     const int S_i = reinterpret_cast<const int *>(spec)[SP_S * SP + i];
     const int dS = S_i - reinterpret_cast<const int *>(spec)[SP_S * SP + i - 1];
+    bool have = true;
+    if (sparse) {
+      const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mv_next & 0xFFFFFFFFull), c.W - 1 - w);
+      const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mv_next >> 32), c.W - 1 - w);
+      const int bit = 63 - lane;
+      have = ((bit < 32 ? lo >> bit : hi >> (bit - 32)) & 1u) != 0;
+      if (i > 1 && lane < c.W) mv_next = __builtin_nontemporal_load(c.masks + (size_t)(i - 1) * c.W + lane);
+    }
+    // TR (one workgroup per CU: nothing else covers an HBM round trip): the row's stored Forward cells are requested
+    // before the row's arithmetic and barriers, not where they are used
+    float4 fmP[TR ? Q4 : 1], fiP[TR ? Q4 : 1];
+    if (TR) {
+      const gf4 *rowp = c.Fs + (size_t)i * (2 * Q4) * NL;
+      const int nlp = opaque_s(NL);
+      if (have) {
+#pragma unroll
+        for (int p4 = 0; p4 < Q4; p4++) { fmP[TR ? p4 : 0] = ldt(rowp, Q4 - 1 - p4, nlp, (unsigned)rv); fiP[TR ? p4 : 0] = ldt(rowp, Q4 + Q4 - 1 - p4, nlp, (unsigned)rv); }
+      } else {
+#pragma unroll
+        for (int p4 = 0; p4 < Q4; p4++) { fmP[TR ? p4 : 0] = make_float4(0.f, 0.f, 0.f, 0.f); fiP[TR ? p4 : 0] = make_float4(0.f, 0.f, 0.f, 0.f); }
+      }
+    }
     float gfront = 0.f;
     if (i < Ld) {
       mirror_scale<Q>(S_next - S_i, Mb, Ib, xJ, xC, xN);
@@ -457,19 +505,21 @@ __device__ __forceinline__ float backward_null2_wide(const WCtxT<NLT> &c, const 
     const float s_p = ldexpf(invZe, -dS);
     const gf4 *row = c.Fs + (size_t)i * (2 * Q4) * NL;
     const int nlr = opaque_s(NL);
-    float idot = 0.f;
+    if (have) {
+      float idot = 0.f;
 #pragma unroll
-    for (int p4 = 0; p4 < Q4; p4++) {
-      const float4 fm = ldt(row, Q4 - 1 - p4, nlr, (unsigned)rv);
-      const float4 fi = ldt(row, Q4 + Q4 - 1 - p4, nlr, (unsigned)rv);
-      fM[4 * p4 + 0] = fmaf(fm.w * Mb[4 * p4 + 0], s_i, fM[4 * p4 + 0]);
-      fM[4 * p4 + 1] = fmaf(fm.z * Mb[4 * p4 + 1], s_i, fM[4 * p4 + 1]);
-      fM[4 * p4 + 2] = fmaf(fm.y * Mb[4 * p4 + 2], s_i, fM[4 * p4 + 2]);
-      fM[4 * p4 + 3] = fmaf(fm.x * Mb[4 * p4 + 3], s_i, fM[4 * p4 + 3]);
-      idot = fmaf(fi.w, Ib[4 * p4 + 0], idot); idot = fmaf(fi.z, Ib[4 * p4 + 1], idot);
-      idot = fmaf(fi.y, Ib[4 * p4 + 2], idot); idot = fmaf(fi.x, Ib[4 * p4 + 3], idot);
+      for (int p4 = 0; p4 < Q4; p4++) {
+        const float4 fm = TR ? fmP[TR ? p4 : 0] : ldt(row, Q4 - 1 - p4, nlr, (unsigned)rv);
+        const float4 fi = TR ? fiP[TR ? p4 : 0] : ldt(row, Q4 + Q4 - 1 - p4, nlr, (unsigned)rv);
+        fM[4 * p4 + 0] = fmaf(fm.w * Mb[4 * p4 + 0], s_i, fM[4 * p4 + 0]);
+        fM[4 * p4 + 1] = fmaf(fm.z * Mb[4 * p4 + 1], s_i, fM[4 * p4 + 1]);
+        fM[4 * p4 + 2] = fmaf(fm.y * Mb[4 * p4 + 2], s_i, fM[4 * p4 + 2]);
+        fM[4 * p4 + 3] = fmaf(fm.x * Mb[4 * p4 + 3], s_i, fM[4 * p4 + 3]);
+        idot = fmaf(fi.w, Ib[4 * p4 + 0], idot); idot = fmaf(fi.z, Ib[4 * p4 + 1], idot);
+        idot = fmaf(fi.y, Ib[4 * p4 + 2], idot); idot = fmaf(fi.x, Ib[4 * p4 + 3], idot);
+      }
+      fIs = fmaf(idot, s_i, fIs);
     }
-    fIs = fmaf(idot, s_i, fIs);
     float nj = spec[SP_N * SP + i - 1] * xN;
     nj = fmaf(spec[SP_J * SP + i - 1], xJ, nj);
     nj = fmaf(spec[SP_C * SP + i - 1], xC, nj);
@@ -478,11 +528,18 @@ __device__ __forceinline__ float backward_null2_wide(const WCtxT<NLT> &c, const 
   }
   // null2[a] = (sum_k fM_k o_k(a) + sum_k fI_k + f_NJC) / Ld over ALL waves, summed in wave order
   const float siw = wave_sum(fIs);
+  float smw = 0.f;
+#pragma unroll
+  for (int p = 0; p < Q; p++) smw += fM[p];
+  smw = wave_sum(smw);
   wg_barrier();
-  if (lane == 0) xch[w * X_N + X_T1] = siw;
+  if (lane == 0) { xch[w * X_N + X_T1] = siw; xch[w * X_N + X_T0] = smw; }
   wg_barrier();
-  float si = 0.f;
-  for (int v = 0; v < c.W; v++) si += xch[v * X_N + X_T1];
+  float si = 0.f, sm = 0.f;
+  for (int v = 0; v < c.W; v++) { si += xch[v * X_N + X_T1]; sm += xch[v * X_N + X_T0]; }
+  const float mass = sm + si + xfac;
+  mass_out = mass;
+  if (!(fabsf((float)Ld - mass) <= mass_tol * (float)Ld)) { wg_barrier(); return 0.f; }   // (every wave holds the same sums: a uniform exit)
   const float norm = 1.0f / (float)Ld;
   for (int x = 0; x < c.K; x++) {
     float s = 0.f;
@@ -543,9 +600,13 @@ __global__ __launch_bounds__(512) void score_wide_kernel(WideArgs a) {
   c.spec = spec; c.xch = xch; c.NLr = NL; c.SP = SP; c.w = w; c.W = W; c.lane = lane; c.K = a.K; c.Kp = a.Kp;
   c.emL = (TR && a.em_lds) ? (const lf4 *)emL : nullptr;
   c.Fs = const_cast<gf4 *>(uniform_global(a.scratch + (size_t)blockIdx.x * a.scratch_stride));
+  // the per-row lane masks of the sparse spill sit behind the rows of the slab
+  c.masks = a.sparse ? reinterpret_cast<unsigned long long *>(a.scratch + (size_t)blockIdx.x * a.scratch_stride + (size_t)(a.Lcap + 1) * 2 * Q * NL) : nullptr;
   c.vl = vl;
   uint32_t degen = 0;
   for (int t = 0; t < 32; t++) if (t == lane) degen = a.degen[t];
+  long long cyc[5] = {0, 0, 0, 0, 0};
+  const long long t_kernel = a.stats ? __builtin_readcyclecounter() : 0;
 
   for (;;) {
     if (threadIdx.x == 0) *s_item = atomicAdd(a.counter, 1);
@@ -578,7 +639,10 @@ __global__ __launch_bounds__(512) void score_wide_kernel(WideArgs a) {
       // ---------------- P1
       const LenCfg cm = len_config(L, true);
       float xC1; int ef1;
+      long long tq = a.stats ? __builtin_readcyclecounter() : 0;
+      auto lap = [&](int slot) { if (a.stats) { const long long t = __builtin_readcyclecounter(); cyc[slot] += t - tq; tq = t; } };
       forward_wide<Q, false, NLT, TR>(c, seq, L, cm, xC1, ef1);
+      lap(0);
       const double fwd_nats = (double)ef1 * LOG2 + log((double)(xC1 * cm.move));
       const float fwdsc = (float)fwd_nats;
       const float p1 = (float)L / (float)(L + 1);
@@ -588,6 +652,7 @@ __global__ __launch_bounds__(512) void score_wide_kernel(WideArgs a) {
       if (xC1 > 0.f && isfinite(fwdsc)) {
         // ---------------- P2 + region scan (wave 0; the others wait)
         backward_decode_wide<Q, NLT, TR>(c, seq, L, cm, 1.0f / (xC1 * cm.move), ef1);
+        lap(1);
         if (w == 0) {
           const float rt1 = 0.25f, rt2 = 0.10f, rt3 = 0.20f;
           int nenv = 0, nreg = 0, fl = 0, i0 = -1;
@@ -626,6 +691,7 @@ __global__ __launch_bounds__(512) void score_wide_kernel(WideArgs a) {
           if (lane == 0) { regs[2 * WH_MAX_ENVELOPES] = nenv; regs[2 * WH_MAX_ENVELOPES + 1] = nreg; regs[2 * WH_MAX_ENVELOPES + 2] = fl; regs[2 * WH_MAX_ENVELOPES + 3] = multi_mask; }
         }
         __syncthreads();
+        lap(2);
         const int nenv = regs[2 * WH_MAX_ENVELOPES], nreg = regs[2 * WH_MAX_ENVELOPES + 1], multi_mask = regs[2 * WH_MAX_ENVELOPES + 3];
         flags |= regs[2 * WH_MAX_ENVELOPES + 2];
         if (dp) { dp->nregions = nreg; dp->nenv = nenv; }
@@ -640,12 +706,23 @@ __global__ __launch_bounds__(512) void score_wide_kernel(WideArgs a) {
             const int ri = regs[2 * e], rj = regs[2 * e + 1];
             const int Ld = rj - ri + 1;
             const uint8_t *eseq = seq + (ri - 1);
-            float xC3; int ef3;
-            forward_wide<Q, true, NLT, TR>(c, eseq, Ld, cu, xC3, ef3);
-            __threadfence_block();
-            const float envsc = (float)((double)ef3 * LOG2 + log((double)(xC3 * cu.move)));
-            float domcorr = 0.f;
-            if (xC3 > 0.f) domcorr = backward_null2_wide<Q, NLT, TR>(c, eseq, Ld, cu, 1.0f / (xC3 * cu.move), n2tab, degen);
+            float xC3 = 0.f, envsc = -INFINITY, domcorr = 0.f; int ef3 = 0;
+#pragma unroll 1
+            for (int attempt = 0; attempt < 2; attempt++) {
+              const bool dense = attempt == 1 || !a.sparse;
+              forward_wide<Q, true, NLT, TR>(c, eseq, Ld, cu, xC3, ef3, dense ? -1.0f : kWideKeepScale);
+              __threadfence_block();
+              lap(3);
+              envsc = (float)((double)ef3 * LOG2 + log((double)(xC3 * cu.move)));
+              domcorr = 0.f;
+              if (!(xC3 > 0.f)) break;
+              float mass = 0.f;
+              domcorr = backward_null2_wide<Q, NLT, TR>(c, eseq, Ld, cu, 1.0f / (xC3 * cu.move), n2tab, degen, dense ? INFINITY : kWideMassTol, mass);
+              lap(4);
+              if (!dense && !(fabsf((float)Ld - mass) <= kWideMassTol * (float)Ld)) continue;     // the sparse rows lost mass: once more with every row
+              if (attempt == 1) flags |= WH_FLAG_EXACT;
+              break;
+            }
             seqbias_sum += domcorr;
             if (envsc - domcorr > 0.0f) { sum_score += envsc; Ld_tot += Ld; sb2 += domcorr; }
             if (dp) { dp->env_i[e] = ri; dp->env_j[e] = rj; dp->envsc[e] = envsc; dp->domcorr[e] = domcorr; }
@@ -687,6 +764,10 @@ __global__ __launch_bounds__(512) void score_wide_kernel(WideArgs a) {
     }
     __syncthreads();
   }
+  if (a.stats && threadIdx.x == 0) {
+    for (int t = 0; t < 5; t++) atomicAdd(a.stats + t, (unsigned long long)cyc[t]);
+    atomicAdd(a.stats + 5, (unsigned long long)(__builtin_readcyclecounter() - t_kernel));
+  }
 }
 
 // ------------------------------------------------------------------------------------------ alignment (A.7)
@@ -709,7 +790,7 @@ __device__ __forceinline__ float scan_apply_max_w(const ScanC &c, float B) {
 }
 __device__ __forceinline__ int wave_max_i32_w(int x) { for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(x, m); x = o > x ? o : x; } return x; }
 
-template <int Q, int NLT>
+template <int Q, int NLT, bool TR>
 __global__ __launch_bounds__(512) void align_wide_kernel(WideAlignArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), W = blockDim.x >> 6;
@@ -722,7 +803,7 @@ __global__ __launch_bounds__(512) void align_wide_kernel(WideAlignArgs a) {
   WCtxT<NLT> c;
   c.spec = spec; c.xch = xch; c.NLr = NL; c.SP = SP; c.w = w; c.W = W; c.lane = lane; c.K = a.K; c.Kp = a.Kp; c.vl = vl;
   c.emL = nullptr;
-  const BackTab<Q, false> tb0{};
+  c.masks = nullptr;
   gf4 *slabA = const_cast<gf4 *>(uniform_global(a.scratch + (size_t)blockIdx.x * a.scratch_stride));      // F -> posteriors: [row][2][Q4][NL]
   gf4 *slabB = slabA + (size_t)(a.Lcap + 1) * 2 * Q4 * NL;                                                 // OA rows: [row][3][Q4][NL]
   c.Fs = slabA;
@@ -753,7 +834,7 @@ __global__ __launch_bounds__(512) void align_wide_kernel(WideAlignArgs a) {
     const LenCfg cu = len_config(L > 0 ? L : 1, false);
     // ---------------- unihit Forward, rows to slab A (spec slots 0..5 = N, B, E, J, C, S)
     float xC_L = 0.f; int ef_L = 0;
-    if (active) forward_wide<Q, true, NLT>(c, seq, L, cu, xC_L, ef_L);
+    if (active) forward_wide<Q, true, NLT, TR>(c, seq, L, cu, xC_L, ef_L);
     __threadfence_block();
     if (!(xC_L > 0.f)) active = false;
     bool clamped = false;
@@ -763,6 +844,8 @@ __global__ __launch_bounds__(512) void align_wide_kernel(WideAlignArgs a) {
       ScanC sc;
       float Aexcl;
       backward_prepare_wide<Q, NLT>(c, sc, Aexcl);
+      BackTab<Q, TR> tb0;
+      tb0.load(c);
       float Mb[Q], Ib[Q];
 #pragma unroll
       for (int p = 0; p < Q; p++) { Mb[p] = 0.f; Ib[p] = 0.f; }
@@ -777,13 +860,13 @@ __global__ __launch_bounds__(512) void align_wide_kernel(WideAlignArgs a) {
         float gfront = 0.f;
         if (i < L) {
           mirror_scale<Q>(reinterpret_cast<const int *>(spec)[WA_S * SP + i + 1] - reinterpret_cast<const int *>(spec)[WA_S * SP + i], Mb, Ib, xJ, xC, xN);
-          xB = backward_emit_wide<Q, NLT>(c, tb0, __builtin_amdgcn_readfirstlane((int)seq[i]), Mb, gfront);
+          xB = backward_emit_wide<Q, NLT, TR>(c, tb0, __builtin_amdgcn_readfirstlane((int)seq[i]), Mb, gfront);
           xJ = fmaf(xJ, cu.loop, xB * cu.move);
           xC = xC * cu.loop;
           xN = fmaf(xN, cu.loop, xB * cu.move);
         }
         const float xE = fmaf(xC, cu.EC, xJ * cu.EJ);
-        backward_cells_wide<Q, NLT>(c, tb0, sc, Aexcl, Mb, Ib, xE, gfront);
+        backward_cells_wide<Q, NLT, TR>(c, tb0, sc, Aexcl, Mb, Ib, xE, gfront);
         clamped |= clamp_backward<Q>(Mb, Ib, xB, xJ, xC, xN);
         const float s_i = invZ;
         const float s_p = ldexpf(invZ, reinterpret_cast<const int *>(spec)[WA_S * SP + i - 1] - reinterpret_cast<const int *>(spec)[WA_S * SP + i]);
@@ -810,7 +893,14 @@ __global__ __launch_bounds__(512) void align_wide_kernel(WideAlignArgs a) {
     const float tEJ = cu.EJ > 0.f ? 1.f : 0.f, tEC = cu.EC > 0.f ? 1.f : 0.f;
     if (active) {
       int nlv = NL;
-      auto T = [&](int arr, int q4) -> float4 { return ldt(c.fw, arr * Q4 + q4, nlv, (unsigned)vl); };
+      float4 tf[TR ? FW_NARR : 1][TR ? Q4 : 1];
+      if (TR) {
+#pragma unroll
+        for (int arr = 0; arr < FW_NARR; arr++)
+#pragma unroll
+          for (int q4 = 0; q4 < Q4; q4++) tf[TR ? arr : 0][TR ? q4 : 0] = ldg4(c.fw, (unsigned)((arr * Q4 + q4) * NL + vl));
+      }
+      auto T = [&](int arr, int q4) -> float4 { if constexpr (TR) return tf[arr][q4]; else return ldt(c.fw, arr * Q4 + q4, nlv, (unsigned)vl); };
       float allpass = 1.f;
 #pragma unroll
       for (int q4 = 0; q4 < Q4; q4++) { const float4 d = T(FW_D2, q4); if (!(d.x > 0.f && d.y > 0.f && d.z > 0.f && d.w > 0.f)) allpass = 0.f; }
@@ -1037,11 +1127,11 @@ size_t wide_align_lds_bytes(int Lcap) {
   return (size_t)(4 + wide::WA_NARR * SP + 8 * wide::X_N) * sizeof(float) + (size_t)(Lcap + 16);
 }
 
-template <int Q, int NLT>
+template <int Q, int NLT, bool TR = false>
 static hipError_t launch_walign_t(const WideAlignArgs &a, int blocks, int waves, size_t lds, hipStream_t s) {
-  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&wide::align_wide_kernel<Q, NLT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&wide::align_wide_kernel<Q, NLT, TR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (err != hipSuccess) return err;
-  hipLaunchKernelGGL((wide::align_wide_kernel<Q, NLT>), dim3(blocks), dim3(waves * 64), lds, s, a);
+  hipLaunchKernelGGL((wide::align_wide_kernel<Q, NLT, TR>), dim3(blocks), dim3(waves * 64), lds, s, a);
   return hipGetLastError();
 }
 
@@ -1050,11 +1140,11 @@ hipError_t launch_align_wide(int Q, const WideAlignArgs &a, int blocks, int wave
   if (Q == 4) return launch_walign_t<4, 0>(a, blocks, waves, lds, s);
   if (Q == kWideQReg) {
     switch (waves) {
-      case 5: return launch_walign_t<kWideQReg, 320>(a, blocks, waves, lds, s);
-      case 6: return launch_walign_t<kWideQReg, 384>(a, blocks, waves, lds, s);
-      case 7: return launch_walign_t<kWideQReg, 448>(a, blocks, waves, lds, s);
-      case 8: return launch_walign_t<kWideQReg, 512>(a, blocks, waves, lds, s);
-      default: return launch_walign_t<kWideQReg, 0>(a, blocks, waves, lds, s);
+      case 5: return launch_walign_t<kWideQReg, 320, true>(a, blocks, waves, lds, s);
+      case 6: return launch_walign_t<kWideQReg, 384, true>(a, blocks, waves, lds, s);
+      case 7: return launch_walign_t<kWideQReg, 448, true>(a, blocks, waves, lds, s);
+      case 8: return launch_walign_t<kWideQReg, 512, true>(a, blocks, waves, lds, s);
+      default: return launch_walign_t<kWideQReg, 0, true>(a, blocks, waves, lds, s);
     }
   }
   if (Q != kWideQ) return hipErrorInvalidValue;

@@ -772,15 +772,21 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
         if (class_mark(e, s, wq * W, 3)) return WH_EHIP;
         if (e->knobs.stats) {
           if (e->d_recs.ensure(320)) return WH_ENOMEM;
-          HIPCHK(hipMemsetAsync(e->d_recs.p, 0, 64, s));
+          HIPCHK(hipMemsetAsync(e->d_recs.p, 0, 320, s));
           a.stats = (unsigned long long *)e->d_recs.p;
         }
         hipError_t werr = launch_score_wide(wq, a, blocks, W, wlds, s);
         if (werr != hipSuccess) { set_error("wide score kernel launch failed: %s", hipGetErrorString(werr)); return WH_EHIP; }
         if (a.stats) {
-          unsigned long long st[6];
+          unsigned long long st[24];
           HIPCHK(hipMemcpyAsync(st, a.stats, sizeof st, hipMemcpyDeviceToHost, s));
           HIPCHK(hipStreamSynchronize(s));
+          for (int wv = 0; wv < 2; wv++) {
+            const unsigned long long *g = st + 8 + 8 * wv;
+            double rt = 0; for (int k = 0; k < 7; k++) rt += (double)g[k];
+            if (rt > 0) fprintf(stderr, "[wh] wide P1 row, %s wave: cells %.1f%%  barrier0 %.1f%%  local D %.1f%%  barrier1 %.1f%%  fix-up+sum %.1f%%  barrier2 %.1f%%  specials+tail %.1f%%\n", wv ? "last" : "first",
+                                100 * g[0] / rt, 100 * g[1] / rt, 100 * g[2] / rt, 100 * g[3] / rt, 100 * g[4] / rt, 100 * g[5] / rt, 100 * g[6] / rt);
+          }
           const double tot = (double)st[5] > 0 ? (double)st[5] : 1.0;
           fprintf(stderr, "[wh] wide %d x %d cells per lane, cycles of the first wave: P1 %.1f%%  P2 %.1f%%  regions %.1f%%  P3 %.1f%%  P4 %.1f%%  (of %.3g)\n", W, wq,
                   100.0 * st[0] / tot, 100.0 * st[1] / tot, 100.0 * st[2] / tot, 100.0 * st[3] / tot, 100.0 * st[4] / tot, tot);

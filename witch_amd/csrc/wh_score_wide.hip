@@ -78,6 +78,7 @@ struct WCtxT {
   float *xch;                   // LDS: W slots of X_N floats
   gf4 *Fs;                      // slab of the workgroup (uniform base): [row][2][Q4][NL]
   unsigned long long *masks;    // sparse spill (scoring): [row][W] the lanes of each wave that stored their cells of the row; or null
+  unsigned long long *rowstat;  // WH_STATS: cycles of the multihit Forward row by segment ([8..15] of the stats block), or null
   int NLr, SP, w, W, lane, K, Kp;
   // lanes over all waves of the workgroup: a compile-time constant in the production instantiations (table accesses then
   // are one scalar base + immediate offsets; with a run-time value the compiler kept 60 offsets per row in scratch)
@@ -85,6 +86,44 @@ struct WCtxT {
 };
 
 __device__ __forceinline__ void wg_barrier() { __syncthreads(); }
+
+// What every wave reads from the exchange slots after a barrier, without a loop of dependent LDS reads: lane v fetches the
+// slot of wave v (ONE round of LDS reads), the sum / the fold then walks the lanes with v_readlane in wave order (the same
+// operations in the same order as the loop over the slots: bit-identical).  With a compile-time wave count the lane
+// numbers are immediates.
+template <int NLT>
+__device__ __forceinline__ float slots_sum(const float *xch, int slot, int W, int lane) {
+  const float v = lane < W ? xch[lane * X_N + slot] : 0.f;
+  float s = 0.f;
+  if constexpr (NLT > 0) {
+#pragma unroll
+    for (int u = 0; u < NLT / 64; u++) s += readlane_f(v, u);
+  } else {
+    for (int u = 0; u < W; u++) s += readlane_f(v, u);
+  }
+  return s;
+}
+// cin of wave w = the D of the last cell of wave w-1 = the fold over the waves in front of D_last(v) = A_v * D_last(v-1) + B_v:
+// an affine prefix scan over the (at most eight) wave slots, lane v holding wave v - three DPP steps for every wave alike
+// instead of w dependent steps for wave w (the last wave's fold was the longest stretch between two barriers).  The A part
+// is model-only: its step multipliers are formed once per sweep.
+struct WaveScan { float s0, s1, s2; };
+__device__ __forceinline__ WaveScan wave_scan_prepare(const float *xch, int W, int lane) {
+  float A = lane < W ? xch[lane * X_N + X_AT] : 1.f;
+  WaveScan c;
+  c.s0 = A; A *= dppf<0x111>(1.f, A);
+  c.s1 = A; A *= dppf<0x112>(1.f, A);
+  c.s2 = A;
+  return c;
+}
+__device__ __forceinline__ float slots_fold(const WaveScan &c, const float *xch, int W, int w, int lane) {
+  float B = lane < W ? xch[lane * X_N + X_BD] : 0.f;
+  asm("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(B) : "v"(c.s0));
+  asm("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %1 row_shr:2 row_mask:0xf bank_mask:0xf" : "+v"(B) : "v"(c.s1));
+  asm("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %1 row_shr:4 row_mask:0xf bank_mask:0xf" : "+v"(B) : "v"(c.s2));
+  asm("s_nop 1" : "+v"(B));
+  return w > 0 ? readlane_f(B, w - 1) : 0.f;
+}
 
 // inclusive product over lanes 0..lane of <a> (model-only; once per sweep)
 __device__ __forceinline__ float lane_prefix_product(float a, int lane) {
@@ -130,6 +169,19 @@ __device__ __forceinline__ void forward_wide(const WCtxT<NLT> &c, const uint8_t 
   float Aexcl = __shfl_up(Aincl, 1);
   if (lane == 0) Aexcl = 1.f;
   if (lane == 63) xch[w * X_N + X_AT] = Aincl;
+  // TR: the in-lane running products of the D->D transitions (what FW_P holds for the one-wave kernels): the carry then
+  // enters every cell with ONE independent FMA instead of a chain of Q dependent multiplications - two waves per SIMD do
+  // not hide a dependent chain
+  float Pq[TR ? Q : 1];
+  if (TR) {
+    float run = 1.f;
+#pragma unroll
+    for (int q4 = 0; q4 < Q4; q4++) {
+      const float4 d = T(FW_D2, q4);
+      run *= d.x; Pq[TR ? 4 * q4 : 0] = run; run *= d.y; Pq[TR ? 4 * q4 + 1 : 0] = run;
+      run *= d.z; Pq[TR ? 4 * q4 + 2 : 0] = run; run *= d.w; Pq[TR ? 4 * q4 + 3 : 0] = run;
+    }
+  }
   float Mp[Q], Ip[Q], Dp[Q];
 #pragma unroll
   for (int q = 0; q < Q; q++) { Mp[q] = 0.f; Ip[q] = 0.f; Dp[q] = 0.f; }
@@ -141,6 +193,11 @@ __device__ __forceinline__ void forward_wide(const WCtxT<NLT> &c, const uint8_t 
     reinterpret_cast<int *>(spec)[SP_S * SP] = 0;
   }
   wg_barrier();                                // X_AT of every wave is visible
+  const WaveScan scW = wave_scan_prepare(xch, c.W, lane);
+  long long seg[7] = {0, 0, 0, 0, 0, 0, 0};
+  const bool timed = !STORE && c.rowstat != nullptr;
+  long long tr = timed ? __builtin_readcyclecounter() : 0;
+  auto mark = [&](int k) { if (timed) { const long long t = __builtin_readcyclecounter(); seg[k] += t - tr; tr = t; } };
 #pragma unroll 1
   for (int i = 1; i <= L; i++) {
     const int x = __builtin_amdgcn_readfirstlane((int)seq[i - 1]);
@@ -170,7 +227,9 @@ __device__ __forceinline__ void forward_wide(const WCtxT<NLT> &c, const uint8_t 
     // D row: chains inside the lane, scan over the lanes of this wave, maps of the waves in front.  The first cell of a
     // wave needs the NEW M of the cell in front of it (the last cell of the previous wave): one exchange of its own
     if (lane == 63) xch[w * X_N + X_T0] = Mp[Q - 1];
+    mark(0);
     wg_barrier();                                                               // #0
+    mark(1);
     float mn1 = wave_shr1(Mp[Q - 1]);
     if (lane == 0) mn1 = w > 0 ? xch[(w - 1) * X_N + X_T0] : 0.f;
     float dprev = 0.f;
@@ -187,30 +246,44 @@ __device__ __forceinline__ void forward_wide(const WCtxT<NLT> &c, const uint8_t 
     }
     const float loc = scan_apply(sc, dprev);        // D of my last cell if nothing entered the wave from the front
     if (lane == 63) xch[w * X_N + X_BD] = loc;
+    mark(2);
     wg_barrier();                                                               // #1
+    mark(3);
     // D of the last cell of the wave in front: D_last(v) = A_v * D_last(v-1) + B_v, folded in wave order
-    float cin = 0.f;
-    for (int v = 0; v < w; v++) cin = fmaf(xch[v * X_N + X_AT], cin, xch[v * X_N + X_BD]);
+    const float cin = slots_fold(scW, xch, c.W, w, lane);
     float carry = wave_shr1(loc);
     carry = fmaf(Aexcl, cin, carry);
     if (lane == 0) carry = cin;
     float es = 0.f;
+    if constexpr (TR) {
+      float part[Q4];
 #pragma unroll
-    for (int q4 = 0; q4 < Q4; q4++) {
-      const float4 D2 = T(FW_D2, q4);
+      for (int q4 = 0; q4 < Q4; q4++) {
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int q = 4 * q4 + j;
-        carry *= f4get(D2, j);
-        Dp[q] += carry;
-        es += Mp[q] + Dp[q];
+        for (int j = 0; j < 4; j++) { const int q = 4 * q4 + j; Dp[q] = fmaf(Pq[q], carry, Dp[q]); }
+        part[q4] = ((Mp[4 * q4] + Dp[4 * q4]) + (Mp[4 * q4 + 1] + Dp[4 * q4 + 1])) + ((Mp[4 * q4 + 2] + Dp[4 * q4 + 2]) + (Mp[4 * q4 + 3] + Dp[4 * q4 + 3]));
+      }
+#pragma unroll
+      for (int q4 = 0; q4 < Q4; q4++) es += part[q4];
+    } else {
+#pragma unroll
+      for (int q4 = 0; q4 < Q4; q4++) {
+        const float4 D2 = T(FW_D2, q4);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int q = 4 * q4 + j;
+          carry *= f4get(D2, j);
+          Dp[q] += carry;
+          es += Mp[q] + Dp[q];
+        }
       }
     }
     const float esw = wave_sum(es);
     if (lane == 63) { xch[w * X_N + X_ES] = esw; xch[w * X_N + X_BM] = Mp[Q - 1]; xch[w * X_N + X_BI] = Ip[Q - 1]; xch[w * X_N + X_BDD] = Dp[Q - 1]; }
+    mark(4);
     wg_barrier();                                                               // #2
-    xE = 0.f;
-    for (int v = 0; v < c.W; v++) xE += xch[v * X_N + X_ES];
+    mark(5);
+    xE = slots_sum<NLT>(xch, X_ES, c.W, lane);
     if (w > 0) { bM = xch[(w - 1) * X_N + X_BM]; bI = xch[(w - 1) * X_N + X_BI]; bD = xch[(w - 1) * X_N + X_BDD]; }
     xN = xN * cfg.loop;
     xC = fmaf(xC, cfg.loop, xE * cfg.EC);
@@ -251,7 +324,9 @@ __device__ __forceinline__ void forward_wide(const WCtxT<NLT> &c, const uint8_t 
         }
       }
     }
+    mark(6);
   }
+  if (timed && lane == 0 && (w == 0 || w == c.W - 1)) for (int k = 0; k < 7; k++) atomicAdd(c.rowstat + (w == 0 ? 0 : 8) + k, (unsigned long long)seg[k]);
   xC_out = xC;
   ef_out = ef;
   wg_barrier();
@@ -269,6 +344,7 @@ struct BackState { float Mb[Q], Ib[Q]; };
 template <int Q, bool TR>
 struct BackTab {
   float4 v[TR ? BW_NARR : 1][TR ? Q / 4 : 1];
+  float P[TR ? Q : 1];           // in-lane running products of the D->D transitions (see forward_wide)
   template <int NLT>
   __device__ __forceinline__ void load(const WCtxT<NLT> &c) {
     if (TR) {
@@ -276,6 +352,13 @@ struct BackTab {
       for (int a = 0; a < BW_NARR; a++)
 #pragma unroll
         for (int q4 = 0; q4 < Q / 4; q4++) v[TR ? a : 0][TR ? q4 : 0] = ldg4(c.bw, (unsigned)((a * (Q / 4) + q4) * c.nl() + c.vl));
+      float run = 1.f;
+#pragma unroll
+      for (int q4 = 0; q4 < Q / 4; q4++) {
+        const float4 d = v[TR ? BW_DD : 0][TR ? q4 : 0];
+        run *= d.x; P[TR ? 4 * q4 : 0] = run; run *= d.y; P[TR ? 4 * q4 + 1 : 0] = run;
+        run *= d.z; P[TR ? 4 * q4 + 2 : 0] = run; run *= d.w; P[TR ? 4 * q4 + 3 : 0] = run;
+      }
     }
   }
 };
@@ -294,22 +377,29 @@ __device__ __forceinline__ float backward_emit_wide(const WCtxT<NLT> &c, const B
     float4 E, O;
     if constexpr (TR) { E = tb.v[BW_E][p4]; O = emission_piece<Q>(c.em, c.emL, c.K, x, Q4 - 1 - p4, nlv, (unsigned)rv); }
     else { E = ldt(c.bw, BW_E * Q4 + p4, nlv, (unsigned)c.vl); O = ldt(c.em, x * Q4 + (Q4 - 1 - p4), nlv, (unsigned)rv); }
-    Mb[4 * p4 + 0] *= O.w; part = fmaf(E.x, Mb[4 * p4 + 0], part);
-    Mb[4 * p4 + 1] *= O.z; part = fmaf(E.y, Mb[4 * p4 + 1], part);
-    Mb[4 * p4 + 2] *= O.y; part = fmaf(E.z, Mb[4 * p4 + 2], part);
-    Mb[4 * p4 + 3] *= O.x; part = fmaf(E.w, Mb[4 * p4 + 3], part);
+    if constexpr (TR) {
+      // (one short chain per piece instead of one of Q dependent FMAs)
+      Mb[4 * p4 + 0] *= O.w; Mb[4 * p4 + 1] *= O.z; Mb[4 * p4 + 2] *= O.y; Mb[4 * p4 + 3] *= O.x;
+      float pp = E.x * Mb[4 * p4 + 0];
+      pp = fmaf(E.y, Mb[4 * p4 + 1], pp); pp = fmaf(E.z, Mb[4 * p4 + 2], pp); pp = fmaf(E.w, Mb[4 * p4 + 3], pp);
+      part += pp;
+    } else {
+      Mb[4 * p4 + 0] *= O.w; part = fmaf(E.x, Mb[4 * p4 + 0], part);
+      Mb[4 * p4 + 1] *= O.z; part = fmaf(E.y, Mb[4 * p4 + 1], part);
+      Mb[4 * p4 + 2] *= O.y; part = fmaf(E.z, Mb[4 * p4 + 2], part);
+      Mb[4 * p4 + 3] *= O.x; part = fmaf(E.w, Mb[4 * p4 + 3], part);
+    }
   }
   const float pw = wave_sum(part);
   if (lane == 63) { xch[w * X_N + X_ES] = pw; xch[w * X_N + X_BM] = Mb[Q - 1]; }
   wg_barrier();                                                                 // #A
-  float xB = 0.f;
-  for (int v = 0; v < c.W; v++) xB += xch[v * X_N + X_ES];
+  const float xB = slots_sum<NLT>(xch, X_ES, c.W, lane);
   gfront = w > 0 ? xch[(w - 1) * X_N + X_BM] : 0.f;     // G of the cell in front of my first one
   return xB;
 }
 
 template <int Q, int NLT, bool TR = false>
-__device__ __forceinline__ void backward_cells_wide(const WCtxT<NLT> &c, const BackTab<Q, TR> &tb, const ScanC &sc, float Aexcl, float (&Mb)[Q], float (&Ib)[Q], float xE, float gfront) {
+__device__ __forceinline__ void backward_cells_wide(const WCtxT<NLT> &c, const BackTab<Q, TR> &tb, const ScanC &sc, const WaveScan &scW, float Aexcl, float (&Mb)[Q], float (&Ib)[Q], float xE, float gfront) {
   constexpr int Q4 = Q / 4;
   const int NL = c.nl(), w = c.w, lane = c.lane;
   float *xch = c.xch;
@@ -333,20 +423,24 @@ __device__ __forceinline__ void backward_cells_wide(const WCtxT<NLT> &c, const B
   const float loc = scan_apply(sc, dprev);
   if (lane == 63) xch[w * X_N + X_BD] = loc;
   wg_barrier();                                                                 // #B
-  float cin = 0.f;
-  for (int v = 0; v < w; v++) cin = fmaf(xch[v * X_N + X_AT], cin, xch[v * X_N + X_BD]);
+  const float cin = slots_fold(scW, xch, c.W, w, lane);
   float carry = wave_shr1(loc);
   carry = fmaf(Aexcl, cin, carry);
   if (lane == 0) carry = cin;
   const float dfront = carry;                  // D of the cell in front of my first one (lane r: last cell of lane r-1)
+  if constexpr (TR) {
 #pragma unroll
-  for (int p4 = 0; p4 < Q4; p4++) {
-    const float4 DD = T(BW_DD, p4);
+    for (int p = 0; p < Q; p++) Dn[p] = fmaf(tb.P[p], carry, Dn[p]);
+  } else {
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int p = 4 * p4 + j;
-      carry *= f4get(DD, j);
-      Dn[p] += carry;
+    for (int p4 = 0; p4 < Q4; p4++) {
+      const float4 DD = T(BW_DD, p4);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int p = 4 * p4 + j;
+        carry *= f4get(DD, j);
+        Dn[p] += carry;
+      }
     }
   }
 #pragma unroll
@@ -370,7 +464,7 @@ __device__ __forceinline__ void backward_cells_wide(const WCtxT<NLT> &c, const B
 
 // model-only parts of the Backward D scans of this sweep (X_AT published; the caller's first barrier makes it visible)
 template <int Q, int NLT>
-__device__ __forceinline__ void backward_prepare_wide(const WCtxT<NLT> &c, ScanC &sc, float &Aexcl) {
+__device__ __forceinline__ void backward_prepare_wide(const WCtxT<NLT> &c, ScanC &sc, float &Aexcl, WaveScan &scW) {
   constexpr int Q4 = Q / 4;
   float A = 1.f;
 #pragma unroll
@@ -381,6 +475,7 @@ __device__ __forceinline__ void backward_prepare_wide(const WCtxT<NLT> &c, ScanC
   if (c.lane == 0) Aexcl = 1.f;
   if (c.lane == 63) c.xch[c.w * X_N + X_AT] = Aincl;
   wg_barrier();
+  scW = wave_scan_prepare(c.xch, c.W, c.lane);
 }
 
 // ------------------------------------------------------------------------------------------ P2: multihit Backward + decoding
@@ -390,7 +485,8 @@ __device__ __forceinline__ void backward_decode_wide(const WCtxT<NLT> &c, const 
   float *spec = c.spec;
   ScanC sc;
   float Aexcl;
-  backward_prepare_wide<Q, NLT>(c, sc, Aexcl);
+  WaveScan scW;
+  backward_prepare_wide<Q, NLT>(c, sc, Aexcl, scW);
   BackTab<Q, TR> tb;
   tb.load(c);
   float Mb[Q], Ib[Q];
@@ -408,7 +504,7 @@ __device__ __forceinline__ void backward_decode_wide(const WCtxT<NLT> &c, const 
       xN = fmaf(xN, cm.loop, xB * cm.move);
     }
     float xE = fmaf(xC, cm.EC, xJ * cm.EJ);
-    if (i >= 1) backward_cells_wide<Q, NLT, TR>(c, tb, sc, Aexcl, Mb, Ib, xE, gfront);
+    if (i >= 1) backward_cells_wide<Q, NLT, TR>(c, tb, sc, scW, Aexcl, Mb, Ib, xE, gfront);
     const float big = fmaxf(xB, xN);
     if (big > kRescaleHi) {
       const int e = f32_exponent(big);
@@ -449,7 +545,8 @@ __device__ __forceinline__ float backward_null2_wide(const WCtxT<NLT> &c, const 
   float *xch = c.xch;
   ScanC sc;
   float Aexcl;
-  backward_prepare_wide<Q, NLT>(c, sc, Aexcl);
+  WaveScan scW;
+  backward_prepare_wide<Q, NLT>(c, sc, Aexcl, scW);
   BackTab<Q, TR> tb;
   tb.load(c);
   float Mb[Q], Ib[Q], fM[Q];
@@ -499,7 +596,7 @@ __device__ __forceinline__ float backward_null2_wide(const WCtxT<NLT> &c, const 
       xN = fmaf(xN, cu.loop, xB * cu.move);
     }
     const float xE = fmaf(xC, cu.EC, xJ * cu.EJ);
-    backward_cells_wide<Q, NLT, TR>(c, tb, sc, Aexcl, Mb, Ib, xE, gfront);
+    backward_cells_wide<Q, NLT, TR>(c, tb, sc, scW, Aexcl, Mb, Ib, xE, gfront);
     clamp_backward<Q>(Mb, Ib, xB, xJ, xC, xN);
     const float s_i = invZe;
     const float s_p = ldexpf(invZe, -dS);
@@ -603,6 +700,7 @@ __global__ __launch_bounds__(512) void score_wide_kernel(WideArgs a) {
   // the per-row lane masks of the sparse spill sit behind the rows of the slab
   c.masks = a.sparse ? reinterpret_cast<unsigned long long *>(a.scratch + (size_t)blockIdx.x * a.scratch_stride + (size_t)(a.Lcap + 1) * 2 * Q * NL) : nullptr;
   c.vl = vl;
+  c.rowstat = a.stats ? a.stats + 8 : nullptr;
   uint32_t degen = 0;
   for (int t = 0; t < 32; t++) if (t == lane) degen = a.degen[t];
   long long cyc[5] = {0, 0, 0, 0, 0};
@@ -804,6 +902,7 @@ __global__ __launch_bounds__(512) void align_wide_kernel(WideAlignArgs a) {
   c.spec = spec; c.xch = xch; c.NLr = NL; c.SP = SP; c.w = w; c.W = W; c.lane = lane; c.K = a.K; c.Kp = a.Kp; c.vl = vl;
   c.emL = nullptr;
   c.masks = nullptr;
+  c.rowstat = nullptr;
   gf4 *slabA = const_cast<gf4 *>(uniform_global(a.scratch + (size_t)blockIdx.x * a.scratch_stride));      // F -> posteriors: [row][2][Q4][NL]
   gf4 *slabB = slabA + (size_t)(a.Lcap + 1) * 2 * Q4 * NL;                                                 // OA rows: [row][3][Q4][NL]
   c.Fs = slabA;
@@ -843,7 +942,8 @@ __global__ __launch_bounds__(512) void align_wide_kernel(WideAlignArgs a) {
       const float invZ = 1.0f / (xC_L * cu.move);
       ScanC sc;
       float Aexcl;
-      backward_prepare_wide<Q, NLT>(c, sc, Aexcl);
+      WaveScan scW;
+  backward_prepare_wide<Q, NLT>(c, sc, Aexcl, scW);
       BackTab<Q, TR> tb0;
       tb0.load(c);
       float Mb[Q], Ib[Q];
@@ -866,7 +966,7 @@ __global__ __launch_bounds__(512) void align_wide_kernel(WideAlignArgs a) {
           xN = fmaf(xN, cu.loop, xB * cu.move);
         }
         const float xE = fmaf(xC, cu.EC, xJ * cu.EJ);
-        backward_cells_wide<Q, NLT, TR>(c, tb0, sc, Aexcl, Mb, Ib, xE, gfront);
+        backward_cells_wide<Q, NLT, TR>(c, tb0, sc, scW, Aexcl, Mb, Ib, xE, gfront);
         clamped |= clamp_backward<Q>(Mb, Ib, xB, xJ, xC, xN);
         const float s_i = invZ;
         const float s_p = ldexpf(invZ, reinterpret_cast<const int *>(spec)[WA_S * SP + i - 1] - reinterpret_cast<const int *>(spec)[WA_S * SP + i]);

@@ -587,6 +587,20 @@ def test_models_beyond_3072_nodes_take_the_any_size_kernels(root_len, alphabet, 
     assert np.max(np.abs(fwd - ofwd)) <= 1e-3, np.max(np.abs(fwd - ofwd))
     assert np.array_equal(flags & 3, of & 3)
     _check_decibits(deci, od, osc, (of & 1) == 1, root_len, LONG_EPS)
+    # round 4: the several-waves-per-pair kernel stores only the lanes of an envelope's Forward rows that matter (per-row
+    # lane masks, posterior-mass certificate) and, up to 6 144 nodes, reads its emission rows from LDS: with every row
+    # stored / the rows read from L2 (environment, read per call) the scores are the same numbers
+    for knob in ("WH_WIDE_DENSE", "WH_WIDE_NO_EM_LDS"):
+        os.environ[knob] = "1"
+        try:
+            deci2, flags2, fwd2 = e.score(res, offs, want_fwd=True)
+        finally:
+            os.environ.pop(knob, None)
+        assert np.array_equal(fwd2, fwd), knob
+        assert np.array_equal(flags2 & 7, flags & 7), knob
+        single = (flags & 2) == 0          # (multidomain pairs: the resolver's float64 path, unchanged by the knobs but checked above)
+        assert np.max(np.abs(deci2[single].astype(np.int64) - deci[single])) <= (1 if knob == "WH_WIDE_DENSE" else 0), knob
+        assert np.array_equal(deci2[~single], deci[~single]), knob
     # alignment, every pair: the two-copy queries hold two hits of thousands of bits each in ONE unihit alignment,
     # beyond the range of a scaled double - the oracle switches to long double there, hmmalign to log space, the
     # any-size kernel to its log-space twins

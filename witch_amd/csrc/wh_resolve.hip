@@ -325,8 +325,8 @@ __global__ __launch_bounds__(64 * kResMaxWaves) void resolve_kernel(ResolveArgs 
               const unsigned long long key = (1ull << 63) | ((unsigned long long)sidx << 60) | ((unsigned long long)(unsigned)i << 30) | kkey;
               const unsigned slot = (((unsigned)i * 0x9E3779B1u) ^ (kkey * 0x85EBCA77u) ^ ((unsigned)sidx * 0xC2B2AE3Du)) >> (32 - kDcBits);
               u4_t *dline = dlines + (size_t)slot * 64 + lane;
-              const u4_t ent = __builtin_nontemporal_load(dline);
-              const unsigned long long tg = __builtin_nontemporal_load(dtags + slot);
+              const u4_t ent = *dline;
+              const unsigned long long tg = dtags[slot];
               if (tg == key) {
                 run_r1 = ent.x; run_r2 = ent.y; run_r3 = ent.z; run_hi = ent.w;
                 if (a.stats) n_hit++;

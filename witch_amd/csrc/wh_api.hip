@@ -193,7 +193,7 @@ wh_ehmm *wh_ehmm_load(const char *const *hmm_paths, const int32_t *hmm_index, co
   e->dev.resize((size_t)n);
   // Parsing the text files and laying out the tables is host work per model (a few ms per 1 500-node model):
   // done on a small thread pool, then concatenated in model order so that the buffers do not depend on timing.
-  struct Built { int rc = WH_OK; std::string err; int Q = -1, wideW = 0; std::vector<float> fw, bw, em, emn, wfw, wbw, wem; std::vector<double> gfw, gem; };
+  struct Built { int rc = WH_OK; std::string err; int Q = -1, wideW = 0; std::vector<float> fw, bw, em, emn, wfw, wbw, wem; std::vector<double> gfw, gem, gsum; };
   // WH_FORCE_WIDE=<4|24>: every model that fits 8 waves of that many cells per lane ALSO gets wide tables and is scored by the
   // several-waves-per-pair kernel (tests run the golden cases through it; production: models beyond 3 072 nodes only)
   const int force_wide_q = getenv("WH_FORCE_WIDE") ? atoi(getenv("WH_FORCE_WIDE")) : 0;
@@ -228,6 +228,11 @@ wh_ehmm *wh_ehmm_load(const char *const *hmm_paths, const int32_t *hmm_index, co
         for (int k = 1; k <= h.M; k++)
           for (int x = 0; x < h.K; x++) b.emn[(size_t)k * h.K + x] = (float)h.odds[(size_t)x * (h.M + 1) + k];
         build_tables_f64(h, b.Q, b.gfw, b.gem);
+        // prefix sums over the nodes of those float32 odds, in double: the null2 vector of a sampled domain is a handful of
+        // differences of these rows (one per run of match states) instead of one table row per residue (wh_resolve.hip)
+        b.gsum.assign((size_t)(h.M + 1) * h.K, 0.0);
+        for (int k = 1; k <= h.M; k++)
+          for (int x = 0; x < h.K; x++) b.gsum[(size_t)k * h.K + x] = b.gsum[(size_t)(k - 1) * h.K + x] + (double)b.emn[(size_t)k * h.K + x];
       }
     };
     const unsigned hw = std::thread::hardware_concurrency();
@@ -270,6 +275,9 @@ wh_ehmm *wh_ehmm_load(const char *const *hmm_paths, const int32_t *hmm_index, co
     }
     d.gfw_off = (int64_t)gtab.size(); gtab.insert(gtab.end(), b.gfw.begin(), b.gfw.end());
     d.gem_off = (int64_t)gtab.size(); gtab.insert(gtab.end(), b.gem.begin(), b.gem.end());
+    gtab.resize((gtab.size() + 1) & ~(size_t)1, 0.0);
+    d.esum_off = (int64_t)gtab.size(); gtab.insert(gtab.end(), b.gsum.begin(), b.gsum.end());
+    gtab.resize((gtab.size() + 1) & ~(size_t)1, 0.0);
     b = Built();                                              // release the per-model copies as we go
     if (Q <= kMaxQ) e->by_q[Q].push_back(i);
     else { e->generic.push_back(i); if (d.wideW == 0) e->generic_front.push_back(i); }

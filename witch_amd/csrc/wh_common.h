@@ -54,6 +54,7 @@ struct DevHMM {
   int64_t fw_off, bw_off, em_off;    // offsets (in floats) into the table buffer
   int64_t gfw_off, gem_off;          // offsets (in doubles) into the float64 table buffer of the resolver
   int64_t emn_off;                   // node-major float32 emission odds [M+1][K] in the float table buffer (resolver: null2 by trace)
+  int64_t esum_off;                  // ... and their prefix sums over the nodes, [M+1][K] doubles in the float64 table buffer
   int32_t wideQ, wideW;              // > 0: float32 tables laid out over wideW x 64 lanes of wideQ cells (wh_score_wide.hip) at ...
   int64_t wfw_off, wbw_off, wem_off; // ... these offsets (floats) of the table buffer
 };

@@ -548,6 +548,56 @@ __global__ __launch_bounds__(64 * kResMaxWaves) void resolve_kernel(ResolveArgs 
         for (int d = 0; d < ndom; d++) {
           const int df = dom[4 * d], dt = dom[4 * d + 1], Ld = dt - df + 1;
           float mine = 1.0f;
+          // Round 4: the sum of the emission odds over the domain's match states from PREFIX SUMS over the nodes (float64,
+          // DevHMM::esum_off): a sampled domain is a dozen runs of consecutive nodes, so its sum is a dozen differences of
+          // table rows - found from the per-residue states in LDS, fetched in one or two rounds of loads - instead of one
+          // table row per residue in three to five dependent rounds (this loop was a third of the trace time).  The sum is
+          // exact to 1e-16 before it is rounded to float (HMMER adds the same terms in float32, in striped node order).
+          bool by_runs = false;
+          {
+            int *blist = reinterpret_cast<int *>(bins);             // signed node numbers: +k adds row k, -k subtracts it (128 entries)
+            int nb = 0, nI = 0;
+            for (int p0 = df; p0 <= dt; p0 += 64) {
+              const int p = p0 + lane;
+              const bool valid = p <= dt;
+              const int kk = valid ? (int)stk[p] : 0;
+              const int km = (valid && p > df) ? (int)stk[p - 1] : -32768, kp = (valid && p < dt) ? (int)stk[p + 1] : -32768;
+              const bool isM = valid && kk > 0;
+              nI += __builtin_popcountll(__ballot(valid && kk <= 0));
+              const bool st = isM && km != kk - 1 && kk > 1, en = isM && kp != kk + 1;
+              const unsigned long long bs = __ballot(st), be = __ballot(en);
+              const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+              const int is_ = nb + __builtin_popcountll(bs & below), ie = nb + __builtin_popcountll(bs) + __builtin_popcountll(be & below);
+              if (st && is_ < 128) blist[is_] = -(kk - 1);
+              if (en && ie < 128) blist[ie] = kk;
+              nb += __builtin_popcountll(bs) + __builtin_popcountll(be);
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (nb <= 128) {
+              by_runs = true;
+              const double *esum = a.gtab + hm.esum_off;
+              const int G = 64 / a.K, g = lane / a.K, x = lane - g * a.K;
+              double sd = 0.0;
+              if (g < G) {
+#pragma unroll 4
+                for (int b = g; b < nb; b += G) {
+                  const int e = blist[b];
+                  const double v = esum[(size_t)(e < 0 ? -e : e) * a.K + x];
+                  sd += e < 0 ? -v : v;
+                }
+              }
+              __builtin_amdgcn_wave_barrier();
+              bins[lane] = sd;
+              __builtin_amdgcn_wave_barrier();
+              if (lane < a.K) {
+                double tot = 0.0;
+                for (int gg = 0; gg < G; gg++) tot += bins[gg * a.K + lane];
+                mine = (float)(tot + (double)nI) / (float)Ld;
+              }
+              __builtin_amdgcn_wave_barrier();
+            }
+          }
+          if (!by_runs) {
           // one lane per sampled position: the K odds of its emitting node are contiguous (node-major float
           // copy, DevHMM::emn_off), summed per residue in registers, then K wave sums
           float part[20];
@@ -583,6 +633,7 @@ __global__ __launch_bounds__(64 * kResMaxWaves) void resolve_kernel(ResolveArgs 
               const float s = wave_sum_f(part[x]);
               if (lane == x) mine = s / (float)Ld;
             }
+          }
           }
           __builtin_amdgcn_wave_barrier();
           if (lane < a.K) dnull[32 * d + lane] = mine;

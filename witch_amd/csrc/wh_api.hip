@@ -87,6 +87,7 @@ struct wh_ehmm {
   std::vector<int32_t> generic;               // models beyond the register-resident classes (wh_generic.hip)
   std::vector<int32_t> generic_front;         // ... of them, those SCORED by the float64 front end (the others: wide_by_w)
   std::map<int, std::vector<int32_t>> wide_by_w;   // cells per lane * 16 + waves per pair -> models scored by wh_score_wide.hip (3 073 - 12 288 nodes)
+  unsigned resolver_launches = 0;             // see ResolveArgs::launch_id
   int force_wide_q = 0;                       // WH_FORCE_WIDE=<4|12|24>: cells per lane of every model's wide tables (tests)
   bool force_wide = false;                    // WH_FORCE_WIDE: EVERY model is scored by the wide kernel (test hook)
   DevBuf d_wscratch;                          // Forward slabs of the wide kernel's workgroups
@@ -894,6 +895,7 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
       r.H = (int)e->hmms.size(); r.K = e->K; r.Kp = e->Kp;
       memcpy(r.degen, e->degen, sizeof r.degen);
       r.dbg = e->knobs.rdbg;
+      r.launch_id = ++e->resolver_launches;
       if (e->knobs.stats) {
         if (e->d_recs.ensure(256)) return WH_ENOMEM;
         HIPCHK(hipMemsetAsync(e->d_recs.p, 0, 256, s));
@@ -1015,7 +1017,7 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
       rlaunches++;
       e->last_resolved = n_multi;
       if (r.stats) {
-        unsigned long long st[20];
+        unsigned long long st[24];
         HIPCHK(hipMemcpyAsync(st, r.stats, sizeof st, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         const double tot = (double)(st[0] + st[1] + st[2] + st[3] + st[4]);
@@ -1027,6 +1029,9 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
                 st[8] / (200.0 * n_multi), st[9] / (200.0 * n_multi), st[10] / (200.0 * n_multi), st[11] / (200.0 * n_multi),
                 (double)st[5] / (double)std::max<unsigned long long>(1, st[8] + st[9] + st[10]));
         fprintf(stderr, "[wh]   threshold-line cache: %.1f%% of the fetches hit\n", 100.0 * st[12] / (double)std::max<unsigned long long>(1, st[8] + st[9] + st[10]));
+        fprintf(stderr, "[wh]   fetch order: %.1f%% of the fetches are the one that followed the last matched fetch in the previous trace, %.1f%% re-synchronise elsewhere in it\n",
+                100.0 * st[20] / (double)std::max<unsigned long long>(1, st[8] + st[9] + st[10]), 100.0 * st[21] / (double)std::max<unsigned long long>(1, st[8] + st[9] + st[10]));
+        fprintf(stderr, "[wh]   the line's load alone (issue -> validated): %.0f cycles per fetch\n", (double)st[23] / (double)std::max<unsigned long long>(1, st[8] + st[9] + st[10]));
         fprintf(stderr, "[wh]   shader clock while a pair is resolved: %.2f GHz (cycle counter / 100 MHz real-time counter); pair cycles %.3g\n", st[15] ? 0.1 * (double)st[14] / (double)st[15] : 0.0, (double)st[14]);
         fprintf(stderr, "[wh]   wave lifetimes: %llu waves, mean %.1f ms, longest %.1f ms (a wave leaves when no slot is left)\n", st[19], st[19] ? 1e-5 * (double)st[17] / (double)st[19] : 0.0, 1e-5 * (double)st[18]);
         fprintf(stderr, "[wh]   waiting at the workgroup's slot barriers: %.1f%% on top of the pair cycles (%d slots on %d models, %d workgroups of %d waves)\n", 100.0 * st[13] / tot, r.n_slots, r.n_chunks, blocks, waves);

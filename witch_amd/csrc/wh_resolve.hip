@@ -33,6 +33,7 @@ namespace {
 constexpr int kSamples = 200;
 constexpr int kDomMax = 32;          // domains per sampled trace kept (more: TRUNC)
 constexpr int kSegCap = 2048;         // sampled segments per region kept (200 traces x ~1-3 domains; more: TRUNC)
+constexpr int kHist = 64;            // decision fetches of a trace whose keys are remembered for the next trace
 constexpr int kEnvMax = 16;          // envelopes per pair kept internally (detail reports WH_MAX_ENVELOPES)
 enum { stM = 1, stD, stI, stN, stC, stJ, stE, stB, stS };
 
@@ -90,7 +91,8 @@ __host__ __device__ inline size_t resolve_uni_ints(int Lcap) {
 }
 __host__ __device__ inline size_t resolve_lds_ints(int Lcap, int Mmax) {
   (void)Mmax;
-  return (((size_t)(Lcap + 8) / 4 + 2 + 1) & ~(size_t)1) /*seq*/ + resolve_uni_ints(Lcap) + 128 /*64 float64 bins of the E-state row pass*/ + 7 * kEnvMax + 16;
+  return (((size_t)(Lcap + 8) / 4 + 2 + 1) & ~(size_t)1) /*seq*/ + resolve_uni_ints(Lcap) + 128 /*64 float64 bins of the E-state row pass*/ + 7 * kEnvMax + 16
+         + 2 * 2 * kHist /*WH_STATS: fetch keys of the previous and the current trace*/;
 }
 // waves per SIMD the kernel is compiled for (registers per lane = 512 / WH_RES_OCC)
 #ifndef WH_RES_OCC
@@ -115,6 +117,14 @@ typedef unsigned u4_t __attribute__((ext_vector_type(4)));
 int resolve_waves_per_cu() { return 4 * WH_RES_OCC; }
 constexpr int kResMaxWaves = 4 * WH_RES_OCC;       // waves per workgroup the kernel is compiled for (512 threads, 256 registers at WH_RES_OCC = 2)
 
+// 29 validation bits of a threshold line per lane (two different mixes in even and odd lanes: 58 bits per line), over the
+// line's key and the epoch of the region: a line left by another region, pair or launch in the wave's slab never matches,
+// so nothing is cleared between regions, and a line torn by a concurrent rewrite fails in some lane
+__device__ __forceinline__ unsigned line_check_bits(unsigned long long key, unsigned epoch, int lane) {
+  unsigned long long z = key ^ (((unsigned long long)epoch << 32) | ((lane & 1) ? 0x5bd1e995u : 0x27d4eb2fu));
+  z ^= z >> 33; z *= 0xff51afd7ed558ccdULL; z ^= z >> 33; z *= 0xc4ceb9fe1a85ec53ULL; z ^= z >> 33;
+  return (unsigned)(z >> 35);
+}
 #define RTICK(slot) do { if (a.stats) { const long long t_now = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(a.stats + (slot), (unsigned long long)(t_now - tk0)); tk0 = t_now; } } while (0)
 
 // Workgroups of <W> waves (one per CU).  The queue is ordered model by model; a workgroup draws SLOTS - each the right to
@@ -143,6 +153,7 @@ __global__ __launch_bounds__(64 * kResMaxWaves) void resolve_kernel(ResolveArgs 
   unsigned short *s_b = s_a + SEGCAP;
   double *bins = reinterpret_cast<double *>(uni + resolve_uni_ints(a.Lcap));   // 64 float64 bins of the E-state row pass (8-byte aligned)
   int *misc = reinterpret_cast<int *>(bins + 64);                // 7 x kEnvMax ints: envelope and cluster lists of the pair
+  unsigned long long *hprev = reinterpret_cast<unsigned long long *>(misc + 7 * kEnvMax + 16), *hcur = hprev + kHist;
   (void)Lp;
   const size_t wslot = (size_t)blockIdx.x * nwaves + wave;        // this wave's slab / segment arrays
   int32_t *sg = a.segs + wslot * a.seg_stride;      // per wave in HBM: 6 arrays of SEGCAP ints + the histogram
@@ -165,6 +176,7 @@ __global__ __launch_bounds__(64 * kResMaxWaves) void resolve_kernel(ResolveArgs 
   const double LOG2 = 0.69314718055994529;
   int cur_h = -1;
   bool use_tl = false;
+  unsigned regions_done = 0;          // regions this wave has walked in this launch (epoch of its threshold-line cache)
   if (a.stats && threadIdx.x == 0) atomicMin(a.stats + 16, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 
   for (;;) {
@@ -276,22 +288,24 @@ __global__ __launch_bounds__(64 * kResMaxWaves) void resolve_kernel(ResolveArgs 
         cN[t] = mx.spec(t, xN); cB[t] = mx.spec(t, xB); cE[t] = mx.spec(t, xE); cJ[t] = mx.spec(t, xJ); cC[t] = mx.spec(t, xC); cLS[t] = mx.spec(t, xLS);
       }
       u4_t *dlines = reinterpret_cast<u4_t *>(mx.p + a.dc_off);
-      unsigned long long *dtags = reinterpret_cast<unsigned long long *>(mx.p + a.dc_off + (size_t)128 * (1 << kDcBits));
       for (int t = lane; t <= Lr; t += 64) ecache[(size_t)t * 65 + 64] = 0.0;
-      for (int t = lane; t < (1 << kDcBits); t += 64) dtags[t] = 0ull;        // the threshold-line cache of the walk, per region
+      const unsigned epoch = a.launch_id * 0x9E3779B1u + (++regions_done) * 0x85EBCA77u;     // (the threshold-line cache needs no clearing: see line_check_bits)
       wave_mem_sync();
       int nseg = 0;
       Rng rng;
       rng.x = mix3(42u, 87654321u, 12345678u);
       if (rng.x == 0) rng.x = 42;
       const int Qs = ((m.M - 1) / 4 + 1) > 2 ? ((m.M - 1) / 4 + 1) : 2;     // HMMER's striping: vectors of 4 floats
-      long long c_build = 0, c_e = 0, c_post = 0;
+      long long c_build = 0, c_e = 0, c_post = 0, c_load = 0;
       unsigned n_bm = 0, n_bd = 0, n_bf = 0, n_i = 0, n_hit = 0;     // WH_STATS: fetches of M / D / flank (C, J) runs, scalar I steps
       // lane t's jump of esl_random's LCG by t+1 steps: x_{n+t+1} = lcgA * x_n + lcgC (mod 2^32)
       unsigned lcgA = 1u, lcgC = 0u;
       for (int u = 0; u < 64; u++) if (u <= lane) { lcgA *= 69069u; lcgC = lcgC * 69069u + 1u; }
+      int n_prev = 0;                            // fetches of the previous trace (keys in hprev)
+      unsigned n_pred = 0, n_resync = 0;
       for (int t = 0; t < kSamples; t++) {
         int i = Lr, k = 0, s0 = stC, ndom = 0, sqto = 0, hmmto = 0, sqfrom = 0, hmmfrom = 0;
+        int jf = 0, jp = 0;                      // fetch number of this trace; the fetch of the previous trace expected next
         int run_state = 0, run_j = 0;            // decision cache of the current run (see below)
         // thresholds as integers: (sum / norm > x / 2^32) <=> x < ceil(2^32 sum / norm), exactly (both sides are exact
         // in double); 33-bit values: a low word and an 'always true' bit (bits 0..2 of run_hi)
@@ -325,10 +339,29 @@ __global__ __launch_bounds__(64 * kResMaxWaves) void resolve_kernel(ResolveArgs 
               const unsigned long long key = (1ull << 63) | ((unsigned long long)sidx << 60) | ((unsigned long long)(unsigned)i << 30) | kkey;
               const unsigned slot = (((unsigned)i * 0x9E3779B1u) ^ (kkey * 0x85EBCA77u) ^ ((unsigned)sidx * 0xC2B2AE3Du)) >> (32 - kDcBits);
               u4_t *dline = dlines + (size_t)slot * 64 + lane;
+              const unsigned chk = line_check_bits(key, epoch, lane);
+              // (Round 4, measured and dropped: 56 % of a trace's fetches are the fetch that followed the last matched one in the
+              // previous trace of the region, so the lines can be requested ahead - by LDS-DMA loads without a register - one
+              // fetch ahead, several ahead, or all of the previous trace's lines at the top of a trace.  None of it shortens a
+              // fetch: a line warm in L2 still takes 1 200 of its 1 350 cycles; the time is queueing behind the float64 matrices
+              // the neighbouring waves write - 594 cycles with one wave per CU, 751 / 948 / 1 347 with two / four / eight.)
+              const long long tl0 = a.stats ? __builtin_readcyclecounter() : 0;
               const u4_t ent = *dline;
-              const unsigned long long tg = dtags[slot];
-              if (tg == key) {
-                run_r1 = ent.x; run_r2 = ent.y; run_r3 = ent.z; run_hi = ent.w;
+              const bool valid = __ballot((ent.w >> 3) == chk) == ~0ull;
+              if (a.stats) c_load += __builtin_readcyclecounter() - tl0;
+              if (a.stats) {
+                // (how far the fetches repeat from trace to trace: the fetch that followed the last matched one in the previous trace?)
+                const bool pred = jp < n_prev && hprev[jp] == key;
+                if (pred) { n_pred++; jp++; }
+                else {
+                  const unsigned long long hit = __ballot(lane < n_prev && hprev[lane] == key);
+                  if (hit) { jp = __ffsll((long long)hit); n_resync++; }
+                }
+                if (jf < kHist && lane == 0) hcur[jf] = key;
+                jf++;
+              }
+              if (valid) {
+                run_r1 = ent.x; run_r2 = ent.y; run_r3 = ent.z; run_hi = ent.w & 7u;
                 if (a.stats) n_hit++;
               } else {
               double pd[4] = {0.0, 0.0, 0.0, 0.0};
@@ -367,9 +400,8 @@ __global__ __launch_bounds__(64 * kResMaxWaves) void resolve_kernel(ResolveArgs 
               as_int(c1 / norm, run_r1, hb); run_hi |= hb;
               as_int(c2 / norm, run_r2, hb); run_hi |= hb << 1;
               as_int(c3 / norm, run_r3, hb); run_hi |= hb << 2;
-              u4_t wr; wr.x = run_r1; wr.y = run_r2; wr.z = run_r3; wr.w = run_hi;
+              u4_t wr; wr.x = run_r1; wr.y = run_r2; wr.z = run_r3; wr.w = run_hi | (chk << 3);
               *dline = wr;
-              if (lane == 0) dtags[slot] = key;
               wave_mem_sync();
               }
               run_state = s0; run_j = 0;
@@ -542,6 +574,7 @@ __global__ __launch_bounds__(64 * kResMaxWaves) void resolve_kernel(ResolveArgs 
           s0 = s1;
         }
         __builtin_amdgcn_wave_barrier();
+        if (a.stats) { n_prev = jf < kHist ? jf : kHist; unsigned long long *tsw = hprev; hprev = hcur; hcur = tsw; }
         const long long tp0 = a.stats ? __builtin_readcyclecounter() : 0;
         // null2 by trace of every sampled domain (A.4b / p7_Null2_ByTrace): mean emission odds of the
         // M/I states that emitted the domain's residues
@@ -678,6 +711,7 @@ __global__ __launch_bounds__(64 * kResMaxWaves) void resolve_kernel(ResolveArgs 
       }
       if (a.stats && lane == 0) {
         atomicAdd(a.stats + 5, (unsigned long long)c_build); atomicAdd(a.stats + 6, (unsigned long long)c_e); atomicAdd(a.stats + 7, (unsigned long long)c_post);
+        atomicAdd(a.stats + 20, (unsigned long long)n_pred); atomicAdd(a.stats + 21, (unsigned long long)n_resync); atomicAdd(a.stats + 23, (unsigned long long)c_load);
         atomicAdd(a.stats + 8, (unsigned long long)n_bm); atomicAdd(a.stats + 9, (unsigned long long)n_bd); atomicAdd(a.stats + 10, (unsigned long long)n_bf); atomicAdd(a.stats + 11, (unsigned long long)n_i); atomicAdd(a.stats + 12, (unsigned long long)n_hit);
       }
       RTICK(1);

@@ -682,19 +682,33 @@ __global__ __launch_bounds__(64 * kResMaxWaves) void resolve_kernel(ResolveArgs 
         // per-residue accumulators: +1 outside sampled domains AND at a domain's first residue (sic),
         // + null2[x] at the domain's other residues
         // (the accumulators live in the wave's HBM slab: eight positions per lane are requested at once)
+        // (the domains' bounds once into a register, lane d holding domain d, read back as scalars: the inner loop was a chain of
+        // dependent LDS reads - two bounds per domain and position)
+        const int dlo_v = lane < ndom ? dom[4 * lane] : 0, dhi_v = lane < ndom ? dom[4 * lane + 1] : -1;
         for (int p0 = 1 + lane; p0 <= Lr; p0 += 512) {
           float old[8];
+          int rsv[8];
 #pragma unroll
-          for (int u = 0; u < 8; u++) old[u] = p0 + 64 * u <= Lr ? __builtin_nontemporal_load(acc + p0 + 64 * u) : 0.f;
+          for (int u = 0; u < 8; u++) {
+            const bool in = p0 + 64 * u <= Lr;
+            old[u] = in ? __builtin_nontemporal_load(acc + p0 + 64 * u) : 0.f;
+            rsv[u] = in ? (int)rs[p0 + 64 * u - 1] : 0;
+          }
+          float add[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) add[u] = 1.0f;
+          for (int d = 0; d < ndom; d++) {
+            const int lo = __builtin_amdgcn_readlane(dlo_v, d), hi = __builtin_amdgcn_readlane(dhi_v, d);
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+              const int pos = p0 + 64 * u;
+              if (pos > lo && pos <= hi) add[u] = dnull[32 * d + rsv[u]];
+            }
+          }
 #pragma unroll
           for (int u = 0; u < 8; u++) {
             const int pos = p0 + 64 * u;
-            if (pos <= Lr) {
-              float add = 1.0f;
-              for (int d = 0; d < ndom; d++)
-                if (pos > dom[4 * d] && pos <= dom[4 * d + 1]) add = dnull[32 * d + rs[pos - 1]];
-              acc[pos] = old[u] + add;
-            }
+            if (pos <= Lr) acc[pos] = old[u] + add[u];
           }
         }
         // the ensemble takes the domains left to right (they were found right to left)

@@ -938,6 +938,33 @@ def test_two_queries_per_wave_kernel_equals_the_one_query_kernel(tmp_path):
     e.close()
 
 
+def test_null2_by_trace_from_prefix_sums_equals_the_row_sums():
+    """Round 4: the resolver forms the null2 vector of a sampled domain from float64 prefix sums of the emission odds over
+    the nodes (a dozen row differences per domain) instead of adding one table row per residue in float32
+    (WH_RES_NULL2_GATHER, environment, read per call: the path it replaced).  Same terms, different rounding of the sum:
+    flags identical, every single-domain pair identical, and a multidomain pair at most one deci-bit apart - rarely
+    (46 of 255 725 on a slice of config 5; here on the golden protein case with 422 multidomain pairs)."""
+    _need_gpu()
+    from tests.conftest import load_case
+    from witch_amd.ehmm import EHMM, pack_queries
+    case = load_case("amino_multidomain")
+    e = EHMM(case.hmm_paths, hmm_index=case.hmm_index, nseq=case.nseq)
+    res, offs = pack_queries([e.digitize(s_) for s_ in case.qseqs])
+    deci, flags = e.score(res, offs)
+    os.environ["WH_RES_NULL2_GATHER"] = "1"
+    try:
+        deci2, flags2 = e.score(res, offs)
+    finally:
+        os.environ.pop("WH_RES_NULL2_GATHER", None)
+    e.close()
+    assert np.array_equal(flags & 7, flags2 & 7)
+    multi = (flags & 2) != 0
+    assert int(multi.sum()) > 300
+    assert np.array_equal(deci[~multi], deci2[~multi])
+    d = np.abs(deci.astype(np.int64) - deci2)
+    assert d.max() <= 1 and int((d != 0).sum()) <= 4, (int(d.max()), int((d != 0).sum()))
+
+
 def test_resolver_queue_overflow_repeats_the_scoring_pass(golden_case):
     """The queue of pairs with a multidomain region is sized by estimate; a call that needs more slots than it got
     counts them, grows the queue and scores again.  Forced here with a queue of 3 slots: same results as the

@@ -896,6 +896,7 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
       memcpy(r.degen, e->degen, sizeof r.degen);
       r.dbg = e->knobs.rdbg;
       r.launch_id = ++e->resolver_launches;
+      r.null2_gather = getenv("WH_RES_NULL2_GATHER") ? 1 : 0;
       if (e->knobs.stats) {
         if (e->d_recs.ensure(256)) return WH_ENOMEM;
         HIPCHK(hipMemsetAsync(e->d_recs.p, 0, 256, s));

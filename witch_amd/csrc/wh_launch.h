@@ -92,6 +92,7 @@ struct ResolveArgs {
   size_t mx_stride;            // doubles per wave
   size_t dc_off;               // offset (doubles, even) of the walk's threshold-line cache inside a wave's slab
   unsigned launch_id;          // differs from launch to launch of a handle: part of the cache's validation bits (the slabs persist)
+  int null2_gather;            // WH_RES_NULL2_GATHER (environment, per call): null2 by trace from one table row per residue (the pre-round-4 path)
   int32_t *segs;               // per-wave segment arrays
   size_t seg_stride;           // ints per wave
   int seg_cap;

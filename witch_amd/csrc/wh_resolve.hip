@@ -606,7 +606,7 @@ __global__ __launch_bounds__(64 * kResMaxWaves) void resolve_kernel(ResolveArgs 
               nb += __builtin_popcountll(bs) + __builtin_popcountll(be);
             }
             __builtin_amdgcn_wave_barrier();
-            if (nb <= 128) {
+            if (nb <= 128 && !a.null2_gather) {
               by_runs = true;
               const double *esum = a.gtab + hm.esum_off;
               const int G = 64 / a.K, g = lane / a.K, x = lane - g * a.K;

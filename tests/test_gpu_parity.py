@@ -1698,13 +1698,13 @@ def test_consensus_with_twenty_models_on_a_20000_column_backbone():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cells_per_lane", [4, 12, 24])
+@pytest.mark.parametrize("cells_per_lane", [4, 12, 16, 24])
 def test_several_waves_per_pair_kernel_on_the_golden_cases(cells_per_lane, orc):
     """wh_score_wide.hip (models of 3 073 - 12 288 nodes in production: several wavefronts per pair, the D scan and the
     row sums crossing the waves through LDS) forced onto the golden cases (WH_FORCE_WIDE, read at wh_ehmm_load): with
-    4 cells per lane a 1 211-node model runs on 5 waves, with 24 on one - every workgroup size from 1 to 5 - and with 12
-    through the variant that keeps the transition tables in registers and the emission rows in LDS (production: 3 073 -
-    6 144 nodes), against the oracle: Forward log-odds, flags and deci-bit scores (multidomain pairs through the same resolver queue), and the
+    4 cells per lane a 1 211-node model runs on 5 waves, with 24 on one - every workgroup size from 1 to 5 - and with 12 / 16
+    through the variants that keep the transition tables in registers and the emission rows in LDS (production: 3 073 -
+    6 144 / 6 145 - 8 192 nodes), against the oracle: Forward log-odds, flags and deci-bit scores (multidomain pairs through the same resolver queue), and the
     aligned columns of the several-waves-per-pair alignment kernel (pairs that leave float32 range are handed to the
     float64 kernel, as in production)."""
     _need_gpu()

@@ -198,11 +198,15 @@ wh_ehmm *wh_ehmm_load(const char *const *hmm_paths, const int32_t *hmm_index, co
   // WH_FORCE_WIDE=<4|24>: every model that fits 8 waves of that many cells per lane ALSO gets wide tables and is scored by the
   // several-waves-per-pair kernel (tests run the golden cases through it; production: models beyond 3 072 nodes only)
   const int force_wide_q = getenv("WH_FORCE_WIDE") ? atoi(getenv("WH_FORCE_WIDE")) : 0;
-  e->force_wide = force_wide_q == 4 || force_wide_q == kWideQ || force_wide_q == kWideQReg;
+  e->force_wide = force_wide_q == 4 || force_wide_q == kWideQ || force_wide_q == kWideQReg || force_wide_q == kWideQReg2;
   e->force_wide_q = e->force_wide ? force_wide_q : 0;
   const bool force_wide = e->force_wide;
   // cells per lane of a model's wide tables: 12 (transition tables in registers) up to 6 144 nodes, 24 beyond
-  auto wide_q_of = [force_wide, force_wide_q](int M) { return force_wide ? force_wide_q : (M <= kWideQReg * kWave * kWideWavesMax ? kWideQReg : kWideQ); };
+  // (12 up to 6 144 nodes, 16 up to 8 192: transition tables in registers; 24 beyond: tables from L2)
+  auto wide_q_of = [force_wide, force_wide_q](int M) {
+    if (force_wide) return force_wide_q;
+    return M <= kWideQReg * kWave * kWideWavesMax ? kWideQReg : M <= kWideQReg2 * kWave * kWideWavesMax ? kWideQReg2 : kWideQ;
+  };
   std::vector<Built> built((size_t)n);
   {
     std::atomic<int> next{0};
@@ -749,7 +753,7 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
         const int W = kv.first & 15, wq = kv.first >> 4;
         // 12-cell classes: the emission rows of the canonical residues go to LDS where they fit behind the block
         const size_t em_floats = (size_t)e->K * wq * W * kWave;
-        const bool em_lds = wq == kWideQReg && !getenv("WH_WIDE_NO_EM_LDS") && wide_lds_bytes(Lc, em_floats) <= kLdsBudget;
+        const bool em_lds = (wq == kWideQReg || wq == kWideQReg2) && !getenv("WH_WIDE_NO_EM_LDS") && wide_lds_bytes(Lc, em_floats) <= kLdsBudget;
         const size_t wlds = em_lds ? wide_lds_bytes(Lc, em_floats) : wlds0;
         WideArgs a;
         memset(&a, 0, sizeof a);

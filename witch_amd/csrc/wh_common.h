@@ -16,6 +16,7 @@ constexpr int kMaxQFast = 24;      // up to here both transition orientations st
 constexpr int kQRegMax = 16;       // up to this Q the transition tables live in VGPRs
 constexpr int kWideQ = 24;         // cells per lane of the several-waves-per-pair scoring kernel
 constexpr int kWideQReg = 12;      // ... its variant with the transition tables in registers: models of up to 8 x 64 x 12 = 6 144 nodes
+constexpr int kWideQReg2 = 16;     // ... and the same with 16 cells per lane: up to 8 192 nodes (no room for the row-ahead requests of P4)
 constexpr int kWideWavesMax = 8;   // ... and its largest workgroup: models of up to 8 x 64 x 24 = 12 288 nodes
 // per-wave LDS block of the scoring kernels: region list (i, j) x WH_MAX_ENVELOPES, 8 spare ints, and the
 // envelope results (envsc, domcorr) x WH_MAX_ENVELOPES staged for the multidomain resolver's record

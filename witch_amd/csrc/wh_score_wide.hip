@@ -343,8 +343,9 @@ struct BackState { float Mb[Q], Ib[Q]; };
 // the Backward sweep's eight transition arrays in registers (TR) - or nothing, and every use is an L2 read
 template <int Q, bool TR>
 struct BackTab {
+  static constexpr bool kP = TR && Q <= kWideQReg;     // (16-cell lanes: the registers go to the tables; the carry walks its chain)
   float4 v[TR ? BW_NARR : 1][TR ? Q / 4 : 1];
-  float P[TR ? Q : 1];           // in-lane running products of the D->D transitions (see forward_wide)
+  float P[kP ? Q : 1];           // in-lane running products of the D->D transitions (see forward_wide)
   template <int NLT>
   __device__ __forceinline__ void load(const WCtxT<NLT> &c) {
     if (TR) {
@@ -352,12 +353,14 @@ struct BackTab {
       for (int a = 0; a < BW_NARR; a++)
 #pragma unroll
         for (int q4 = 0; q4 < Q / 4; q4++) v[TR ? a : 0][TR ? q4 : 0] = ldg4(c.bw, (unsigned)((a * (Q / 4) + q4) * c.nl() + c.vl));
-      float run = 1.f;
+      if (kP) {
+        float run = 1.f;
 #pragma unroll
-      for (int q4 = 0; q4 < Q / 4; q4++) {
-        const float4 d = v[TR ? BW_DD : 0][TR ? q4 : 0];
-        run *= d.x; P[TR ? 4 * q4 : 0] = run; run *= d.y; P[TR ? 4 * q4 + 1 : 0] = run;
-        run *= d.z; P[TR ? 4 * q4 + 2 : 0] = run; run *= d.w; P[TR ? 4 * q4 + 3 : 0] = run;
+        for (int q4 = 0; q4 < Q / 4; q4++) {
+          const float4 d = v[TR ? BW_DD : 0][TR ? q4 : 0];
+          run *= d.x; P[kP ? 4 * q4 : 0] = run; run *= d.y; P[kP ? 4 * q4 + 1 : 0] = run;
+          run *= d.z; P[kP ? 4 * q4 + 2 : 0] = run; run *= d.w; P[kP ? 4 * q4 + 3 : 0] = run;
+        }
       }
     }
   }
@@ -428,7 +431,7 @@ __device__ __forceinline__ void backward_cells_wide(const WCtxT<NLT> &c, const B
   carry = fmaf(Aexcl, cin, carry);
   if (lane == 0) carry = cin;
   const float dfront = carry;                  // D of the cell in front of my first one (lane r: last cell of lane r-1)
-  if constexpr (TR) {
+  if constexpr (BackTab<Q, TR>::kP) {
 #pragma unroll
     for (int p = 0; p < Q; p++) Dn[p] = fmaf(tb.P[p], carry, Dn[p]);
   } else {
@@ -575,16 +578,17 @@ __device__ __forceinline__ float backward_null2_wide(const WCtxT<NLT> &c, const 
     }
     // TR (one workgroup per CU: nothing else covers an HBM round trip): the row's stored Forward cells are requested
     // before the row's arithmetic and barriers, not where they are used
-    float4 fmP[TR ? Q4 : 1], fiP[TR ? Q4 : 1];
-    if (TR) {
+    constexpr bool PF = TR && Q <= kWideQReg;            // (16-cell lanes: no registers left for a row in flight)
+    float4 fmP[PF ? Q4 : 1], fiP[PF ? Q4 : 1];
+    if (PF) {
       const gf4 *rowp = c.Fs + (size_t)i * (2 * Q4) * NL;
       const int nlp = opaque_s(NL);
       if (have) {
 #pragma unroll
-        for (int p4 = 0; p4 < Q4; p4++) { fmP[TR ? p4 : 0] = ldt(rowp, Q4 - 1 - p4, nlp, (unsigned)rv); fiP[TR ? p4 : 0] = ldt(rowp, Q4 + Q4 - 1 - p4, nlp, (unsigned)rv); }
+        for (int p4 = 0; p4 < Q4; p4++) { fmP[PF ? p4 : 0] = ldt(rowp, Q4 - 1 - p4, nlp, (unsigned)rv); fiP[PF ? p4 : 0] = ldt(rowp, Q4 + Q4 - 1 - p4, nlp, (unsigned)rv); }
       } else {
 #pragma unroll
-        for (int p4 = 0; p4 < Q4; p4++) { fmP[TR ? p4 : 0] = make_float4(0.f, 0.f, 0.f, 0.f); fiP[TR ? p4 : 0] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        for (int p4 = 0; p4 < Q4; p4++) { fmP[PF ? p4 : 0] = make_float4(0.f, 0.f, 0.f, 0.f); fiP[PF ? p4 : 0] = make_float4(0.f, 0.f, 0.f, 0.f); }
       }
     }
     float gfront = 0.f;
@@ -606,8 +610,8 @@ __device__ __forceinline__ float backward_null2_wide(const WCtxT<NLT> &c, const 
       float idot = 0.f;
 #pragma unroll
       for (int p4 = 0; p4 < Q4; p4++) {
-        const float4 fm = TR ? fmP[TR ? p4 : 0] : ldt(row, Q4 - 1 - p4, nlr, (unsigned)rv);
-        const float4 fi = TR ? fiP[TR ? p4 : 0] : ldt(row, Q4 + Q4 - 1 - p4, nlr, (unsigned)rv);
+        const float4 fm = PF ? fmP[PF ? p4 : 0] : ldt(row, Q4 - 1 - p4, nlr, (unsigned)rv);
+        const float4 fi = PF ? fiP[PF ? p4 : 0] : ldt(row, Q4 + Q4 - 1 - p4, nlr, (unsigned)rv);
         fM[4 * p4 + 0] = fmaf(fm.w * Mb[4 * p4 + 0], s_i, fM[4 * p4 + 0]);
         fM[4 * p4 + 1] = fmaf(fm.z * Mb[4 * p4 + 1], s_i, fM[4 * p4 + 1]);
         fM[4 * p4 + 2] = fmaf(fm.y * Mb[4 * p4 + 2], s_i, fM[4 * p4 + 2]);
@@ -1247,6 +1251,13 @@ hipError_t launch_align_wide(int Q, const WideAlignArgs &a, int blocks, int wave
       default: return launch_walign_t<kWideQReg, 0, true>(a, blocks, waves, lds, s);
     }
   }
+  if (Q == kWideQReg2) {
+    switch (waves) {
+      case 7: return launch_walign_t<kWideQReg2, 448, true>(a, blocks, waves, lds, s);
+      case 8: return launch_walign_t<kWideQReg2, 512, true>(a, blocks, waves, lds, s);
+      default: return launch_walign_t<kWideQReg2, 0, true>(a, blocks, waves, lds, s);
+    }
+  }
   if (Q != kWideQ) return hipErrorInvalidValue;
   switch (waves) {
     case 3: return launch_walign_t<kWideQ, 192>(a, blocks, waves, lds, s);
@@ -1282,6 +1293,14 @@ hipError_t launch_score_wide(int Q, const WideArgs &a, int blocks, int waves, si
       case 7: return launch_wide_t<kWideQReg, 448, true>(a, blocks, waves, lds, s);
       case 8: return launch_wide_t<kWideQReg, 512, true>(a, blocks, waves, lds, s);
       default: return launch_wide_t<kWideQReg, 0, true>(a, blocks, waves, lds, s);   // 1 - 4 waves: WH_FORCE_WIDE=12 on small models
+    }
+  }
+  if (Q == kWideQReg2) {
+    // 16 cells per lane, transition tables in registers: models of 6 145 - 8 192 nodes (seven or eight waves)
+    switch (waves) {
+      case 7: return launch_wide_t<kWideQReg2, 448, true>(a, blocks, waves, lds, s);
+      case 8: return launch_wide_t<kWideQReg2, 512, true>(a, blocks, waves, lds, s);
+      default: return launch_wide_t<kWideQReg2, 0, true>(a, blocks, waves, lds, s);   // WH_FORCE_WIDE=16 on small models
     }
   }
   if (Q != kWideQ || a.em_lds) return hipErrorInvalidValue;

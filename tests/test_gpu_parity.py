@@ -1813,6 +1813,7 @@ def test_forward_rows_that_underflow_to_zero_are_written(orc, tmp_path):
     ("fuzz_align.py", ["3000", "2", "1600", "3072"]),      # pass-synchronous kernels
     ("fuzz_align.py", ["6000", "1", "3100", "6000"]),      # several-waves-per-pair kernels: 12-cell lanes, tables in registers
     ("fuzz_align.py", ["6501", "1", "6200", "8000"]),      # ... 24-cell lanes, tables from L2 (beyond 6 144 nodes)
+    ("fuzz_resolver.py", ["1", "8"]),                      # multidomain resolver: two- and three-copy queries, DNA and protein
     ("fuzz_built_models.py", ["1", "10"]),                 # models written by wh_hmmbuild from random alignments
     ("fuzz_level1.py", ["200", "4", "4"]),                 # consensus rows and merged files through the level-1 functions
     ("fuzz_topk.py", ["1", "12"]),                         # weights / top-k / cut with engineered ties

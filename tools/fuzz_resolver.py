@@ -27,7 +27,7 @@ def main():
         rng = np.random.default_rng(90000 + seed)
         alph = "amino" if seed % 2 == 0 else "dna"
         root = int(rng.integers(150, 1500 if alph == "dna" else 900))
-        fam = synth.make_family(91000 + seed, root, 12, alph, 0.04, 1e-3)
+        fam = synth.make_family(91000 + seed, root, 16, alph, 0.04, 1e-3)
         eh = synth.make_ehmm(fam, 2, tempfile.mkdtemp(prefix="fuzz_res_"), witch_layout=False)
         _, seqs = synth.make_queries(fam, 92000 + seed, 6, (2 * root, 3 * root), flank_frac=0.3)
         _, one = synth.make_queries(fam, 93000 + seed, 2, (root // 2, root), flank_frac=0.2)

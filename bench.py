@@ -547,7 +547,7 @@ def main():
                                                   "(score + top-k + align), %.1f s" % (min(n_sample, nq_total), H, cdt)}
                 # the reference's real CPU path (HMMER 3.1b2 binaries, the reference's process scheme) on a
                 # subsample of the same seeded inputs, timed in the build container by
-                # tools/time_reference_cpu.py - the binaries cannot travel to the GPU box
+                # tests/tools/time_reference_cpu.py - the binaries cannot travel to the GPU box
                 rpath = os.path.join(ROOT, "profiles", "cpu_reference_%s.json" % args.workload)
                 if os.path.exists(rpath) and not args.nh:
                     rj = json.load(open(rpath))

@@ -44,6 +44,24 @@ def test_product_does_not_use_the_oracle():
                     assert needle not in text, (f, needle)
 
 
+def test_only_tests_smoke_and_the_cpu_baseline_leg_import_the_oracle():
+    """oracle/ is test infrastructure: outside tests/ only __graft_entry__.py (build + smoke) and bench.py (its cpu_baseline
+    leg) may name it - no program under tools/, witch_amd/ or the repository root."""
+    allowed = {os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")}
+    for top in ("tools", "witch_amd", "."):
+        base = os.path.join(ROOT, top)
+        for dirpath, dirs, files in os.walk(base):
+            if top == ".":
+                dirs[:] = []           # the root's own files only
+            for f in files:
+                path = os.path.normpath(os.path.join(dirpath, f))
+                if not f.endswith((".py", ".sh")) or path in allowed:
+                    continue
+                text = open(path).read()
+                for needle in ("import oracle", "from oracle", "libp7oracle"):
+                    assert needle not in text, (path, needle)
+
+
 def test_no_gpu_fails_loudly_instead_of_falling_back():
     """On a box without a GPU the product must raise, never compute on the CPU."""
     import pytest

@@ -1786,13 +1786,13 @@ def test_forward_rows_that_underflow_to_zero_are_written(orc, tmp_path):
     """A strong family window followed by a long random flank: after the hit the Forward sweep has rescaled by ~2^-300,
     the flank's rows underflow to zero in every cell, and `0 > -0` must not keep them from being written - the
     full-width Backward sweep reads rows without looking at the masks and used to see the previous pair's cells there
-    (found by tools/fuzz_align.py, seed 103; before the fix one of the three pairs below differed from the oracle in
+    (found by tests/tools/fuzz_align.py, seed 103; before the fix one of the three pairs below differed from the oracle in
     every call that followed another pair in the same slab)."""
     _need_gpu()
     import importlib.util
     from tests.conftest import ROOT
     from witch_amd.ehmm import EHMM, pack_queries
-    spec = importlib.util.spec_from_file_location("fuzz_align", os.path.join(ROOT, "tools", "fuzz_align.py"))
+    spec = importlib.util.spec_from_file_location("fuzz_align", os.path.join(ROOT, "tests", "tools", "fuzz_align.py"))
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
     alph, root, eh, seqs = fz.make_case(103, str(tmp_path))
@@ -1826,5 +1826,5 @@ def test_randomised_tools_find_no_difference(tool, args):
     import subprocess
     import sys
     from tests.conftest import ROOT
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool)] + args, capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", tool)] + args, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (tool, r.stdout[-1500:], r.stderr[-1500:])

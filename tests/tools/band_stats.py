@@ -2,7 +2,7 @@
 """Design aid for the banded envelope sweeps: on a sample of pairs of a bench workload, how many model
 nodes hold posterior mass >= 2^e on some envelope row (lane-block granularity), as known from the
 multihit sweeps and as needed by the unihit envelope sweeps.  Uses the CPU oracle (tool, not product).
-usage: tools/band_stats.py [workload] [n_pairs] [log2 eps]"""
+usage: tests/tools/band_stats.py [workload] [n_pairs] [log2 eps]"""
 import ctypes as C
 import os
 import sys
@@ -10,7 +10,7 @@ import tempfile
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from oracle import oracle as orc  # noqa: E402

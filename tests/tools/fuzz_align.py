@@ -3,14 +3,14 @@
 residues - family windows with and without random flanks, unrelated sequences, degenerate residue codes - every
 (query, model) pair aligned in one batch and compared, column by column, with the float64 oracle.  Found the
 round-3 bug of the full-width passes (Forward rows that had underflowed to zero everywhere were not written, the
-Backward sweep then read the previous pair's cells: seed 103).  usage: tools/fuzz_align.py [first_seed] [n_seeds] [min_nodes] [max_nodes] [length_scale]"""
+Backward sweep then read the previous pair's cells: seed 103).  usage: tests/tools/fuzz_align.py [first_seed] [n_seeds] [min_nodes] [max_nodes] [length_scale]"""
 import os
 import sys
 import tempfile
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from witch_amd import synth  # noqa: E402
 from witch_amd.ehmm import EHMM, pack_queries  # noqa: E402

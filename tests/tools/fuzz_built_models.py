@@ -3,7 +3,7 @@
 generator: 1-40 sequences, 8-400 columns, gaps, fragments, degenerate residues - Dirichlet-prior transitions, tiny and
 single-sequence models, entropy weighting), instead of the synthetic families' directly written model files: scores
 (exact boundary rule), flags and aligned columns of the alignment's own rows, their fragments and unrelated sequences
-against the float64 oracle.  usage: tools/fuzz_built_models.py [first_seed] [n_seeds]"""
+against the float64 oracle.  usage: tests/tools/fuzz_built_models.py [first_seed] [n_seeds]"""
 import importlib.util
 import os
 import sys
@@ -11,7 +11,7 @@ import tempfile
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from witch_amd.ehmm import EHMM, pack_queries  # noqa: E402

@@ -1,15 +1,15 @@
 #!/usr/bin/env python3
-"""Randomised check of the level-1 chain's consensus step on the GPU box: the cases of tools/fuzz_align.py (families
+"""Randomised check of the level-1 chain's consensus step on the GPU box: the cases of tests/tools/fuzz_align.py (families
 of 300-1 600 nodes, flanked / degenerate / unrelated queries) through witch_amd.gcmm - engine run, ranking, weights,
 alignSubQueriesNew - and every query's merged row against the numpy restatement of the reference's consensus DP
-(oracle/consensus.py) on the same top-k and weights.  usage: tools/fuzz_level1.py [first_seed] [n_seeds] [k]"""
+(oracle/consensus.py) on the same top-k and weights.  usage: tests/tools/fuzz_level1.py [first_seed] [n_seeds] [k]"""
 import os
 import sys
 import tempfile
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
 import fuzz_align  # noqa: E402
 from oracle import consensus as ocons  # noqa: E402
 from witch_amd import gcmm, synth  # noqa: E402

@@ -5,7 +5,7 @@ fragments of them and unrelated sequences through the bundled `hmmsearch --cpu 1
 (algorithm.py:526-532) and `hmmalign` (aligner.py:98-100), compared with oracle/p7_oracle.c: the printed "%6.1f" score
 as deci-bits, the reported set, and the aligned columns decoded from the Stockholm row the way the reference does
 (aligner.py:126-142: upper case or '-' = match column, lower case = insert).  The golden vectors under tests/golden pin
-the oracle on fixed cases; this counts agreement on random ones.  usage: tools/fuzz_oracle_vs_hmmer.py [first_seed] [n]"""
+the oracle on fixed cases; this counts agreement on random ones.  usage: tests/tools/fuzz_oracle_vs_hmmer.py [first_seed] [n]"""
 import os
 import re
 import subprocess
@@ -14,7 +14,7 @@ import tempfile
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import oracle as orc  # noqa: E402
 

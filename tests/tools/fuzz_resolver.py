@@ -3,14 +3,14 @@
 queries that hold two or three copies of the family (with random flanks and a few degenerate codes), every (query,
 model) pair scored and compared with the float64 oracle, which runs the same 200 seeded tracebacks: reported mask,
 multidomain flag, Forward log-odds, deci-bit scores under the tests' boundary rule (0.02 bit for this class).
-usage: tools/fuzz_resolver.py [first_seed] [n_seeds]"""
+usage: tests/tools/fuzz_resolver.py [first_seed] [n_seeds]"""
 import os
 import sys
 import tempfile
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from witch_amd import synth  # noqa: E402

@@ -3,14 +3,14 @@
 values: many exact ties), random reported masks, model sizes with shared odd parts and powers of two (the integer tie
 key of wh_topk.hip), H from 1 to 200 and k from 1 to 40, against the oracle's restatement of the reference's
 rankBitscores / calculateWeights / 0.999 cut (the comparison of tests/test_gpu_parity.py::test_topk_*).
-usage: tools/fuzz_topk.py [first_seed] [n_seeds]"""
+usage: tests/tools/fuzz_topk.py [first_seed] [n_seeds]"""
 import os
 import sys
 import tempfile
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from witch_amd import synth  # noqa: E402
 from witch_amd.ehmm import EHMM  # noqa: E402

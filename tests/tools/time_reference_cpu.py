@@ -17,7 +17,7 @@ DP cost is linear in (query, HMM) pairs, so queries/s of the subsample is the fi
 full workload (stated in the JSON).  Writes profiles/cpu_reference_<workload>.json, which
 bench.py echoes as cpu_baseline.reference next to the float64 port it times live.
 
-    python tools/time_reference_cpu.py --workload dna_100k_x200 --nq 1000 --cpus 8
+    python tests/tools/time_reference_cpu.py --workload dna_100k_x200 --nq 1000 --cpus 8
 """
 import argparse
 import json
@@ -31,7 +31,7 @@ from concurrent.futures import ProcessPoolExecutor
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 HMMER = "/root/reference/witch_msa/tools/magus/tools/hmmer"
 

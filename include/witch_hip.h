@@ -60,6 +60,18 @@ extern "C" {
 
 #define WH_MAX_ENVELOPES 16
 
+/* Which code path a pair took through the scoring kernels (optional per-pair byte, wh_set_path_buffer; written by
+ * the staged launches only).  A pair's result does not depend on the path except in the last bits of the float32
+ * null2 correction (window vs full width): the tests draw their oracle samples per path. */
+#define WH_PATH_P2_WIN     1   /* regions from the multihit Backward sweep on a node window (certified)  */
+#define WH_PATH_P2_FULL    2   /* ... from the full-width sweep (no window fitted, or a decision in doubt) */
+#define WH_PATH_P4_W256    4   /* an envelope's Backward sweep kept from a 256-node window                */
+#define WH_PATH_P4_W512    8   /* ... from a 512-node window                                              */
+#define WH_PATH_P4_WFAIL  16   /* a window failed the mass certificate and was redone at full width       */
+#define WH_PATH_P4_FULL   32   /* an envelope's Backward sweep at full width                              */
+#define WH_PATH_DENSE     64   /* an envelope redone with every Forward row stored (WH_FLAG_EXACT)        */
+#define WH_PATH_MULTI    128   /* finished by the multidomain resolver                                    */
+
 typedef struct wh_ehmm wh_ehmm;
 
 /* Optional per-pair diagnostics (tests compare them with the oracle stage by stage). */
@@ -150,6 +162,12 @@ int wh_last_align_paths(wh_ehmm *e, int64_t *paths4);
  * decision in doubt and whose sweep ran again at full width (pairs that never tried a window are in neither).
  * Waits for the device.  (What a window is: DESIGN.md section 4.1; WH_NO_WINDOW switches both off.) */
 int wh_last_score_paths(wh_ehmm *e, int64_t *paths6);
+
+/* Optional per-PAIR record of the same: a device array of nq x H bytes that the scoring calls made after this one fill
+ * with WH_PATH_* bits (NULL switches it off again).  Written by the staged launches only (WH_SCORE_KERNEL=10; pairs
+ * of the other kernels keep whatever the array held).  The buffer belongs to the caller and must stay valid for as many
+ * pairs as the calls score.  tests/test_gpu_parity.py draws its headline-size oracle samples per path from it. */
+int wh_set_path_buffer(wh_ehmm *e, uint8_t *d_paths);
 
 /* Scoring passes the last wh_score call REPEATED (0 or 1).  The queue that hands pairs with a multidomain region to the
  * resolver stage is sized by estimate (5 % of the pairs, or 1.25 x the largest share an earlier call on the handle

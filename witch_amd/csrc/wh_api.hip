@@ -59,7 +59,8 @@ struct KernelTimer {
 // wh_set_option changes them on a live handle (tools/ab_score.py).  None is needed in production.
 struct Knobs {
   int kernel = 7;            // 7 phase-call scoring kernel (one query per wavefront); 8 its second compilation (A/B slot);
-                             // 9 two queries per wavefront where a batch fits (wh_score9.hip; measured slower, kept for A/B: DESIGN.md)
+                             // 9 two queries per wavefront where a batch fits (wh_score9.hip; measured slower, kept for A/B: DESIGN.md);
+                             // 10 staged launches (wh_staged.hip) for the size classes and batches they serve, 7 for the rest
   float keep_scale = 0.f;    // Forward-row spill threshold relative to E(row); 0 = the kernel's default
   int max_waves = 0;         // cap on waves per workgroup (0 = planner's choice)
   bool force_specg = false;  // force the HBM special-state mode
@@ -69,6 +70,7 @@ struct Knobs {
   bool no_p2win = false;     // the multihit Backward sweep runs full width only (A/B and debugging)
   bool no_resolve = false;   // multidomain regions stay ONE envelope (round-1 behaviour) instead of HMMER's stochastic resolver
   int rqueue_cap = 0;        // test hook: size the resolver's queue for this many pairs instead of the estimate (forces the overflow re-run)
+  int st_units = 0;          // staged launches: envelope units (Forward slabs) per batch (0 = sized from the free HBM)
   bool stats = false, trace = false;
   int dbg = 0;
   int rdbg = 0;              // resolver: print the first <n> sampled segments and the cluster statistics of every region
@@ -99,6 +101,13 @@ struct wh_ehmm {
   double rq_rate = 0.0;                     // largest share of queued pairs any call on this handle has seen (sizes the next queue)
   int64_t rq_floor = 0;                     // ... at least this many (set when a call overflowed its estimate; the call then runs again)
   int last_queue_reruns = 0;                // scoring passes the last wh_score call repeated because its queue overflowed (0 or 1)
+  // staged launches (wh_staged.hip): per-batch state in HBM
+  DevBuf d_st_pairs, d_st_p1spec, d_st_units, d_st_p3spec, d_st_slabs, d_st_lists, d_st_cnt;
+  double st_upp = 1.25;                     // envelope units per pair the next call's batches are sized for (learned: 1.25 x the largest seen)
+  bool st_off = false;                      // a batch of the current call ran out of units: the call is repeated with the fused kernel
+  int last_staged_batches = 0;              // batches the staged launches of the last scoring call went through
+  std::vector<int> st_cnt_host;             // the batches' counters of the last call (read back once, at the end of the scoring pass)
+  uint8_t *path_buf = nullptr;              // wh_set_path_buffer: device array [nq x H] the next scoring calls fill with WH_PATH_* bits
   // staging for the host-pointer entry points
   DevBuf s_res, s_off, s_deci, s_flags, s_fwd, s_det, s_idx, s_w, s_nk, s_nu, s_pq, s_ph, s_co, s_cols, s_pos;
   DevBuf d_rkeys, d_rorder, d_rchunks, d_qorder, d_order, d_items, d_recs, d_spec, d_back, d_cwj, d_cwv, d_cwn, d_crow, c_buf[10];
@@ -119,6 +128,7 @@ struct wh_ehmm {
 };
 
 static int g_device = -1;
+static inline bool kn_trace(const wh_ehmm *e) { return e->knobs.trace; }
 
 extern "C" {
 
@@ -168,7 +178,8 @@ void wh_ehmm_free(wh_ehmm *e) {
                     &e->s_res, &e->s_off, &e->s_deci, &e->s_flags, &e->s_fwd, &e->s_det, &e->s_idx, &e->s_w,
                     &e->s_nk, &e->s_nu, &e->s_pq, &e->s_ph, &e->s_co, &e->s_cols, &e->s_pos, &e->d_rkeys, &e->d_rorder, &e->d_rchunks, &e->d_qorder, &e->d_order, &e->d_items, &e->d_recs, &e->d_spec, &e->d_back, &e->d_cwj, &e->d_cwv, &e->d_cwn, &e->d_crow,
                     &e->c_buf[0], &e->c_buf[1], &e->c_buf[2], &e->c_buf[3], &e->c_buf[4], &e->c_buf[5], &e->c_buf[6],
-                    &e->c_buf[7], &e->c_buf[8], &e->c_buf[9]})
+                    &e->c_buf[7], &e->c_buf[8], &e->c_buf[9],
+                    &e->d_st_pairs, &e->d_st_p1spec, &e->d_st_units, &e->d_st_p3spec, &e->d_st_slabs, &e->d_st_lists, &e->d_st_cnt})
     b->release();
   for (hipEvent_t ev : e->cls_ev) (void)hipEventDestroy(ev);
   for (auto &t : e->timers) {
@@ -344,7 +355,7 @@ int wh_set_option(wh_ehmm *e, const char *name, const char *value) {
   Knobs &k = e->knobs;
   if (!strcmp(name, "WH_SCORE_KERNEL")) {
     const int kv = *v ? atoi(v) : 7;
-    if (kv != 7 && kv != 8 && kv != 9) { set_error("WH_SCORE_KERNEL=%s: this build has kernels 7, 8 and 9", v); return WH_EINVAL; }
+    if (kv != 7 && kv != 8 && kv != 9 && kv != 10) { set_error("WH_SCORE_KERNEL=%s: this build has kernels 7, 8, 9 and 10", v); return WH_EINVAL; }
     k.kernel = kv;
   } else if (!strcmp(name, "WH_KEEP_LOG2")) k.keep_scale = *v ? ldexpf(1.0f, atoi(v)) : 0.f;
   else if (!strcmp(name, "WH_MAX_WAVES")) k.max_waves = *v ? std::max(1, std::min(16, atoi(v))) : 0;
@@ -354,6 +365,7 @@ int wh_set_option(wh_ehmm *e, const char *name, const char *value) {
   else if (!strcmp(name, "WH_NO_WINDOW")) k.no_window = on;
   else if (!strcmp(name, "WH_NO_P2WIN")) k.no_p2win = on;
   else if (!strcmp(name, "WH_RQUEUE_CAP")) k.rqueue_cap = *v ? std::max(1, atoi(v)) : 0;
+  else if (!strcmp(name, "WH_ST_UNITS")) k.st_units = *v ? std::max(64, atoi(v)) : 0;
   else if (!strcmp(name, "WH_NO_WIDE_ALIGN")) k.no_wide_align = on;
   else if (!strcmp(name, "WH_STATS")) k.stats = on;
   else if (!strcmp(name, "WH_TRACE")) k.trace = on;
@@ -364,7 +376,7 @@ int wh_set_option(wh_ehmm *e, const char *name, const char *value) {
 }
 
 static void knobs_from_env(wh_ehmm *e) {
-  for (const char *name : {"WH_SCORE_KERNEL", "WH_KEEP_LOG2", "WH_MAX_WAVES", "WH_FORCE_SPECG", "WH_NO_LOGSPACE", "WH_NO_RESOLVE", "WH_NO_WINDOW", "WH_NO_P2WIN", "WH_RQUEUE_CAP", "WH_NO_WIDE_ALIGN", "WH_STATS", "WH_TRACE", "WH_DBG", "WH_RDBG"})
+  for (const char *name : {"WH_SCORE_KERNEL", "WH_ST_UNITS", "WH_KEEP_LOG2", "WH_MAX_WAVES", "WH_FORCE_SPECG", "WH_NO_LOGSPACE", "WH_NO_RESOLVE", "WH_NO_WINDOW", "WH_NO_P2WIN", "WH_RQUEUE_CAP", "WH_NO_WIDE_ALIGN", "WH_STATS", "WH_TRACE", "WH_DBG", "WH_RDBG"})
     if (const char *v = getenv(name)) (void)wh_set_option(e, name, v);
 }
 
@@ -424,6 +436,12 @@ int wh_last_score_paths(wh_ehmm *e, int64_t *paths6) {
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(v, (int *)e->d_counter.p + kScorePathSlot, sizeof v, hipMemcpyDeviceToHost));
   for (int t = 0; t < 6; t++) paths4[t] = (int64_t)v[t];
+  return WH_OK;
+}
+
+int wh_set_path_buffer(wh_ehmm *e, uint8_t *d_paths) {
+  if (!e) { set_error("wh_set_path_buffer: null handle"); return WH_EINVAL; }
+  e->path_buf = d_paths;
   return WH_OK;
 }
 
@@ -498,6 +516,114 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
                           int64_t total_residues, int32_t max_len, int32_t *d_decibits, uint8_t *d_flags,
                           float *d_fwd_bits, wh_pair_detail *d_detail, void *stream, bool *overflow);
 
+// One size class through the staged launches (wh_staged.hip).  <a> arrives with the class's model list, the queries, the
+// outputs and the resolver's queue filled in; this function plans the LDS blocks of the three kinds of kernel, sizes the
+// batches from the free HBM, and enqueues eight to ten launches per batch - nothing is read back in between: every
+// kernel takes its work from device-side lists and counters.  Batches are ranges of the class's work items (model-major,
+// a.QB queries each), so a batch holds one or two models' tables worth of pairs.
+static int score_staged_class(wh_ehmm *e, ScoreArgs a, int Q, int Lc, hipStream_t s, int *launches) {
+  const Knobs &kn = e->knobs;
+  const int sp = (Lc + 1 + 3) / 4 * 4;
+  const int wl = kScoreSpecArrays * sp + 32 + kRegsInts + (Lc + 3) / 4 + 4;           // floats per wave block (plan_block1's, no extra rows)
+  const size_t tbl = (size_t)Q * kWave * sizeof(float);
+  auto lds_of = [&](int arrays, int waves) { return kLdsHeader + (size_t)arrays * tbl + (size_t)waves * wl * sizeof(float); };
+  // dense kernels: twelve waves beside one orientation (+ the emission rows); the rare dense redo needs both
+  int w_one = 12, w_both = 12;
+  while (w_one >= 1 && lds_of(e->K + FW_NARR, w_one) > kLdsBudget) w_one--;
+  while (w_both >= 1 && lds_of(e->K + 2 * FW_NARR, w_both) > kLdsBudget) w_both--;
+  // light kernels: two workgroups per CU, the emission rows only
+  int w_p2 = 12, w_p4 = 10;
+  while (w_p2 >= 1 && 2 * lds_of(e->K, w_p2) > kLdsBudget) w_p2--;
+  while (w_p4 >= 1 && 2 * lds_of(e->K, w_p4) > kLdsBudget) w_p4--;
+  if (w_one < 4 || w_both < 1 || w_p2 < 4 || w_p4 < 4) { set_error("staged launches: query length %d with model class Q=%d does not fit in LDS", Lc, Q); return WH_ERANGE; }
+  a.SP = sp; a.wave_lds = wl; a.spec_arrays = kScoreSpecArrays;
+  a.paths = reinterpret_cast<unsigned long long *>((int *)e->d_counter.p + kScorePathSlot);
+  a.p2win = 0; a.qorder = nullptr;
+  a.QB = w_one * 4;
+  if ((int64_t)a.n_list * ((a.nq + a.QB - 1) / a.QB) < 4 * (int64_t)e->cu_count) a.QB = w_one;
+  a.n_qblocks = (int)((a.nq + a.QB - 1) / a.QB);
+  a.n_items = a.n_list * a.n_qblocks;
+  StagedArgs g;
+  memset(&g, 0, sizeof g);
+  g.slab_stride = (size_t)(Lc + 1) * 2 * Q * kWave;
+  g.p1stride = (size_t)kScoreSpecArrays * sp;
+  g.p3stride = g.p1stride;
+  // ---- batch size: units (Forward slabs) from the free HBM, at most sixteen per resident dense wave; pairs = units / (units per pair)
+  const int resident = e->cu_count * w_one;
+  int64_t NS = (int64_t)resident * 16;
+  {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+      const size_t have = e->d_st_slabs.cap + e->d_st_p3spec.cap;
+      const size_t budget = (size_t)((double)(free_b + have) * 0.45);
+      NS = std::min<int64_t>(NS, (int64_t)(budget / ((g.slab_stride + g.p3stride) * sizeof(float))));
+    }
+  }
+  if (kn.st_units > 0) NS = kn.st_units;
+  const int64_t total_pairs = (int64_t)a.n_items * a.QB;
+  NS = std::min<int64_t>(NS, (int64_t)((double)total_pairs * e->st_upp) + a.QB * WH_MAX_ENVELOPES);
+  if (NS < 64) { set_error("staged launches: no HBM for the Forward slabs (Q=%d, L=%d)", Q, Lc); return WH_ENOMEM; }
+  int items_b = (int)std::max<int64_t>(1, (int64_t)((double)NS / e->st_upp) / a.QB);
+  items_b = std::min(items_b, a.n_items);
+  const int NB = items_b * a.QB;
+  const int n_batches = (a.n_items + items_b - 1) / items_b;
+  if (e->d_st_pairs.ensure(sizeof(StPair) * (size_t)NB) || e->d_st_p1spec.ensure(sizeof(float) * g.p1stride * (size_t)NB) ||
+      e->d_st_units.ensure(sizeof(StUnit) * (size_t)NS) || e->d_st_p3spec.ensure(sizeof(float) * g.p3stride * (size_t)NS) ||
+      e->d_st_slabs.ensure(sizeof(float) * g.slab_stride * (size_t)NS) || e->d_st_lists.ensure(sizeof(int32_t) * ((size_t)NB + 4 * (size_t)NS)) ||
+      e->d_st_cnt.ensure(sizeof(int) * 32 * (size_t)(e->last_staged_batches + n_batches)))
+    return WH_ENOMEM;
+  g.NB = NB; g.NS = (int)NS;
+  g.pairs = (StPair *)e->d_st_pairs.p; g.p1spec = (float *)e->d_st_p1spec.p;
+  g.units = (StUnit *)e->d_st_units.p; g.p3spec = (float *)e->d_st_p3spec.p; g.slabs = (float *)e->d_st_slabs.p;
+  g.doubt_list = (int32_t *)e->d_st_lists.p;
+  g.list256 = g.doubt_list + NB; g.list512 = g.list256 + NS; g.listfull = g.list512 + NS; g.listdense = g.listfull + NS;
+  g.wave_lds_light = wl;
+  g.pair_paths = e->path_buf;
+  int *cnt0 = (int *)e->d_st_cnt.p + 32 * (size_t)e->last_staged_batches;
+  HIPCHK(hipMemsetAsync(cnt0, 0, sizeof(int) * 32 * (size_t)n_batches, s));
+  const bool w512 = Q == 16 || Q == 24;
+  if (kn.trace) fprintf(stderr, "[wh] staged Q=%d: %d items of %d queries in %d batches of %d pairs, %lld units (%.1f GB of slabs), waves dense %d / both %d / p2win %d / p4win %d, lds dense %zu light %zu\n",
+                        Q, a.n_items, a.QB, n_batches, NB, (long long)NS, (double)NS * g.slab_stride * 4e-9, w_one, w_both, w_p2, w_p4, lds_of(e->K + FW_NARR, w_one), lds_of(e->K, w_p2));
+  if (class_mark(e, s, Q, 4)) return WH_EHIP;
+  if (kn.stats) {
+    if (e->d_recs.ensure(512)) return WH_ENOMEM;
+    HIPCHK(hipMemsetAsync(e->d_recs.p, 0, 512, s));
+    a.stats = (unsigned long long *)e->d_recs.p;
+  }
+  const int cu = e->cu_count;
+  for (int b = 0; b < n_batches; b++) {
+    g.a = a;
+    g.item0 = b * items_b;
+    g.n_items_b = std::min(items_b, a.n_items - g.item0);
+    g.cnt = cnt0 + 32 * (size_t)b;
+    const int wg = std::min(g.n_items_b, cu);
+    hipError_t err = launch_staged_p1(Q, g, wg, w_one * kWave, lds_of(e->K + FW_NARR, w_one), s);
+    if (err == hipSuccess) err = launch_staged_p2win(Q, 4, g, std::min(g.n_items_b, 2 * cu), w_p2 * kWave, lds_of(e->K, w_p2), s);
+    if (err == hipSuccess && w512) err = launch_staged_p2win(Q, 8, g, std::min(g.n_items_b, 2 * cu), w_p2 * kWave, lds_of(e->K, w_p2), s);
+    if (err == hipSuccess) err = launch_staged_p2full(Q, g, wg, w_one * kWave, lds_of(e->K + BW_NARR, w_one), s);
+    if (err == hipSuccess) err = launch_staged_p3(Q, g, wg, w_one * kWave, lds_of(e->K + FW_NARR, w_one), s);
+    if (err == hipSuccess) err = launch_staged_p4win(Q, 4, g, 2 * cu, w_p4 * kWave, lds_of(e->K, w_p4), s);
+    if (err == hipSuccess && w512) err = launch_staged_p4win(Q, 8, g, 2 * cu, w_p4 * kWave, lds_of(e->K, w_p4), s);
+    if (err == hipSuccess) err = launch_staged_p4full(Q, g, cu, w_one * kWave, lds_of(e->K + BW_NARR, w_one), s);
+    if (err == hipSuccess) err = launch_staged_dense(Q, g, cu, w_both * kWave, lds_of(e->K + 2 * FW_NARR, w_both), s);
+    if (err == hipSuccess) err = launch_staged_assemble(g, s);
+    if (err != hipSuccess) { set_error("staged launch (Q=%d, batch %d) failed: %s", Q, b, hipGetErrorString(err)); return WH_EHIP; }
+  }
+  e->last_staged_batches += n_batches;
+  (*launches)++;
+  if (a.stats) {
+    unsigned long long st[64];
+    HIPCHK(hipMemcpyAsync(st, a.stats, sizeof st, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    static const char *kind[9] = {"p1", "p2win 256", "p2win 512", "p2full", "p3", "p4win 256", "p4win 512", "p4full", "dense"};
+    for (int k = 0; k < 9; k++)
+      fprintf(stderr, "[wh] staged Q=%d %-10s sweeps %9llu  shader cycles per sweep %10.0f  real time per sweep %8.1f us  (clock %.2f GHz)  wave lifetimes %.3g cycles, in sweeps %.1f%%\n", Q, kind[k], st[4 * k + 3],
+              st[4 * k + 3] ? (double)st[4 * k] / (double)st[4 * k + 3] : 0.0, st[4 * k + 3] ? 0.01 * (double)st[4 * k + 1] / (double)st[4 * k + 3] : 0.0,
+              st[4 * k + 1] ? 0.1 * (double)st[4 * k] / (double)st[4 * k + 1] : 0.0, (double)st[4 * k + 2], st[4 * k + 2] ? 100.0 * (double)st[4 * k] / (double)st[4 * k + 2] : 0.0);
+  }
+  return WH_OK;
+}
+
 int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets, int64_t nq,
                  int64_t total_residues, int32_t max_len, int32_t *d_decibits, uint8_t *d_flags,
                  float *d_fwd_bits, wh_pair_detail *d_detail, void *stream) {
@@ -511,15 +637,18 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
   // runs once more (every pair is scored again, so the queue then holds exactly what the first pass counted).
   e->last_queue_reruns = 0;
   e->rq_floor = 0;
+  e->st_off = false;
   bool overflow = false;
   int rc = score_dev_pass(e, d_residues, d_offsets, nq, total_residues, max_len, d_decibits, d_flags, d_fwd_bits, d_detail, stream, &overflow);
-  if (rc == WH_OK && overflow) {
-    e->last_queue_reruns = 1;
+  // (two independent reasons to repeat a pass: the resolver's queue, and a staged batch that ran out of envelope units)
+  for (int again = 0; rc == WH_OK && overflow; again++) {
+    if (again == 2) { set_error("wh_score_dev: the resolver's queue overflowed twice"); rc = WH_ERANGE; break; }
+    e->last_queue_reruns++;
     overflow = false;
     rc = score_dev_pass(e, d_residues, d_offsets, nq, total_residues, max_len, d_decibits, d_flags, d_fwd_bits, d_detail, stream, &overflow);
-    if (rc == WH_OK && overflow) { set_error("wh_score_dev: the resolver's queue overflowed twice"); rc = WH_ERANGE; }
   }
   e->rq_floor = 0;
+  e->st_off = false;
   return rc;
 }
 
@@ -530,6 +659,7 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
   HIPCHK(hipSetDevice(e->device));
   if (timer_begin(e, 0, s)) return WH_EHIP;
   e->cls_n = 0;
+  e->last_staged_batches = 0;
   int launches = 0;
   const int32_t *qorder_all = nullptr;     // queries in descending length order, when the call formed it
   bool wide_done = false;
@@ -673,6 +803,15 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
         if (lds > kLdsBudget) { set_error("query length %d with model class Q=%d does not fit in LDS", max_len, Q); return WH_ERANGE; }
         SP = (Lc + 1 + 3) / 4 * 4;
         specg = true;
+      }
+      // ---- staged launches (wh_staged.hip): short-query batches of the one-wave classes, special states in LDS
+      const bool staged = kn.kernel == 10 && !e->st_off && !big && !pairk && !specg && !mixed && !kn.dbg &&
+                          (Q == 8 || Q == 12 || Q == 16 || Q == 20 || Q == 24);
+      if (staged) {
+        if (pass == 0) continue;
+        int rc_st = score_staged_class(e, a, Q, Lc, s, &launches);
+        if (rc_st != WH_OK) return rc_st;
+        continue;
       }
       a.SP = SP; a.wave_lds = wave_lds; a.spec_arrays = kScoreSpecArrays;
       a.paths = reinterpret_cast<unsigned long long *>((int *)e->d_counter.p + kScorePathSlot);
@@ -851,6 +990,24 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
   }
   if (class_mark(e, s, 0, -1)) return WH_EHIP;        // closes the last launch's interval
   if (timer_end(e, 0, s, launches)) return WH_EHIP;
+  if (e->last_staged_batches > 0) {
+    // the staged batches' counters, once per call: units per pair (sizes the next call's batches) and the overflow flag
+    e->st_cnt_host.resize((size_t)32 * e->last_staged_batches);
+    HIPCHK(hipMemcpyAsync(e->st_cnt_host.data(), e->d_st_cnt.p, sizeof(int) * e->st_cnt_host.size(), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    bool over = false;
+    for (int b = 0; b < e->last_staged_batches; b++) over = over || e->st_cnt_host[(size_t)32 * b + ST_OVERFLOW] != 0;
+    if (over) {
+      // a batch held more envelopes than it had slabs for (sixteen regions per pair are possible, batches are sized for the
+      // rate seen so far): this call runs again with the fused kernel, the next ones with batches sized for what was seen
+      if (kn_trace(e)) fprintf(stderr, "[wh] staged launches: a batch ran out of envelope units, the scoring pass is repeated with the fused kernel\n");
+      e->st_upp = std::min<double>(WH_MAX_ENVELOPES, e->st_upp * 2.0);
+      e->st_off = true;
+      *overflow = true;
+      if (timer_begin(e, 4, s) || timer_end(e, 4, s, 0)) return WH_EHIP;
+      return WH_OK;
+    }
+  }
   if (nq > 0 && !e->by_q.empty()) {
     // While the scoring kernels run, the host sets up what the NEXT stage needs: the alignment kernels' per-wave slabs
     // ((L+1) x 5 x Q x 64 floats per resident wave: 6 GB at L = 150, Q = 16 - a first-call hipMalloc of 0.3 s that used to

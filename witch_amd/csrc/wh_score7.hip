@@ -341,9 +341,12 @@ __device__ __noinline__ P4Out sweep_backward_null2(const WaveCtx c, lds_u8 *eseq
 // paths that leave the window; the Forward rows are exact, so every accumulated posterior is a lower bound and the
 // SAME mass certificate that guards the sparse spill guards the window: mass must reach Ld (1 - tol), otherwise the
 // caller runs the full-width sweep on the same rows.
-template <int QB, int Q, int TH, bool SG>
+// BWG (staged launches, wh_staged.hip): the reversed transition arrays are gathered from the table buffer in L2
+// (c.specg points at them there) instead of an LDS copy - the window sweep reads them once per envelope.
+template <int QB, int Q, int TH, bool SG, bool BWG = false>
 __device__ __noinline__ P4Out sweep_backward_null2_win(const WaveCtx c, lds_u8 *eseq3, int Ld, LenCfg cu, float invZe, float mass_tol, int m0) {
   static_assert(Q % QB == 0 && QB % 4 == 0, "a window lane must stay inside one forward lane block");
+  static_assert(!(SG && BWG), "c.specg cannot be both");
   constexpr int Q4 = Q / 4, B4 = QB / 4;
   const uint8_t *eseq = (const uint8_t *)eseq3;
   const int lane = c.lane, SP = c.SP, Klds = ctxKlds(c);
@@ -356,7 +359,7 @@ __device__ __noinline__ P4Out sweep_backward_null2_win(const WaveCtx c, lds_u8 *
   int fwd[B4];
   TransTab<QB, true> T;
   {
-    const float4 *bw4 = reinterpret_cast<const float4 *>((const float *)c.bwL);
+    const float4 *bw4 = BWG ? reinterpret_cast<const float4 *>((const float *)c.specg) : reinterpret_cast<const float4 *>((const float *)c.bwL);
 #pragma unroll
     for (int p4 = 0; p4 < B4; p4++) {
       const int m4 = (m0 >> 2) + lane * B4 + p4;
@@ -514,8 +517,11 @@ __device__ __noinline__ P4Out sweep_backward_null2_win(const WaveCtx c, lds_u8 *
 // only then are its regions used - they are then the regions of the full-width sweep, decision by decision - otherwise
 // P2 runs at full width as before.  The windowed posteriors go to three arrays of their own (tmp = spec + kSpArr * SP):
 // the Forward rows of P1 stay intact for the full-width sweep.
+// INPL (staged launches, wh_staged.hip): the wave's block is a COPY of P1's rows (the originals stay in HBM), so the
+// three posterior rows overwrite the E, B and N rows in place as the full-width sweep does - row i reads E(i), B(i) and
+// N(i-1), and N(i) was read one row earlier.  BWG: as in sweep_backward_null2_win.
 struct WinDec { float eps; };
-template <int QB, int Q, int TH>
+template <int QB, int Q, int TH, bool INPL = false, bool BWG = false>
 __device__ __noinline__ WinDec sweep_backward_decode_win(const WaveCtx c, lds_u8 *seq3, int L, LenCfg cm, float invZ, int ef_L, int m0) {
   static_assert(Q % QB == 0 && QB % 4 == 0, "a window lane must stay inside one forward lane block");
   constexpr int Q4 = Q / 4, B4 = QB / 4;
@@ -523,11 +529,12 @@ __device__ __noinline__ WinDec sweep_backward_decode_win(const WaveCtx c, lds_u8
   const int lane = c.lane, SP = c.SP, Klds = ctxKlds(c);
   const float *spec = (const float *)c.spec;
   float *tmp = (float *)c.spec + kSpArr * SP;          // [0] pe, [1] pb, [2] njc rows of the window sweep
+  float *tE = INPL ? (float *)c.spec + SP_E * SP : tmp, *tB = INPL ? (float *)c.spec + SP_B * SP : tmp + SP, *tN = INPL ? (float *)c.spec + SP_N * SP : tmp + 2 * SP;
   const int *speci = reinterpret_cast<const int *>(spec);
   int fwd[B4];
   TransTab<QB, true> T;
   {
-    const float4 *bw4 = reinterpret_cast<const float4 *>((const float *)c.bwL);
+    const float4 *bw4 = BWG ? reinterpret_cast<const float4 *>((const float *)c.specg) : reinterpret_cast<const float4 *>((const float *)c.bwL);
 #pragma unroll
     for (int p4 = 0; p4 < B4; p4++) {
       const int m4 = (m0 >> 2) + lane * B4 + p4;
@@ -596,7 +603,7 @@ __device__ __noinline__ WinDec sweep_backward_decode_win(const WaveCtx c, lds_u8
       ratio = spec[SP_N * SP] * xN * s_i;               // N_F(0) N_B(0) / Z: the share of the paths that stay inside the window
     }
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) { tmp[i] = pe; tmp[SP + i] = pb; tmp[2 * SP + i] = njc; }
+    if (lane == 0) { tE[i] = pe; tB[i] = pb; tN[i] = njc; }
     __builtin_amdgcn_wave_barrier();
   }
   WinDec o;
@@ -608,10 +615,10 @@ __device__ __noinline__ WinDec sweep_backward_decode_win(const WaveCtx c, lds_u8
 // the slack of the window (header above): a windowed posterior p_w stands for a true value in [p_w, p_w + eps].
 // Returns the regions and, in bit 24 of flags, whether any decision was in doubt (the caller then discards the result).
 // The cumulative sums go back into the pe row (etot) and the njc row (btot): both are read at the row they are written.
-template <int TH>
+template <int TH, bool INPL = false>
 __device__ __noinline__ RegOut region_scan_cert(lds_f *spec3, int SP, int L, lds_i *regs3, int lane, float eps) {
   float *tmp = (float *)spec3 + kSpArr * SP;
-  float *tE = tmp, *tB = tmp + SP, *tN = tmp + 2 * SP;
+  float *tE = INPL ? (float *)spec3 + SP_E * SP : tmp, *tB = INPL ? (float *)spec3 + SP_B * SP : tmp + SP, *tN = INPL ? (float *)spec3 + SP_N * SP : tmp + 2 * SP;
   int *regs = (int *)regs3;
   const float rt1 = 0.25f, rt2 = 0.10f, rt3 = 0.20f;
   const float slack = 2e-5f;                // float32 rounding of the sums, on top of eps

@@ -1,0 +1,807 @@
+// Staged scoring launches (round 5): the five sweeps of hmmsearch --max per (query, HMM) pair - P1 multihit Forward,
+// P2 multihit Backward + domain decoding + region scan, per envelope P3 unihit Forward and P4 unihit Backward + null2,
+// score assembly - as KERNELS OF THEIR OWN over batches of pairs, instead of one fused kernel (wh_score7.hip).
+// (hmmsearch per pair: witch_msa/gcmm/algorithm.py:526-532; algorithm SURVEY.md A.2-A.6.)
+//
+// Why: the dense sweeps (P1, P3: 16 cells per lane at full width, 168 registers) fill a SIMD at three waves; the window
+// sweeps (P2 and P4 on 256 nodes: 4 cells per lane, ~70 registers) are one dependent chain per row and three waves do
+// not cover it - in the fused kernel they are a fifth of the instructions and more than a third of the time.  Here every
+// kind of sweep runs at the occupancy it can use:
+//   p1      dense   12 waves/CU   tables: forward orientation + emission rows     -> per pair: six per-row arrays + C(L) in HBM
+//   p2win   light   24 waves/CU   tables: emission rows (reversed arrays gathered from L2 once per pair)
+//                                 window sweep + certified region scan             -> regions, or the pair joins the doubt list
+//   p2full  dense   12 waves/CU   tables: reversed orientation + emission rows; the doubt list at full width
+//   p3      dense   12 waves/CU   one unit per envelope: Forward rows to the unit's slab, per-row arrays to HBM
+//   p4win   light   20-24 waves   the 256-node (512-node) list; a window that fails the mass certificate joins the full list
+//   p4full  dense   12 waves/CU   the full-width list; a sweep that fails the spill certificate joins the dense list
+//   dense   dense                 P3 with every row stored + P4 at full width (rare)
+//   assemble        one thread per pair: HMMER's float32 score assembly, or the pair's record for the multidomain resolver
+// Every sweep IS the fused kernel's device function (this file compiles wh_score7.hip's sweeps into its own namespace;
+// non-inlined, so the arithmetic of a sweep does not depend on the kernel around it): a pair takes the same path through
+// the same instructions as in the fused kernel and the results are bit-identical (tests/test_gpu_parity.py:
+// test_staged_launches_equal_the_fused_kernel).
+#include <hip/hip_runtime.h>
+
+#ifndef WH_ST_PART
+#define WH_ST_PART 0          // 0: everything; 1: dense kernels only; 2: light kernels + assembly only (parallel builds)
+#endif
+#if WH_ST_PART == 2
+#define WH_K7NS ksl
+#else
+#define WH_K7NS ksd
+#endif
+#define WH_K7LAUNCH launch_score_staged_unused
+#define WH_SWEEPS_ONLY 1
+#ifndef WH_SLIM_SPEC
+#define WH_SLIM_SPEC 1
+#endif
+#include "wh_score7.hip"
+
+namespace wh {
+namespace WH_K7NS {
+
+// WH_STATS: per kernel kind k, stats[4k] shader cycles inside the sweeps, [4k+1] the same in 100 MHz real-time ticks,
+// [4k+2] wave lifetimes (shader cycles), [4k+3] sweeps.  Kinds: 0 p1, 1 p2win 256, 2 p2win 512, 3 p2full, 4 p3, 5 p4win 256,
+// 6 p4win 512, 7 p4full, 8 dense
+#define ST_T0() const long long st_c0 = a.stats ? (long long)__builtin_readcyclecounter() : 0; const long long st_r0 = a.stats ? (long long)wall_clock64() : 0
+#define ST_T1(kind) do { if (a.stats) { const long long st_c1 = (long long)__builtin_readcyclecounter(), st_r1 = (long long)wall_clock64(); if (lane == 0) { \
+    atomicAdd(a.stats + 4 * (kind), (unsigned long long)(st_c1 - st_c0)); atomicAdd(a.stats + 4 * (kind) + 1, (unsigned long long)(st_r1 - st_r0)); atomicAdd(a.stats + 4 * (kind) + 3, 1ull); } } } while (0)
+#define ST_K0() const long long st_k0 = a.stats ? (long long)__builtin_readcyclecounter() : 0
+#define ST_K1(kind) do { if (a.stats && lane == 0) atomicAdd(a.stats + 4 * (kind) + 2, (unsigned long long)((long long)__builtin_readcyclecounter() - st_k0)); } while (0)
+constexpr int kStTH = 768;            // dense kernels: twelve waves, 168 registers
+constexpr int kStChunk = 48;          // list entries a workgroup draws at a time
+
+// pair -> (work item, query, model) inside a batch
+struct PairPos { int h; int64_t qi; };
+__device__ __forceinline__ PairPos pair_pos(const StagedArgs &g, int pl) {
+  const ScoreArgs &a = g.a;
+  const int gitem = g.item0 + pl / a.QB;
+  PairPos p;
+  p.h = a.hmm_list[gitem / a.n_qblocks];
+  p.qi = (int64_t)(gitem % a.n_qblocks) * a.QB + pl % a.QB;
+  return p;
+}
+
+// what a workgroup keeps in LDS: [16-byte header][emission rows K x TBL][NT transition arrays x TBL][per-wave blocks]
+template <int Q>
+struct StLds {
+  float *em, *tr, *wbase;
+  volatile int *slot;
+  __device__ __forceinline__ StLds(float *raw, int K, int ntr, int wave, int wave_lds) {
+    slot = reinterpret_cast<volatile int *>(raw);
+    em = raw + 4;
+    tr = em + (size_t)K * Q * kWave;
+    wbase = tr + (size_t)ntr * Q * kWave + (size_t)wave * wave_lds;
+  }
+};
+
+__device__ __forceinline__ void copy_f4(float *dst, const float *src, int nfloats) {
+  const float4 *s4 = reinterpret_cast<const float4 *>(src);
+  float4 *d4 = reinterpret_cast<float4 *>(dst);
+  for (int t = threadIdx.x; t < nfloats / 4; t += blockDim.x) d4[t] = s4[t];
+}
+
+// per-wave context with the block laid out as the fused kernel's: [kSpArr x SP rows][n2tab 32][regs][residues]
+__device__ __forceinline__ WaveCtx make_ctx(const ScoreArgs &a, float *em, float *fw, float *bw, float *wbase, int lane) {
+  WaveCtx c;
+  c.emL = (lds_f *)em; c.fwL = (lds_f *)fw; c.bwL = (lds_f *)bw;
+  c.spec = (lds_f *)wbase; c.n2tab = (lds_f *)(wbase + kSpArr * a.SP);
+  c.specg = nullptr; c.Fs = nullptr; c.emG = nullptr;
+  c.degen = 0;
+  for (int t = 0; t < 32; t++) if (t == lane) c.degen = a.degen[t];
+  c.SP = a.SP; c.alpha = a.K | (a.Kp << 8) | (a.K << 16); c.lane = lane;
+  return c;
+}
+__device__ __forceinline__ int *ctx_regs(const ScoreArgs &a, float *wbase) { return reinterpret_cast<int *>(wbase + kSpArr * a.SP + 32); }
+__device__ __forceinline__ uint8_t *ctx_seq(const ScoreArgs &a, float *wbase) { return reinterpret_cast<uint8_t *>(ctx_regs(a, wbase) + kRegsInts); }
+
+__device__ __forceinline__ void load_seq(const ScoreArgs &a, uint8_t *seq, int64_t off, int L, int lane) {
+  for (int t = lane; t < L; t += kWave) {
+    int r = a.residues[off + t];
+    seq[t] = (uint8_t)(r < a.Kp ? r : a.Kp - 1);
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// the six per-row arrays of a wave's block <-> HBM (rows 0..L of each; coalesced)
+__device__ __forceinline__ void rows_out(float *dst, const float *spec, int SP, int L, int lane) {
+  __builtin_amdgcn_wave_barrier();
+  for (int arr = 0; arr < kSpArr; arr++)
+    for (int t = lane; t <= L; t += kWave) __builtin_nontemporal_store(spec[arr * SP + t], dst + arr * SP + t);
+}
+__device__ __forceinline__ void rows_in(float *spec, const float *src, int SP, int L, int lane) {
+  __builtin_amdgcn_wave_barrier();
+  for (int arr = 0; arr < kSpArr; arr++)
+    for (int t = lane; t <= L; t += kWave) spec[arr * SP + t] = __builtin_nontemporal_load(src + arr * SP + t);
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ int bcast_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// the window of 64*QB nodes around the lane blocks of <um> (two blocks in front, one behind), as the fused kernel places
+// it: returns QB (4 or 8) and the first reversed node, or 0 when no window fits
+template <int Q>
+__device__ __forceinline__ int place_window(unsigned long long um, int &m0) {
+  if (um == 0) return 0;
+  int lo = __builtin_ctzll(um), hi = 63 - __builtin_clzll(um);
+  lo = lo > 1 ? lo - 2 : 0; hi = hi < 63 ? hi + 1 : 63;
+  const int nodes = (hi - lo + 1) * Q;
+  if (nodes <= 4 * kWave) { m0 = min((63 - hi) * Q, kWave * (Q - 4)); return 4; }
+  if (Q % 8 == 0 && Q > 8 && nodes <= 8 * kWave) { m0 = min((63 - hi) * Q, kWave * (Q - 8)); return 8; }
+  return 0;
+}
+
+__device__ __forceinline__ void store_regions(StPair *pp, const RegOut &ro, const int *regs, int lane, wh_pair_detail *dp) {
+  if (lane == 0) {
+    pp->nenv = ro.nenv; pp->nreg = ro.nreg; pp->flags = ro.flags & 0xFFFFFF;
+    for (int e = 0; e < ro.nenv; e++) { pp->regs[2 * e] = regs[2 * e]; pp->regs[2 * e + 1] = regs[2 * e + 1]; }
+    pp->state = 2;
+    if (dp) { dp->nregions = ro.nreg; dp->nenv = ro.nenv; }
+  }
+}
+
+#if WH_ST_PART != 2
+// ================================================================================================ p1: multihit Forward
+template <int Q>
+__global__ __launch_bounds__(kStTH) void staged_p1_kernel(StagedArgs g) {
+  const ScoreArgs &a = g.a;
+  extern __shared__ __attribute__((aligned(16))) float smem_raw[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  constexpr int TBL = Q * kWave;
+  StLds<Q> S(smem_raw, a.K, FW_NARR, wave, a.wave_lds);
+  WaveCtx c = make_ctx(a, S.em, S.tr, nullptr, S.wbase, lane);
+  uint8_t *seq = ctx_seq(a, S.wbase);
+  float *spec = S.wbase;
+  const int SP = a.SP;
+  const double LOG2 = 0.69314718055994529;
+  ST_K0();
+  int cur_h = -1;
+  const DevHMM *hm = nullptr;
+  for (;;) {
+    if (threadIdx.x == 0) *S.slot = atomicAdd(g.cnt + ST_C_P1, 1);
+    __syncthreads();
+    const int item = *S.slot;
+    __syncthreads();
+    if (item >= g.n_items_b) break;
+    const int gitem = g.item0 + item;
+    const int h = a.hmm_list[gitem / a.n_qblocks];
+    const int64_t q_lo = (int64_t)(gitem % a.n_qblocks) * a.QB;
+    const int64_t q_hi = q_lo + a.QB < a.nq ? q_lo + a.QB : a.nq;
+    if (h != cur_h) {
+      hm = a.hmms + h;
+      copy_f4(S.em, a.tables + hm->em_off, a.K * TBL);
+      copy_f4(S.tr, a.tables + hm->fw_off, FW_NARR * TBL);
+      cur_h = h;
+      __syncthreads();
+    }
+    c.emG = (const glb_f *)(a.tables + hm->em_off);
+    for (int64_t qi = q_lo + wave; qi < q_hi; qi += nwaves) {
+      const int pl = item * a.QB + (int)(qi - q_lo);
+      StPair *pp = g.pairs + pl;
+      const int64_t off = a.offsets[qi];
+      const int L = (int)(a.offsets[qi + 1] - off);
+      const size_t out = (size_t)qi * a.H + h;
+      float fwd_bits_out = -INFINITY;
+      wh_pair_detail *dp = (a.detail && lane == 0) ? a.detail + out : nullptr;
+      if (dp) {
+        dp->fwd_bits = -INFINITY; dp->seq_score = 0.f; dp->pre_score = 0.f; dp->seqbias_nats = 0.f;
+        dp->nregions = 0; dp->nenv = 0;
+      }
+      int state = 0;
+      if (L > 0 && L <= a.Lcap) {
+        load_seq(a, seq, off, L, lane);
+        const LenCfg cm = len_config(L, true);
+        ST_T0();
+        const FwdOut f1 = sweep_forward<Q, false, kStTH, false>(c, (lds_u8 *)seq, L, cm, 0.f);
+        ST_T1(0);
+        const double fwd_nats = (double)f1.ef * LOG2 + log((double)(f1.xC * cm.move));
+        const float fwdsc = (float)fwd_nats;
+        const float p1 = (float)L / (float)(L + 1);
+        const float nullsc = (float)((double)(float)L * log((double)p1) + log(1.0 - (double)p1));
+        fwd_bits_out = (float)((fwd_nats - (double)nullsc) / LOG2);
+        if (dp) dp->fwd_bits = fwd_bits_out;
+        if (f1.xC > 0.f && isfinite(fwdsc)) {
+          state = 1;
+          rows_out(g.p1spec + (size_t)pl * g.p1stride, spec, SP, L, lane);
+          if (lane == 0) {
+            const unsigned *su = reinterpret_cast<const unsigned *>((const float *)c.n2tab) + kUmSlot;
+            pp->xC = f1.xC; pp->ef = f1.ef;
+            pp->um_lo = Q >= 8 ? su[0] : 0u; pp->um_hi = Q >= 8 ? su[1] : 0u;
+          }
+        }
+      }
+      if (lane == 0) {
+        pp->state = state; pp->path = 0; pp->nenv = 0; pp->nreg = 0; pp->flags = 0;
+        if (state == 0) { a.decibits[out] = 0; a.flags[out] = 0; if (g.pair_paths) g.pair_paths[out] = 0; }
+        if (a.fwd_bits) a.fwd_bits[out] = fwd_bits_out;
+      }
+    }
+  }
+  ST_K1(0);
+}
+
+// list-driven dense kernels: a workgroup draws kStChunk entries, works through them model by model (the lists are
+// written in model-major order up to the interleaving of concurrent workgroups, so a chunk is nearly always one model)
+template <int Q, class Stage, class Body>
+__device__ __forceinline__ void list_loop(const StagedArgs &g, volatile int *slot, const int32_t *list, int n_slot, int head_slot,
+                                          bool units, int &cur_h, Stage stage, Body body) {
+  const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int n = min(g.cnt[n_slot], units ? g.NS : g.NB);
+  for (;;) {
+    if (threadIdx.x == 0) *slot = atomicAdd(g.cnt + head_slot, kStChunk);
+    __syncthreads();
+    const int c0 = *slot;
+    __syncthreads();
+    if (c0 >= n) break;
+    const int c1 = min(c0 + kStChunk, n);
+    int pos = c0;
+    while (pos < c1) {
+      auto model_at = [&](int idx) { const int ent = list[idx]; return pair_pos(g, units ? g.units[ent].pl : ent).h; };
+      const int h = model_at(pos);
+      int r = pos + 1;
+      while (r < c1 && model_at(r) == h) r++;
+      if (h != cur_h) { __syncthreads(); stage(h); cur_h = h; __syncthreads(); }
+      for (int idx = pos + wave; idx < r; idx += nwaves) body(list[idx], h);
+      pos = r;
+    }
+  }
+}
+
+// ================================================================================================ p2full: the doubt list
+template <int Q>
+__global__ __launch_bounds__(kStTH) void staged_p2full_kernel(StagedArgs g) {
+  const ScoreArgs &a = g.a;
+  extern __shared__ __attribute__((aligned(16))) float smem_raw[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int TBL = Q * kWave;
+  StLds<Q> S(smem_raw, a.K, BW_NARR, wave, a.wave_lds);
+  WaveCtx c = make_ctx(a, S.em, nullptr, S.tr, S.wbase, lane);
+  uint8_t *seq = ctx_seq(a, S.wbase);
+  int *regs = ctx_regs(a, S.wbase);
+  ST_K0();
+  int cur_h = -1;
+  list_loop<Q>(g, S.slot, g.doubt_list, ST_N_DOUBT, ST_C_P2B, false, cur_h,
+    [&](int h) {
+      const DevHMM *hm = a.hmms + h;
+      copy_f4(S.em, a.tables + hm->em_off, a.K * TBL);
+      copy_f4(S.tr, a.tables + hm->bw_off, BW_NARR * TBL);
+      c.emG = (const glb_f *)(a.tables + hm->em_off);
+    },
+    [&](int pl, int h) {
+      StPair *pp = g.pairs + pl;
+      const PairPos P = pair_pos(g, pl);
+      const int64_t off = a.offsets[P.qi];
+      const int L = (int)(a.offsets[P.qi + 1] - off);
+      load_seq(a, seq, off, L, lane);
+      rows_in(S.wbase, g.p1spec + (size_t)pl * g.p1stride, a.SP, L, lane);
+      const LenCfg cm = len_config(L, true);
+      const float xC = pp->xC; const int ef = pp->ef;
+      ST_T0();
+      sweep_backward_decode<Q, kStTH, false>(c, (lds_u8 *)seq, L, cm, 1.0f / (xC * cm.move), ef);
+      ST_T1(3);
+      const RegOut ro = region_scan<kStTH, false>(c.spec, nullptr, a.SP, L, (lds_i *)regs, lane);
+      __builtin_amdgcn_wave_barrier();
+      wh_pair_detail *dp = (a.detail && lane == 0) ? a.detail + ((size_t)P.qi * a.H + h) : nullptr;
+      store_regions(pp, ro, regs, lane, dp);
+      if (lane == 0) pp->path |= WH_PATH_P2_FULL;
+    });
+  ST_K1(3);
+}
+
+// ================================================================================================ p3: unihit Forward per envelope
+template <int Q>
+__global__ __launch_bounds__(kStTH) void staged_p3_kernel(StagedArgs g) {
+  const ScoreArgs &a = g.a;
+  extern __shared__ __attribute__((aligned(16))) float smem_raw[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  constexpr int TBL = Q * kWave;
+  StLds<Q> S(smem_raw, a.K, FW_NARR, wave, a.wave_lds);
+  WaveCtx c = make_ctx(a, S.em, S.tr, nullptr, S.wbase, lane);
+  uint8_t *seq = ctx_seq(a, S.wbase);
+  float *spec = S.wbase;
+  const int SP = a.SP;
+  const double LOG2 = 0.69314718055994529;
+  ST_K0();
+  int cur_h = -1;
+  const DevHMM *hm = nullptr;
+  for (;;) {
+    if (threadIdx.x == 0) *S.slot = atomicAdd(g.cnt + ST_C_P3, 1);
+    __syncthreads();
+    const int item = *S.slot;
+    __syncthreads();
+    if (item >= g.n_items_b) break;
+    const int gitem = g.item0 + item;
+    const int h = a.hmm_list[gitem / a.n_qblocks];
+    const int64_t q_lo = (int64_t)(gitem % a.n_qblocks) * a.QB;
+    const int64_t q_hi = q_lo + a.QB < a.nq ? q_lo + a.QB : a.nq;
+    if (h != cur_h) {
+      hm = a.hmms + h;
+      copy_f4(S.em, a.tables + hm->em_off, a.K * TBL);
+      copy_f4(S.tr, a.tables + hm->fw_off, FW_NARR * TBL);
+      cur_h = h;
+      __syncthreads();
+    }
+    c.emG = (const glb_f *)(a.tables + hm->em_off);
+    for (int64_t qi = q_lo + wave; qi < q_hi; qi += nwaves) {
+      const int pl = item * a.QB + (int)(qi - q_lo);
+      StPair *pp = g.pairs + pl;
+      if (bcast_i(pp->state) != 2) continue;
+      const int nenv = bcast_i(pp->nenv);
+      if (nenv <= 0) continue;
+      const int multi_mask = bcast_i(pp->flags) >> 8;
+      const bool queue_pair = multi_mask != 0 && a.rrecs != nullptr;
+      const int64_t off = a.offsets[qi];
+      const int L = (int)(a.offsets[qi + 1] - off);
+      load_seq(a, seq, off, L, lane);
+      const LenCfg cu = len_config(L, false);
+      for (int e = 0; e < nenv; e++) {
+        if (queue_pair && ((multi_mask >> e) & 1)) { if (lane == 0) { pp->envsc[e] = 0.f; pp->domcorr[e] = 0.f; } continue; }
+        const int ri = bcast_i(pp->regs[2 * e]), rj = bcast_i(pp->regs[2 * e + 1]);
+        const int Ld = rj - ri + 1;
+        int uid = 0;
+        if (lane == 0) uid = atomicAdd(g.cnt + ST_N_UNITS, 1);
+        uid = bcast_i(uid);
+        if (uid >= g.NS) { if (lane == 0) g.cnt[ST_OVERFLOW] = 1; continue; }     // the host repeats the call (see wh_api.hip)
+        c.Fs = (glb_f *)(g.slabs + (size_t)uid * g.slab_stride);
+        const float keep_scale = a.keep_scale > 0.f ? a.keep_scale : kKeepScale7;
+        ST_T0();
+        const FwdOut f3 = sweep_forward<Q, true, kStTH, false>(c, (lds_u8 *)(seq + (ri - 1)), Ld, cu, keep_scale);
+        ST_T1(4);
+        const float envsc = (float)((double)f3.ef * LOG2 + log((double)(f3.xC * cu.move)));
+        StUnit *u = g.units + uid;
+        int cls = -1, m0 = 0;          // -1: no Backward sweep (no Forward mass), 0 full width, 4 / 8 window
+        if (f3.xC > 0.f) {
+          rows_out(g.p3spec + (size_t)uid * g.p3stride, spec, SP, Ld, lane);
+          cls = 0;
+          if (Q >= 8 && !a.no_window) {
+            const unsigned *su = reinterpret_cast<const unsigned *>(spec);
+            const unsigned long long um = ((unsigned long long)su[kSpMH * SP] << 32) | su[kSpML * SP];
+            cls = place_window<Q>(um, m0);
+          }
+        }
+        if (lane == 0) {
+          u->pl = pl; u->e = e; u->ri = ri; u->Ld = Ld; u->xC = f3.xC; u->ef = f3.ef; u->m0 = m0;
+          pp->envsc[e] = envsc; pp->domcorr[e] = 0.f;
+          if (cls == 4) g.list256[atomicAdd(g.cnt + ST_N_256, 1)] = uid;
+          else if (cls == 8) g.list512[atomicAdd(g.cnt + ST_N_512, 1)] = uid;
+          else if (cls == 0) g.listfull[atomicAdd(g.cnt + ST_N_FULL, 1)] = uid;
+        }
+      }
+    }
+  }
+  ST_K1(4);
+  // the row stores of this kernel are read by other workgroups in the next launch: kernel boundary = release
+}
+
+// ================================================================================================ p4full: the full-width list
+template <int Q>
+__global__ __launch_bounds__(kStTH) void staged_p4full_kernel(StagedArgs g) {
+  const ScoreArgs &a = g.a;
+  extern __shared__ __attribute__((aligned(16))) float smem_raw[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int TBL = Q * kWave;
+  StLds<Q> S(smem_raw, a.K, BW_NARR, wave, a.wave_lds);
+  WaveCtx c = make_ctx(a, S.em, nullptr, S.tr, S.wbase, lane);
+  uint8_t *seq = ctx_seq(a, S.wbase);
+  ST_K0();
+  int cur_h = -1;
+  unsigned n_full = 0;
+  list_loop<Q>(g, S.slot, g.listfull, ST_N_FULL, ST_C_FULL, true, cur_h,
+    [&](int h) {
+      const DevHMM *hm = a.hmms + h;
+      copy_f4(S.em, a.tables + hm->em_off, a.K * TBL);
+      copy_f4(S.tr, a.tables + hm->bw_off, BW_NARR * TBL);
+      c.emG = (const glb_f *)(a.tables + hm->em_off);
+    },
+    [&](int uid, int h) {
+      const StUnit *u = g.units + uid;
+      const int pl = bcast_i(u->pl), e = bcast_i(u->e), ri = bcast_i(u->ri), Ld = bcast_i(u->Ld);
+      StPair *pp = g.pairs + pl;
+      const PairPos P = pair_pos(g, pl);
+      const int64_t off = a.offsets[P.qi];
+      const int L = (int)(a.offsets[P.qi + 1] - off);
+      load_seq(a, seq, off + (ri - 1), Ld, lane);
+      rows_in(S.wbase, g.p3spec + (size_t)uid * g.p3stride, a.SP, Ld, lane);
+      c.Fs = (glb_f *)(g.slabs + (size_t)uid * g.slab_stride);
+      const LenCfg cu = len_config(L, false);
+      const float xC = u->xC; const int ef = u->ef;
+      ST_T0();
+      const P4Out p4 = sweep_backward_null2<Q, kStTH, false>(c, (lds_u8 *)seq, Ld, cu, 1.0f / (xC * cu.move), ef, kMassTol7);
+      ST_T1(7);
+      n_full++;
+      const bool ok = fabsf((float)Ld - p4.mass) <= kMassTol7 * (float)Ld;
+      if (lane == 0) {
+        atomicOr(&pp->path, WH_PATH_P4_FULL);
+        if (ok) pp->domcorr[e] = p4.domcorr;
+        else g.listdense[atomicAdd(g.cnt + ST_N_DENSE, 1)] = uid;
+      }
+    });
+  if (a.paths && lane == 0 && n_full) atomicAdd(a.paths + 3, (unsigned long long)n_full);
+  ST_K1(7);
+}
+
+// ================================================================================================ dense: every row stored, full width
+template <int Q>
+__global__ __launch_bounds__(kStTH) void staged_dense_kernel(StagedArgs g) {
+  const ScoreArgs &a = g.a;
+  extern __shared__ __attribute__((aligned(16))) float smem_raw[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int TBL = Q * kWave;
+  StLds<Q> S(smem_raw, a.K, 2 * FW_NARR, wave, a.wave_lds);
+  WaveCtx c = make_ctx(a, S.em, S.tr, S.tr + FW_NARR * TBL, S.wbase, lane);
+  uint8_t *seq = ctx_seq(a, S.wbase);
+  const double LOG2 = 0.69314718055994529;
+  ST_K0();
+  int cur_h = -1;
+  unsigned n_full = 0;
+  list_loop<Q>(g, S.slot, g.listdense, ST_N_DENSE, ST_C_DENSE, true, cur_h,
+    [&](int h) {
+      const DevHMM *hm = a.hmms + h;
+      copy_f4(S.em, a.tables + hm->em_off, a.K * TBL);
+      copy_f4(S.tr, a.tables + hm->fw_off, FW_NARR * TBL);
+      copy_f4(S.tr + FW_NARR * TBL, a.tables + hm->bw_off, BW_NARR * TBL);
+      c.emG = (const glb_f *)(a.tables + hm->em_off);
+    },
+    [&](int uid, int h) {
+      const StUnit *u = g.units + uid;
+      const int pl = bcast_i(u->pl), e = bcast_i(u->e), ri = bcast_i(u->ri), Ld = bcast_i(u->Ld);
+      StPair *pp = g.pairs + pl;
+      const PairPos P = pair_pos(g, pl);
+      const int64_t off = a.offsets[P.qi];
+      const int L = (int)(a.offsets[P.qi + 1] - off);
+      load_seq(a, seq, off + (ri - 1), Ld, lane);
+      c.Fs = (glb_f *)(g.slabs + (size_t)uid * g.slab_stride);
+      const LenCfg cu = len_config(L, false);
+      const FwdOut f3 = sweep_forward<Q, true, kStTH, false>(c, (lds_u8 *)seq, Ld, cu, -1.0f);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      const float envsc = (float)((double)f3.ef * LOG2 + log((double)(f3.xC * cu.move)));
+      float domcorr = 0.f;
+      if (f3.xC > 0.f) {
+        const P4Out p4 = sweep_backward_null2<Q, kStTH, false>(c, (lds_u8 *)seq, Ld, cu, 1.0f / (f3.xC * cu.move), f3.ef, INFINITY);
+        n_full++;
+        domcorr = p4.domcorr;
+      }
+      if (lane == 0) {
+        pp->envsc[e] = envsc; pp->domcorr[e] = domcorr;
+        atomicOr(&pp->flags, WH_FLAG_EXACT);
+        atomicOr(&pp->path, WH_PATH_DENSE);
+      }
+    });
+  if (a.paths && lane == 0 && n_full) atomicAdd(a.paths + 3, (unsigned long long)n_full);
+}
+
+template <int Q, class K>
+static hipError_t launch_dense_kind(K kern, const StagedArgs &g, int blocks, int threads, size_t lds, hipStream_t s) {
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (err != hipSuccess) return err;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, s, g);
+  return hipGetLastError();
+}
+#endif   // dense part
+
+#if WH_ST_PART != 1
+// ================================================================================================ p2win: window sweep + certified scan
+// Light kernel: the workgroup stages the emission rows only; a wave gathers its window's reversed transition arrays from
+// L2 once per pair (BWG) and works on a COPY of P1's rows (INPL).
+constexpr int kLightTH = 768;
+template <int Q, int QB>
+__global__ __launch_bounds__(kLightTH) __attribute__((amdgpu_waves_per_eu(6, 6))) void staged_p2win_kernel(StagedArgs g) {
+  const ScoreArgs &a = g.a;
+  extern __shared__ __attribute__((aligned(16))) float smem_raw[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  constexpr int TBL = Q * kWave;
+  StLds<Q> S(smem_raw, a.K, 0, wave, g.wave_lds_light);
+  WaveCtx c = make_ctx(a, S.em, nullptr, nullptr, S.wbase, lane);
+  uint8_t *seq = ctx_seq(a, S.wbase);
+  int *regs = ctx_regs(a, S.wbase);
+  ST_K0();
+  int cur_h = -1;
+  const DevHMM *hm = nullptr;
+  unsigned n_p2w = 0, n_p2rej = 0;
+  for (;;) {
+    if (threadIdx.x == 0) *S.slot = atomicAdd(g.cnt + (QB == 8 ? ST_C_P2W8 : ST_C_P2), 1);
+    __syncthreads();
+    const int item = *S.slot;
+    __syncthreads();
+    if (item >= g.n_items_b) break;
+    const int gitem = g.item0 + item;
+    const int h = a.hmm_list[gitem / a.n_qblocks];
+    const int64_t q_lo = (int64_t)(gitem % a.n_qblocks) * a.QB;
+    const int64_t q_hi = q_lo + a.QB < a.nq ? q_lo + a.QB : a.nq;
+    if (h != cur_h) {
+      __syncthreads();
+      hm = a.hmms + h;
+      copy_f4(S.em, a.tables + hm->em_off, a.K * TBL);
+      cur_h = h;
+      __syncthreads();
+    }
+    c.emG = (const glb_f *)(a.tables + hm->em_off);
+    c.specg = (glb_f *)const_cast<float *>(a.tables + hm->bw_off);
+    for (int64_t qi = q_lo + wave; qi < q_hi; qi += nwaves) {
+      const int pl = item * a.QB + (int)(qi - q_lo);
+      StPair *pp = g.pairs + pl;
+      const int st = bcast_i(pp->state);
+      // the 256-node launch sees every pair after P1 (state 1) and sends what it cannot certify on: to the 512-node launch
+      // (state 4) or to the doubt list (state 3); the 512-node launch takes state 4
+      if (st != (QB == 4 ? 1 : 4)) continue;
+      const unsigned long long um = ((unsigned long long)(unsigned)bcast_i((int)pp->um_hi) << 32) | (unsigned)bcast_i((int)pp->um_lo);
+      int m0 = 0;
+      const int cls = (Q >= 8 && !a.no_window) ? place_window<Q>(um, m0) : 0;
+      bool have_ro = false;
+      if (cls == QB) {
+        const int64_t off = a.offsets[qi];
+        const int L = (int)(a.offsets[qi + 1] - off);
+        load_seq(a, seq, off, L, lane);
+        rows_in(S.wbase, g.p1spec + (size_t)pl * g.p1stride, a.SP, L, lane);
+        const LenCfg cm = len_config(L, true);
+        const float xC = pp->xC; const int ef = pp->ef;
+        ST_T0();
+        const WinDec wd = sweep_backward_decode_win<QB, Q, kLightTH, true, true>(c, (lds_u8 *)seq, L, cm, 1.0f / (xC * cm.move), ef, m0);
+        ST_T1((QB == 4 ? 1 : 2));
+        if (wd.eps > -1e-4f && wd.eps < 0.01f) {
+          RegOut ro = region_scan_cert<kLightTH, true>(c.spec, a.SP, L, (lds_i *)regs, lane, fmaxf(wd.eps, 0.f));
+          have_ro = ((ro.flags >> 24) & 3) == 0;
+          if (have_ro) {
+            ro.flags &= 0xFFFFFF;
+            __builtin_amdgcn_wave_barrier();
+            wh_pair_detail *dp = (a.detail && lane == 0) ? a.detail + ((size_t)qi * a.H + h) : nullptr;
+            store_regions(pp, ro, regs, lane, dp);
+            if (lane == 0) pp->path |= WH_PATH_P2_WIN;
+          }
+        }
+        if (have_ro) n_p2w++; else n_p2rej++;
+      } else if (QB == 4 && cls == 8) {
+        if (lane == 0) pp->state = 4;
+        continue;
+      } else if (um != 0) n_p2rej++;       // (a dominant alignment wider than any window: counted as the fused kernel counts it)
+      if (!have_ro && lane == 0) {
+        pp->state = 3;
+        g.doubt_list[atomicAdd(g.cnt + ST_N_DOUBT, 1)] = pl;
+      }
+    }
+  }
+  if (a.paths && lane == 0) {
+    if (n_p2w) atomicAdd(a.paths + 4, (unsigned long long)n_p2w);
+    if (n_p2rej) atomicAdd(a.paths + 5, (unsigned long long)n_p2rej);
+  }
+  ST_K1((QB == 4 ? 1 : 2));
+}
+
+// ================================================================================================ p4win: envelope Backward on a node window
+template <int Q, int QB>
+__global__ __launch_bounds__(kLightTH) __attribute__((amdgpu_waves_per_eu(5, 5))) void staged_p4win_kernel(StagedArgs g) {
+  const ScoreArgs &a = g.a;
+  extern __shared__ __attribute__((aligned(16))) float smem_raw[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  constexpr int TBL = Q * kWave;
+  StLds<Q> S(smem_raw, a.K, 0, wave, g.wave_lds_light);
+  WaveCtx c = make_ctx(a, S.em, nullptr, nullptr, S.wbase, lane);
+  uint8_t *seq = ctx_seq(a, S.wbase);
+  const int32_t *list = QB == 4 ? g.list256 : g.list512;
+  const int n = min(g.cnt[QB == 4 ? ST_N_256 : ST_N_512], g.NS);
+  ST_K0();
+  int cur_h = -1;
+  unsigned n_ok = 0, n_fail = 0;
+  for (;;) {
+    if (threadIdx.x == 0) *S.slot = atomicAdd(g.cnt + (QB == 4 ? ST_C_256 : ST_C_512), kStChunk);
+    __syncthreads();
+    const int c0 = *S.slot;
+    __syncthreads();
+    if (c0 >= n) break;
+    const int c1 = min(c0 + kStChunk, n);
+    int pos = c0;
+    while (pos < c1) {
+      auto model_at = [&](int idx) { return pair_pos(g, g.units[list[idx]].pl).h; };
+      const int h = model_at(pos);
+      int r = pos + 1;
+      while (r < c1 && model_at(r) == h) r++;
+      const DevHMM *hm = a.hmms + h;
+      if (h != cur_h) {
+        __syncthreads();
+        copy_f4(S.em, a.tables + hm->em_off, a.K * TBL);
+        cur_h = h;
+        __syncthreads();
+      }
+      c.emG = (const glb_f *)(a.tables + hm->em_off);
+      c.specg = (glb_f *)const_cast<float *>(a.tables + hm->bw_off);
+      for (int idx = pos + wave; idx < r; idx += nwaves) {
+        const int uid = list[idx];
+        const StUnit *u = g.units + uid;
+        const int pl = bcast_i(u->pl), e = bcast_i(u->e), ri = bcast_i(u->ri), Ld = bcast_i(u->Ld), m0 = bcast_i(u->m0);
+        StPair *pp = g.pairs + pl;
+        const PairPos P = pair_pos(g, pl);
+        const int64_t off = a.offsets[P.qi];
+        const int L = (int)(a.offsets[P.qi + 1] - off);
+        load_seq(a, seq, off + (ri - 1), Ld, lane);
+        rows_in(S.wbase, g.p3spec + (size_t)uid * g.p3stride, a.SP, Ld, lane);
+        c.Fs = (glb_f *)(g.slabs + (size_t)uid * g.slab_stride);
+        const LenCfg cu = len_config(L, false);
+        const float xC = u->xC;
+        ST_T0();
+        const P4Out p4 = sweep_backward_null2_win<QB, Q, kLightTH, false, true>(c, (lds_u8 *)seq, Ld, cu, 1.0f / (xC * cu.move), kWinTol7, m0);
+        ST_T1((QB == 4 ? 5 : 6));
+        const bool ok = fabsf((float)Ld - p4.mass) <= kWinTol7 * (float)Ld;
+        if (ok) n_ok++; else n_fail++;
+        if (lane == 0) {
+          if (ok) { pp->domcorr[e] = p4.domcorr; atomicOr(&pp->path, QB == 4 ? WH_PATH_P4_W256 : WH_PATH_P4_W512); }
+          else { atomicOr(&pp->path, WH_PATH_P4_WFAIL); g.listfull[atomicAdd(g.cnt + ST_N_FULL, 1)] = uid; }
+        }
+      }
+      pos = r;
+    }
+  }
+  if (a.paths && lane == 0) {
+    if (n_ok) atomicAdd(a.paths + (QB == 4 ? 0 : 1), (unsigned long long)n_ok);
+    if (n_fail) atomicAdd(a.paths + 2, (unsigned long long)n_fail);
+  }
+  ST_K1((QB == 4 ? 5 : 6));
+}
+
+// ================================================================================================ assemble: A.6, one thread per pair
+__global__ __launch_bounds__(256) void staged_assemble_kernel(StagedArgs g) {
+  const ScoreArgs &a = g.a;
+  const int pl = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pl >= g.NB) return;
+  const int gitem = g.item0 + pl / a.QB;
+  if (pl / a.QB >= g.n_items_b) return;
+  const int h = a.hmm_list[gitem / a.n_qblocks];
+  const int64_t qi = (int64_t)(gitem % a.n_qblocks) * a.QB + pl % a.QB;
+  if (qi >= a.nq) return;
+  StPair *pp = g.pairs + pl;
+  if (pp->state == 0) return;                       // P1 wrote the result
+  const size_t out = (size_t)qi * a.H + h;
+  const int L = (int)(a.offsets[qi + 1] - a.offsets[qi]);
+  const double LOG2 = 0.69314718055994529;
+  const LenCfg cm = len_config(L, true);
+  const double fwd_nats = (double)pp->ef * LOG2 + log((double)(pp->xC * cm.move));
+  const float fwdsc = (float)fwd_nats;
+  const float p1 = (float)L / (float)(L + 1);
+  const float nullsc = (float)((double)(float)L * log((double)p1) + log(1.0 - (double)p1));
+  const float fwd_bits_out = (float)((fwd_nats - (double)nullsc) / LOG2);
+  int flags = pp->flags & 0xFF, decibits = 0;
+  const int nenv = pp->nenv, nreg = pp->nreg, multi_mask = (pp->flags >> 8) & 0xFFFF;
+  wh_pair_detail *dp = a.detail ? a.detail + out : nullptr;
+  int path = pp->path;
+  if (nenv > 0) {
+    const bool queue_pair = multi_mask != 0 && a.rrecs != nullptr;
+    float seqbias_sum = 0.f, sum_score = 0.f, sb2 = 0.f;
+    int Ld_tot = 0;
+    for (int e = 0; e < nenv; e++) {
+      if (queue_pair && ((multi_mask >> e) & 1)) continue;
+      const int ri = pp->regs[2 * e], rj = pp->regs[2 * e + 1];
+      const int Ld = rj - ri + 1;
+      const float envsc = pp->envsc[e], domcorr = pp->domcorr[e];
+      seqbias_sum += domcorr;
+      if (envsc - domcorr > 0.0f) { sum_score += envsc; Ld_tot += Ld; sb2 += domcorr; }
+      if (dp) { dp->env_i[e] = ri; dp->env_j[e] = rj; dp->envsc[e] = envsc; dp->domcorr[e] = domcorr; }
+    }
+    if (queue_pair) {
+      path |= WH_PATH_MULTI;
+      const int slot = atomicAdd(a.rcount, 1);
+      if (slot < a.rcap) {
+        ResolveRec *rr = a.rrecs + slot;
+        rr->q = qi; rr->h = h; rr->fwdsc = fwdsc; rr->fwd_bits = fwd_bits_out; rr->nreg = nreg; rr->nenv = nenv;
+        rr->multi_mask = multi_mask; rr->flags = flags;
+        for (int e = 0; e < nenv; e++) {
+          const bool md = (multi_mask >> e) & 1;
+          rr->ri[e] = pp->regs[2 * e]; rr->rj[e] = pp->regs[2 * e + 1];
+          rr->envsc[e] = md ? 0.f : pp->envsc[e]; rr->domcorr[e] = md ? 0.f : pp->domcorr[e];
+        }
+      }
+    } else {
+      const float lomega = (float)log(1.0 / 256.0);
+      const float seqbias = flogsum0_v7(lomega + seqbias_sum);
+      float pre_score = (float)(((double)fwdsc - (double)nullsc) / LOG2);
+      float seq_score = (float)(((double)fwdsc - (double)(nullsc + seqbias)) / LOG2);
+      sb2 = flogsum0_v7(lomega + sb2);
+      sum_score += (float)((double)(L - Ld_tot) * log((double)((float)L / (float)(L + 3))));
+      const float pre2 = (float)(((double)sum_score - (double)nullsc) / LOG2);
+      sum_score = (float)(((double)sum_score - (double)(nullsc + sb2)) / LOG2);
+      if (Ld_tot > 0 && sum_score > seq_score) { seq_score = sum_score; pre_score = pre2; flags |= WH_FLAG_OVERRIDE; }
+      decibits = (int)rint((double)seq_score * 10.0);
+      flags |= WH_FLAG_REPORTED;
+      if (dp) { dp->seq_score = seq_score; dp->pre_score = pre_score; dp->seqbias_nats = seqbias; }
+    }
+  }
+  a.decibits[out] = decibits;
+  a.flags[out] = (uint8_t)flags;
+  if (g.pair_paths) g.pair_paths[out] = (uint8_t)path;
+}
+
+template <class K>
+static hipError_t launch_light_kind(K kern, const StagedArgs &g, int blocks, int threads, size_t lds, hipStream_t s) {
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (err != hipSuccess) return err;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, s, g);
+  return hipGetLastError();
+}
+#endif   // light part
+
+}  // namespace WH_K7NS
+
+#define WH_ST_Q_CASES(CALL) \
+  switch (Q) {              \
+    case 8:  CALL(8);       \
+    case 12: CALL(12);      \
+    case 16: CALL(16);      \
+    case 20: CALL(20);      \
+    case 24: CALL(24);      \
+    default: return hipErrorInvalidValue; \
+  }
+
+#if WH_ST_PART != 2
+hipError_t launch_staged_p1(int Q, const StagedArgs &g, int blocks, int threads, size_t lds, hipStream_t s) {
+  using namespace WH_K7NS;
+  if (g.a.spec_arrays != kSpArr || threads > kStTH) return hipErrorInvalidValue;
+#define WH_CALL(q) return launch_dense_kind<q>(&staged_p1_kernel<q>, g, blocks, threads, lds, s)
+  WH_ST_Q_CASES(WH_CALL)
+#undef WH_CALL
+}
+hipError_t launch_staged_p2full(int Q, const StagedArgs &g, int blocks, int threads, size_t lds, hipStream_t s) {
+  using namespace WH_K7NS;
+  if (g.a.spec_arrays != kSpArr || threads > kStTH) return hipErrorInvalidValue;
+#define WH_CALL(q) return launch_dense_kind<q>(&staged_p2full_kernel<q>, g, blocks, threads, lds, s)
+  WH_ST_Q_CASES(WH_CALL)
+#undef WH_CALL
+}
+hipError_t launch_staged_p3(int Q, const StagedArgs &g, int blocks, int threads, size_t lds, hipStream_t s) {
+  using namespace WH_K7NS;
+  if (g.a.spec_arrays != kSpArr || threads > kStTH) return hipErrorInvalidValue;
+#define WH_CALL(q) return launch_dense_kind<q>(&staged_p3_kernel<q>, g, blocks, threads, lds, s)
+  WH_ST_Q_CASES(WH_CALL)
+#undef WH_CALL
+}
+hipError_t launch_staged_p4full(int Q, const StagedArgs &g, int blocks, int threads, size_t lds, hipStream_t s) {
+  using namespace WH_K7NS;
+  if (g.a.spec_arrays != kSpArr || threads > kStTH) return hipErrorInvalidValue;
+#define WH_CALL(q) return launch_dense_kind<q>(&staged_p4full_kernel<q>, g, blocks, threads, lds, s)
+  WH_ST_Q_CASES(WH_CALL)
+#undef WH_CALL
+}
+hipError_t launch_staged_dense(int Q, const StagedArgs &g, int blocks, int threads, size_t lds, hipStream_t s) {
+  using namespace WH_K7NS;
+  if (g.a.spec_arrays != kSpArr || threads > kStTH) return hipErrorInvalidValue;
+#define WH_CALL(q) return launch_dense_kind<q>(&staged_dense_kernel<q>, g, blocks, threads, lds, s)
+  WH_ST_Q_CASES(WH_CALL)
+#undef WH_CALL
+}
+#endif
+
+#if WH_ST_PART != 1
+hipError_t launch_staged_p2win(int Q, int QB, const StagedArgs &g, int blocks, int threads, size_t lds, hipStream_t s) {
+  using namespace WH_K7NS;
+  if (g.a.spec_arrays != kSpArr || threads > kLightTH) return hipErrorInvalidValue;
+  if (QB == 4) {
+#define WH_CALL(q) return launch_light_kind(&staged_p2win_kernel<q, 4>, g, blocks, threads, lds, s)
+    WH_ST_Q_CASES(WH_CALL)
+#undef WH_CALL
+  }
+  if (QB == 8) {
+    if (Q == 16) return launch_light_kind(&staged_p2win_kernel<16, 8>, g, blocks, threads, lds, s);
+    if (Q == 24) return launch_light_kind(&staged_p2win_kernel<24, 8>, g, blocks, threads, lds, s);
+  }
+  return hipErrorInvalidValue;
+}
+hipError_t launch_staged_p4win(int Q, int QB, const StagedArgs &g, int blocks, int threads, size_t lds, hipStream_t s) {
+  using namespace WH_K7NS;
+  if (g.a.spec_arrays != kSpArr || threads > kLightTH) return hipErrorInvalidValue;
+  if (QB == 4) {
+#define WH_CALL(q) return launch_light_kind(&staged_p4win_kernel<q, 4>, g, blocks, threads, lds, s)
+    WH_ST_Q_CASES(WH_CALL)
+#undef WH_CALL
+  }
+  if (QB == 8) {
+    if (Q == 16) return launch_light_kind(&staged_p4win_kernel<16, 8>, g, blocks, threads, lds, s);
+    if (Q == 24) return launch_light_kind(&staged_p4win_kernel<24, 8>, g, blocks, threads, lds, s);
+  }
+  return hipErrorInvalidValue;
+}
+hipError_t launch_staged_assemble(const StagedArgs &g, hipStream_t s) {
+  using namespace WH_K7NS;
+  const int blocks = (g.NB + 255) / 256;
+  hipLaunchKernelGGL(staged_assemble_kernel, dim3(blocks), dim3(256), 0, s, g);
+  return hipGetLastError();
+}
+#endif
+
+}  // namespace wh

@@ -118,6 +118,12 @@ class EHMM:
         return {"window256": int(p6[0]), "window512": int(p6[1]), "window_rejected": int(p6[2]), "full_width": int(p6[3]),
                 "p2_window": int(p6[4]), "p2_window_in_doubt": int(p6[5])}
 
+    def set_path_buffer(self, paths_t):
+        """Registers a CUDA uint8 tensor of nq x H bytes that later score calls fill with WH_PATH_* bits per pair
+        (staged launches only; None switches it off).  The caller keeps the tensor alive (include/witch_hip.h)."""
+        check(lib().wh_set_path_buffer(self._h, paths_t.data_ptr() if paths_t is not None else None), "wh_set_path_buffer")
+        self._path_t = paths_t
+
     def last_queue_reruns(self) -> int:
         """Scoring passes the last score call repeated because the resolver's queue overflowed its estimate (0 or 1)."""
         n = lib().wh_last_queue_reruns(self._h)

@@ -102,7 +102,7 @@ struct wh_ehmm {
   int64_t rq_floor = 0;                     // ... at least this many (set when a call overflowed its estimate; the call then runs again)
   int last_queue_reruns = 0;                // scoring passes the last wh_score call repeated because its queue overflowed (0 or 1)
   // staged launches (wh_staged.hip): per-batch state in HBM
-  DevBuf d_st_pairs, d_st_p1spec, d_st_units, d_st_p3spec, d_st_slabs, d_st_lists, d_st_cnt;
+  DevBuf d_st_pairs, d_st_p1spec, d_st_units, d_st_p3spec, d_st_slabs, d_st_cnt;
   double st_upp = 1.25;                     // envelope units per pair the next call's batches are sized for (learned: 1.25 x the largest seen)
   bool st_off = false;                      // a batch of the current call ran out of units: the call is repeated with the fused kernel
   int last_staged_batches = 0;              // batches the staged launches of the last scoring call went through
@@ -179,7 +179,7 @@ void wh_ehmm_free(wh_ehmm *e) {
                     &e->s_nk, &e->s_nu, &e->s_pq, &e->s_ph, &e->s_co, &e->s_cols, &e->s_pos, &e->d_rkeys, &e->d_rorder, &e->d_rchunks, &e->d_qorder, &e->d_order, &e->d_items, &e->d_recs, &e->d_spec, &e->d_back, &e->d_cwj, &e->d_cwv, &e->d_cwn, &e->d_crow,
                     &e->c_buf[0], &e->c_buf[1], &e->c_buf[2], &e->c_buf[3], &e->c_buf[4], &e->c_buf[5], &e->c_buf[6],
                     &e->c_buf[7], &e->c_buf[8], &e->c_buf[9],
-                    &e->d_st_pairs, &e->d_st_p1spec, &e->d_st_units, &e->d_st_p3spec, &e->d_st_slabs, &e->d_st_lists, &e->d_st_cnt})
+                    &e->d_st_pairs, &e->d_st_p1spec, &e->d_st_units, &e->d_st_p3spec, &e->d_st_slabs, &e->d_st_cnt})
     b->release();
   for (hipEvent_t ev : e->cls_ev) (void)hipEventDestroy(ev);
   for (auto &t : e->timers) {
@@ -526,21 +526,24 @@ static int score_staged_class(wh_ehmm *e, ScoreArgs a, int Q, int Lc, hipStream_
   const int sp = (Lc + 1 + 3) / 4 * 4;
   const int wl = kScoreSpecArrays * sp + 32 + kRegsInts + (Lc + 3) / 4 + 4;           // floats per wave block (plan_block1's, no extra rows)
   const size_t tbl = (size_t)Q * kWave * sizeof(float);
-  auto lds_of = [&](int arrays, int waves) { return kLdsHeader + (size_t)arrays * tbl + (size_t)waves * wl * sizeof(float); };
+  auto lds_of = [&](int arrays, int waves, int cand) { return kLdsHeader + (size_t)arrays * tbl + (size_t)waves * wl * sizeof(float) + (size_t)cand * sizeof(int); };
+  // work items of QB queries; a workgroup draws G of them at a time and deals their candidates to its waves one by one
+  const int QB = 48;
+  const int G_all = 1, G_most = 4, G_few = 8, G_rare = 32;        // kernels that serve every pair / most / a few per cent / next to none
+  auto cap_of = [&](int G, int per_pair) { return std::min(G * QB * per_pair, 2048); };
   // dense kernels: twelve waves beside one orientation (+ the emission rows); the rare dense redo needs both
   int w_one = 12, w_both = 12;
-  while (w_one >= 1 && lds_of(e->K + FW_NARR, w_one) > kLdsBudget) w_one--;
-  while (w_both >= 1 && lds_of(e->K + 2 * FW_NARR, w_both) > kLdsBudget) w_both--;
+  while (w_one >= 1 && lds_of(e->K + FW_NARR, w_one, cap_of(G_few, WH_MAX_ENVELOPES)) > kLdsBudget) w_one--;
+  while (w_both >= 1 && lds_of(e->K + 2 * FW_NARR, w_both, cap_of(G_rare, WH_MAX_ENVELOPES)) > kLdsBudget) w_both--;
   // light kernels: two workgroups per CU, the emission rows only
   int w_p2 = 12, w_p4 = 10;
-  while (w_p2 >= 1 && 2 * lds_of(e->K, w_p2) > kLdsBudget) w_p2--;
-  while (w_p4 >= 1 && 2 * lds_of(e->K, w_p4) > kLdsBudget) w_p4--;
+  while (w_p2 >= 1 && 2 * lds_of(e->K, w_p2, cap_of(G_most, 1)) > kLdsBudget) w_p2--;
+  while (w_p4 >= 1 && 2 * lds_of(e->K, w_p4, cap_of(G_most, WH_MAX_ENVELOPES)) > kLdsBudget) w_p4--;
   if (w_one < 4 || w_both < 1 || w_p2 < 4 || w_p4 < 4) { set_error("staged launches: query length %d with model class Q=%d does not fit in LDS", Lc, Q); return WH_ERANGE; }
   a.SP = sp; a.wave_lds = wl; a.spec_arrays = kScoreSpecArrays;
   a.paths = reinterpret_cast<unsigned long long *>((int *)e->d_counter.p + kScorePathSlot);
   a.p2win = 0; a.qorder = nullptr;
-  a.QB = w_one * 4;
-  if ((int64_t)a.n_list * ((a.nq + a.QB - 1) / a.QB) < 4 * (int64_t)e->cu_count) a.QB = w_one;
+  a.QB = QB;
   a.n_qblocks = (int)((a.nq + a.QB - 1) / a.QB);
   a.n_items = a.n_list * a.n_qblocks;
   StagedArgs g;
@@ -548,7 +551,7 @@ static int score_staged_class(wh_ehmm *e, ScoreArgs a, int Q, int Lc, hipStream_
   g.slab_stride = (size_t)(Lc + 1) * 2 * Q * kWave;
   g.p1stride = (size_t)kScoreSpecArrays * sp;
   g.p3stride = g.p1stride;
-  // ---- batch size: units (Forward slabs) from the free HBM, at most sixteen per resident dense wave; pairs = units / (units per pair)
+  // ---- batch size: units (Forward slabs) from the free HBM, at most <mult> per resident dense wave; pairs = units / (units per pair)
   const int resident = e->cu_count * w_one;
   int64_t NS = (int64_t)resident * 16;
   {
@@ -565,25 +568,28 @@ static int score_staged_class(wh_ehmm *e, ScoreArgs a, int Q, int Lc, hipStream_
   if (NS < 64) { set_error("staged launches: no HBM for the Forward slabs (Q=%d, L=%d)", Q, Lc); return WH_ENOMEM; }
   int items_b = (int)std::max<int64_t>(1, (int64_t)((double)NS / e->st_upp) / a.QB);
   items_b = std::min(items_b, a.n_items);
+  // (batches of equal size, each a multiple of the workgroup count where the class is large enough for that)
+  {
+    const int nb = (a.n_items + items_b - 1) / items_b;
+    items_b = (a.n_items + nb - 1) / nb;
+    if (items_b > 2 * e->cu_count) items_b = std::min((items_b + e->cu_count - 1) / e->cu_count * e->cu_count, (int)std::max<int64_t>(1, (int64_t)((double)NS / e->st_upp) / a.QB));
+  }
   const int NB = items_b * a.QB;
   const int n_batches = (a.n_items + items_b - 1) / items_b;
   if (e->d_st_pairs.ensure(sizeof(StPair) * (size_t)NB) || e->d_st_p1spec.ensure(sizeof(float) * g.p1stride * (size_t)NB) ||
       e->d_st_units.ensure(sizeof(StUnit) * (size_t)NS) || e->d_st_p3spec.ensure(sizeof(float) * g.p3stride * (size_t)NS) ||
-      e->d_st_slabs.ensure(sizeof(float) * g.slab_stride * (size_t)NS) || e->d_st_lists.ensure(sizeof(int32_t) * ((size_t)NB + 4 * (size_t)NS)) ||
+      e->d_st_slabs.ensure(sizeof(float) * g.slab_stride * (size_t)NS) ||
       e->d_st_cnt.ensure(sizeof(int) * 32 * (size_t)(e->last_staged_batches + n_batches)))
     return WH_ENOMEM;
   g.NB = NB; g.NS = (int)NS;
   g.pairs = (StPair *)e->d_st_pairs.p; g.p1spec = (float *)e->d_st_p1spec.p;
   g.units = (StUnit *)e->d_st_units.p; g.p3spec = (float *)e->d_st_p3spec.p; g.slabs = (float *)e->d_st_slabs.p;
-  g.doubt_list = (int32_t *)e->d_st_lists.p;
-  g.list256 = g.doubt_list + NB; g.list512 = g.list256 + NS; g.listfull = g.list512 + NS; g.listdense = g.listfull + NS;
-  g.wave_lds_light = wl;
   g.pair_paths = e->path_buf;
   int *cnt0 = (int *)e->d_st_cnt.p + 32 * (size_t)e->last_staged_batches;
   HIPCHK(hipMemsetAsync(cnt0, 0, sizeof(int) * 32 * (size_t)n_batches, s));
   const bool w512 = Q == 16 || Q == 24;
-  if (kn.trace) fprintf(stderr, "[wh] staged Q=%d: %d items of %d queries in %d batches of %d pairs, %lld units (%.1f GB of slabs), waves dense %d / both %d / p2win %d / p4win %d, lds dense %zu light %zu\n",
-                        Q, a.n_items, a.QB, n_batches, NB, (long long)NS, (double)NS * g.slab_stride * 4e-9, w_one, w_both, w_p2, w_p4, lds_of(e->K + FW_NARR, w_one), lds_of(e->K, w_p2));
+  if (kn.trace) fprintf(stderr, "[wh] staged Q=%d: %d items of %d queries in %d batches of %d pairs, %lld units (%.1f GB of slabs), waves dense %d / both %d / p2win %d / p4win %d\n",
+                        Q, a.n_items, a.QB, n_batches, NB, (long long)NS, (double)NS * g.slab_stride * 4e-9, w_one, w_both, w_p2, w_p4);
   if (class_mark(e, s, Q, 4)) return WH_EHIP;
   if (kn.stats) {
     if (e->d_recs.ensure(512)) return WH_ENOMEM;
@@ -596,16 +602,18 @@ static int score_staged_class(wh_ehmm *e, ScoreArgs a, int Q, int Lc, hipStream_
     g.item0 = b * items_b;
     g.n_items_b = std::min(items_b, a.n_items - g.item0);
     g.cnt = cnt0 + 32 * (size_t)b;
-    const int wg = std::min(g.n_items_b, cu);
-    hipError_t err = launch_staged_p1(Q, g, wg, w_one * kWave, lds_of(e->K + FW_NARR, w_one), s);
-    if (err == hipSuccess) err = launch_staged_p2win(Q, 4, g, std::min(g.n_items_b, 2 * cu), w_p2 * kWave, lds_of(e->K, w_p2), s);
-    if (err == hipSuccess && w512) err = launch_staged_p2win(Q, 8, g, std::min(g.n_items_b, 2 * cu), w_p2 * kWave, lds_of(e->K, w_p2), s);
-    if (err == hipSuccess) err = launch_staged_p2full(Q, g, wg, w_one * kWave, lds_of(e->K + BW_NARR, w_one), s);
-    if (err == hipSuccess) err = launch_staged_p3(Q, g, wg, w_one * kWave, lds_of(e->K + FW_NARR, w_one), s);
-    if (err == hipSuccess) err = launch_staged_p4win(Q, 4, g, 2 * cu, w_p4 * kWave, lds_of(e->K, w_p4), s);
-    if (err == hipSuccess && w512) err = launch_staged_p4win(Q, 8, g, 2 * cu, w_p4 * kWave, lds_of(e->K, w_p4), s);
-    if (err == hipSuccess) err = launch_staged_p4full(Q, g, cu, w_one * kWave, lds_of(e->K + BW_NARR, w_one), s);
-    if (err == hipSuccess) err = launch_staged_dense(Q, g, cu, w_both * kWave, lds_of(e->K + 2 * FW_NARR, w_both), s);
+    auto groups = [&](int G) { return (g.n_items_b + G - 1) / G; };
+    hipError_t err = hipSuccess;
+    auto go = [&](int G, int per_pair) { g.G = G; g.cand_cap = cap_of(G, per_pair); return err == hipSuccess; };
+    if (go(G_all, 1)) err = launch_staged_p1(Q, g, std::min(groups(g.G), cu), w_one * kWave, lds_of(e->K + FW_NARR, w_one, g.cand_cap), s);
+    if (go(G_most, 1)) err = launch_staged_p2win(Q, 4, g, std::min(groups(g.G), 2 * cu), w_p2 * kWave, lds_of(e->K, w_p2, g.cand_cap), s);
+    if (w512 && go(G_few, 1)) err = launch_staged_p2win(Q, 8, g, std::min(groups(g.G), 2 * cu), w_p2 * kWave, lds_of(e->K, w_p2, g.cand_cap), s);
+    if (go(G_few, 1)) err = launch_staged_p2full(Q, g, std::min(groups(g.G), cu), w_one * kWave, lds_of(e->K + BW_NARR, w_one, g.cand_cap), s);
+    if (go(G_all, WH_MAX_ENVELOPES)) err = launch_staged_p3(Q, g, std::min(groups(g.G), cu), w_one * kWave, lds_of(e->K + FW_NARR, w_one, g.cand_cap), s);
+    if (go(G_most, WH_MAX_ENVELOPES)) err = launch_staged_p4win(Q, 4, g, std::min(groups(g.G), 2 * cu), w_p4 * kWave, lds_of(e->K, w_p4, g.cand_cap), s);
+    if (w512 && go(G_few, WH_MAX_ENVELOPES)) err = launch_staged_p4win(Q, 8, g, std::min(groups(g.G), 2 * cu), w_p4 * kWave, lds_of(e->K, w_p4, g.cand_cap), s);
+    if (go(G_few, WH_MAX_ENVELOPES)) err = launch_staged_p4full(Q, g, std::min(groups(g.G), cu), w_one * kWave, lds_of(e->K + BW_NARR, w_one, g.cand_cap), s);
+    if (go(G_rare, WH_MAX_ENVELOPES)) err = launch_staged_dense(Q, g, std::min(groups(g.G), cu), w_both * kWave, lds_of(e->K + 2 * FW_NARR, w_both, g.cand_cap), s);
     if (err == hipSuccess) err = launch_staged_assemble(g, s);
     if (err != hipSuccess) { set_error("staged launch (Q=%d, batch %d) failed: %s", Q, b, hipGetErrorString(err)); return WH_EHIP; }
   }

@@ -64,43 +64,44 @@ struct ScoreArgs {
 
 // ---- staged scoring launches (wh_staged.hip): the five sweeps of a pair as kernels of their own, each at the
 // occupancy it can use, over batches of pairs whose intermediate results live in HBM.
+enum { ST_CLS_NONE = 0, ST_CLS_FULL = 1, ST_CLS_DENSE = 2, ST_CLS_W256 = 4, ST_CLS_W512 = 8 };   // what an envelope still needs
 // Per pair of a batch:
 struct StPair {
   float xC; int32_t ef;              // P1: C(L) and its scale exponent (the multihit Forward score)
   uint32_t um_lo, um_hi;             // P1: lane blocks the dominant alignment runs through (places the window of P2)
   int32_t state;                     // 0 nothing to do (empty / too long / no Forward mass: result written by P1), 1 P1 done,
-                                     // 2 regions known, 3 the windowed region scan was in doubt (full-width P2 follows)
+                                     // 2 regions known, 3 the windowed region scan was in doubt (full-width P2 follows),
+                                     // 4 the window of P2 needs 512 nodes
   int32_t nenv, nreg, flags;         // regions: flags = WH_FLAG_* | multidomain mask << 8
-  int32_t units_left;                // envelope units still in flight (assembly runs when every unit of the batch is done)
-  int32_t path;                      // WH_PATH_* bits of the pair (wh_last_pair_paths)
-  int32_t pad[2];
+  int32_t path;                      // WH_PATH_* bits of the pair (wh_set_path_buffer)
+  int32_t pad[3];
   int32_t regs[2 * WH_MAX_ENVELOPES];
   float envsc[WH_MAX_ENVELOPES], domcorr[WH_MAX_ENVELOPES];
+  int32_t uid[WH_MAX_ENVELOPES];     // per envelope: its unit (Forward slab) in the batch
+  uint8_t cls[WH_MAX_ENVELOPES];     // per envelope: ST_CLS_* - the Backward sweep it still needs
 };
-// Per envelope of a batch (one Forward slab each):
+// Per envelope unit of a batch (one Forward slab each):
 struct StUnit {
-  int32_t pl, e;                     // pair of the batch, envelope number
-  int32_t ri, Ld;                    // first row (1-based) and length of the envelope
   float xC; int32_t ef;              // P3: unihit Forward of the envelope
   int32_t m0, pad;                   // first reversed node of the window P4 runs on
 };
-enum { ST_C_P1 = 0, ST_C_P2, ST_C_P2W8, ST_C_P2B, ST_N_DOUBT, ST_C_P3, ST_N_UNITS, ST_N_256, ST_N_512, ST_N_FULL, ST_C_256, ST_C_512,
-       ST_C_FULL, ST_N_DENSE, ST_C_DENSE, ST_C_ASM, ST_OVERFLOW, ST_NCOUNT };
+enum { ST_C_P1 = 0, ST_C_P2, ST_C_P2W8, ST_C_P2B, ST_C_P3, ST_N_UNITS, ST_C_256, ST_C_512, ST_C_FULL, ST_C_DENSE, ST_OVERFLOW, ST_NCOUNT };
 struct StagedArgs {
   ScoreArgs a;                       // the class launch (tables, queries, outputs, items) as the fused kernel gets it
   int item0, n_items_b;              // this batch: work items [item0, item0 + n_items_b) of the class launch
   int NB;                            // pairs per batch = n_items_b * QB (per-pair arrays are indexed inside the batch)
   int NS;                            // envelope units (Forward slabs) a batch may use
+  int G;                             // work items a workgroup draws at a time in THIS launch
+  int cand_cap;                      // entries of the workgroup's candidate list in LDS (behind the wave blocks)
   StPair *pairs;
   float *p1spec; size_t p1stride;    // per pair: P1's six per-row arrays (floats per pair)
   StUnit *units;
   float *p3spec; size_t p3stride;    // per unit: P3's six per-row arrays
   float *slabs; size_t slab_stride;  // per unit: Forward rows (floats per unit)
-  int32_t *doubt_list, *list256, *list512, *listfull, *listdense;
   int *cnt;                          // ST_NCOUNT counters of the batch (zeroed before its first launch)
-  int wave_lds_light;                // floats of LDS per wave in the light kernels
   uint8_t *pair_paths;               // optional [nq x H]: WH_PATH_* bits per pair (or NULL)
 };
+// <threads> = 64 x waves; <lds> covers the header, the tables of the kind, the wave blocks and the candidate list
 hipError_t launch_staged_p1(int Q, const StagedArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
 hipError_t launch_staged_p2win(int Q, int QB, const StagedArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
 hipError_t launch_staged_p2full(int Q, const StagedArgs &a, int blocks, int threads, size_t lds, hipStream_t s);

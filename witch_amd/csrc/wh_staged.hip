@@ -9,11 +9,12 @@
 // kind of sweep runs at the occupancy it can use:
 //   p1      dense   12 waves/CU   tables: forward orientation + emission rows     -> per pair: six per-row arrays + C(L) in HBM
 //   p2win   light   24 waves/CU   tables: emission rows (reversed arrays gathered from L2 once per pair)
-//                                 window sweep + certified region scan             -> regions, or the pair joins the doubt list
-//   p2full  dense   12 waves/CU   tables: reversed orientation + emission rows; the doubt list at full width
+//                                 window sweep + certified region scan             -> regions, or the pair is marked "in doubt"
+//   p2full  dense   12 waves/CU   tables: reversed orientation + emission rows; the pairs in doubt at full width
 //   p3      dense   12 waves/CU   one unit per envelope: Forward rows to the unit's slab, per-row arrays to HBM
-//   p4win   light   20-24 waves   the 256-node (512-node) list; a window that fails the mass certificate joins the full list
-//   p4full  dense   12 waves/CU   the full-width list; a sweep that fails the spill certificate joins the dense list
+//   p4win   light   20-24 waves   envelopes of the 256-node (512-node) class; a window that fails the mass certificate
+//                                 moves its envelope to the full-width class
+//   p4full  dense   12 waves/CU   the full-width class; a sweep that fails the spill certificate moves its envelope on
 //   dense   dense                 P3 with every row stored + P4 at full width (rare)
 //   assemble        one thread per pair: HMMER's float32 score assembly, or the pair's record for the multidomain resolver
 // Every sweep IS the fused kernel's device function (this file compiles wh_score7.hip's sweeps into its own namespace;
@@ -49,9 +50,9 @@ namespace WH_K7NS {
 #define ST_K0() const long long st_k0 = a.stats ? (long long)__builtin_readcyclecounter() : 0
 #define ST_K1(kind) do { if (a.stats && lane == 0) atomicAdd(a.stats + 4 * (kind) + 2, (unsigned long long)((long long)__builtin_readcyclecounter() - st_k0)); } while (0)
 constexpr int kStTH = 768;            // dense kernels: twelve waves, 168 registers
-constexpr int kStChunk = 48;          // list entries a workgroup draws at a time
+constexpr int kLightTH = 768;         // light kernels: two workgroups of up to twelve waves per CU
 
-// pair -> (work item, query, model) inside a batch
+// pair of a batch -> query and model
 struct PairPos { int h; int64_t qi; };
 __device__ __forceinline__ PairPos pair_pos(const StagedArgs &g, int pl) {
   const ScoreArgs &a = g.a;
@@ -62,16 +63,19 @@ __device__ __forceinline__ PairPos pair_pos(const StagedArgs &g, int pl) {
   return p;
 }
 
-// what a workgroup keeps in LDS: [16-byte header][emission rows K x TBL][NT transition arrays x TBL][per-wave blocks]
+// what a workgroup keeps in LDS: [16-byte header][emission rows K x TBL][NT transition arrays x TBL][per-wave blocks][candidates]
 template <int Q>
 struct StLds {
   float *em, *tr, *wbase;
-  volatile int *slot;
-  __device__ __forceinline__ StLds(float *raw, int K, int ntr, int wave, int wave_lds) {
+  volatile int *slot;                 // [0] the group drawn, [1] candidates of the segment, [2] next candidate to hand out
+  int *cand;
+  __device__ __forceinline__ StLds(float *raw, int K, int ntr, int wave, int nwaves, int wave_lds) {
     slot = reinterpret_cast<volatile int *>(raw);
     em = raw + 4;
     tr = em + (size_t)K * Q * kWave;
-    wbase = tr + (size_t)ntr * Q * kWave + (size_t)wave * wave_lds;
+    float *w0 = tr + (size_t)ntr * Q * kWave;
+    wbase = w0 + (size_t)wave * wave_lds;
+    cand = reinterpret_cast<int *>(w0 + (size_t)nwaves * wave_lds);
   }
 };
 
@@ -131,10 +135,69 @@ __device__ __forceinline__ int place_window(unsigned long long um, int &m0) {
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ the work loop of every kernel
+// A workgroup draws GROUPS of g.G consecutive work items of the batch (an item = a.QB queries of one model, model-major), cuts a
+// group at model boundaries into SEGMENTS, stages the segment's tables when the model changed, and collects the segment's
+// CANDIDATES - the pairs (or envelopes) this kernel has something to do for, found by <pred> from the per-pair records - in
+// an LDS list; the waves then take candidates one by one from an LDS counter.  So a kernel that serves 6 % of the envelopes
+// keeps all its waves on those, and queries of different lengths do not leave waves idle behind a fixed deal.
+// <pred(pl, emit)>: called by one thread per pair, emit(code) adds a candidate; <body(code, h)>: one wave per candidate.
+// A segment whose candidates exceed the list is handled in pieces of cand_cap / per_pair pairs (per_pair = the most one pair can emit).
+template <class Stage, class Pred, class Body>
+__device__ __forceinline__ void group_loop(const StagedArgs &g, int head_slot, volatile int *slot, int *cand, int per_pair, Stage stage, Pred pred, Body body) {
+  const ScoreArgs &a = g.a;
+  const int lane = threadIdx.x & 63;
+  const int G = g.G;
+  const int n_groups = (g.n_items_b + G - 1) / G;
+  int cur_h = -1;
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) slot[0] = atomicAdd(g.cnt + head_slot, 1);
+    __syncthreads();
+    const int gi = slot[0];
+    if (gi >= n_groups) break;
+    int it = gi * G;
+    const int it_end = min(it + G, g.n_items_b);
+    while (it < it_end) {
+      const int m = (g.item0 + it) / a.n_qblocks;
+      const int h = a.hmm_list[m];
+      const int it2 = min(it_end, (m + 1) * a.n_qblocks - g.item0);      // first item of the next model
+      if (h != cur_h) { __syncthreads(); stage(h); cur_h = h; __syncthreads(); }
+      const int seg0 = it * a.QB, seg1 = it2 * a.QB;
+      const int piece = (seg1 - seg0) * per_pair <= g.cand_cap ? seg1 - seg0 : max(1, g.cand_cap / per_pair);
+      for (int pl0 = seg0; pl0 < seg1; pl0 += piece) {
+        const int pl1 = min(pl0 + piece, seg1);
+        __syncthreads();
+        if (threadIdx.x == 0) { slot[1] = 0; slot[2] = 0; }
+        __syncthreads();
+        for (int pl = pl0 + threadIdx.x; pl < pl1; pl += blockDim.x)
+          pred(pl, [&](int code) { const int k = atomicAdd(const_cast<int *>(slot) + 1, 1); if (k < g.cand_cap) cand[k] = code; });
+        __syncthreads();
+        const int n = min(slot[1], g.cand_cap);
+        for (;;) {
+          int k = 0;
+          if (lane == 0) k = atomicAdd(const_cast<int *>(slot) + 2, 1);
+          k = bcast_i(k);
+          if (k >= n) break;
+          body(cand[k], h);
+        }
+      }
+      it = it2;
+    }
+  }
+}
+
+// is pair <pl> of the batch a real pair (the last query block of a model is ragged)?
+__device__ __forceinline__ bool pair_valid(const StagedArgs &g, int pl) {
+  const ScoreArgs &a = g.a;
+  const int gitem = g.item0 + pl / a.QB;
+  return (int64_t)(gitem % a.n_qblocks) * a.QB + pl % a.QB < a.nq;
+}
+
 __device__ __forceinline__ void store_regions(StPair *pp, const RegOut &ro, const int *regs, int lane, wh_pair_detail *dp) {
   if (lane == 0) {
     pp->nenv = ro.nenv; pp->nreg = ro.nreg; pp->flags = ro.flags & 0xFFFFFF;
-    for (int e = 0; e < ro.nenv; e++) { pp->regs[2 * e] = regs[2 * e]; pp->regs[2 * e + 1] = regs[2 * e + 1]; }
+    for (int e = 0; e < ro.nenv; e++) { pp->regs[2 * e] = regs[2 * e]; pp->regs[2 * e + 1] = regs[2 * e + 1]; pp->cls[e] = ST_CLS_NONE; }
     pp->state = 2;
     if (dp) { dp->nregions = ro.nreg; dp->nenv = ro.nenv; }
   }
@@ -148,36 +211,25 @@ __global__ __launch_bounds__(kStTH) void staged_p1_kernel(StagedArgs g) {
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   constexpr int TBL = Q * kWave;
-  StLds<Q> S(smem_raw, a.K, FW_NARR, wave, a.wave_lds);
+  StLds<Q> S(smem_raw, a.K, FW_NARR, wave, nwaves, a.wave_lds);
   WaveCtx c = make_ctx(a, S.em, S.tr, nullptr, S.wbase, lane);
   uint8_t *seq = ctx_seq(a, S.wbase);
   float *spec = S.wbase;
   const int SP = a.SP;
   const double LOG2 = 0.69314718055994529;
   ST_K0();
-  int cur_h = -1;
-  const DevHMM *hm = nullptr;
-  for (;;) {
-    if (threadIdx.x == 0) *S.slot = atomicAdd(g.cnt + ST_C_P1, 1);
-    __syncthreads();
-    const int item = *S.slot;
-    __syncthreads();
-    if (item >= g.n_items_b) break;
-    const int gitem = g.item0 + item;
-    const int h = a.hmm_list[gitem / a.n_qblocks];
-    const int64_t q_lo = (int64_t)(gitem % a.n_qblocks) * a.QB;
-    const int64_t q_hi = q_lo + a.QB < a.nq ? q_lo + a.QB : a.nq;
-    if (h != cur_h) {
-      hm = a.hmms + h;
+  group_loop(g, ST_C_P1, S.slot, S.cand, 1,
+    [&](int h) {
+      const DevHMM *hm = a.hmms + h;
       copy_f4(S.em, a.tables + hm->em_off, a.K * TBL);
       copy_f4(S.tr, a.tables + hm->fw_off, FW_NARR * TBL);
-      cur_h = h;
-      __syncthreads();
-    }
-    c.emG = (const glb_f *)(a.tables + hm->em_off);
-    for (int64_t qi = q_lo + wave; qi < q_hi; qi += nwaves) {
-      const int pl = item * a.QB + (int)(qi - q_lo);
+      c.emG = (const glb_f *)(a.tables + hm->em_off);
+    },
+    [&](int pl, auto emit) { if (pair_valid(g, pl)) emit(pl); },
+    [&](int pl, int h) {
       StPair *pp = g.pairs + pl;
+      const PairPos P = pair_pos(g, pl);
+      const int64_t qi = P.qi;
       const int64_t off = a.offsets[qi];
       const int L = (int)(a.offsets[qi + 1] - off);
       const size_t out = (size_t)qi * a.H + h;
@@ -215,58 +267,30 @@ __global__ __launch_bounds__(kStTH) void staged_p1_kernel(StagedArgs g) {
         if (state == 0) { a.decibits[out] = 0; a.flags[out] = 0; if (g.pair_paths) g.pair_paths[out] = 0; }
         if (a.fwd_bits) a.fwd_bits[out] = fwd_bits_out;
       }
-    }
-  }
+    });
   ST_K1(0);
 }
 
-// list-driven dense kernels: a workgroup draws kStChunk entries, works through them model by model (the lists are
-// written in model-major order up to the interleaving of concurrent workgroups, so a chunk is nearly always one model)
-template <int Q, class Stage, class Body>
-__device__ __forceinline__ void list_loop(const StagedArgs &g, volatile int *slot, const int32_t *list, int n_slot, int head_slot,
-                                          bool units, int &cur_h, Stage stage, Body body) {
-  const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-  const int n = min(g.cnt[n_slot], units ? g.NS : g.NB);
-  for (;;) {
-    if (threadIdx.x == 0) *slot = atomicAdd(g.cnt + head_slot, kStChunk);
-    __syncthreads();
-    const int c0 = *slot;
-    __syncthreads();
-    if (c0 >= n) break;
-    const int c1 = min(c0 + kStChunk, n);
-    int pos = c0;
-    while (pos < c1) {
-      auto model_at = [&](int idx) { const int ent = list[idx]; return pair_pos(g, units ? g.units[ent].pl : ent).h; };
-      const int h = model_at(pos);
-      int r = pos + 1;
-      while (r < c1 && model_at(r) == h) r++;
-      if (h != cur_h) { __syncthreads(); stage(h); cur_h = h; __syncthreads(); }
-      for (int idx = pos + wave; idx < r; idx += nwaves) body(list[idx], h);
-      pos = r;
-    }
-  }
-}
-
-// ================================================================================================ p2full: the doubt list
+// ================================================================================================ p2full: pairs whose window left a doubt
 template <int Q>
 __global__ __launch_bounds__(kStTH) void staged_p2full_kernel(StagedArgs g) {
   const ScoreArgs &a = g.a;
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   constexpr int TBL = Q * kWave;
-  StLds<Q> S(smem_raw, a.K, BW_NARR, wave, a.wave_lds);
+  StLds<Q> S(smem_raw, a.K, BW_NARR, wave, nwaves, a.wave_lds);
   WaveCtx c = make_ctx(a, S.em, nullptr, S.tr, S.wbase, lane);
   uint8_t *seq = ctx_seq(a, S.wbase);
   int *regs = ctx_regs(a, S.wbase);
   ST_K0();
-  int cur_h = -1;
-  list_loop<Q>(g, S.slot, g.doubt_list, ST_N_DOUBT, ST_C_P2B, false, cur_h,
+  group_loop(g, ST_C_P2B, S.slot, S.cand, 1,
     [&](int h) {
       const DevHMM *hm = a.hmms + h;
       copy_f4(S.em, a.tables + hm->em_off, a.K * TBL);
       copy_f4(S.tr, a.tables + hm->bw_off, BW_NARR * TBL);
       c.emG = (const glb_f *)(a.tables + hm->em_off);
     },
+    [&](int pl, auto emit) { if (pair_valid(g, pl) && g.pairs[pl].state == 3) emit(pl); },
     [&](int pl, int h) {
       StPair *pp = g.pairs + pl;
       const PairPos P = pair_pos(g, pl);
@@ -295,108 +319,104 @@ __global__ __launch_bounds__(kStTH) void staged_p3_kernel(StagedArgs g) {
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   constexpr int TBL = Q * kWave;
-  StLds<Q> S(smem_raw, a.K, FW_NARR, wave, a.wave_lds);
+  StLds<Q> S(smem_raw, a.K, FW_NARR, wave, nwaves, a.wave_lds);
   WaveCtx c = make_ctx(a, S.em, S.tr, nullptr, S.wbase, lane);
   uint8_t *seq = ctx_seq(a, S.wbase);
   float *spec = S.wbase;
   const int SP = a.SP;
   const double LOG2 = 0.69314718055994529;
   ST_K0();
-  int cur_h = -1;
-  const DevHMM *hm = nullptr;
-  for (;;) {
-    if (threadIdx.x == 0) *S.slot = atomicAdd(g.cnt + ST_C_P3, 1);
-    __syncthreads();
-    const int item = *S.slot;
-    __syncthreads();
-    if (item >= g.n_items_b) break;
-    const int gitem = g.item0 + item;
-    const int h = a.hmm_list[gitem / a.n_qblocks];
-    const int64_t q_lo = (int64_t)(gitem % a.n_qblocks) * a.QB;
-    const int64_t q_hi = q_lo + a.QB < a.nq ? q_lo + a.QB : a.nq;
-    if (h != cur_h) {
-      hm = a.hmms + h;
+  group_loop(g, ST_C_P3, S.slot, S.cand, WH_MAX_ENVELOPES,
+    [&](int h) {
+      const DevHMM *hm = a.hmms + h;
       copy_f4(S.em, a.tables + hm->em_off, a.K * TBL);
       copy_f4(S.tr, a.tables + hm->fw_off, FW_NARR * TBL);
-      cur_h = h;
-      __syncthreads();
-    }
-    c.emG = (const glb_f *)(a.tables + hm->em_off);
-    for (int64_t qi = q_lo + wave; qi < q_hi; qi += nwaves) {
-      const int pl = item * a.QB + (int)(qi - q_lo);
+      c.emG = (const glb_f *)(a.tables + hm->em_off);
+    },
+    [&](int pl, auto emit) {
+      if (!pair_valid(g, pl)) return;
       StPair *pp = g.pairs + pl;
-      if (bcast_i(pp->state) != 2) continue;
-      const int nenv = bcast_i(pp->nenv);
-      if (nenv <= 0) continue;
-      const int multi_mask = bcast_i(pp->flags) >> 8;
+      if (pp->state != 2) return;
+      const int nenv = pp->nenv, multi_mask = pp->flags >> 8;
       const bool queue_pair = multi_mask != 0 && a.rrecs != nullptr;
-      const int64_t off = a.offsets[qi];
-      const int L = (int)(a.offsets[qi + 1] - off);
-      load_seq(a, seq, off, L, lane);
-      const LenCfg cu = len_config(L, false);
       for (int e = 0; e < nenv; e++) {
-        if (queue_pair && ((multi_mask >> e) & 1)) { if (lane == 0) { pp->envsc[e] = 0.f; pp->domcorr[e] = 0.f; } continue; }
-        const int ri = bcast_i(pp->regs[2 * e]), rj = bcast_i(pp->regs[2 * e + 1]);
-        const int Ld = rj - ri + 1;
-        int uid = 0;
-        if (lane == 0) uid = atomicAdd(g.cnt + ST_N_UNITS, 1);
-        uid = bcast_i(uid);
-        if (uid >= g.NS) { if (lane == 0) g.cnt[ST_OVERFLOW] = 1; continue; }     // the host repeats the call (see wh_api.hip)
-        c.Fs = (glb_f *)(g.slabs + (size_t)uid * g.slab_stride);
-        const float keep_scale = a.keep_scale > 0.f ? a.keep_scale : kKeepScale7;
-        ST_T0();
-        const FwdOut f3 = sweep_forward<Q, true, kStTH, false>(c, (lds_u8 *)(seq + (ri - 1)), Ld, cu, keep_scale);
-        ST_T1(4);
-        const float envsc = (float)((double)f3.ef * LOG2 + log((double)(f3.xC * cu.move)));
-        StUnit *u = g.units + uid;
-        int cls = -1, m0 = 0;          // -1: no Backward sweep (no Forward mass), 0 full width, 4 / 8 window
-        if (f3.xC > 0.f) {
-          rows_out(g.p3spec + (size_t)uid * g.p3stride, spec, SP, Ld, lane);
-          cls = 0;
-          if (Q >= 8 && !a.no_window) {
-            const unsigned *su = reinterpret_cast<const unsigned *>(spec);
-            const unsigned long long um = ((unsigned long long)su[kSpMH * SP] << 32) | su[kSpML * SP];
-            cls = place_window<Q>(um, m0);
-          }
-        }
-        if (lane == 0) {
-          u->pl = pl; u->e = e; u->ri = ri; u->Ld = Ld; u->xC = f3.xC; u->ef = f3.ef; u->m0 = m0;
-          pp->envsc[e] = envsc; pp->domcorr[e] = 0.f;
-          if (cls == 4) g.list256[atomicAdd(g.cnt + ST_N_256, 1)] = uid;
-          else if (cls == 8) g.list512[atomicAdd(g.cnt + ST_N_512, 1)] = uid;
-          else if (cls == 0) g.listfull[atomicAdd(g.cnt + ST_N_FULL, 1)] = uid;
+        // a pair with a multidomain region is finished by resolve_kernel; its single-domain regions are still scored here
+        if (queue_pair && ((multi_mask >> e) & 1)) { pp->envsc[e] = 0.f; pp->domcorr[e] = 0.f; continue; }
+        emit(pl * WH_MAX_ENVELOPES + e);
+      }
+    },
+    [&](int code, int h) {
+      const int pl = code / WH_MAX_ENVELOPES, e = code % WH_MAX_ENVELOPES;
+      StPair *pp = g.pairs + pl;
+      const PairPos P = pair_pos(g, pl);
+      const int64_t off = a.offsets[P.qi];
+      const int L = (int)(a.offsets[P.qi + 1] - off);
+      const int ri = bcast_i(pp->regs[2 * e]), rj = bcast_i(pp->regs[2 * e + 1]);
+      const int Ld = rj - ri + 1;
+      int uid = 0;
+      if (lane == 0) uid = atomicAdd(g.cnt + ST_N_UNITS, 1);
+      uid = bcast_i(uid);
+      if (uid >= g.NS) { if (lane == 0) g.cnt[ST_OVERFLOW] = 1; return; }      // the host repeats the call (wh_api.hip)
+      load_seq(a, seq, off + (ri - 1), Ld, lane);
+      const LenCfg cu = len_config(L, false);
+      c.Fs = (glb_f *)(g.slabs + (size_t)uid * g.slab_stride);
+      const float keep_scale = a.keep_scale > 0.f ? a.keep_scale : kKeepScale7;
+      ST_T0();
+      const FwdOut f3 = sweep_forward<Q, true, kStTH, false>(c, (lds_u8 *)seq, Ld, cu, keep_scale);
+      ST_T1(4);
+      const float envsc = (float)((double)f3.ef * LOG2 + log((double)(f3.xC * cu.move)));
+      int cls = ST_CLS_NONE, m0 = 0;
+      if (f3.xC > 0.f) {
+        rows_out(g.p3spec + (size_t)uid * g.p3stride, spec, SP, Ld, lane);
+        cls = ST_CLS_FULL;
+        if (Q >= 8 && !a.no_window) {
+          const unsigned *su = reinterpret_cast<const unsigned *>(spec);
+          const unsigned long long um = ((unsigned long long)su[kSpMH * SP] << 32) | su[kSpML * SP];
+          const int w = place_window<Q>(um, m0);
+          if (w == 4) cls = ST_CLS_W256; else if (w == 8) cls = ST_CLS_W512;
         }
       }
-    }
-  }
+      if (lane == 0) {
+        StUnit *u = g.units + uid;
+        u->xC = f3.xC; u->ef = f3.ef; u->m0 = m0;
+        pp->envsc[e] = envsc; pp->domcorr[e] = 0.f; pp->uid[e] = uid; pp->cls[e] = (uint8_t)cls;
+      }
+    });
   ST_K1(4);
   // the row stores of this kernel are read by other workgroups in the next launch: kernel boundary = release
 }
 
-// ================================================================================================ p4full: the full-width list
+// ================================================================================================ p4full: envelopes at full width
 template <int Q>
 __global__ __launch_bounds__(kStTH) void staged_p4full_kernel(StagedArgs g) {
   const ScoreArgs &a = g.a;
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   constexpr int TBL = Q * kWave;
-  StLds<Q> S(smem_raw, a.K, BW_NARR, wave, a.wave_lds);
+  StLds<Q> S(smem_raw, a.K, BW_NARR, wave, nwaves, a.wave_lds);
   WaveCtx c = make_ctx(a, S.em, nullptr, S.tr, S.wbase, lane);
   uint8_t *seq = ctx_seq(a, S.wbase);
-  ST_K0();
-  int cur_h = -1;
   unsigned n_full = 0;
-  list_loop<Q>(g, S.slot, g.listfull, ST_N_FULL, ST_C_FULL, true, cur_h,
+  ST_K0();
+  group_loop(g, ST_C_FULL, S.slot, S.cand, WH_MAX_ENVELOPES,
     [&](int h) {
       const DevHMM *hm = a.hmms + h;
       copy_f4(S.em, a.tables + hm->em_off, a.K * TBL);
       copy_f4(S.tr, a.tables + hm->bw_off, BW_NARR * TBL);
       c.emG = (const glb_f *)(a.tables + hm->em_off);
     },
-    [&](int uid, int h) {
-      const StUnit *u = g.units + uid;
-      const int pl = bcast_i(u->pl), e = bcast_i(u->e), ri = bcast_i(u->ri), Ld = bcast_i(u->Ld);
+    [&](int pl, auto emit) {
+      if (!pair_valid(g, pl)) return;
+      const StPair *pp = g.pairs + pl;
+      if (pp->state != 2) return;
+      for (int e = 0; e < pp->nenv; e++) if (pp->cls[e] == ST_CLS_FULL) emit(pl * WH_MAX_ENVELOPES + e);
+    },
+    [&](int code, int h) {
+      const int pl = code / WH_MAX_ENVELOPES, e = code % WH_MAX_ENVELOPES;
       StPair *pp = g.pairs + pl;
+      const int uid = bcast_i(pp->uid[e]), ri = bcast_i(pp->regs[2 * e]), rj = bcast_i(pp->regs[2 * e + 1]);
+      const int Ld = rj - ri + 1;
+      const StUnit *u = g.units + uid;
       const PairPos P = pair_pos(g, pl);
       const int64_t off = a.offsets[P.qi];
       const int L = (int)(a.offsets[P.qi + 1] - off);
@@ -412,8 +432,8 @@ __global__ __launch_bounds__(kStTH) void staged_p4full_kernel(StagedArgs g) {
       const bool ok = fabsf((float)Ld - p4.mass) <= kMassTol7 * (float)Ld;
       if (lane == 0) {
         atomicOr(&pp->path, WH_PATH_P4_FULL);
-        if (ok) pp->domcorr[e] = p4.domcorr;
-        else g.listdense[atomicAdd(g.cnt + ST_N_DENSE, 1)] = uid;
+        if (ok) { pp->domcorr[e] = p4.domcorr; pp->cls[e] = ST_CLS_NONE; }
+        else pp->cls[e] = ST_CLS_DENSE;
       }
     });
   if (a.paths && lane == 0 && n_full) atomicAdd(a.paths + 3, (unsigned long long)n_full);
@@ -425,16 +445,15 @@ template <int Q>
 __global__ __launch_bounds__(kStTH) void staged_dense_kernel(StagedArgs g) {
   const ScoreArgs &a = g.a;
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   constexpr int TBL = Q * kWave;
-  StLds<Q> S(smem_raw, a.K, 2 * FW_NARR, wave, a.wave_lds);
+  StLds<Q> S(smem_raw, a.K, 2 * FW_NARR, wave, nwaves, a.wave_lds);
   WaveCtx c = make_ctx(a, S.em, S.tr, S.tr + FW_NARR * TBL, S.wbase, lane);
   uint8_t *seq = ctx_seq(a, S.wbase);
   const double LOG2 = 0.69314718055994529;
-  ST_K0();
-  int cur_h = -1;
   unsigned n_full = 0;
-  list_loop<Q>(g, S.slot, g.listdense, ST_N_DENSE, ST_C_DENSE, true, cur_h,
+  ST_K0();
+  group_loop(g, ST_C_DENSE, S.slot, S.cand, WH_MAX_ENVELOPES,
     [&](int h) {
       const DevHMM *hm = a.hmms + h;
       copy_f4(S.em, a.tables + hm->em_off, a.K * TBL);
@@ -442,10 +461,17 @@ __global__ __launch_bounds__(kStTH) void staged_dense_kernel(StagedArgs g) {
       copy_f4(S.tr + FW_NARR * TBL, a.tables + hm->bw_off, BW_NARR * TBL);
       c.emG = (const glb_f *)(a.tables + hm->em_off);
     },
-    [&](int uid, int h) {
-      const StUnit *u = g.units + uid;
-      const int pl = bcast_i(u->pl), e = bcast_i(u->e), ri = bcast_i(u->ri), Ld = bcast_i(u->Ld);
+    [&](int pl, auto emit) {
+      if (!pair_valid(g, pl)) return;
+      const StPair *pp = g.pairs + pl;
+      if (pp->state != 2) return;
+      for (int e = 0; e < pp->nenv; e++) if (pp->cls[e] == ST_CLS_DENSE) emit(pl * WH_MAX_ENVELOPES + e);
+    },
+    [&](int code, int h) {
+      const int pl = code / WH_MAX_ENVELOPES, e = code % WH_MAX_ENVELOPES;
       StPair *pp = g.pairs + pl;
+      const int uid = bcast_i(pp->uid[e]), ri = bcast_i(pp->regs[2 * e]), rj = bcast_i(pp->regs[2 * e + 1]);
+      const int Ld = rj - ri + 1;
       const PairPos P = pair_pos(g, pl);
       const int64_t off = a.offsets[P.qi];
       const int L = (int)(a.offsets[P.qi + 1] - off);
@@ -453,7 +479,7 @@ __global__ __launch_bounds__(kStTH) void staged_dense_kernel(StagedArgs g) {
       c.Fs = (glb_f *)(g.slabs + (size_t)uid * g.slab_stride);
       const LenCfg cu = len_config(L, false);
       const FwdOut f3 = sweep_forward<Q, true, kStTH, false>(c, (lds_u8 *)seq, Ld, cu, -1.0f);
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      // the rows were written by other lanes of this wave
       const float envsc = (float)((double)f3.ef * LOG2 + log((double)(f3.xC * cu.move)));
       float domcorr = 0.f;
       if (f3.xC > 0.f) {
@@ -462,16 +488,17 @@ __global__ __launch_bounds__(kStTH) void staged_dense_kernel(StagedArgs g) {
         domcorr = p4.domcorr;
       }
       if (lane == 0) {
-        pp->envsc[e] = envsc; pp->domcorr[e] = domcorr;
+        pp->envsc[e] = envsc; pp->domcorr[e] = domcorr; pp->cls[e] = ST_CLS_NONE;
         atomicOr(&pp->flags, WH_FLAG_EXACT);
         atomicOr(&pp->path, WH_PATH_DENSE);
       }
     });
   if (a.paths && lane == 0 && n_full) atomicAdd(a.paths + 3, (unsigned long long)n_full);
+  ST_K1(8);
 }
 
-template <int Q, class K>
-static hipError_t launch_dense_kind(K kern, const StagedArgs &g, int blocks, int threads, size_t lds, hipStream_t s) {
+template <class K>
+static hipError_t launch_kind(K kern, const StagedArgs &g, int blocks, int threads, size_t lds, hipStream_t s) {
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (err != hipSuccess) return err;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, s, g);
@@ -482,84 +509,70 @@ static hipError_t launch_dense_kind(K kern, const StagedArgs &g, int blocks, int
 #if WH_ST_PART != 1
 // ================================================================================================ p2win: window sweep + certified scan
 // Light kernel: the workgroup stages the emission rows only; a wave gathers its window's reversed transition arrays from
-// L2 once per pair (BWG) and works on a COPY of P1's rows (INPL).
-constexpr int kLightTH = 768;
+// L2 once per pair (BWG) and works on a COPY of P1's rows (INPL).  The 256-node launch sees every pair after P1 (state 1)
+// and passes on what it cannot serve: to the 512-node launch (state 4) or to the full-width launch (state 3).
 template <int Q, int QB>
 __global__ __launch_bounds__(kLightTH) __attribute__((amdgpu_waves_per_eu(6, 6))) void staged_p2win_kernel(StagedArgs g) {
   const ScoreArgs &a = g.a;
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   constexpr int TBL = Q * kWave;
-  StLds<Q> S(smem_raw, a.K, 0, wave, g.wave_lds_light);
+  StLds<Q> S(smem_raw, a.K, 0, wave, nwaves, a.wave_lds);
   WaveCtx c = make_ctx(a, S.em, nullptr, nullptr, S.wbase, lane);
   uint8_t *seq = ctx_seq(a, S.wbase);
   int *regs = ctx_regs(a, S.wbase);
-  ST_K0();
-  int cur_h = -1;
-  const DevHMM *hm = nullptr;
   unsigned n_p2w = 0, n_p2rej = 0;
-  for (;;) {
-    if (threadIdx.x == 0) *S.slot = atomicAdd(g.cnt + (QB == 8 ? ST_C_P2W8 : ST_C_P2), 1);
-    __syncthreads();
-    const int item = *S.slot;
-    __syncthreads();
-    if (item >= g.n_items_b) break;
-    const int gitem = g.item0 + item;
-    const int h = a.hmm_list[gitem / a.n_qblocks];
-    const int64_t q_lo = (int64_t)(gitem % a.n_qblocks) * a.QB;
-    const int64_t q_hi = q_lo + a.QB < a.nq ? q_lo + a.QB : a.nq;
-    if (h != cur_h) {
-      __syncthreads();
-      hm = a.hmms + h;
+  ST_K0();
+  group_loop(g, QB == 8 ? ST_C_P2W8 : ST_C_P2, S.slot, S.cand, 1,
+    [&](int h) {
+      const DevHMM *hm = a.hmms + h;
       copy_f4(S.em, a.tables + hm->em_off, a.K * TBL);
-      cur_h = h;
-      __syncthreads();
-    }
-    c.emG = (const glb_f *)(a.tables + hm->em_off);
-    c.specg = (glb_f *)const_cast<float *>(a.tables + hm->bw_off);
-    for (int64_t qi = q_lo + wave; qi < q_hi; qi += nwaves) {
-      const int pl = item * a.QB + (int)(qi - q_lo);
+      c.emG = (const glb_f *)(a.tables + hm->em_off);
+      c.specg = (glb_f *)const_cast<float *>(a.tables + hm->bw_off);
+    },
+    [&](int pl, auto emit) {
+      if (!pair_valid(g, pl)) return;
       StPair *pp = g.pairs + pl;
-      const int st = bcast_i(pp->state);
-      // the 256-node launch sees every pair after P1 (state 1) and sends what it cannot certify on: to the 512-node launch
-      // (state 4) or to the doubt list (state 3); the 512-node launch takes state 4
-      if (st != (QB == 4 ? 1 : 4)) continue;
+      if (pp->state != (QB == 4 ? 1 : 4)) return;
+      if (QB == 4) {
+        // pairs no window serves go on without a wave's time: 512 nodes -> state 4, none -> state 3
+        const unsigned long long um = ((unsigned long long)pp->um_hi << 32) | pp->um_lo;
+        int m0 = 0;
+        const int w = (Q >= 8 && !a.no_window) ? place_window<Q>(um, m0) : 0;
+        if (w == 8) { pp->state = 4; return; }
+        if (w == 0) { pp->state = 3; if (um != 0) pp->path |= 256; return; }     // (bit 8: a window was wanted - counted below)
+      }
+      emit(pl);
+    },
+    [&](int pl, int h) {
+      StPair *pp = g.pairs + pl;
+      const PairPos P = pair_pos(g, pl);
+      const int64_t off = a.offsets[P.qi];
+      const int L = (int)(a.offsets[P.qi + 1] - off);
       const unsigned long long um = ((unsigned long long)(unsigned)bcast_i((int)pp->um_hi) << 32) | (unsigned)bcast_i((int)pp->um_lo);
       int m0 = 0;
-      const int cls = (Q >= 8 && !a.no_window) ? place_window<Q>(um, m0) : 0;
+      place_window<Q>(um, m0);
+      load_seq(a, seq, off, L, lane);
+      rows_in(S.wbase, g.p1spec + (size_t)pl * g.p1stride, a.SP, L, lane);
+      const LenCfg cm = len_config(L, true);
+      const float xC = pp->xC; const int ef = pp->ef;
+      ST_T0();
+      const WinDec wd = sweep_backward_decode_win<QB, Q, kLightTH, true, true>(c, (lds_u8 *)seq, L, cm, 1.0f / (xC * cm.move), ef, m0);
+      ST_T1((QB == 4 ? 1 : 2));
       bool have_ro = false;
-      if (cls == QB) {
-        const int64_t off = a.offsets[qi];
-        const int L = (int)(a.offsets[qi + 1] - off);
-        load_seq(a, seq, off, L, lane);
-        rows_in(S.wbase, g.p1spec + (size_t)pl * g.p1stride, a.SP, L, lane);
-        const LenCfg cm = len_config(L, true);
-        const float xC = pp->xC; const int ef = pp->ef;
-        ST_T0();
-        const WinDec wd = sweep_backward_decode_win<QB, Q, kLightTH, true, true>(c, (lds_u8 *)seq, L, cm, 1.0f / (xC * cm.move), ef, m0);
-        ST_T1((QB == 4 ? 1 : 2));
-        if (wd.eps > -1e-4f && wd.eps < 0.01f) {
-          RegOut ro = region_scan_cert<kLightTH, true>(c.spec, a.SP, L, (lds_i *)regs, lane, fmaxf(wd.eps, 0.f));
-          have_ro = ((ro.flags >> 24) & 3) == 0;
-          if (have_ro) {
-            ro.flags &= 0xFFFFFF;
-            __builtin_amdgcn_wave_barrier();
-            wh_pair_detail *dp = (a.detail && lane == 0) ? a.detail + ((size_t)qi * a.H + h) : nullptr;
-            store_regions(pp, ro, regs, lane, dp);
-            if (lane == 0) pp->path |= WH_PATH_P2_WIN;
-          }
+      if (wd.eps > -1e-4f && wd.eps < 0.01f) {
+        RegOut ro = region_scan_cert<kLightTH, true>(c.spec, a.SP, L, (lds_i *)regs, lane, fmaxf(wd.eps, 0.f));
+        have_ro = ((ro.flags >> 24) & 3) == 0;
+        if (have_ro) {
+          ro.flags &= 0xFFFFFF;
+          __builtin_amdgcn_wave_barrier();
+          wh_pair_detail *dp = (a.detail && lane == 0) ? a.detail + ((size_t)P.qi * a.H + h) : nullptr;
+          store_regions(pp, ro, regs, lane, dp);
+          if (lane == 0) pp->path |= WH_PATH_P2_WIN;
         }
-        if (have_ro) n_p2w++; else n_p2rej++;
-      } else if (QB == 4 && cls == 8) {
-        if (lane == 0) pp->state = 4;
-        continue;
-      } else if (um != 0) n_p2rej++;       // (a dominant alignment wider than any window: counted as the fused kernel counts it)
-      if (!have_ro && lane == 0) {
-        pp->state = 3;
-        g.doubt_list[atomicAdd(g.cnt + ST_N_DOUBT, 1)] = pl;
       }
-    }
-  }
+      if (have_ro) n_p2w++; else { n_p2rej++; if (lane == 0) pp->state = 3; }
+    });
   if (a.paths && lane == 0) {
     if (n_p2w) atomicAdd(a.paths + 4, (unsigned long long)n_p2w);
     if (n_p2rej) atomicAdd(a.paths + 5, (unsigned long long)n_p2rej);
@@ -574,62 +587,49 @@ __global__ __launch_bounds__(kLightTH) __attribute__((amdgpu_waves_per_eu(5, 5))
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   constexpr int TBL = Q * kWave;
-  StLds<Q> S(smem_raw, a.K, 0, wave, g.wave_lds_light);
+  StLds<Q> S(smem_raw, a.K, 0, wave, nwaves, a.wave_lds);
   WaveCtx c = make_ctx(a, S.em, nullptr, nullptr, S.wbase, lane);
   uint8_t *seq = ctx_seq(a, S.wbase);
-  const int32_t *list = QB == 4 ? g.list256 : g.list512;
-  const int n = min(g.cnt[QB == 4 ? ST_N_256 : ST_N_512], g.NS);
-  ST_K0();
-  int cur_h = -1;
   unsigned n_ok = 0, n_fail = 0;
-  for (;;) {
-    if (threadIdx.x == 0) *S.slot = atomicAdd(g.cnt + (QB == 4 ? ST_C_256 : ST_C_512), kStChunk);
-    __syncthreads();
-    const int c0 = *S.slot;
-    __syncthreads();
-    if (c0 >= n) break;
-    const int c1 = min(c0 + kStChunk, n);
-    int pos = c0;
-    while (pos < c1) {
-      auto model_at = [&](int idx) { return pair_pos(g, g.units[list[idx]].pl).h; };
-      const int h = model_at(pos);
-      int r = pos + 1;
-      while (r < c1 && model_at(r) == h) r++;
+  ST_K0();
+  group_loop(g, QB == 4 ? ST_C_256 : ST_C_512, S.slot, S.cand, WH_MAX_ENVELOPES,
+    [&](int h) {
       const DevHMM *hm = a.hmms + h;
-      if (h != cur_h) {
-        __syncthreads();
-        copy_f4(S.em, a.tables + hm->em_off, a.K * TBL);
-        cur_h = h;
-        __syncthreads();
-      }
+      copy_f4(S.em, a.tables + hm->em_off, a.K * TBL);
       c.emG = (const glb_f *)(a.tables + hm->em_off);
       c.specg = (glb_f *)const_cast<float *>(a.tables + hm->bw_off);
-      for (int idx = pos + wave; idx < r; idx += nwaves) {
-        const int uid = list[idx];
-        const StUnit *u = g.units + uid;
-        const int pl = bcast_i(u->pl), e = bcast_i(u->e), ri = bcast_i(u->ri), Ld = bcast_i(u->Ld), m0 = bcast_i(u->m0);
-        StPair *pp = g.pairs + pl;
-        const PairPos P = pair_pos(g, pl);
-        const int64_t off = a.offsets[P.qi];
-        const int L = (int)(a.offsets[P.qi + 1] - off);
-        load_seq(a, seq, off + (ri - 1), Ld, lane);
-        rows_in(S.wbase, g.p3spec + (size_t)uid * g.p3stride, a.SP, Ld, lane);
-        c.Fs = (glb_f *)(g.slabs + (size_t)uid * g.slab_stride);
-        const LenCfg cu = len_config(L, false);
-        const float xC = u->xC;
-        ST_T0();
-        const P4Out p4 = sweep_backward_null2_win<QB, Q, kLightTH, false, true>(c, (lds_u8 *)seq, Ld, cu, 1.0f / (xC * cu.move), kWinTol7, m0);
-        ST_T1((QB == 4 ? 5 : 6));
-        const bool ok = fabsf((float)Ld - p4.mass) <= kWinTol7 * (float)Ld;
-        if (ok) n_ok++; else n_fail++;
-        if (lane == 0) {
-          if (ok) { pp->domcorr[e] = p4.domcorr; atomicOr(&pp->path, QB == 4 ? WH_PATH_P4_W256 : WH_PATH_P4_W512); }
-          else { atomicOr(&pp->path, WH_PATH_P4_WFAIL); g.listfull[atomicAdd(g.cnt + ST_N_FULL, 1)] = uid; }
-        }
+    },
+    [&](int pl, auto emit) {
+      if (!pair_valid(g, pl)) return;
+      const StPair *pp = g.pairs + pl;
+      if (pp->state != 2) return;
+      for (int e = 0; e < pp->nenv; e++) if (pp->cls[e] == (QB == 4 ? ST_CLS_W256 : ST_CLS_W512)) emit(pl * WH_MAX_ENVELOPES + e);
+    },
+    [&](int code, int h) {
+      const int pl = code / WH_MAX_ENVELOPES, e = code % WH_MAX_ENVELOPES;
+      StPair *pp = g.pairs + pl;
+      const int uid = bcast_i(pp->uid[e]), ri = bcast_i(pp->regs[2 * e]), rj = bcast_i(pp->regs[2 * e + 1]);
+      const int Ld = rj - ri + 1;
+      const StUnit *u = g.units + uid;
+      const int m0 = bcast_i(u->m0);
+      const PairPos P = pair_pos(g, pl);
+      const int64_t off = a.offsets[P.qi];
+      const int L = (int)(a.offsets[P.qi + 1] - off);
+      load_seq(a, seq, off + (ri - 1), Ld, lane);
+      rows_in(S.wbase, g.p3spec + (size_t)uid * g.p3stride, a.SP, Ld, lane);
+      c.Fs = (glb_f *)(g.slabs + (size_t)uid * g.slab_stride);
+      const LenCfg cu = len_config(L, false);
+      const float xC = u->xC;
+      ST_T0();
+      const P4Out p4 = sweep_backward_null2_win<QB, Q, kLightTH, false, true>(c, (lds_u8 *)seq, Ld, cu, 1.0f / (xC * cu.move), kWinTol7, m0);
+      ST_T1((QB == 4 ? 5 : 6));
+      const bool ok = fabsf((float)Ld - p4.mass) <= kWinTol7 * (float)Ld;
+      if (ok) n_ok++; else n_fail++;
+      if (lane == 0) {
+        if (ok) { pp->domcorr[e] = p4.domcorr; pp->cls[e] = ST_CLS_NONE; atomicOr(&pp->path, QB == 4 ? WH_PATH_P4_W256 : WH_PATH_P4_W512); }
+        else { pp->cls[e] = ST_CLS_FULL; atomicOr(&pp->path, WH_PATH_P4_WFAIL); }
       }
-      pos = r;
-    }
-  }
+    });
   if (a.paths && lane == 0) {
     if (n_ok) atomicAdd(a.paths + (QB == 4 ? 0 : 1), (unsigned long long)n_ok);
     if (n_fail) atomicAdd(a.paths + 2, (unsigned long long)n_fail);
@@ -641,12 +641,10 @@ __global__ __launch_bounds__(kLightTH) __attribute__((amdgpu_waves_per_eu(5, 5))
 __global__ __launch_bounds__(256) void staged_assemble_kernel(StagedArgs g) {
   const ScoreArgs &a = g.a;
   const int pl = blockIdx.x * blockDim.x + threadIdx.x;
-  if (pl >= g.NB) return;
-  const int gitem = g.item0 + pl / a.QB;
-  if (pl / a.QB >= g.n_items_b) return;
-  const int h = a.hmm_list[gitem / a.n_qblocks];
-  const int64_t qi = (int64_t)(gitem % a.n_qblocks) * a.QB + pl % a.QB;
-  if (qi >= a.nq) return;
+  if (pl >= g.n_items_b * a.QB || !pair_valid(g, pl)) return;
+  const PairPos P = pair_pos(g, pl);
+  const int h = P.h;
+  const int64_t qi = P.qi;
   StPair *pp = g.pairs + pl;
   if (pp->state == 0) return;                       // P1 wrote the result
   const size_t out = (size_t)qi * a.H + h;
@@ -662,6 +660,8 @@ __global__ __launch_bounds__(256) void staged_assemble_kernel(StagedArgs g) {
   const int nenv = pp->nenv, nreg = pp->nreg, multi_mask = (pp->flags >> 8) & 0xFFFF;
   wh_pair_detail *dp = a.detail ? a.detail + out : nullptr;
   int path = pp->path;
+  if ((path & 256) && a.paths) atomicAdd(a.paths + 5, 1ull);     // wanted a window for P2, none fitted (the fused kernel counts these as rejected)
+  path &= 255;
   if (nenv > 0) {
     const bool queue_pair = multi_mask != 0 && a.rrecs != nullptr;
     float seqbias_sum = 0.f, sum_score = 0.f, sb2 = 0.f;
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(256) void staged_assemble_kernel(StagedArgs g) {
 }
 
 template <class K>
-static hipError_t launch_light_kind(K kern, const StagedArgs &g, int blocks, int threads, size_t lds, hipStream_t s) {
+static hipError_t launch_kind(K kern, const StagedArgs &g, int blocks, int threads, size_t lds, hipStream_t s) {
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (err != hipSuccess) return err;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, s, g);
@@ -719,86 +719,51 @@ static hipError_t launch_light_kind(K kern, const StagedArgs &g, int blocks, int
 
 }  // namespace WH_K7NS
 
-#define WH_ST_Q_CASES(CALL) \
-  switch (Q) {              \
-    case 8:  CALL(8);       \
-    case 12: CALL(12);      \
-    case 16: CALL(16);      \
-    case 20: CALL(20);      \
-    case 24: CALL(24);      \
-    default: return hipErrorInvalidValue; \
-  }
-
 #if WH_ST_PART != 2
-hipError_t launch_staged_p1(int Q, const StagedArgs &g, int blocks, int threads, size_t lds, hipStream_t s) {
-  using namespace WH_K7NS;
-  if (g.a.spec_arrays != kSpArr || threads > kStTH) return hipErrorInvalidValue;
-#define WH_CALL(q) return launch_dense_kind<q>(&staged_p1_kernel<q>, g, blocks, threads, lds, s)
-  WH_ST_Q_CASES(WH_CALL)
-#undef WH_CALL
-}
-hipError_t launch_staged_p2full(int Q, const StagedArgs &g, int blocks, int threads, size_t lds, hipStream_t s) {
-  using namespace WH_K7NS;
-  if (g.a.spec_arrays != kSpArr || threads > kStTH) return hipErrorInvalidValue;
-#define WH_CALL(q) return launch_dense_kind<q>(&staged_p2full_kernel<q>, g, blocks, threads, lds, s)
-  WH_ST_Q_CASES(WH_CALL)
-#undef WH_CALL
-}
-hipError_t launch_staged_p3(int Q, const StagedArgs &g, int blocks, int threads, size_t lds, hipStream_t s) {
-  using namespace WH_K7NS;
-  if (g.a.spec_arrays != kSpArr || threads > kStTH) return hipErrorInvalidValue;
-#define WH_CALL(q) return launch_dense_kind<q>(&staged_p3_kernel<q>, g, blocks, threads, lds, s)
-  WH_ST_Q_CASES(WH_CALL)
-#undef WH_CALL
-}
-hipError_t launch_staged_p4full(int Q, const StagedArgs &g, int blocks, int threads, size_t lds, hipStream_t s) {
-  using namespace WH_K7NS;
-  if (g.a.spec_arrays != kSpArr || threads > kStTH) return hipErrorInvalidValue;
-#define WH_CALL(q) return launch_dense_kind<q>(&staged_p4full_kernel<q>, g, blocks, threads, lds, s)
-  WH_ST_Q_CASES(WH_CALL)
-#undef WH_CALL
-}
-hipError_t launch_staged_dense(int Q, const StagedArgs &g, int blocks, int threads, size_t lds, hipStream_t s) {
-  using namespace WH_K7NS;
-  if (g.a.spec_arrays != kSpArr || threads > kStTH) return hipErrorInvalidValue;
-#define WH_CALL(q) return launch_dense_kind<q>(&staged_dense_kernel<q>, g, blocks, threads, lds, s)
-  WH_ST_Q_CASES(WH_CALL)
-#undef WH_CALL
-}
+#define WH_ST_DENSE_LAUNCHER(NAME, KERNEL)                                                                                  \
+  hipError_t NAME(int Q, const StagedArgs &g, int blocks, int threads, size_t lds, hipStream_t s) {                         \
+    using namespace WH_K7NS;                                                                                                \
+    if (g.a.spec_arrays != kSpArr || threads > kStTH) return hipErrorInvalidValue;                                          \
+    switch (Q) {                                                                                                            \
+      case 8:  return launch_kind(&KERNEL<8>, g, blocks, threads, lds, s);                                                  \
+      case 12: return launch_kind(&KERNEL<12>, g, blocks, threads, lds, s);                                                 \
+      case 16: return launch_kind(&KERNEL<16>, g, blocks, threads, lds, s);                                                 \
+      case 20: return launch_kind(&KERNEL<20>, g, blocks, threads, lds, s);                                                 \
+      case 24: return launch_kind(&KERNEL<24>, g, blocks, threads, lds, s);                                                 \
+      default: return hipErrorInvalidValue;                                                                                 \
+    }                                                                                                                       \
+  }
+WH_ST_DENSE_LAUNCHER(launch_staged_p1, staged_p1_kernel)
+WH_ST_DENSE_LAUNCHER(launch_staged_p2full, staged_p2full_kernel)
+WH_ST_DENSE_LAUNCHER(launch_staged_p3, staged_p3_kernel)
+WH_ST_DENSE_LAUNCHER(launch_staged_p4full, staged_p4full_kernel)
+WH_ST_DENSE_LAUNCHER(launch_staged_dense, staged_dense_kernel)
 #endif
 
 #if WH_ST_PART != 1
-hipError_t launch_staged_p2win(int Q, int QB, const StagedArgs &g, int blocks, int threads, size_t lds, hipStream_t s) {
-  using namespace WH_K7NS;
-  if (g.a.spec_arrays != kSpArr || threads > kLightTH) return hipErrorInvalidValue;
-  if (QB == 4) {
-#define WH_CALL(q) return launch_light_kind(&staged_p2win_kernel<q, 4>, g, blocks, threads, lds, s)
-    WH_ST_Q_CASES(WH_CALL)
-#undef WH_CALL
+#define WH_ST_LIGHT_LAUNCHER(NAME, KERNEL)                                                                                  \
+  hipError_t NAME(int Q, int QB, const StagedArgs &g, int blocks, int threads, size_t lds, hipStream_t s) {                 \
+    using namespace WH_K7NS;                                                                                                \
+    if (g.a.spec_arrays != kSpArr || threads > kLightTH) return hipErrorInvalidValue;                                       \
+    if (QB == 4) {                                                                                                          \
+      switch (Q) {                                                                                                          \
+        case 8:  return launch_kind(&KERNEL<8, 4>, g, blocks, threads, lds, s);                                             \
+        case 12: return launch_kind(&KERNEL<12, 4>, g, blocks, threads, lds, s);                                            \
+        case 16: return launch_kind(&KERNEL<16, 4>, g, blocks, threads, lds, s);                                            \
+        case 20: return launch_kind(&KERNEL<20, 4>, g, blocks, threads, lds, s);                                            \
+        case 24: return launch_kind(&KERNEL<24, 4>, g, blocks, threads, lds, s);                                            \
+        default: return hipErrorInvalidValue;                                                                               \
+      }                                                                                                                     \
+    }                                                                                                                       \
+    if (QB == 8 && Q == 16) return launch_kind(&KERNEL<16, 8>, g, blocks, threads, lds, s);                                 \
+    if (QB == 8 && Q == 24) return launch_kind(&KERNEL<24, 8>, g, blocks, threads, lds, s);                                 \
+    return hipErrorInvalidValue;                                                                                            \
   }
-  if (QB == 8) {
-    if (Q == 16) return launch_light_kind(&staged_p2win_kernel<16, 8>, g, blocks, threads, lds, s);
-    if (Q == 24) return launch_light_kind(&staged_p2win_kernel<24, 8>, g, blocks, threads, lds, s);
-  }
-  return hipErrorInvalidValue;
-}
-hipError_t launch_staged_p4win(int Q, int QB, const StagedArgs &g, int blocks, int threads, size_t lds, hipStream_t s) {
-  using namespace WH_K7NS;
-  if (g.a.spec_arrays != kSpArr || threads > kLightTH) return hipErrorInvalidValue;
-  if (QB == 4) {
-#define WH_CALL(q) return launch_light_kind(&staged_p4win_kernel<q, 4>, g, blocks, threads, lds, s)
-    WH_ST_Q_CASES(WH_CALL)
-#undef WH_CALL
-  }
-  if (QB == 8) {
-    if (Q == 16) return launch_light_kind(&staged_p4win_kernel<16, 8>, g, blocks, threads, lds, s);
-    if (Q == 24) return launch_light_kind(&staged_p4win_kernel<24, 8>, g, blocks, threads, lds, s);
-  }
-  return hipErrorInvalidValue;
-}
+WH_ST_LIGHT_LAUNCHER(launch_staged_p2win, staged_p2win_kernel)
+WH_ST_LIGHT_LAUNCHER(launch_staged_p4win, staged_p4win_kernel)
 hipError_t launch_staged_assemble(const StagedArgs &g, hipStream_t s) {
   using namespace WH_K7NS;
-  const int blocks = (g.NB + 255) / 256;
+  const int blocks = (g.n_items_b * g.a.QB + 255) / 256;
   hipLaunchKernelGGL(staged_assemble_kernel, dim3(blocks), dim3(256), 0, s, g);
   return hipGetLastError();
 }

@@ -938,6 +938,87 @@ def test_two_queries_per_wave_kernel_equals_the_one_query_kernel(tmp_path):
     e.close()
 
 
+@pytest.mark.gpu
+def test_staged_launches_equal_the_fused_kernel(tmp_path):
+    """wh_staged.hip (round 5; WH_SCORE_KERNEL=10: P1 | P2 on a window + certified scan | P2 at full width | envelopes as
+    launches of their own over batches of pairs; 11: P3 | P4 window | P4 full | dense redo | assembly split as well, one
+    Forward slab per envelope) calls the fused kernel's own sweep functions on the same inputs: deci-bits, flags, Forward
+    log-odds and EVERY field of the per-pair detail record are identical bitwise, the path counters of the envelope sweeps
+    too - on 1 024 x 200 headline pairs, on ragged / empty / unrelated / two-copy queries, with the resolver and without
+    it (multidomain regions as one envelope), with a batch size that forces several batches, and with too few envelope
+    units (the pass is repeated with the fused kernel and says so).  The per-pair path bytes (wh_set_path_buffer) agree
+    with the counters."""
+    _need_gpu()
+    import torch
+    import bench
+    from witch_amd.ehmm import EHMM, pack_queries
+    fam, se, names, seqs, k = bench.make_workload("dna_100k_x200", str(tmp_path), 1024, None)
+    e = EHMM(se.paths, hmm_index=se.index, nseq=se.nseq)
+    rng = np.random.default_rng(7)
+    ragged = [s_.astype(np.uint8)[: int(rng.integers(20, 151))] for s_ in seqs[:301]]
+    junk = [rng.integers(0, 4, size=int(n)).astype(np.uint8) for n in rng.integers(1, 150, size=40)]
+    twice = [np.concatenate([s_[:70], s_[:70]]).astype(np.uint8) for s_ in seqs[:60]]
+    mixed = ragged[:7] + [np.zeros(0, dtype=np.uint8)] + junk + twice
+
+    def run(batch, kernel, **opts):
+        res, offs = pack_queries(batch)
+        e.set_option("WH_SCORE_KERNEL", kernel)
+        for k_, v_ in opts.items():
+            e.set_option(k_, v_)
+        try:
+            d, f, w, det = e.score(res, offs, want_fwd=True, want_detail=True)
+            paths, reruns = e.last_score_paths(), e.last_queue_reruns()
+        finally:
+            e.set_option("WH_SCORE_KERNEL", "")
+            for k_ in opts:
+                e.set_option(k_, "")
+        return d, f, w, np.ctypeslib.as_array(det).copy(), paths, reruns
+
+    def same(a, b, what):
+        assert np.array_equal(a[1], b[1]), what
+        assert np.array_equal(a[0], b[0]), what
+        assert np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32)), what
+        for name in a[3].dtype.names:
+            x, y = a[3][name], b[3][name]
+            assert np.array_equal(x.view(np.int32) if x.dtype.kind == "f" else x, y.view(np.int32) if y.dtype.kind == "f" else y), (what, name)
+        env = ("window256", "window512", "window_rejected", "full_width")
+        assert [a[4][t] for t in env] == [b[4][t] for t in env], (what, a[4], b[4])
+
+    full = [s_.astype(np.uint8) for s_ in seqs]
+    for batch, tag in ((full, "headline"), (ragged, "ragged"), (mixed, "mixed")):
+        ref = run(batch, "7")
+        for kern in ("10", "11"):
+            got = run(batch, kern)
+            same(ref, got, (tag, kern))
+            assert got[5] == 0
+        if tag == "mixed":
+            assert int(((ref[1] & 2) != 0).sum()) > 0                          # the resolver's class is present
+            same(run(batch, "7", WH_NO_RESOLVE="1"), run(batch, "10", WH_NO_RESOLVE="1"), (tag, "no resolver"))
+            same(run(batch, "7", WH_NO_WINDOW="1"), run(batch, "11", WH_NO_WINDOW="1"), (tag, "no window"))
+    # several batches (units for ~1/6 of the pairs at a time), and too few units for even one work item's envelopes
+    ref = run(full, "7")
+    got = run(full, "11", WH_ST_UNITS="40000")
+    same(ref, got, "several batches")
+    got = run(mixed, "11", WH_ST_UNITS="16")
+    same(run(mixed, "7"), got, "unit overflow")
+    assert got[5] >= 1                                                         # ... repeated with the fused kernel
+    # per-pair path bytes: every reported pair of the headline batch went through one kind of P2 and its envelopes through P4
+    res, offs = pack_queries(full)
+    paths_t = torch.zeros((len(full), e.H), dtype=torch.uint8, device="cuda")
+    e.set_path_buffer(paths_t)
+    e.set_option("WH_SCORE_KERNEL", "10")
+    d, f = e.score(res, offs)
+    cnt = e.last_score_paths()
+    e.set_option("WH_SCORE_KERNEL", "")
+    e.set_path_buffer(None)
+    pb = paths_t.cpu().numpy()
+    rep = (f & 1) != 0
+    assert np.array_equal(d, ref[0]) and np.array_equal(f, ref[1])
+    assert np.all(((pb[rep] & 1) != 0) ^ ((pb[rep] & 2) != 0))                 # P2: window kept XOR full width
+    assert int(((pb & 1) != 0).sum()) == cnt["p2_window"]
+    e.close()
+
+
 def test_null2_by_trace_from_prefix_sums_equals_the_row_sums():
     """Round 4: the resolver forms the null2 vector of a sampled domain from float64 prefix sums of the emission odds over
     the nodes (a dozen row differences per domain) instead of adding one table row per residue in float32

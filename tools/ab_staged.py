@@ -30,7 +30,7 @@ def main():
         if os.environ.get("AB_STATS"):
             e.set_option("WH_STATS", "1")
         for rep in range(2):
-            for name, kern in (("fused", "7"), ("staged", "10")):
+            for name, kern in [("fused", "7")] + [("staged%s" % k, k) for k in os.environ.get("AB_KERNELS", "10").split(",")]:
                 e.set_option("WH_SCORE_KERNEL", kern)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
@@ -39,7 +39,16 @@ def main():
                 ms, _ = e.last_kernel_ms(0)
                 print("rep %d %-6s kernels %9.3f ms  (call %.3f s)  paths %s  reruns %d" % (rep, name, ms, dt, e.last_score_paths(), e.last_queue_reruns()), flush=True)
                 out[name] = (deci, flags, fwd, det)
-        a, b = out["fused"], out["staged"]
+        for key in [k for k in out if k != "fused"]:
+            compare(out["fused"], out[key], key)
+        e.close()
+    finally:
+        shutil.rmtree(wd, ignore_errors=True)
+
+
+def compare(a, b, key):
+    if True:
+        print("== fused vs", key)
         print("pairs %d  decibit diffs %d  flag diffs %d  fwd_bits diffs %d" % (a[0].size, int((a[0] != b[0]).sum()), int((a[1] != b[1]).sum()),
               int((a[2].view(np.int32) != b[2].view(np.int32)).sum())))
         da, db = np.ctypeslib.as_array(a[3]), np.ctypeslib.as_array(b[3])
@@ -55,9 +64,6 @@ def main():
                 idx = np.argwhere(neq)[:5]
                 for i in idx:
                     print("     at", tuple(int(v) for v in i), x[tuple(i)], y[tuple(i)])
-        e.close()
-    finally:
-        shutil.rmtree(wd, ignore_errors=True)
 
 
 if __name__ == "__main__":

@@ -355,7 +355,7 @@ int wh_set_option(wh_ehmm *e, const char *name, const char *value) {
   Knobs &k = e->knobs;
   if (!strcmp(name, "WH_SCORE_KERNEL")) {
     const int kv = *v ? atoi(v) : 7;
-    if (kv != 7 && kv != 8 && kv != 9 && kv != 10) { set_error("WH_SCORE_KERNEL=%s: this build has kernels 7, 8, 9 and 10", v); return WH_EINVAL; }
+    if (kv < 7 || kv > 11) { set_error("WH_SCORE_KERNEL=%s: this build has kernels 7 to 11", v); return WH_EINVAL; }
     k.kernel = kv;
   } else if (!strcmp(name, "WH_KEEP_LOG2")) k.keep_scale = *v ? ldexpf(1.0f, atoi(v)) : 0.f;
   else if (!strcmp(name, "WH_MAX_WAVES")) k.max_waves = *v ? std::max(1, std::min(16, atoi(v))) : 0;
@@ -365,7 +365,7 @@ int wh_set_option(wh_ehmm *e, const char *name, const char *value) {
   else if (!strcmp(name, "WH_NO_WINDOW")) k.no_window = on;
   else if (!strcmp(name, "WH_NO_P2WIN")) k.no_p2win = on;
   else if (!strcmp(name, "WH_RQUEUE_CAP")) k.rqueue_cap = *v ? std::max(1, atoi(v)) : 0;
-  else if (!strcmp(name, "WH_ST_UNITS")) k.st_units = *v ? std::max(64, atoi(v)) : 0;
+  else if (!strcmp(name, "WH_ST_UNITS")) k.st_units = *v ? std::max(16, atoi(v)) : 0;
   else if (!strcmp(name, "WH_NO_WIDE_ALIGN")) k.no_wide_align = on;
   else if (!strcmp(name, "WH_STATS")) k.stats = on;
   else if (!strcmp(name, "WH_TRACE")) k.trace = on;
@@ -521,8 +521,9 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
 // batches from the free HBM, and enqueues eight to ten launches per batch - nothing is read back in between: every
 // kernel takes its work from device-side lists and counters.  Batches are ranges of the class's work items (model-major,
 // a.QB queries each), so a batch holds one or two models' tables worth of pairs.
-static int score_staged_class(wh_ehmm *e, ScoreArgs a, int Q, int Lc, hipStream_t s, int *launches) {
+static int score_staged_class(wh_ehmm *e, ScoreArgs a, int Q, int Lc, hipStream_t s, int *launches, size_t *need_scratch) {
   const Knobs &kn = e->knobs;
+  const bool split = kn.kernel == 11;           // 11: P3 and P4 as launches of their own too (one Forward slab per envelope of a batch)
   const int sp = (Lc + 1 + 3) / 4 * 4;
   const int wl = kScoreSpecArrays * sp + 32 + kRegsInts + (Lc + 3) / 4 + 4;           // floats per wave block (plan_block1's, no extra rows)
   const size_t tbl = (size_t)Q * kWave * sizeof(float);
@@ -544,6 +545,12 @@ static int score_staged_class(wh_ehmm *e, ScoreArgs a, int Q, int Lc, hipStream_
   a.paths = reinterpret_cast<unsigned long long *>((int *)e->d_counter.p + kScorePathSlot);
   a.p2win = 0; a.qorder = nullptr;
   a.QB = QB;
+  a.scratch_stride = (size_t)(Lc + 1) * 2 * Q * kWave;          // the envelope kernel's per-wave Forward slab (as the fused kernel's)
+  if (need_scratch) {                                           // planning pass: the caller allocates once for all classes
+    if (!split) *need_scratch = std::max(*need_scratch, (size_t)e->cu_count * w_both * a.scratch_stride * sizeof(float));
+    return WH_OK;
+  }
+  a.scratch = (float *)e->d_scratch.p;
   a.n_qblocks = (int)((a.nq + a.QB - 1) / a.QB);
   a.n_items = a.n_list * a.n_qblocks;
   StagedArgs g;
@@ -551,10 +558,12 @@ static int score_staged_class(wh_ehmm *e, ScoreArgs a, int Q, int Lc, hipStream_
   g.slab_stride = (size_t)(Lc + 1) * 2 * Q * kWave;
   g.p1stride = (size_t)kScoreSpecArrays * sp;
   g.p3stride = g.p1stride;
-  // ---- batch size: units (Forward slabs) from the free HBM, at most <mult> per resident dense wave; pairs = units / (units per pair)
+  // ---- batch size.  Full split: units (Forward slabs) from the free HBM, at most sixteen per resident dense wave; pairs =
+  // units / (units per pair).  Otherwise a batch is bounded by its per-pair rows alone (3.6 KB per pair at L = 150).
   const int resident = e->cu_count * w_one;
   int64_t NS = (int64_t)resident * 16;
-  {
+  if (!split) NS = (int64_t)1 << 20;
+  if (split) {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
       const size_t have = e->d_st_slabs.cap + e->d_st_p3spec.cap;
@@ -565,21 +574,23 @@ static int score_staged_class(wh_ehmm *e, ScoreArgs a, int Q, int Lc, hipStream_
   if (kn.st_units > 0) NS = kn.st_units;
   const int64_t total_pairs = (int64_t)a.n_items * a.QB;
   NS = std::min<int64_t>(NS, (int64_t)((double)total_pairs * e->st_upp) + a.QB * WH_MAX_ENVELOPES);
-  if (NS < 64) { set_error("staged launches: no HBM for the Forward slabs (Q=%d, L=%d)", Q, Lc); return WH_ENOMEM; }
-  int items_b = (int)std::max<int64_t>(1, (int64_t)((double)NS / e->st_upp) / a.QB);
+  if (NS < 16) { set_error("staged launches: no HBM for the Forward slabs (Q=%d, L=%d)", Q, Lc); return WH_ENOMEM; }
+  const double upp = split ? e->st_upp : 1.0;
+  int items_b = (int)std::max<int64_t>(1, (int64_t)((double)NS / upp) / a.QB);
   items_b = std::min(items_b, a.n_items);
   // (batches of equal size, each a multiple of the workgroup count where the class is large enough for that)
   {
     const int nb = (a.n_items + items_b - 1) / items_b;
     items_b = (a.n_items + nb - 1) / nb;
-    if (items_b > 2 * e->cu_count) items_b = std::min((items_b + e->cu_count - 1) / e->cu_count * e->cu_count, (int)std::max<int64_t>(1, (int64_t)((double)NS / e->st_upp) / a.QB));
+    if (items_b > 2 * e->cu_count) items_b = std::min((items_b + e->cu_count - 1) / e->cu_count * e->cu_count, (int)std::max<int64_t>(1, (int64_t)((double)NS / upp) / a.QB));
   }
   const int NB = items_b * a.QB;
   const int n_batches = (a.n_items + items_b - 1) / items_b;
   if (e->d_st_pairs.ensure(sizeof(StPair) * (size_t)NB) || e->d_st_p1spec.ensure(sizeof(float) * g.p1stride * (size_t)NB) ||
-      e->d_st_units.ensure(sizeof(StUnit) * (size_t)NS) || e->d_st_p3spec.ensure(sizeof(float) * g.p3stride * (size_t)NS) ||
-      e->d_st_slabs.ensure(sizeof(float) * g.slab_stride * (size_t)NS) ||
       e->d_st_cnt.ensure(sizeof(int) * 32 * (size_t)(e->last_staged_batches + n_batches)))
+    return WH_ENOMEM;
+  if (split && (e->d_st_units.ensure(sizeof(StUnit) * (size_t)NS) || e->d_st_p3spec.ensure(sizeof(float) * g.p3stride * (size_t)NS) ||
+                e->d_st_slabs.ensure(sizeof(float) * g.slab_stride * (size_t)NS)))
     return WH_ENOMEM;
   g.NB = NB; g.NS = (int)NS;
   g.pairs = (StPair *)e->d_st_pairs.p; g.p1spec = (float *)e->d_st_p1spec.p;
@@ -609,6 +620,11 @@ static int score_staged_class(wh_ehmm *e, ScoreArgs a, int Q, int Lc, hipStream_
     if (go(G_most, 1)) err = launch_staged_p2win(Q, 4, g, std::min(groups(g.G), 2 * cu), w_p2 * kWave, lds_of(e->K, w_p2, g.cand_cap), s);
     if (w512 && go(G_few, 1)) err = launch_staged_p2win(Q, 8, g, std::min(groups(g.G), 2 * cu), w_p2 * kWave, lds_of(e->K, w_p2, g.cand_cap), s);
     if (go(G_few, 1)) err = launch_staged_p2full(Q, g, std::min(groups(g.G), cu), w_one * kWave, lds_of(e->K + BW_NARR, w_one, g.cand_cap), s);
+    if (!split) {
+      if (go(G_all, 1)) err = launch_staged_env(Q, g, std::min(groups(g.G), cu), w_both * kWave, lds_of(e->K + 2 * FW_NARR, w_both, g.cand_cap), s);
+      if (err != hipSuccess) { set_error("staged launch (Q=%d, batch %d) failed: %s", Q, b, hipGetErrorString(err)); return WH_EHIP; }
+      continue;
+    }
     if (go(G_all, WH_MAX_ENVELOPES)) err = launch_staged_p3(Q, g, std::min(groups(g.G), cu), w_one * kWave, lds_of(e->K + FW_NARR, w_one, g.cand_cap), s);
     if (go(G_most, WH_MAX_ENVELOPES)) err = launch_staged_p4win(Q, 4, g, std::min(groups(g.G), 2 * cu), w_p4 * kWave, lds_of(e->K, w_p4, g.cand_cap), s);
     if (w512 && go(G_few, WH_MAX_ENVELOPES)) err = launch_staged_p4win(Q, 8, g, std::min(groups(g.G), 2 * cu), w_p4 * kWave, lds_of(e->K, w_p4, g.cand_cap), s);
@@ -813,11 +829,11 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
         specg = true;
       }
       // ---- staged launches (wh_staged.hip): short-query batches of the one-wave classes, special states in LDS
-      const bool staged = kn.kernel == 10 && !e->st_off && !big && !pairk && !specg && !mixed && !kn.dbg &&
+      const bool staged = (kn.kernel == 10 || kn.kernel == 11) && !e->st_off && !big && !pairk && !specg && !mixed && !kn.dbg &&
                           (Q == 8 || Q == 12 || Q == 16 || Q == 20 || Q == 24);
       if (staged) {
-        if (pass == 0) continue;
-        int rc_st = score_staged_class(e, a, Q, Lc, s, &launches);
+        int rc_st = score_staged_class(e, a, Q, Lc, s, &launches, pass == 0 ? &need_scratch : nullptr);
+        if (pass == 0 && rc_st == WH_OK) continue;
         if (rc_st != WH_OK) return rc_st;
         continue;
       }

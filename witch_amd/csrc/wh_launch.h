@@ -109,6 +109,7 @@ hipError_t launch_staged_p3(int Q, const StagedArgs &a, int blocks, int threads,
 hipError_t launch_staged_p4win(int Q, int QB, const StagedArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
 hipError_t launch_staged_p4full(int Q, const StagedArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
 hipError_t launch_staged_dense(int Q, const StagedArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
+hipError_t launch_staged_env(int Q, const StagedArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
 hipError_t launch_staged_assemble(const StagedArgs &a, hipStream_t s);
 
 hipError_t launch_score_big(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);

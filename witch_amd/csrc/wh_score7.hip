@@ -721,8 +721,129 @@ __device__ __noinline__ RegOut region_scan(lds_f *spec3, glb_f *specg, int SP, i
   return o;
 }
 
-#ifndef WH_SWEEPS_ONLY
+// ---------------------------------------------------------------- envelopes + score assembly (A.5, A.6)
+// Everything a pair needs after its regions are known: per envelope P3 (sparse spill) -> P4 on a node window / at full
+// width / dense redo -> null2; then HMMER's float32 score assembly, or the pair's record for the multidomain resolver.
+// Inlined into its two callers: the fused kernel below, and the envelope kernel of the staged launches (wh_staged.hip),
+// whose P1 / P2 ran as launches of their own.
+struct EnvCounters { unsigned n_w256, n_w512, n_wfail, n_full; };
 #define WH_TICK7(slot) do { if (a.stats) { const long long t_now = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(a.stats + (slot), (unsigned long long)(t_now - t_last)); t_last = t_now; } } while (0)
+template <int Q, int TH, bool SG>
+__device__ __forceinline__ void score_envelopes(const ScoreArgs &a, WaveCtx &c, uint8_t *seq, int *regs, int L, int lane, int h, int64_t qi, int nenv, int nreg,
+                                                int multi_mask, float fwdsc, float nullsc, float fwd_bits_out, wh_pair_detail *dp, int &flags, int &decibits,
+                                                EnvCounters &ec, long long &t_last) {
+  const double LOG2 = 0.69314718055994529;
+  const int SP = c.SP;
+  {
+  // ---------------- envelopes
+  const LenCfg cu = len_config(L, false);
+  float seqbias_sum = 0.f, sum_score = 0.f, sb2 = 0.f;
+  int Ld_tot = 0;
+  // a pair with a multidomain region is finished by resolve_kernel (A.4b); its single-domain
+  // regions are still scored here, their results staged in LDS for the pair's queue record
+  const bool queue_pair = multi_mask != 0 && a.rrecs != nullptr;
+  float *envres = reinterpret_cast<float *>(regs + 3 * WH_MAX_ENVELOPES);
+  for (int e = 0; e < nenv; e++) {
+    if (queue_pair && ((multi_mask >> e) & 1)) { if (lane == 0) { envres[e] = 0.f; envres[WH_MAX_ENVELOPES + e] = 0.f; } continue; }
+    const int ri = regs[2 * e], rj = regs[2 * e + 1];
+    const int Ld = rj - ri + 1;
+    const uint8_t *eseq = seq + (ri - 1);
+    float envsc = -INFINITY, domcorr = 0.f;
+#pragma unroll 1
+    for (int attempt = 0; attempt < 2; attempt++) {
+      const float keep_scale = attempt == 0 ? (a.keep_scale > 0.f ? a.keep_scale : kKeepScale7) : -1.0f;
+      const FwdOut f3 = sweep_forward<Q, true, TH, SG>(c, (lds_u8 *)eseq, Ld, cu, keep_scale);
+      // the rows were written by other lanes of this wave: order the stores before the loads
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      envsc = (float)((double)f3.ef * LOG2 + log((double)(f3.xC * cu.move)));
+      domcorr = 0.f;
+      if (!(f3.xC > 0.f)) break;
+      WH_TICK7(7);
+      const float tol = attempt == 0 ? kMassTol7 : INFINITY;
+      P4Out p4;
+      bool have4 = false;
+      if constexpr (Q >= 8) {
+        if (attempt == 0 && !a.no_window) {
+          // the node window around the lane blocks the dominant alignment runs through (two blocks in
+          // front: the envelope's first ~25 rows set no bit and lie that many nodes ahead; one block behind)
+          const unsigned *su = reinterpret_cast<const unsigned *>(SG ? (const float *)c.specg : (const float *)c.spec);
+          const unsigned long long um = ((unsigned long long)su[kSpMH * SP] << 32) | su[kSpML * SP];
+          if (um != 0) {
+            int lo = __builtin_ctzll(um), hi = 63 - __builtin_clzll(um);
+            lo = lo > 1 ? lo - 2 : 0; hi = hi < 63 ? hi + 1 : 63;
+            const int nodes = (hi - lo + 1) * Q;
+            if (a.stats && lane == 0) { atomicAdd(a.stats + 12, (unsigned long long)(hi - lo + 1)); atomicAdd(a.stats + 14, 1ull); atomicAdd(a.stats + 15, (unsigned long long)__builtin_popcountll(um)); }
+            if (nodes <= 4 * kWave) {
+              const int m0 = min((63 - hi) * Q, kWave * (Q - 4));
+              p4 = sweep_backward_null2_win<4, Q, TH, SG>(c, (lds_u8 *)eseq, Ld, cu, 1.0f / (f3.xC * cu.move), kWinTol7, m0);
+              have4 = fabsf((float)Ld - p4.mass) <= kWinTol7 * (float)Ld;
+              if (have4) ec.n_w256++; else ec.n_wfail++;
+              if (a.stats && lane == 0) {
+                atomicAdd(a.stats + (have4 ? 0 : 2), 1ull);
+                const float dev = fabsf((float)Ld - p4.mass) / (float)Ld;
+                atomicAdd(a.stats + (dev < 3e-7f ? 16 : dev < 1e-6f ? 17 : dev < 3e-6f ? 18 : dev < 1e-5f ? 19 : dev < 2e-5f ? 20 : 21), 1ull);
+              }
+            } else if (Q % 8 == 0 && Q > 8 && nodes <= 8 * kWave) {
+              const int m0 = min((63 - hi) * Q, kWave * (Q - 8));
+              p4 = sweep_backward_null2_win<(Q % 8 == 0 ? 8 : 4), Q, TH, SG>(c, (lds_u8 *)eseq, Ld, cu, 1.0f / (f3.xC * cu.move), kWinTol7, m0);
+              have4 = fabsf((float)Ld - p4.mass) <= kWinTol7 * (float)Ld;
+              if (have4) ec.n_w512++; else ec.n_wfail++;
+              if (a.stats && lane == 0) atomicAdd(a.stats + (have4 ? 1 : 2), 1ull);
+            }
+          }
+        }
+      }
+      if (!have4) {
+        p4 = sweep_backward_null2<Q, TH, SG>(c, (lds_u8 *)eseq, Ld, cu, 1.0f / (f3.xC * cu.move), f3.ef, tol);
+        ec.n_full++;
+        if (a.stats && lane == 0) {
+          atomicAdd(a.stats + 3, 1ull);
+          const float dev = fabsf((float)Ld - p4.mass) / (float)Ld;
+          atomicAdd(a.stats + (dev < 3e-7f ? 22 : dev < 1e-6f ? 23 : dev < 3e-6f ? 24 : dev < 1e-5f ? 25 : dev < 2e-5f ? 26 : 27), 1ull);
+        }
+      }
+      domcorr = p4.domcorr;
+      WH_TICK7(8);
+      if (attempt == 0 && !(fabsf((float)Ld - p4.mass) <= kMassTol7 * (float)Ld)) continue;
+      if (attempt == 1) flags |= WH_FLAG_EXACT;
+      break;
+    }
+    seqbias_sum += domcorr;
+    if (envsc - domcorr > 0.0f) { sum_score += envsc; Ld_tot += Ld; sb2 += domcorr; }
+    if (dp) { dp->env_i[e] = ri; dp->env_j[e] = rj; dp->envsc[e] = envsc; dp->domcorr[e] = domcorr; }
+    if (queue_pair && lane == 0) { envres[e] = envsc; envres[WH_MAX_ENVELOPES + e] = domcorr; }
+  }
+  if (queue_pair) {
+    __builtin_amdgcn_wave_barrier();
+    int slot = 0;
+    if (lane == 0) slot = atomicAdd(a.rcount, 1);
+    slot = __shfl(slot, 0);
+    if (slot < a.rcap && lane == 0) {
+      ResolveRec *rr = a.rrecs + slot;
+      rr->q = qi; rr->h = h; rr->fwdsc = fwdsc; rr->fwd_bits = fwd_bits_out; rr->nreg = nreg; rr->nenv = nenv;
+      rr->multi_mask = multi_mask; rr->flags = flags;
+      for (int e = 0; e < nenv; e++) { rr->ri[e] = regs[2 * e]; rr->rj[e] = regs[2 * e + 1]; rr->envsc[e] = envres[e]; rr->domcorr[e] = envres[WH_MAX_ENVELOPES + e]; }
+    }
+    // provisional result: resolve_kernel writes the final score and flags of this pair
+  } else {
+  // ---------------- A.6 score assembly (float32 where HMMER is float32)
+  const float lomega = (float)log(1.0 / 256.0);
+  const float seqbias = flogsum0_v7(lomega + seqbias_sum);
+  float pre_score = (float)(((double)fwdsc - (double)nullsc) / LOG2);
+  float seq_score = (float)(((double)fwdsc - (double)(nullsc + seqbias)) / LOG2);
+  sb2 = flogsum0_v7(lomega + sb2);
+  sum_score += (float)((double)(L - Ld_tot) * log((double)((float)L / (float)(L + 3))));
+  const float pre2 = (float)(((double)sum_score - (double)nullsc) / LOG2);
+  sum_score = (float)(((double)sum_score - (double)(nullsc + sb2)) / LOG2);
+  if (Ld_tot > 0 && sum_score > seq_score) { seq_score = sum_score; pre_score = pre2; flags |= WH_FLAG_OVERRIDE; }
+  decibits = (int)rint((double)seq_score * 10.0);
+  flags |= WH_FLAG_REPORTED;
+  if (dp) { dp->seq_score = seq_score; dp->pre_score = pre_score; dp->seqbias_nats = seqbias; }
+  }
+  }
+}
+
+#ifndef WH_SWEEPS_ONLY
 
 template <int Q, int TH, bool SG>
 __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
@@ -750,7 +871,7 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
   const double LOG2 = 0.69314718055994529;
   int cur_h = -1;
   const DevHMM *hm = nullptr;
-  unsigned n_w256 = 0, n_w512 = 0, n_wfail = 0, n_full = 0;   // this wave's envelope Backward sweeps by path (wh_last_score_paths)
+  EnvCounters ec = {0, 0, 0, 0};                              // this wave's envelope Backward sweeps by path (wh_last_score_paths)
   unsigned n_p2w = 0, n_p2rej = 0;                            // multihit Backward sweeps kept from a window / windows in doubt (redone at full width)
   float eps_prev = 0.f, eps_prev2 = 0.f;                      // slack of the last two windows tried on the current model
   unsigned n_pairs_h = 0;                                     // pairs of the current model this wave has scored
@@ -858,111 +979,7 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
           if (dp) { dp->nregions = nreg; dp->nenv = nenv; }
           if (nenv > 0) {
             WH_TICK7(6);
-            // ---------------- envelopes
-            const LenCfg cu = len_config(L, false);
-            float seqbias_sum = 0.f, sum_score = 0.f, sb2 = 0.f;
-            int Ld_tot = 0;
-            // a pair with a multidomain region is finished by resolve_kernel (A.4b); its single-domain
-            // regions are still scored here, their results staged in LDS for the pair's queue record
-            const bool queue_pair = multi_mask != 0 && a.rrecs != nullptr;
-            float *envres = reinterpret_cast<float *>(regs + 3 * WH_MAX_ENVELOPES);
-            for (int e = 0; e < nenv; e++) {
-              if (queue_pair && ((multi_mask >> e) & 1)) { if (lane == 0) { envres[e] = 0.f; envres[WH_MAX_ENVELOPES + e] = 0.f; } continue; }
-              const int ri = regs[2 * e], rj = regs[2 * e + 1];
-              const int Ld = rj - ri + 1;
-              const uint8_t *eseq = seq + (ri - 1);
-              float envsc = -INFINITY, domcorr = 0.f;
-#pragma unroll 1
-              for (int attempt = 0; attempt < 2; attempt++) {
-                const float keep_scale = attempt == 0 ? (a.keep_scale > 0.f ? a.keep_scale : kKeepScale7) : -1.0f;
-                const FwdOut f3 = sweep_forward<Q, true, TH, SG>(c, (lds_u8 *)eseq, Ld, cu, keep_scale);
-                // the rows were written by other lanes of this wave: order the stores before the loads
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                envsc = (float)((double)f3.ef * LOG2 + log((double)(f3.xC * cu.move)));
-                domcorr = 0.f;
-                if (!(f3.xC > 0.f)) break;
-                WH_TICK7(7);
-                const float tol = attempt == 0 ? kMassTol7 : INFINITY;
-                P4Out p4;
-                bool have4 = false;
-                if constexpr (Q >= 8) {
-                  if (attempt == 0 && !a.no_window) {
-                    // the node window around the lane blocks the dominant alignment runs through (two blocks in
-                    // front: the envelope's first ~25 rows set no bit and lie that many nodes ahead; one block behind)
-                    const unsigned *su = reinterpret_cast<const unsigned *>(SG ? (const float *)c.specg : (const float *)c.spec);
-                    const unsigned long long um = ((unsigned long long)su[kSpMH * SP] << 32) | su[kSpML * SP];
-                    if (um != 0) {
-                      int lo = __builtin_ctzll(um), hi = 63 - __builtin_clzll(um);
-                      lo = lo > 1 ? lo - 2 : 0; hi = hi < 63 ? hi + 1 : 63;
-                      const int nodes = (hi - lo + 1) * Q;
-                      if (a.stats && lane == 0) { atomicAdd(a.stats + 12, (unsigned long long)(hi - lo + 1)); atomicAdd(a.stats + 14, 1ull); atomicAdd(a.stats + 15, (unsigned long long)__builtin_popcountll(um)); }
-                      if (nodes <= 4 * kWave) {
-                        const int m0 = min((63 - hi) * Q, kWave * (Q - 4));
-                        p4 = sweep_backward_null2_win<4, Q, TH, SG>(c, (lds_u8 *)eseq, Ld, cu, 1.0f / (f3.xC * cu.move), kWinTol7, m0);
-                        have4 = fabsf((float)Ld - p4.mass) <= kWinTol7 * (float)Ld;
-                        if (have4) n_w256++; else n_wfail++;
-                        if (a.stats && lane == 0) {
-                          atomicAdd(a.stats + (have4 ? 0 : 2), 1ull);
-                          const float dev = fabsf((float)Ld - p4.mass) / (float)Ld;
-                          atomicAdd(a.stats + (dev < 3e-7f ? 16 : dev < 1e-6f ? 17 : dev < 3e-6f ? 18 : dev < 1e-5f ? 19 : dev < 2e-5f ? 20 : 21), 1ull);
-                        }
-                      } else if (Q % 8 == 0 && Q > 8 && nodes <= 8 * kWave) {
-                        const int m0 = min((63 - hi) * Q, kWave * (Q - 8));
-                        p4 = sweep_backward_null2_win<(Q % 8 == 0 ? 8 : 4), Q, TH, SG>(c, (lds_u8 *)eseq, Ld, cu, 1.0f / (f3.xC * cu.move), kWinTol7, m0);
-                        have4 = fabsf((float)Ld - p4.mass) <= kWinTol7 * (float)Ld;
-                        if (have4) n_w512++; else n_wfail++;
-                        if (a.stats && lane == 0) atomicAdd(a.stats + (have4 ? 1 : 2), 1ull);
-                      }
-                    }
-                  }
-                }
-                if (!have4) {
-                  p4 = sweep_backward_null2<Q, TH, SG>(c, (lds_u8 *)eseq, Ld, cu, 1.0f / (f3.xC * cu.move), f3.ef, tol);
-                  n_full++;
-                  if (a.stats && lane == 0) {
-                    atomicAdd(a.stats + 3, 1ull);
-                    const float dev = fabsf((float)Ld - p4.mass) / (float)Ld;
-                    atomicAdd(a.stats + (dev < 3e-7f ? 22 : dev < 1e-6f ? 23 : dev < 3e-6f ? 24 : dev < 1e-5f ? 25 : dev < 2e-5f ? 26 : 27), 1ull);
-                  }
-                }
-                domcorr = p4.domcorr;
-                WH_TICK7(8);
-                if (attempt == 0 && !(fabsf((float)Ld - p4.mass) <= kMassTol7 * (float)Ld)) continue;
-                if (attempt == 1) flags |= WH_FLAG_EXACT;
-                break;
-              }
-              seqbias_sum += domcorr;
-              if (envsc - domcorr > 0.0f) { sum_score += envsc; Ld_tot += Ld; sb2 += domcorr; }
-              if (dp) { dp->env_i[e] = ri; dp->env_j[e] = rj; dp->envsc[e] = envsc; dp->domcorr[e] = domcorr; }
-              if (queue_pair && lane == 0) { envres[e] = envsc; envres[WH_MAX_ENVELOPES + e] = domcorr; }
-            }
-            if (queue_pair) {
-              __builtin_amdgcn_wave_barrier();
-              int slot = 0;
-              if (lane == 0) slot = atomicAdd(a.rcount, 1);
-              slot = __shfl(slot, 0);
-              if (slot < a.rcap && lane == 0) {
-                ResolveRec *rr = a.rrecs + slot;
-                rr->q = qi; rr->h = h; rr->fwdsc = fwdsc; rr->fwd_bits = fwd_bits_out; rr->nreg = nreg; rr->nenv = nenv;
-                rr->multi_mask = multi_mask; rr->flags = flags;
-                for (int e = 0; e < nenv; e++) { rr->ri[e] = regs[2 * e]; rr->rj[e] = regs[2 * e + 1]; rr->envsc[e] = envres[e]; rr->domcorr[e] = envres[WH_MAX_ENVELOPES + e]; }
-              }
-              // provisional result: resolve_kernel writes the final score and flags of this pair
-            } else {
-            // ---------------- A.6 score assembly (float32 where HMMER is float32)
-            const float lomega = (float)log(1.0 / 256.0);
-            const float seqbias = flogsum0_v7(lomega + seqbias_sum);
-            float pre_score = (float)(((double)fwdsc - (double)nullsc) / LOG2);
-            float seq_score = (float)(((double)fwdsc - (double)(nullsc + seqbias)) / LOG2);
-            sb2 = flogsum0_v7(lomega + sb2);
-            sum_score += (float)((double)(L - Ld_tot) * log((double)((float)L / (float)(L + 3))));
-            const float pre2 = (float)(((double)sum_score - (double)nullsc) / LOG2);
-            sum_score = (float)(((double)sum_score - (double)(nullsc + sb2)) / LOG2);
-            if (Ld_tot > 0 && sum_score > seq_score) { seq_score = sum_score; pre_score = pre2; flags |= WH_FLAG_OVERRIDE; }
-            decibits = (int)rint((double)seq_score * 10.0);
-            flags |= WH_FLAG_REPORTED;
-            if (dp) { dp->seq_score = seq_score; dp->pre_score = pre_score; dp->seqbias_nats = seqbias; }
-            }
+            score_envelopes<Q, TH, SG>(a, c, seq, regs, L, lane, h, qi, nenv, nreg, multi_mask, fwdsc, nullsc, fwd_bits_out, dp, flags, decibits, ec, t_last);
           }
         }
       }
@@ -974,10 +991,10 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
     }
   }
   if (a.paths && lane == 0) {
-    if (n_w256) atomicAdd(a.paths + 0, (unsigned long long)n_w256);
-    if (n_w512) atomicAdd(a.paths + 1, (unsigned long long)n_w512);
-    if (n_wfail) atomicAdd(a.paths + 2, (unsigned long long)n_wfail);
-    if (n_full) atomicAdd(a.paths + 3, (unsigned long long)n_full);
+    if (ec.n_w256) atomicAdd(a.paths + 0, (unsigned long long)ec.n_w256);
+    if (ec.n_w512) atomicAdd(a.paths + 1, (unsigned long long)ec.n_w512);
+    if (ec.n_wfail) atomicAdd(a.paths + 2, (unsigned long long)ec.n_wfail);
+    if (ec.n_full) atomicAdd(a.paths + 3, (unsigned long long)ec.n_full);
     if (n_p2w) atomicAdd(a.paths + 4, (unsigned long long)n_p2w);
     if (n_p2rej) atomicAdd(a.paths + 5, (unsigned long long)n_p2rej);
   }

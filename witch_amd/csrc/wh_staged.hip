@@ -497,6 +497,78 @@ __global__ __launch_bounds__(kStTH) void staged_dense_kernel(StagedArgs g) {
   ST_K1(8);
 }
 
+// ================================================================================================ env: P3 + P4 + assembly, fused per pair
+// The envelope half of the fused kernel (score_envelopes, wh_score7.hip) for pairs whose regions are known: one wavefront
+// per pair, its Forward slab reused from pair to pair as in the fused kernel - the spill traffic of P3 then overlaps with
+// the other waves' arithmetic instead of being a launch of its own (the full split above is HBM-bound in P3 and P4).
+template <int Q>
+__global__ __launch_bounds__(kStTH) void staged_env_kernel(StagedArgs g) {
+  const ScoreArgs &a = g.a;
+  extern __shared__ __attribute__((aligned(16))) float smem_raw[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  constexpr int TBL = Q * kWave;
+  StLds<Q> S(smem_raw, a.K, 2 * FW_NARR, wave, nwaves, a.wave_lds);
+  WaveCtx c = make_ctx(a, S.em, S.tr, S.tr + FW_NARR * TBL, S.wbase, lane);
+  c.Fs = (glb_f *)(a.scratch + ((size_t)blockIdx.x * nwaves + wave) * a.scratch_stride);
+  uint8_t *seq = ctx_seq(a, S.wbase);
+  int *regs = ctx_regs(a, S.wbase);
+  const double LOG2 = 0.69314718055994529;
+  EnvCounters ec = {0, 0, 0, 0};
+  ST_K0();
+  group_loop(g, ST_C_P3, S.slot, S.cand, 1,
+    [&](int h) {
+      const DevHMM *hm = a.hmms + h;
+      copy_f4(S.em, a.tables + hm->em_off, a.K * TBL);
+      copy_f4(S.tr, a.tables + hm->fw_off, FW_NARR * TBL);
+      copy_f4(S.tr + FW_NARR * TBL, a.tables + hm->bw_off, BW_NARR * TBL);
+      c.emG = (const glb_f *)(a.tables + hm->em_off);
+    },
+    [&](int pl, auto emit) { if (pair_valid(g, pl) && g.pairs[pl].state == 2) emit(pl); },
+    [&](int pl, int h) {
+      StPair *pp = g.pairs + pl;
+      const PairPos P = pair_pos(g, pl);
+      const int64_t qi = P.qi;
+      const int64_t off = a.offsets[qi];
+      const int L = (int)(a.offsets[qi + 1] - off);
+      const size_t out = (size_t)qi * a.H + h;
+      const int nenv = bcast_i(pp->nenv), nreg = bcast_i(pp->nreg), pflags = bcast_i(pp->flags);
+      int flags = pflags & 0xFF, decibits = 0;
+      const int multi_mask = pflags >> 8;
+      const LenCfg cm = len_config(L, true);
+      const float xC = pp->xC; const int ef = pp->ef;
+      const double fwd_nats = (double)ef * LOG2 + log((double)(xC * cm.move));
+      const float fwdsc = (float)fwd_nats;
+      const float p1 = (float)L / (float)(L + 1);
+      const float nullsc = (float)((double)(float)L * log((double)p1) + log(1.0 - (double)p1));
+      const float fwd_bits_out = (float)((fwd_nats - (double)nullsc) / LOG2);
+      wh_pair_detail *dp = (a.detail && lane == 0) ? a.detail + out : nullptr;
+      int path = bcast_i(pp->path);
+      if (nenv > 0) {
+        load_seq(a, seq, off, L, lane);
+        if (lane < 2 * nenv) regs[lane] = pp->regs[lane];
+        __builtin_amdgcn_wave_barrier();
+        long long t_last = 0;
+        ST_T0();
+        score_envelopes<Q, kStTH, false>(a, c, seq, regs, L, lane, h, qi, nenv, nreg, multi_mask, fwdsc, nullsc, fwd_bits_out, dp, flags, decibits, ec, t_last);
+        ST_T1(4);
+        if (multi_mask != 0 && a.rrecs != nullptr) path |= WH_PATH_MULTI;
+      }
+      if (lane == 0) {
+        if ((path & 256) && a.paths) atomicAdd(a.paths + 5, 1ull);      // wanted a window for P2, none fitted (counted as the fused kernel counts it)
+        a.decibits[out] = decibits;
+        a.flags[out] = (uint8_t)flags;
+        if (g.pair_paths) g.pair_paths[out] = (uint8_t)path;
+      }
+    });
+  if (a.paths && lane == 0) {
+    if (ec.n_w256) atomicAdd(a.paths + 0, (unsigned long long)ec.n_w256);
+    if (ec.n_w512) atomicAdd(a.paths + 1, (unsigned long long)ec.n_w512);
+    if (ec.n_wfail) atomicAdd(a.paths + 2, (unsigned long long)ec.n_wfail);
+    if (ec.n_full) atomicAdd(a.paths + 3, (unsigned long long)ec.n_full);
+  }
+  ST_K1(4);
+}
+
 template <class K>
 static hipError_t launch_kind(K kern, const StagedArgs &g, int blocks, int threads, size_t lds, hipStream_t s) {
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -512,7 +584,7 @@ static hipError_t launch_kind(K kern, const StagedArgs &g, int blocks, int threa
 // L2 once per pair (BWG) and works on a COPY of P1's rows (INPL).  The 256-node launch sees every pair after P1 (state 1)
 // and passes on what it cannot serve: to the 512-node launch (state 4) or to the full-width launch (state 3).
 template <int Q, int QB>
-__global__ __launch_bounds__(kLightTH) __attribute__((amdgpu_waves_per_eu(6, 6))) void staged_p2win_kernel(StagedArgs g) {
+__global__ __launch_bounds__(kLightTH) __attribute__((amdgpu_waves_per_eu(QB == 4 ? 6 : 4, QB == 4 ? 6 : 4))) void staged_p2win_kernel(StagedArgs g) {
   const ScoreArgs &a = g.a;
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
@@ -582,7 +654,7 @@ __global__ __launch_bounds__(kLightTH) __attribute__((amdgpu_waves_per_eu(6, 6))
 
 // ================================================================================================ p4win: envelope Backward on a node window
 template <int Q, int QB>
-__global__ __launch_bounds__(kLightTH) __attribute__((amdgpu_waves_per_eu(5, 5))) void staged_p4win_kernel(StagedArgs g) {
+__global__ __launch_bounds__(kLightTH) __attribute__((amdgpu_waves_per_eu(QB == 4 ? 5 : 3, QB == 4 ? 5 : 3))) void staged_p4win_kernel(StagedArgs g) {
   const ScoreArgs &a = g.a;
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
@@ -738,6 +810,7 @@ WH_ST_DENSE_LAUNCHER(launch_staged_p2full, staged_p2full_kernel)
 WH_ST_DENSE_LAUNCHER(launch_staged_p3, staged_p3_kernel)
 WH_ST_DENSE_LAUNCHER(launch_staged_p4full, staged_p4full_kernel)
 WH_ST_DENSE_LAUNCHER(launch_staged_dense, staged_dense_kernel)
+WH_ST_DENSE_LAUNCHER(launch_staged_env, staged_env_kernel)
 #endif
 
 #if WH_ST_PART != 1

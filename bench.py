@@ -259,17 +259,22 @@ def score_roofline(M, lens_local, class_ms, kern_ms0, kern_n0, steps, H, stamp, 
     of the scoring time (one launch per cells-per-lane class); its cells = the local residues x the nodes of ITS models."""
     def cls_of(m):      # cells-per-lane class of a model (witch_amd/csrc/wh_hmm.cpp choose_Q: next multiple of 4)
         return max(4, (-(-int(m) // 64) + 3) // 4 * 4)
+
+    def wide_class(m):  # (cells per lane, waves per pair) of the several-waves-per-pair kernels (wh_api.hip wide_q_of: 12 cells up to 6 144 nodes, 16 up to 8 192, 24 beyond)
+        wq = 12 if m <= 6144 else 16 if m <= 8192 else 24
+        return wq, -(-int(m) // (64 * wq))
     if class_ms:
         (dom_q, dom_kind), (dom_ms, dom_n) = max(class_ms.items(), key=lambda kv: kv[1][0])
         if dom_kind == 2:
             dom_M = M[M > 3072]
-        elif dom_kind == 3:         # several waves per pair: the class key is cells per lane x waves (24 x W)
-            dom_M = M[np.array([m > 3072 and -(-int(m) // 1536) * 24 == dom_q for m in M])]
+        elif dom_kind == 3:         # several waves per pair: the class key is cells per lane x waves, as the library forms it
+            dom_M = M[np.array([m > 3072 and wide_class(m)[0] * wide_class(m)[1] == dom_q for m in M])]
         else:
             dom_M = M[np.array([cls_of(m) == dom_q for m in M])]
         score_launches, score_ms = max(dom_n, 1), dom_ms / max(dom_n, 1)
         cells_launch = float(lens_local.sum() * dom_M.sum()) * steps / score_launches
-        dom_name = (FAM_NAMES[2] if dom_kind == 2 else "%s<24 cells per lane, %d waves per pair>" % (FAM_NAMES[3], dom_q // 24) if dom_kind == 3
+        wq_w = wide_class(int(dom_M.max())) if dom_kind == 3 and len(dom_M) else (0, 0)
+        dom_name = (FAM_NAMES[2] if dom_kind == 2 else "%s<%d cells per lane, %d waves per pair>" % ((FAM_NAMES[3],) + wq_w) if dom_kind == 3
                     else "%s<%d cells per lane>" % (FAM_NAMES.get(dom_kind, "?"), dom_q))
         dom_share = dom_ms / max(kern_ms0, 1e-9)
     else:

@@ -47,6 +47,41 @@ def test_sharded_topk_gather(tmp_path, nq, world):
         assert open(tmp_path / ("rank%d" % r)).read() == "ok"
 
 
+def _mismatch_worker(rank, world, port, outdir):
+    import torch
+    import torch.distributed as dist
+    from witch_amd.distributed import gather_topk, shard_range
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    nq, k = 11, 4
+    lo, hi = shard_range(nq, rank, world)
+    n = hi - lo + (1 if rank == 1 else 0)                 # rank 1 brings one row too many
+    args = (torch.zeros((n, k), dtype=torch.int32), torch.zeros((n, k), dtype=torch.float64), torch.zeros(n, dtype=torch.int32), torch.zeros(n, dtype=torch.int32))
+    try:
+        gather_topk(*args, n_total=nq)
+        out = "returned"
+    except ValueError:
+        out = "raised"
+    try:                                                  # wrong dtype: refused before anything is packed (on every rank alike)
+        gather_topk(args[0], args[1].float(), args[2], args[3], n_total=None)
+        out += " returned"
+    except TypeError:
+        out += " typeerror"
+    open(os.path.join(outdir, "rank%d" % rank), "w").write(out)
+    dist.destroy_process_group()
+
+
+def test_a_rank_with_the_wrong_row_count_fails_on_every_rank(tmp_path):
+    """One rank's table is not its shard's: every rank raises (they agree on the failure with one all-reduce) instead of
+    one raising and the others waiting in the collective until the backend times out."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_mismatch_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert open(tmp_path / ("rank%d" % r)).read() == "raised typeerror"
+
+
 def test_shard_ranges_cover_and_are_contiguous():
     from witch_amd.distributed import shard_range
     for n in (0, 1, 7, 100000):

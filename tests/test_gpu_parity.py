@@ -15,6 +15,8 @@ import os
 import numpy as np
 import pytest
 
+from witch_amd._lib import WH_MAX_ENVELOPES
+
 pytestmark = pytest.mark.gpu
 
 BOUNDARY_EPS = 2e-3   # bits; float32 ulp at 100+ bits is 8e-6, null2 sums differ by a few ulp
@@ -96,7 +98,7 @@ def test_score_against_oracle_and_golden(golden_case, orc):
             r = ohm[hj].score(seqs[qi])
             d = det[qi * H + hj]
             assert d.nregions == r.nregions, (case.name, qi, hj)
-            assert d.nenv == min(r.nenv, 8), (case.name, qi, hj, d.nenv, r.nenv, r.flags)
+            assert d.nenv == min(r.nenv, WH_MAX_ENVELOPES), (case.name, qi, hj, d.nenv, r.nenv, r.flags)
             for t in range(d.nenv):
                 assert (d.env_i[t], d.env_j[t]) == (r.env_i[t], r.env_j[t]), (case.name, qi, hj, t)
                 assert abs(d.envsc[t] - r.envsc[t]) <= 2e-4 * max(1.0, abs(r.envsc[t]) / 50), (case.name, qi, hj, d.envsc[t], r.envsc[t])

@@ -75,7 +75,8 @@ struct Knobs {
   int dbg = 0;
   int rdbg = 0;              // resolver: print the first <n> sampled segments and the cluster statistics of every region
 };
-static const int kScorePathSlot = 112;   // d_counter[112..123]: six 64-bit path counters of the last scoring call (wh_last_score_paths)
+static const int kScorePathSlot = 128;   // d_counter[128..139]: six 64-bit path counters of the last scoring call (wh_last_score_paths); [96..123] belong to wh_align_dev
+static const int kResolveErrSlot = 140;  // d_counter[140]: queue records the resolver found in a segment of another model (never, for a well-formed segment list)
 static const int kMaxLaunches = 60;   // work-queue heads in d_counter (slot 63 belongs to the consensus kernel)
 
 struct wh_ehmm {
@@ -309,8 +310,9 @@ wh_ehmm *wh_ehmm_load(const char *const *hmm_paths, const int32_t *hmm_index, co
   for (int i = 0; i < n; i++) { ns[(size_t)i] = e->hmms[(size_t)i].nseq; ix[(size_t)i] = e->hmms[(size_t)i].index; }
   if (e->d_hmms.ensure(sizeof(DevHMM) * (size_t)n) || e->d_tables.ensure(sizeof(float) * tables.size()) ||
       e->d_nseq.ensure(sizeof(int32_t) * (size_t)n) || e->d_index.ensure(sizeof(int32_t) * (size_t)n) ||
-      e->d_lists.ensure(sizeof(int32_t) * (size_t)(2 * n + 4)) || e->d_counter.ensure(512) || e->d_gtab.ensure(sizeof(double) * gtab.size()))
+      e->d_lists.ensure(sizeof(int32_t) * (size_t)(2 * n + 4)) || e->d_counter.ensure(1024) || e->d_gtab.ensure(sizeof(double) * gtab.size()))
     return nullptr;
+  if (hipMemset(e->d_counter.p, 0, 1024) != hipSuccess) { set_error("hipMemset of the counter block failed"); return nullptr; }
   const double t_l3 = now_ms();
   auto up = [&](void *dst, const void *src, size_t bytes) { return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess; };
   std::vector<int32_t> lists;
@@ -655,7 +657,7 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
     set_error("wh_score_dev: bad argument");
     return WH_EINVAL;
   }
-  // The queue of pairs with a multidomain region is sized by ESTIMATE (a per-pair record is 168 bytes; the worst case,
+  // The queue of pairs with a multidomain region is sized by ESTIMATE (a per-pair record is 296 bytes; the worst case,
   // one record per pair, was 3.4 GB at the headline for a class that is 0.005 % of its pairs).  The kernels count every
   // pair that wants a slot; when the count exceeds the capacity, the queue is grown to the count and the scoring pass
   // runs once more (every pair is scored again, so the queue then holds exactly what the first pass counted).
@@ -1049,8 +1051,15 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
     int *d_rcount = (int *)e->d_counter.p + 64, *d_rwork = (int *)e->d_counter.p + 65;
     int n_multi = 0;
     if (rlds <= kLdsBudget && nq * (int64_t)e->hmms.size() < 0x7FFFFFFF) {
+      int n_bad = 0;          // (the resolver launches of EARLIER calls: counted on the device, read at this call's first synchronisation)
       HIPCHK(hipMemcpyAsync(&n_multi, d_rcount, sizeof(int), hipMemcpyDeviceToHost, s));
+      HIPCHK(hipMemcpyAsync(&n_bad, (int *)e->d_counter.p + kResolveErrSlot, sizeof(int), hipMemcpyDeviceToHost, s));
       HIPCHK(hipStreamSynchronize(s));
+      if (n_bad != 0) {
+        HIPCHK(hipMemsetAsync((int *)e->d_counter.p + kResolveErrSlot, 0, sizeof(int), s));
+        set_error("resolver: %d queued pair(s) sat in a segment of another model and were NOT scored (internal error)", n_bad);
+        return WH_EHIP;
+      }
       if (nq > 0) e->rq_rate = std::max(e->rq_rate, (double)n_multi / (double)(nq * (int64_t)e->hmms.size()));
       if ((int64_t)n_multi > e->rq_cap) {
         // more pairs asked for a slot than the estimate allowed: the caller repeats the scoring pass with room for all
@@ -1081,6 +1090,7 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
       memcpy(r.degen, e->degen, sizeof r.degen);
       r.dbg = e->knobs.rdbg;
       r.launch_id = ++e->resolver_launches;
+      r.err = (int *)e->d_counter.p + kResolveErrSlot;
       r.null2_gather = getenv("WH_RES_NULL2_GATHER") ? 1 : 0;
       if (e->knobs.stats) {
         if (e->d_recs.ensure(256)) return WH_ENOMEM;

@@ -153,6 +153,7 @@ struct ResolveArgs {
   uint32_t degen[32];
   unsigned long long *stats;   // WH_STATS: wave cycles per phase [0] region Forward [1] traces [2] clustering [3] cluster statistics [4] envelope Forward
   int dbg;                     // WH_RDBG > 0: print the first <dbg> sampled segments and the cluster statistics of every region
+  int *err;                    // device counter: records dropped because their model is not the segment's (the host turns it into WH_EHIP)
 };
 hipError_t launch_resolve(const ResolveArgs &a, int blocks, int waves, size_t lds, hipStream_t s);
 size_t resolve_lds_header_bytes(int Qt);

@@ -232,7 +232,10 @@ __global__ __launch_bounds__(64 * kResMaxWaves) void resolve_kernel(ResolveArgs 
     const long long t_pair0 = a.stats ? __builtin_readcyclecounter() : 0;
     const unsigned long long r_pair0 = a.stats ? __builtin_amdgcn_s_memrealtime() : 0;
     const ResolveRec rec = a.recs[a.order ? a.order[c_start + item] : c_start + item];
-    if (c_h >= 0 && rec.h != c_h) continue;            // never true for a well-formed segment list (the staged tables are c_h's)
+    if (c_h >= 0 && rec.h != c_h) {                    // never true for a well-formed segment list (the staged tables are c_h's):
+      if (lane == 0 && a.err) atomicAdd(a.err, 1);     // counted, and the next scoring call on the handle fails with WH_EHIP
+      continue;
+    }
     const DevHMM hm = a.hmms[rec.h];
     GModel m;
     m.tf = a.gtab + hm.gfw_off; m.te = a.gtab + hm.gem_off;

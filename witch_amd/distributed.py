@@ -32,10 +32,19 @@ def gather_topk(idx, w, nk, nu, group=None, n_total=None):
     if world == 1 and not collectives_forced():
         return idx, w, nk, nu
     n_local, k = int(idx.shape[0]), int(idx.shape[1])
+    # the record layout below is byte arithmetic: refuse anything but the types it was written for
+    if w.dtype != torch.float64 or idx.dtype != torch.int32 or nk.dtype != torch.int32 or nu.dtype != torch.int32:
+        raise TypeError("gather_topk: expects w float64, idx / n_kept / n_used int32 (got %s, %s, %s, %s)" % (w.dtype, idx.dtype, nk.dtype, nu.dtype))
     if n_total is not None:
         sizes = [shard_range(int(n_total), r, world)[1] - shard_range(int(n_total), r, world)[0] for r in range(world)]
-        if sizes[dist.get_rank(group)] != n_local:
-            raise ValueError("gather_topk: %d local rows, but shard_range(%d, rank, %d) owns %d" % (n_local, n_total, world, sizes[dist.get_rank(group)]))
+        # A rank whose row count is not its shard's must not raise ALONE: the others would wait in the collective until
+        # the backend times out.  The ranks agree on the failure first (one MAX all-reduce of a flag, 8 bytes) and then
+        # all raise - or, if nobody disagrees, nothing else was exchanged about the sizes.
+        bad = torch.tensor([1 if sizes[dist.get_rank(group)] != n_local else 0], device=idx.device, dtype=torch.int64)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)
+        if int(bad.item()):
+            raise ValueError("gather_topk: a rank's row count is not its shard's (this rank: %d local rows, shard_range(%d, rank, %d) owns %d)"
+                             % (n_local, n_total, world, sizes[dist.get_rank(group)]))
     else:
         mine = torch.tensor([n_local], device=idx.device, dtype=torch.int64)
         got = torch.empty(world, device=idx.device, dtype=torch.int64)

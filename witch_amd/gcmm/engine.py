@@ -125,8 +125,9 @@ class QueryAlignmentEngine:
             # WH_FLAG_TRUNC: the pair has more envelopes than the kernels keep (WH_MAX_ENVELOPES); its null2 correction
             # misses the dropped ones, so its score may differ from hmmsearch's.  Never silent.
             self.truncated_pairs = [(self.taxa[int(q) + self.row_lo], int(labels[int(h)])) for q, h in trunc]
-            warnings.warn("witch_amd: %d (query, HMM) pair(s) have more than 8 envelopes; their scores may differ from "
-                          "hmmsearch's (first: %s vs A_0_%d)" % ((len(trunc),) + self.truncated_pairs[0]), RuntimeWarning)
+            from .._lib import WH_MAX_ENVELOPES
+            warnings.warn("witch_amd: %d (query, HMM) pair(s) have more than %d envelopes; their scores may differ from "
+                          "hmmsearch's (first: %s vs A_0_%d)" % ((len(trunc), WH_MAX_ENVELOPES) + self.truncated_pairs[0]), RuntimeWarning)
         t1 = time.time()
         self.topk_idx, self.topk_w, self.n_kept, self.n_used = e.topk(self.decibits, self.flags, self.num_hmms)
         self.topk_rows = (self.row_lo, self.row_hi)

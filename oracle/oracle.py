@@ -70,6 +70,8 @@ def lib():
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_align_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_int64, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_score_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_result_size.restype = C.c_int
         assert L.orc_result_size() == C.sizeof(OrcResult)
         _LIB = L
@@ -154,6 +156,26 @@ def score_batch(hmms, residues, offsets, nthreads: int = 0):
     offsets = np.ascontiguousarray(offsets, dtype=np.int64)
     lib().orc_score_batch(arr, nh, residues.ctypes.data, offsets.ctypes.data, nq, deci.ctypes.data,
                           flags.ctypes.data, fwd.ctypes.data, sc.ctypes.data, nthreads)
+    return deci, flags, fwd, sc
+
+
+def score_pairs(hmms, residues, offsets, pair_q, pair_h, nthreads: int = 0):
+    """Scores a LIST of (query, model position) pairs (OpenMP over the pairs): returns (decibits int32, flags uint8,
+    fwd_bits float64, seq_score float32), one entry per pair.  <hmms> may hold None for models no pair uses."""
+    nh = len(hmms)
+    arr = (C.c_void_p * nh)(*[h._h if h is not None else None for h in hmms])
+    pair_q = np.ascontiguousarray(pair_q, dtype=np.int64)
+    pair_h = np.ascontiguousarray(pair_h, dtype=np.int32)
+    n = len(pair_q)
+    deci = np.zeros(n, dtype=np.int32)
+    flags = np.zeros(n, dtype=np.uint8)
+    fwd = np.zeros(n, dtype=np.float64)
+    sc = np.zeros(n, dtype=np.float32)
+    residues = np.ascontiguousarray(residues, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    if n:
+        lib().orc_score_pairs(arr, residues.ctypes.data, offsets.ctypes.data, pair_q.ctypes.data, pair_h.ctypes.data, n,
+                              deci.ctypes.data, flags.ctypes.data, fwd.ctypes.data, sc.ctypes.data, nthreads)
     return deci, flags, fwd, sc
 
 

@@ -1282,6 +1282,29 @@ int orc_score_batch(orc_hmm *const *hmms, int nh, const uint8_t *residues, const
   return 0;
 }
 
+/* the same for a LIST of (query, model) pairs: the stratified samples of the headline-size tests */
+int orc_score_pairs(orc_hmm *const *hmms, const uint8_t *residues, const int64_t *offsets,
+                    const int64_t *pair_q, const int32_t *pair_h, int64_t npairs, int32_t *decibits, uint8_t *flags,
+                    double *fwd_bits, float *seq_score, int nthreads)
+{
+  int64_t p;
+  flogsum_init();
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel for schedule(dynamic, 4)
+  for (p = 0; p < npairs; p++) {
+    int64_t q = pair_q[p];
+    orc_result r;
+    orc_score_pair(hmms[pair_h[p]], residues + offsets[q], (int) (offsets[q + 1] - offsets[q]), &r);
+    decibits[p] = r.decibits;
+    flags[p] = (uint8_t) r.flags;
+    if (fwd_bits) fwd_bits[p] = r.fwd_bits;
+    if (seq_score) seq_score[p] = r.seq_score;
+  }
+  return 0;
+}
+
 int orc_align_batch(orc_hmm *const *hmms, const uint8_t *residues, const int64_t *offsets,
                     const int64_t *pair_q, const int32_t *pair_h, int64_t npairs,
                     const int64_t *col_offsets, int32_t *cols, int nthreads)

@@ -1145,18 +1145,104 @@ def test_headline_size_properties(orc, tmp_path):
         c = cols[co[p]:co[p + 1]]
         c = c[c >= 0]
         assert (np.diff(c) > 0).all()
-    # oracle spot check: 48 random (query, model) pairs
-    rng = np.random.default_rng(1)
-    qs = rng.choice(100000, size=48, replace=False)
-    ohm = {}
-    for q in qs:
-        h = int(rng.integers(0, e.H))
-        if h not in ohm:
-            ohm[h] = orc.OracleHMM(se.paths[h])
-        r = ohm[h].score(seqs[q].astype(np.uint8))
-        assert bool(flags[q, h] & 1) == bool(r.flags & 1)
-        _check_one_decibit(deci[q, h], r.decibits, r.seq_score, ("headline spot check", int(q), h))
     assert (flags & 8).sum() == 0                                         # no pair lost an envelope (WH_FLAG_TRUNC)
+    # ---- oracle evidence at this size, STRATIFIED BY CODE PATH.  The staged launches (WH_SCORE_KERNEL=11) run the same
+    # sweep functions and record per pair which path it took; their results are asserted identical to the default
+    # kernel's at full size (all 2e7 pairs, bitwise), so the strata describe the numbers checked above.  From every class
+    # a sample goes through the float64 oracle: reported / multidomain flags identical, Forward log-odds within 1e-4 bit,
+    # deci-bits under the rounding-boundary rule of SURVEY 8.0.
+    paths_t = torch.zeros((100000, e.H), dtype=torch.uint8, device="cuda")
+    e.set_path_buffer(paths_t)
+    e.set_option("WH_SCORE_KERNEL", "11")
+    d3, f3, w3 = e.score_t(res_t, off_t, maxlen, want_fwd=True)
+    e.set_option("WH_SCORE_KERNEL", "")
+    e.set_path_buffer(None)
+    assert e.last_queue_reruns() == 0
+    assert torch.equal(d3, d1) and torch.equal(f3, f1)
+    pb, fwd = paths_t.cpu().numpy(), w3.cpu().numpy()
+    strata = {
+        "p2 window kept, p4 on 256 nodes": ((pb & 1) != 0) & ((pb & 4) != 0) & ((pb & (8 | 16 | 32 | 64 | 128)) == 0),
+        "p2 window in doubt -> full width": (pb & 2) != 0,
+        "p4 on 512 nodes": (pb & 8) != 0,
+        "p4 window rejected -> full width": (pb & 16) != 0,
+        "p4 full width from the start": ((pb & 32) != 0) & ((pb & 16) == 0),
+        "dense redo": (pb & 64) != 0,
+        "multidomain (resolver)": (pb & 128) != 0,
+        "not reported": ~rep,
+    }
+    want = {"p2 window kept, p4 on 256 nodes": 7000, "p2 window in doubt -> full width": 4000, "p4 on 512 nodes": 3000,
+            "p4 window rejected -> full width": 2500, "p4 full width from the start": 3000, "dense redo": 500,
+            "multidomain (resolver)": 1000, "not reported": 500}
+    rng = np.random.default_rng(1)
+    pq, ph, tags = [], [], []
+    for name, mask in strata.items():
+        where = np.argwhere(mask)
+        if name not in ("dense redo", "not reported"):
+            assert len(where) > 100, (name, len(where))                    # the class exists at this size
+        take = where[rng.choice(len(where), size=min(want[name], len(where)), replace=False)] if len(where) else where
+        pq += [int(x) for x in take[:, 0]]
+        ph += [int(x) for x in take[:, 1]]
+        tags += [name] * len(take)
+    assert len(pq) >= 20000, len(pq)
+    ohm = [None] * e.H
+    for h in set(ph):
+        ohm[h] = orc.OracleHMM(se.paths[h])
+    od, of, ofwd, osc = orc.score_pairs(ohm, res, offs, pq, ph)
+    pq, ph = np.array(pq), np.array(ph)
+    gd, gf, gw = deci[pq, ph], flags[pq, ph], fwd[pq, ph]
+    bad = np.nonzero((gf & 3) != (of & 3))[0]
+    assert len(bad) == 0, [(tags[i], int(pq[i]), int(ph[i]), int(gf[i]), int(of[i])) for i in bad[:5]]
+    fin = np.isfinite(ofwd)
+    assert np.all(np.abs(gw[fin] - ofwd[fin]) <= 1e-4), float(np.max(np.abs(gw[fin] - ofwd[fin])))
+    n_off = {}
+    for i in np.nonzero(gd != od)[0]:
+        eps = 0.02 if of[i] & 2 else BOUNDARY_EPS
+        n_off[tags[i]] = n_off.get(tags[i], 0) + _check_one_decibit(gd[i], od[i], osc[i], ("headline", tags[i], int(pq[i]), int(ph[i])), eps)
+    print("headline oracle sample: %d pairs in %d strata; one deci-bit off at a rounding boundary: %s" % (len(pq), len(strata), n_off))
+    e.close()
+
+
+def test_survey_family_sketch_every_size_class_against_the_oracle(orc, tmp_path):
+    """SURVEY 8(d)'s own sketch of config 3 (`dna_100k_x200_m1000`: root 1 000 nt, 0.2 % indels per branch - models of
+    996-2 996 nodes in FIVE cells-per-lane classes: 16, 20, 24 on the one-wave kernels, 32 and 48 on the pass-synchronous
+    kernel) at 2 000 queries: a sample of at least 400 pairs from EVERY class through the float64 oracle - flags,
+    Forward log-odds within 1e-4 bit, deci-bits under the rounding-boundary rule."""
+    _need_gpu()
+    import bench
+    from witch_amd.ehmm import EHMM, pack_queries
+    fam, se, names, seqs, k = bench.make_workload("dna_100k_x200_m1000", str(tmp_path), 2000, None)
+    seqs = [s_.astype(np.uint8) for s_ in seqs]
+    e = EHMM(se.paths, hmm_index=se.index, nseq=se.nseq)
+    res, offs = pack_queries(seqs)
+    deci, flags, fwd = e.score(res, offs, want_fwd=True)
+    assert (flags & 8).sum() == 0
+    cls = np.maximum(4, (-(-e.M // 64) + 3) // 4 * 4)                      # cells per lane of every model (wh_hmm.cpp choose_Q)
+    classes = sorted(set(int(c) for c in cls))
+    assert set(classes) >= {16, 20, 24} and max(classes) >= 32, classes
+    rng = np.random.default_rng(3)
+    pq, ph, tags = [], [], []
+    for c in classes:
+        models = np.nonzero(cls == c)[0]
+        n = max(400, 2000 // len(classes))
+        pq += [int(x) for x in rng.integers(0, len(seqs), size=n)]
+        ph += [int(x) for x in rng.choice(models, size=n)]
+        tags += [c] * n
+    ohm = [None] * e.H
+    for h in set(ph):
+        ohm[h] = orc.OracleHMM(se.paths[h])
+    od, of, ofwd, osc = orc.score_pairs(ohm, res, offs, pq, ph)
+    pq, ph = np.array(pq), np.array(ph)
+    gd, gf, gw = deci[pq, ph], flags[pq, ph], fwd[pq, ph]
+    bad = np.nonzero((gf & 3) != (of & 3))[0]
+    assert len(bad) == 0, [(tags[i], int(pq[i]), int(ph[i]), int(gf[i]), int(of[i])) for i in bad[:5]]
+    fin = np.isfinite(ofwd)
+    assert np.all(np.abs(gw[fin] - ofwd[fin]) <= 1e-4), float(np.max(np.abs(gw[fin] - ofwd[fin])))
+    n_off = {}
+    for i in np.nonzero(gd != od)[0]:
+        eps = 0.02 if of[i] & 2 else BOUNDARY_EPS
+        n_off[tags[i]] = n_off.get(tags[i], 0) + _check_one_decibit(gd[i], od[i], osc[i], ("m1000", tags[i], int(pq[i]), int(ph[i])), eps)
+    print("[dna_100k_x200_m1000] %d pairs over the classes %s; one deci-bit off at a rounding boundary per class: %s; multidomain pairs in the sample: %d"
+          % (len(pq), classes, n_off, int(((of & 2) != 0).sum())))
     e.close()
 
 
@@ -1213,7 +1299,7 @@ def test_config2_dna_1k_x10_at_its_stated_size(orc, tmp_path):
 
 def test_config5_shape_all_500_hmms(orc, tmp_path):
     """BASELINE.json configs[4] shape (aa_50k_x500): ALL 500 protein HMMs (more than 256 candidates per
-    query: the multi-slot path of the top-k kernel) x 64 mixed-length queries (50-2000 residues) against
+    query: the multi-slot path of the top-k kernel) x 256 mixed-length queries (50-2000 residues) against
     the oracle, then the structural properties of the top-k table and the aligned columns at 2 000 queries
     (a quarter of these pairs hold several hits: each goes through the 200-trace resolver)."""
     _need_gpu()
@@ -1224,13 +1310,14 @@ def test_config5_shape_all_500_hmms(orc, tmp_path):
     assert len(se.paths) == 500 and k == 10
     seqs = [s_.astype(np.uint8) for s_ in seqs]
     e = EHMM(se.paths, hmm_index=se.index, nseq=se.nseq)
-    # ---- 64 queries x 500 HMMs against the oracle
-    sub = seqs[:64]
+    # ---- 256 queries x 500 HMMs against the oracle (round 5: 64 until then)
+    NSUB = 256
+    sub = seqs[:NSUB]
     assert min(len(s_) for s_ in sub) < 400 and max(len(s_) for s_ in sub) > 1500
     res, offs = pack_queries(sub)
     deci, flags, fwd = e.score(res, offs, want_fwd=True)
     ohm = [orc.OracleHMM(p) for p in se.paths]
-    od, of, ofwd, osc = orc.score_batch(ohm, res, offs, nthreads=16)
+    od, of, ofwd, osc = orc.score_batch(ohm, res, offs, nthreads=os.cpu_count() or 16)
     fin = np.isfinite(ofwd)
     assert np.max(np.abs(fwd[fin] - ofwd[fin]) / np.maximum(1.0, np.abs(ofwd[fin]) / 1000)) <= 2e-4
     assert np.array_equal(flags & 3, of & 3)
@@ -1247,9 +1334,9 @@ def test_config5_shape_all_500_hmms(orc, tmp_path):
     pq = [q for q in range(len(sub)) for _ in range(int(nu[q]))]
     ph = [e.pos_of_index[int(idx[q, j])] for q in range(len(sub)) for j in range(int(nu[q]))]
     cols, co = e.align(res, offs, pq, ph)
-    ocols, oco = orc.align_batch(ohm, res, offs, pq, ph, nthreads=16)
+    ocols, oco = orc.align_batch(ohm, res, offs, pq, ph, nthreads=os.cpu_count() or 16)
     assert np.array_equal(cols, ocols), int((cols != ocols).sum())
-    print("\n[aa_50k_x500] 64 x 500 pairs: %d single-domain pairs one deci-bit off (boundary), %d multidomain pairs, %d pairs aligned identically"
+    print("\n[aa_50k_x500] 256 x 500 pairs: %d single-domain pairs one deci-bit off (boundary), %d multidomain pairs, %d pairs aligned identically"
           % (n_off, int(((of & 2) != 0).sum()), len(pq)))
     # ---- 2 000 queries x 500 HMMs: size-independent properties
     res, offs = pack_queries(seqs)
@@ -1258,7 +1345,7 @@ def test_config5_shape_all_500_hmms(orc, tmp_path):
     d1, f1 = e.score_t(res_t, off_t, maxlen)
     d2, f2 = e.score_t(res_t, off_t, maxlen)
     assert torch.equal(d1, d2) and torch.equal(f1, f2)
-    assert torch.equal(d1[:64].cpu(), torch.from_numpy(deci)) and torch.equal(f1[:64].cpu(), torch.from_numpy(flags))   # batch-size independent
+    assert torch.equal(d1[:NSUB].cpu(), torch.from_numpy(deci)) and torch.equal(f1[:NSUB].cpu(), torch.from_numpy(flags))   # batch-size independent
     idx, w, nk, nu = [t.cpu().numpy() for t in e.topk_t(d1, f1, k)]
     fl = f1.cpu().numpy()
     assert (fl & 8).sum() == 0                                            # nor at 2 000 queries

@@ -831,7 +831,7 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
         specg = true;
       }
       // ---- staged launches (wh_staged.hip): short-query batches of the one-wave classes, special states in LDS
-      const bool staged = (kn.kernel == 10 || kn.kernel == 11) && !e->st_off && !big && !pairk && !specg && !mixed && !kn.dbg &&
+      const bool staged = (kn.kernel == 10 || kn.kernel == 11) && !e->st_off && !big && !pairk && !specg && !kn.dbg &&
                           (Q == 8 || Q == 12 || Q == 16 || Q == 20 || Q == 24);
       if (staged) {
         int rc_st = score_staged_class(e, a, Q, Lc, s, &launches, pass == 0 ? &need_scratch : nullptr);

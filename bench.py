@@ -221,7 +221,7 @@ def cpu_baseline(ehmm_paths, nseq, seqs, k, n_sample, threads):
 
 
 
-FAM_NAMES = {0: "wh::k7::score_kernel7", 1: "wh::score_big_kernel", 2: "wh::generic_front_kernel", 3: "wh::wide::score_wide_kernel"}
+FAM_NAMES = {0: "wh::k7::score_kernel7", 1: "wh::score_big_kernel", 2: "wh::generic_front_kernel", 3: "wh::wide::score_wide_kernel", 4: "wh::staged launches (wh_staged.hip)"}
 
 
 def lib_sha16():
@@ -303,15 +303,17 @@ def score_roofline(M, lens_local, class_ms, kern_ms0, kern_n0, steps, H, stamp, 
     return r
 
 
-def also_block(name, steps, warmup, device):
-    """A second workload measured in the same run, reported beside <value> (never part of it): one-GPU hot-path rate
-    and the VALU roofline of its dominant launch class.  Used for SURVEY.md 8(d)'s own sketch of config 3
-    (dna_100k_x200_m1000: root 1000 nt, 0.2 % indels per branch; models of 996-2996 nodes in five size classes)."""
+def also_block(name, steps, warmup, device, nq=None, note=None):
+    """Another workload measured in the same run, reported beside <value> (never part of it): one-GPU hot-path rate,
+    stage split and the VALU roofline of its dominant launch class.  Used for SURVEY.md 8(d)'s own sketch of config 3
+    (dna_100k_x200_m1000: root 1000 nt, 0.2 % indels per branch; models of 996-2996 nodes in five size classes) at full
+    size, and for a slice of BASELINE config 5 (aa_50k_x500: ALL 500 protein HMMs x the first <nq> of its 50 000
+    mixed-length queries - a quarter of those pairs go through the multidomain resolver, reported as an entry of its own)."""
     import torch
     from witch_amd.ehmm import EHMM, pack_queries
     wd = tempfile.mkdtemp(prefix="witch_bench_also_")
     try:
-        fam, se, names, seqs, k = make_workload(name, wd)
+        fam, se, names, seqs, k = make_workload(name, wd, nq)
         e = EHMM(se.paths, hmm_index=se.index, nseq=se.nseq, device=device)
         res, offs = pack_queries([s_.astype(np.uint8) for s_ in seqs])
         maxlen = int(np.max(np.diff(offs)))
@@ -344,7 +346,22 @@ def also_block(name, steps, warmup, device):
                "cells_per_s_all_classes": round(float(lens.sum() * M.sum()) * steps / (kern_ms[0] * 1e-3), 1) if kern_ms[0] > 0 else 0.0,
                "roofline": score_roofline(M, lens, class_ms, kern_ms[0], kern_n[0], steps, e.H, None, "not profiled"),
                "pairs_multidomain": hot_path_step.multidomain,
-               "note": "SURVEY.md 8(d) config 3 as sketched there (root 1000 nt, 0.2 % indels per branch), same timed region as <value>, one GPU"}
+               "note": note or "SURVEY.md 8(d) config 3 as sketched there (root 1000 nt, 0.2 % indels per branch), same timed region as <value>, one GPU"}
+        if nq:
+            out["n_queries_of_config"] = WORKLOADS[name][7]
+            out["query_len_min_max"] = [int(lens.min()), int(lens.max())]
+        if kern_ms[4] > 0 and hot_path_step.multidomain:
+            # the resolver is a latency machine: one wavefront per queued pair, 200 stochastic traces whose
+            # decisions are fetched as 1 KB threshold lines (16 B per decision x 64 lanes); its rate is (waves in flight) /
+            # (wave time per pair)
+            import torch as _t
+            cu = _t.cuda.get_device_properties(device).multi_processor_count
+            rs = kern_ms[4] / steps * 1e-3
+            npair = float(hot_path_step.multidomain)
+            out["resolver"] = {"pairs": int(npair), "ms_per_step": round(rs * 1e3, 3), "pairs_per_s": round(npair / rs, 1),
+                               "waves_in_flight": cu * 8, "wave_ms_per_pair": round(rs * 1e3 * cu * 8 / npair, 3),
+                               "threshold_line_bytes": 1024, "decisions_per_line": 64, "bytes_per_decision": 16,
+                               "share_of_step": round(rs / (dt / steps), 4)}
         e.close()
         return out
     finally:
@@ -361,7 +378,7 @@ def main():
     ap.add_argument("--nh", type=int, default=0, help="override the HMM count (development only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-level1", action="store_true", help="skip the level-1 end-to-end stage (reported beside the hot-path value)")
-    ap.add_argument("--no-also", action="store_true", help="skip the second workload reported beside the headline (dna_100k_x200_m1000)")
+    ap.add_argument("--no-also", action="store_true", help="skip the two workloads reported beside the headline (dna_100k_x200_m1000 in full, a 3 000-query slice of aa_50k_x500)")
     args = ap.parse_args()
 
     import torch
@@ -535,10 +552,14 @@ def main():
                 except Exception as ex:       # an extra stage must never take the bench line down
                     line["level1_e2e"] = {"failed": "%s: %s" % (type(ex).__name__, ex)}
             if not args.no_also and world == 1 and args.workload == "dna_100k_x200" and not args.nq and not args.nh:
-                try:
-                    line["also"] = also_block("dna_100k_x200_m1000", 2, 1, local_rank)
-                except Exception as ex:       # an extra workload must never take the bench line down
-                    line["also"] = {"workload": "dna_100k_x200_m1000", "failed": "%s: %s" % (type(ex).__name__, ex)}
+                line["also"] = []
+                for wl_, steps_, nq_, note_ in (("dna_100k_x200_m1000", 2, None, None),
+                                                ("aa_50k_x500", 1, 3000, "BASELINE.json configs[4] (SURVEY.md 8(d) config 5) as a SLICE: all 500 protein HMMs x its first 3 000 "
+                                                                         "mixed-length queries (50-2 000 aa), one warm-up + one step, same timed region as <value>, one GPU")):
+                    try:
+                        line["also"].append(also_block(wl_, steps_, 1, local_rank, nq_, note_))
+                    except Exception as ex:       # an extra workload must never take the bench line down
+                        line["also"].append({"workload": wl_, "failed": "%s: %s" % (type(ex).__name__, ex)})
             if not args.no_cpu_baseline:
                 threads = min(os.cpu_count() or 1, 64)
                 # about 15 s of CPU work on 64 host threads: 384 queries of the headline (150 nt x 200 models of ~900

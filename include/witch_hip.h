@@ -111,7 +111,9 @@ int      wh_ehmm_info(const wh_ehmm *e, int32_t *M, int32_t *nseq, int32_t *hmm_
 int      wh_ehmm_map(const wh_ehmm *e, int h, int32_t *map_cols);
 int      wh_ehmm_max_query_len(const wh_ehmm *e);
 
-/* All-vs-all scoring: nq queries (digital residues, CSR offsets[nq+1]) x H models. */
+/* All-vs-all scoring: nq queries (digital residues, CSR offsets[nq+1]) x H models.  One call serves fewer than 2^31
+ * pairs (WH_ERANGE beyond: feed the queries in chunks, as the reference feeds hmmsearch 20 000 sequences at a time,
+ * witch_msa/gcmm/algorithm.py:209,280-284; witch_amd.gcmm.QueryAlignmentEngine.run does). */
 int wh_score(wh_ehmm *e, const uint8_t *residues, const int64_t *offsets, int64_t nq,
              int32_t *decibits, uint8_t *flags, float *fwd_bits, wh_pair_detail *detail);
 int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets, int64_t nq,

@@ -1590,6 +1590,52 @@ def test_end_to_end_example_against_the_reference_pipeline(tmp_path, ehmm_source
 
 
 @pytest.mark.gpu
+def test_chunked_engine_run_equals_the_one_pass_run(tmp_path):
+    """QueryAlignmentEngine.run feeds the GPU in chunks of at most 20 000 queries like the reference feeds hmmsearch
+    (algorithm.py:209,280-284), so nothing on the device grows with the query count.  Chunks are independent, so a run
+    in chunks of 257 on the reference's example data (500 fragments x 15 HMMs) gives the tables of the one-pass run -
+    scores, flags, top-k records, aligned columns, consensus codes - and the device merge writes the same two files,
+    whose sha256 are the reference pipeline's.  With keep_scores=False the score table is dropped and says so."""
+    _need_gpu()
+    import gzip
+    import hashlib
+    from tests.conftest import load_case
+    from witch_amd import gcmm
+    case = load_case("example_e2e")
+    g = case.g
+
+    class _Sub:
+        def __init__(self, path, n):
+            self.hmm_model_path, self.num_taxa = path, n
+    index_to_hmm = {i: _Sub(p, n) for i, p, n in zip(case.hmm_index, case.hmm_paths, case.nseq)}
+    retained = {int(k): v for k, v in g["retained"].items()}
+    nongaps = {int(k): v for k, v in g["nongaps"].items()}
+    B = g["backbone_length"]
+    bpath = str(tmp_path / "backbone.fasta")
+    with gzip.open(os.path.join(case.dir, "backbone.fasta.gz"), "rt") as f, open(bpath, "w") as o:
+        o.write(f.read())
+    queries = list(zip(case.qnames, case.qseqs))
+    kw = dict(subset_to_retained_columns=retained, subset_to_nongaps_per_column=nongaps, backbone_length=B)
+    one = gcmm.QueryAlignmentEngine.run(index_to_hmm, queries, case.k, chunk=0, **kw)
+    many = gcmm.QueryAlignmentEngine.run(index_to_hmm, queries, case.k, chunk=257, **kw)
+    assert one.timings["chunks"] == 1 and many.timings["chunks"] == 2
+    for name in ("decibits", "flags", "topk_idx", "n_kept", "n_used", "cols", "col_offsets", "merged", "merged_minmax", "qpair_off"):
+        assert np.array_equal(getattr(one, name), getattr(many, name)), name
+    assert np.array_equal(one.topk_w.view(np.uint64), many.topk_w.view(np.uint64))
+    for row in (0, 256, 257, 499):
+        for lab, _ in many.weights(row)[:int(many.n_used[row])]:
+            assert many.aligned_columns(row, lab) == one.aligned_columns(row, lab)
+    gcmm.install(many)
+    o, m = gcmm.mergeAlignmentsDevice(bpath, {}, output_path=str(tmp_path / "chunked.fasta"))
+    assert hashlib.sha256(open(o, "rb").read()).hexdigest() == g["final_sha256"]["full"]
+    assert hashlib.sha256(open(m, "rb").read()).hexdigest() == g["final_sha256"]["masked"]
+    lean = gcmm.QueryAlignmentEngine.run(index_to_hmm, queries, case.k, chunk=100, keep_scores=False, **kw)
+    assert lean.decibits is None and lean.flags is None and np.array_equal(lean.merged, one.merged)
+    with pytest.raises(RuntimeError):
+        lean.ranked(0)
+
+
+@pytest.mark.gpu
 def test_ehmm_built_without_hmmbuild_scores_identically(tmp_path):
     """the eHMM of the end-to-end example built by wh_hmmbuild (no STATS / MAXL lines, from the
     reduced subset alignments as the reference builds them) loads and scores exactly like the files HMMER's

@@ -657,6 +657,13 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
     set_error("wh_score_dev: bad argument");
     return WH_EINVAL;
   }
+  // One call serves fewer than 2^31 pairs (pair numbers and the resolver's queue are 32-bit).  Until round 4 a larger call
+  // ran WITHOUT the multidomain resolver and said nothing - a different reported set; now it is refused: the caller feeds
+  // the queries in chunks (QueryAlignmentEngine.run: 20 000 at a time, the reference's own hmmsearch chunk).
+  if (nq * (int64_t)e->hmms.size() >= 0x7FFFFFFF) {
+    set_error("wh_score_dev: %lld queries x %zu models is 2^31 pairs or more; score the queries in chunks", (long long)nq, e->hmms.size());
+    return WH_ERANGE;
+  }
   // The queue of pairs with a multidomain region is sized by ESTIMATE (a per-pair record is 296 bytes; the worst case,
   // one record per pair, was 3.4 GB at the headline for a class that is 0.005 % of its pairs).  The kernels count every
   // pair that wants a slot; when the count exceeds the capacity, the queue is grown to the count and the scoring pass

@@ -52,7 +52,8 @@ class QueryAlignmentEngine:
         self.n_used = None
         self.cols = None              # int32 CSR
         self.col_offsets = None       # int64 [npairs+1]
-        self.pair_of = {}             # (row, hmm label) -> pair number
+        self.pair_of = None           # (row, hmm label) -> pair number: only for engines built from precomputed arrays (from_results)
+        self.qpair_off = None         # int64 [nloc+1]: first aligned pair of every local query (pairs of a query in top-k order)
         self.num_hmms = 0
         self.timings = {}
         self.merged = None            # int32 CSR by query: consensus codes (gcmm/merge.py)
@@ -72,7 +73,7 @@ class QueryAlignmentEngine:
     @classmethod
     def run(cls, index_to_hmm, unaligned, num_hmms: int, device: int = 0, multidomain_policy: str = "resolve",
             subset_to_retained_columns=None, subset_to_nongaps_per_column=None, backbone_length=None,
-            world: int = 1, rank: int = 0, group=None):
+            world: int = 1, rank: int = 0, group=None, chunk: int = 20000, keep_scores: bool = True):
         """Score, weight and align every query of ``unaligned`` ({taxon: sequence text} or a list of
         (taxon, text)) against every HMM of ``index_to_hmm``.
 
@@ -81,7 +82,11 @@ class QueryAlignmentEngine:
         (distributed.shard_range; the eHMM is replicated), the per-query top-k records of all ranks are
         all-gathered (the path's only exchange step), aligned columns and consensus results stay
         rank-local.  multidomain_policy: "resolve" (HMMER's stochastic resolver, default) or "drop"
-        (pairs with a multidomain region are not reported)."""
+        (pairs with a multidomain region are not reported).
+
+        ``chunk``: queries per pass (default 20 000, the reference's own hmmsearch chunk, algorithm.py:209; 0 = all at
+        once).  ``keep_scores=False`` drops the nq x H deci-bit / flag tables once a chunk's top-k is formed - the host
+        then holds top-k records, aligned columns and consensus codes only (rankBitscores / ranked() need the tables)."""
         import time
         import warnings
         if multidomain_policy not in ("resolve", "drop", "envelope"):
@@ -115,57 +120,101 @@ class QueryAlignmentEngine:
         self.query_text = np.frombuffer("".join(upper).encode("ascii"), dtype=np.uint8)
         self.device = int(device)
         t_digit = time.time() - t0
-        t0 = time.time()
-        self.decibits, self.flags = e.score(res, offs)
-        if multidomain_policy == "drop":
-            drop = (self.flags & 2) != 0
-            self.flags = np.where(drop, self.flags & ~np.uint8(1), self.flags).astype(np.uint8)
-        trunc = np.argwhere((self.flags & 8) != 0)
-        if len(trunc):
-            # WH_FLAG_TRUNC: the pair has more envelopes than the kernels keep (WH_MAX_ENVELOPES); its null2 correction
-            # misses the dropped ones, so its score may differ from hmmsearch's.  Never silent.
-            self.truncated_pairs = [(self.taxa[int(q) + self.row_lo], int(labels[int(h)])) for q, h in trunc]
-            from .._lib import WH_MAX_ENVELOPES
-            warnings.warn("witch_amd: %d (query, HMM) pair(s) have more than %d envelopes; their scores may differ from "
-                          "hmmsearch's (first: %s vs A_0_%d)" % ((len(trunc), WH_MAX_ENVELOPES) + self.truncated_pairs[0]), RuntimeWarning)
-        t1 = time.time()
-        self.topk_idx, self.topk_w, self.n_kept, self.n_used = e.topk(self.decibits, self.flags, self.num_hmms)
-        self.topk_rows = (self.row_lo, self.row_hi)
-        t2 = time.time()
-        # pairs (local query, kept model) of the 0.999 prefix (aligner.py:58-63), built with array ops
+        # ---- the batch in CHUNKS of at most <chunk> queries, as the reference feeds hmmsearch (algorithm.py:209,280-284:
+        # chunks of <= 20 000 sequences): score -> top-k -> align -> consensus per chunk, so the device-side tables and
+        # workspaces are bounded by the chunk whatever the query count, and a chunk is far below the 2^31 pairs one
+        # scoring call serves.  Chunks are independent (every stage is per query), so the concatenated results ARE the
+        # one-call results (tests/test_gpu_parity.py: chunk = 257 on the example data).
         nloc = len(local)
-        keep = np.arange(self.num_hmms)[None, :] < self.n_used[:, None]
-        pq = np.nonzero(keep)[0].astype(np.int64)
-        plab = self.topk_idx[keep].astype(np.int64)
+        step = nloc if not chunk or int(chunk) <= 0 else int(chunk)
         lut = np.full(int(self.hmm_index.max()) + 1, -1, dtype=np.int32)
         lut[self.hmm_index] = np.arange(len(labels), dtype=np.int32)
-        ph = lut[plab]
-        self.cols, self.col_offsets = e.align(res, offs, pq, ph)
-        _, unal_pairs = e.last_align_status()
-        pw_mask = np.ones(len(pq), dtype=bool)
-        if len(unal_pairs):
-            # pairs the any-size kernel could not align come back all -1: they are NOT all-insertion alignments.
-            # They are dropped from the consensus (weight 0: the max-weight trace is invariant to the common
-            # scale of the remaining weights) and reported.
-            pw_mask[unal_pairs] = False
-            self.unaligned_pairs = [(self.taxa[int(pq[p]) + self.row_lo], int(plab[p])) for p in unal_pairs]
-            warnings.warn("witch_amd: %d pair(s) on models of more than 3072 nodes could not be aligned and are left out "
-                          "of the consensus (first: %s vs A_0_%d)" % ((len(unal_pairs),) + self.unaligned_pairs[0]), RuntimeWarning)
-        self.pair_of = {(int(q) + self.row_lo, int(lab)): p for p, (q, lab) in enumerate(zip(pq.tolist(), plab.tolist()))}
-        t3 = time.time()
-        # same three stage names the reference logs (algorithm.py:333-335, weighting.py:165-168, aligner.py:520-525)
-        self.timings = {"load_ehmm": t_load, "digitize": t_digit, "search": t1 - t0, "weights": t2 - t1, "align": t3 - t2}
-        self.query_offsets = offs
-        if subset_to_retained_columns is not None:
-            # the weighted consensus DP of alignSubQueriesNew (aligner.py:376-473), all local queries at once
-            qpo = np.zeros(nloc + 1, dtype=np.int64)
-            qpo[1:] = np.cumsum(self.n_used)
-            pw = np.where(pw_mask, self.topk_w[keep].astype(np.float64), 0.0)
+        do_merge = subset_to_retained_columns is not None
+        if do_merge:
             ret = [np.asarray(subset_to_retained_columns[i], dtype=np.int32) for i in labels]
             ng = [np.asarray(subset_to_nongaps_per_column[i], dtype=np.int32) for i in labels]
-            self.merged, self.merged_minmax = e.consensus(offs, qpo, ph, pw, self.col_offsets, self.cols, ret, ng,
-                                                          int(backbone_length))
-            self.timings["merge"] = time.time() - t3
+        parts = {k_: [] for k_ in ("deci", "flags", "idx", "w", "nk", "nu", "cols", "colen", "merged", "mm")}
+        tim = {"search": 0.0, "weights": 0.0, "align": 0.0, "merge": 0.0}
+        n_pairs_before = 0
+        for c0 in range(0, max(nloc, 1), max(step, 1)):
+            c1 = min(c0 + step, nloc)
+            coffs = offs[c0:c1 + 1] - offs[c0]
+            cres = res[offs[c0]:offs[c1]]
+            t0 = time.time()
+            deci, flags = e.score(cres, coffs)
+            if multidomain_policy == "drop":
+                drop = (flags & 2) != 0
+                flags = np.where(drop, flags & ~np.uint8(1), flags).astype(np.uint8)
+            trunc = np.argwhere((flags & 8) != 0)
+            if len(trunc):
+                # WH_FLAG_TRUNC: the pair has more envelopes than the kernels keep (WH_MAX_ENVELOPES); its null2 correction
+                # misses the dropped ones, so its score may differ from hmmsearch's.  Never silent.
+                self.truncated_pairs += [(self.taxa[int(q) + c0 + self.row_lo], int(labels[int(h)])) for q, h in trunc]
+            t1 = time.time()
+            idx, w, nk, nu = e.topk(deci, flags, self.num_hmms)
+            t2 = time.time()
+            # pairs (local query, kept model) of the 0.999 prefix (aligner.py:58-63), built with array ops
+            keep = np.arange(self.num_hmms)[None, :] < nu[:, None]
+            pq = np.nonzero(keep)[0].astype(np.int64)
+            plab = idx[keep].astype(np.int64)
+            ph = lut[plab]
+            cols, co = e.align(cres, coffs, pq, ph)
+            _, unal_pairs = e.last_align_status()
+            pw_mask = np.ones(len(pq), dtype=bool)
+            if len(unal_pairs):
+                # pairs the any-size kernel could not align come back all -1: they are NOT all-insertion alignments.
+                # They are dropped from the consensus (weight 0: the max-weight trace is invariant to the common
+                # scale of the remaining weights) and reported.
+                pw_mask[unal_pairs] = False
+                self.unaligned_pairs += [(self.taxa[int(pq[p_]) + c0 + self.row_lo], int(plab[p_])) for p_ in unal_pairs]
+            t3 = time.time()
+            if do_merge:
+                # the weighted consensus DP of alignSubQueriesNew (aligner.py:376-473), all queries of the chunk at once
+                qpo = np.zeros(c1 - c0 + 1, dtype=np.int64)
+                qpo[1:] = np.cumsum(nu)
+                pw = np.where(pw_mask, w[keep].astype(np.float64), 0.0)
+                merged, mm = e.consensus(coffs, qpo, ph, pw, co, cols, ret, ng, int(backbone_length))
+                parts["merged"].append(merged)
+                parts["mm"].append(mm)
+                tim["merge"] += time.time() - t3
+            if keep_scores:
+                parts["deci"].append(deci)
+                parts["flags"].append(flags)
+            for k_, v_ in (("idx", idx), ("w", w), ("nk", nk), ("nu", nu), ("cols", cols), ("colen", np.diff(co))):
+                parts[k_].append(v_)
+            n_pairs_before += len(pq)
+            tim["search"] += t1 - t0
+            tim["weights"] += t2 - t1
+            tim["align"] += t3 - t2
+        cat = lambda k_, empty: np.concatenate(parts[k_]) if parts[k_] else empty
+        H_ = len(labels)
+        self.decibits = cat("deci", np.zeros((0, H_), np.int32)) if keep_scores else None
+        self.flags = cat("flags", np.zeros((0, H_), np.uint8)) if keep_scores else None
+        self.topk_idx, self.topk_w = cat("idx", np.zeros((0, self.num_hmms), np.int32)), cat("w", np.zeros((0, self.num_hmms), np.float64))
+        self.n_kept, self.n_used = cat("nk", np.zeros(0, np.int32)), cat("nu", np.zeros(0, np.int32))
+        self.topk_rows = (self.row_lo, self.row_hi)
+        self.cols = cat("cols", np.zeros(0, np.int32))
+        self.col_offsets = np.zeros(n_pairs_before + 1, dtype=np.int64)
+        self.col_offsets[1:] = np.cumsum(cat("colen", np.zeros(0, np.int64)))
+        # pair number of (local row r, its j-th kept model) = qpair_off[r] + j: no dictionary over the pairs
+        self.qpair_off = np.zeros(nloc + 1, dtype=np.int64)
+        self.qpair_off[1:] = np.cumsum(self.n_used)
+        self.pair_of = None
+        if self.truncated_pairs:
+            from .._lib import WH_MAX_ENVELOPES
+            warnings.warn("witch_amd: %d (query, HMM) pair(s) have more than %d envelopes; their scores may differ from "
+                          "hmmsearch's (first: %s vs A_0_%d)" % ((len(self.truncated_pairs), WH_MAX_ENVELOPES) + self.truncated_pairs[0]), RuntimeWarning)
+        if self.unaligned_pairs:
+            warnings.warn("witch_amd: %d pair(s) on models of more than 3072 nodes could not be aligned and are left out "
+                          "of the consensus (first: %s vs A_0_%d)" % ((len(self.unaligned_pairs),) + self.unaligned_pairs[0]), RuntimeWarning)
+        # same three stage names the reference logs (algorithm.py:333-335, weighting.py:165-168, aligner.py:520-525)
+        self.timings = {"load_ehmm": t_load, "digitize": t_digit, "search": tim["search"], "weights": tim["weights"], "align": tim["align"],
+                        "chunks": (nloc + max(step, 1) - 1) // max(step, 1)}
+        self.query_offsets = offs
+        if do_merge:
+            self.merged = cat("merged", np.zeros(0, np.int32))
+            self.merged_minmax = cat("mm", np.zeros((0, 2), np.int32))
+            self.timings["merge"] = tim["merge"]
         e.close()
         from ..distributed import collectives_forced
         if self.world > 1 or collectives_forced():
@@ -231,27 +280,32 @@ class QueryAlignmentEngine:
                 return lo, hi
         return 0, 0
 
-    def _rank_order(self):
-        """Per local row the model positions sorted by (-score, +hmm index), reported ones first: ONE argsort
-        over the whole table (a composite integer key), computed on first use."""
-        if getattr(self, "_order", None) is None:
-            rep = (self.flags & 1) != 0
-            rank_of_label = np.argsort(np.argsort(self.hmm_index, kind="stable"), kind="stable").astype(np.int64)
-            key = (-self.decibits.astype(np.int64)) * (len(self.hmm_index) + 1) + rank_of_label[None, :]
-            key = np.where(rep, key, np.iinfo(np.int64).max)
-            self._order = np.argsort(key, axis=1, kind="stable")
-            self._nrep = rep.sum(axis=1)
-        return self._order, self._nrep
+    def _need_scores(self):
+        if self.decibits is None:
+            raise RuntimeError("this engine ran with keep_scores=False: the nq x H score table was not kept (top-k records, aligned "
+                               "columns and consensus codes are; rankBitscores / ranked() need keep_scores=True)")
+
+    def reported_counts(self):
+        """Per local row the number of models that reported the query (one pass over the flag table, cached)."""
+        if getattr(self, "_nrep", None) is None:
+            self._need_scores()
+            self._nrep = ((self.flags & 1) != 0).sum(axis=1)
+        return self._nrep
 
     def ranked(self, row: int):
-        """[(idx, score)] sorted by score descending (loader.py:325-330), ties by idx."""
+        """[(idx, score)] sorted by score descending (loader.py:325-330), ties by idx.  ONE row is sorted on request
+        (a composite integer key over its reported models): nobody walks all 10^5 lists, writeWeights reads the keys only."""
         r = self._local(row, "the scores")
-        order, nrep = self._rank_order()
-        js = order[r, :nrep[r]]
+        self._need_scores()
+        if getattr(self, "_label_rank", None) is None:
+            self._label_rank = np.argsort(np.argsort(self.hmm_index, kind="stable"), kind="stable").astype(np.int64)
+        js = np.nonzero(self.flags[r] & 1)[0]
+        key = (-self.decibits[r, js].astype(np.int64)) * (len(self.hmm_index) + 1) + self._label_rank[js]
+        js = js[np.argsort(key, kind="stable")]
         return list(zip(self.hmm_index[js].tolist(), (self.decibits[r, js] / 10.0).tolist()))
 
     def has_hit(self, row: int) -> bool:
-        return bool(self._rank_order()[1][self._local(row, "the scores")])
+        return bool(self.reported_counts()[self._local(row, "the scores")])
 
     def weights(self, row: int):
         """((idx, np.float64 w), ...) - the value type calculateWeights returns (weighting.py:71-74)."""
@@ -262,7 +316,18 @@ class QueryAlignmentEngine:
         n = int(self.n_kept[r])
         return tuple((int(self.topk_idx[r, j]), np.float64(self.topk_w[r, j])) for j in range(n))
 
+    def pair_number(self, row: int, label: int) -> int:
+        """Number of the aligned pair (query row, model label) in cols / col_offsets: the pairs are ordered by query and,
+        inside a query, by rank in its top-k table - qpair_off[r] + j (KeyError for a model outside the query's 0.999 prefix)."""
+        r = self._local(row, "the aligned columns")
+        if self.pair_of is not None:                      # engines assembled from precomputed arrays bring a dictionary
+            return self.pair_of[(row, int(label))]
+        t = row - self.topk_rows[0]
+        js = np.nonzero(self.topk_idx[t, :int(self.n_used[t])] == int(label))[0]
+        if not len(js):
+            raise KeyError((row, int(label)))
+        return int(self.qpair_off[r] + js[0])
+
     def aligned_columns(self, row: int, label: int):
-        self._local(row, "the aligned columns")
-        p = self.pair_of[(row, int(label))]
+        p = self.pair_number(row, label)
         return self.cols[self.col_offsets[p]:self.col_offsets[p + 1]].tolist()

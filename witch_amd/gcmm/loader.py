@@ -2,6 +2,8 @@
 (witch_msa/gcmm/loader.py:299-376), answered from the batched GPU run."""
 from collections.abc import Mapping
 
+import numpy as np
+
 from .engine import current_engine
 
 
@@ -14,13 +16,13 @@ class RankedBitscores(Mapping):
         self._eng, self._wanted = eng, wanted
         all_wanted = set(int(i) for i in eng.hmm_index.tolist()) <= wanted
         self._filter = not all_wanted
-        self._row = {}
-        for row in range(eng.row_lo, eng.row_hi):
-            if not eng.has_hit(row):
-                continue          # a taxon with no reported HMM never appears (loader.py:291-293)
-            taxon = eng.taxa[row]
-            name = renamed_taxa[taxon] if renamed_taxa and taxon in renamed_taxa else taxon
-            self._row[name] = row
+        # a taxon with no reported HMM never appears (loader.py:291-293): the rows with a hit, from one pass over the flags
+        rows = (np.nonzero(eng.reported_counts() > 0)[0] + eng.row_lo).tolist()
+        taxa = eng.taxa
+        if renamed_taxa:
+            self._row = {renamed_taxa.get(taxa[r], taxa[r]): r for r in rows}
+        else:
+            self._row = dict(zip([taxa[r] for r in rows], rows))
         if self._filter:
             self._row = {n: r for n, r in self._row.items() if self._get(r)}
 

@@ -242,17 +242,36 @@ def mergeAlignmentsDevice(backbone_alignment_path, renamed_taxa=None, output_pat
     local_row = {g: nb + i for i, g in enumerate(mine)}
     mpath = masked_path(output_path)
     if exchange:
+        # Only rank 0 writes, so only rank 0 receives: ONE gather of a uint8 tensor per rank - its rendered rows, full and
+        # masked side by side (the row length is global after the MAX all-reduce above), padded to the largest shard.  How
+        # many rows every rank brings follows from the append list and the shard ranges, which every rank computes alike:
+        # nothing is exchanged about sizes and nothing is pickled (until round 4: all_gather_object of a dictionary of
+        # byte strings, every rank receiving every row).
+        import torch
         import torch.distributed as dist
-        part = {g: (full[local_row[g]].tobytes(), masked[local_row[g]].tobytes()) for g in mine}
-        parts = [None] * world
-        dist.all_gather_object(parts, part, group=group)          # rows x width bytes: small next to the DP
+        from ..distributed import shard_range
+        bounds = [shard_range(len(eng.taxa), r, world) for r in range(world)] if world > 1 else [(lo, hi)]
+        per_rank = [sorted(g for g, _ in appended if a_ <= g < b_) for a_, b_ in bounds]
+        nmax = max(1, max(len(v) for v in per_rank))
+        rowlen = width + B
+        send = np.zeros((nmax, rowlen), dtype=np.uint8)
+        if mine:
+            sel = np.array([local_row[g] for g in mine], dtype=np.int64)
+            send[:len(mine), :width] = full[sel]
+            send[:len(mine), width:] = masked[sel]
+        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+        send_t = torch.from_numpy(send).to(dev)
+        recv = [torch.empty_like(send_t) for _ in range(world)] if eng.rank == 0 else None
+        dist.gather(send_t, recv, dst=0, group=group)
         if eng.rank != 0:
             return output_path, mpath
-        rows = {}
-        for p_ in parts:
-            rows.update(p_)
-        full_rows = [full[i].tobytes() for i in range(nb)] + [rows[g][0] for g, _ in appended]
-        masked_rows = [masked[i].tobytes() for i in range(nb)] + [rows[g][1] for g, _ in appended]
+        where = {}
+        for r, gs in enumerate(per_rank):
+            block = recv[r].cpu().numpy()
+            for i, g in enumerate(gs):
+                where[g] = block[i]
+        full_rows = [full[i].tobytes() for i in range(nb)] + [where[g][:width].tobytes() for g, _ in appended]
+        masked_rows = [masked[i].tobytes() for i in range(nb)] + [where[g][width:].tobytes() for g, _ in appended]
     else:
         full_rows = [full[i].tobytes() for i in range(nb)] + [full[local_row[g]].tobytes() for g, _ in appended]
         masked_rows = [masked[i].tobytes() for i in range(nb)] + [masked[local_row[g]].tobytes() for g, _ in appended]

@@ -1,5 +1,6 @@
 """writeWeights and friends with the reference's signatures (witch_msa/gcmm/weighting.py)."""
 import re
+from collections.abc import Mapping
 
 import numpy as np
 
@@ -25,22 +26,48 @@ def calculateWeights(packed_data, num_hmms=None):
     return {taxon: tuple(kept)}
 
 
+class WeightTable(Mapping):
+    """{taxon: ((idx, np.float64 weight), ...)} answered from the engine's (gathered) top-k table on access.  The
+    reference materialises every tuple (weighting.py:140-163); at 10^5 queries x 10 kept models that is 10^6 Python
+    objects per rank - and with several ranks EVERY rank answers for EVERY query - that the callers then read once or
+    never (getBackbones reads one row per query, writeWeightsToLocal walks them once).  Same values, built when asked."""
+
+    def __init__(self, eng, rows, extra):
+        self._eng, self._rows, self._extra = eng, rows, extra      # taxon -> row of the top-k table; foreign taxa -> their tuples
+
+    def __getitem__(self, taxon):
+        row = self._rows.get(taxon)
+        return self._eng.weights(row) if row is not None else self._extra[taxon]
+
+    def __iter__(self):
+        yield from self._rows
+        yield from self._extra
+
+    def __len__(self):
+        return len(self._rows) + len(self._extra)
+
+    def __contains__(self, taxon):
+        return taxon in self._rows or taxon in self._extra
+
+
 def writeWeights(index_to_hmm, ranked_bitscores, pool=None):
     """{taxon: ((idx, np.float64 weight), ...)} for every taxon of ranked_bitscores
-    (weighting.py:121-169).  Weights come from the device top-k kernel."""
+    (weighting.py:121-169).  Weights come from the device top-k kernel; the mapping is read-only and builds a query's
+    tuple on access (WeightTable)."""
     eng = current_engine()
-    out = {}
+    taxon_row = eng.taxon_row
+    rows, extra = {}, {}
     for taxon in ranked_bitscores.keys():
-        row = eng.taxon_row.get(taxon)
+        row = taxon_row.get(taxon)
         if row is None:
             # renamed or foreign taxon: fall back to the formula on the scores handed in
             scores = ranked_bitscores[taxon]
             idxs = [x[0] for x in scores]
-            out.update(calculateWeights((taxon, idxs, [x[1] for x in scores],
-                                         [index_to_hmm[i].num_taxa for i in idxs])))
+            extra.update(calculateWeights((taxon, idxs, [x[1] for x in scores],
+                                           [index_to_hmm[i].num_taxa for i in idxs])))
         else:
-            out[taxon] = eng.weights(row)
-    return out
+            rows[taxon] = row
+    return WeightTable(eng, rows, extra)
 
 
 def writeWeightsToLocal(taxon_to_weights, path):

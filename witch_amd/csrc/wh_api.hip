@@ -357,7 +357,7 @@ int wh_set_option(wh_ehmm *e, const char *name, const char *value) {
   Knobs &k = e->knobs;
   if (!strcmp(name, "WH_SCORE_KERNEL")) {
     const int kv = *v ? atoi(v) : 7;
-    if (kv < 7 || kv > 11) { set_error("WH_SCORE_KERNEL=%s: this build has kernels 7 to 11", v); return WH_EINVAL; }
+    if (kv < 7 || kv > 12) { set_error("WH_SCORE_KERNEL=%s: this build has kernels 7 to 12", v); return WH_EINVAL; }
     k.kernel = kv;
   } else if (!strcmp(name, "WH_KEEP_LOG2")) k.keep_scale = *v ? ldexpf(1.0f, atoi(v)) : 0.f;
   else if (!strcmp(name, "WH_MAX_WAVES")) k.max_waves = *v ? std::max(1, std::min(16, atoi(v))) : 0;
@@ -846,6 +846,17 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
         if (rc_st != WH_OK) return rc_st;
         continue;
       }
+      // ---- four envelopes per Backward sweep (score_kernel7q, WH_SCORE_KERNEL=12): 16-cell models, special states in LDS
+      bool quadk = false;
+      if (kn.kernel == 12 && !big && !pairk && !specg && Q == 16) {
+        const int spq = (Lc + 1 + 3) / 4 * 4, seqw = (Lc + 3) / 4 + 4;
+        const int wlq = kScoreSpecArrays * spq + 128 + kRegsInts + 4 * 16 + 4 * 16 + 4 * seqw;
+        const size_t table = (size_t)(e->K + 2 * FW_NARR) * Q * kWave * sizeof(float);
+        int wq = 12;
+        if (kn.max_waves > 0) wq = std::max(1, std::min(12, kn.max_waves));
+        while (wq >= 1 && kLdsHeader + table + (size_t)wq * wlq * sizeof(float) > kLdsBudget) wq--;
+        if (wq >= 8) { quadk = true; waves = wq; SP = spq; wave_lds = wlq; lds = kLdsHeader + table + (size_t)wq * wlq * sizeof(float); }
+      }
       a.SP = SP; a.wave_lds = wave_lds; a.spec_arrays = kScoreSpecArrays;
       a.paths = reinterpret_cast<unsigned long long *>((int *)e->d_counter.p + kScorePathSlot);
       a.p2win = (p2win && !specg && !big && !pairk) ? 1 : 0;
@@ -862,8 +873,9 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
       }
       a.n_qblocks = (int)((nq + a.QB - 1) / a.QB);
       a.n_items = a.n_list * a.n_qblocks;
-      a.scratch_stride = (size_t)per_turn * (size_t)(a.Lcap + 1) * 2 * Q * kWave;   // Forward slab(s) per wave
-      a.spec_stride = specg ? (size_t)8 * a.SP : 0;
+      a.scratch_stride = (size_t)(quadk ? 5 : per_turn) * (size_t)(a.Lcap + 1) * 2 * Q * kWave;   // Forward slab(s) per wave
+      a.spec_stride = specg ? (size_t)8 * a.SP : quadk ? (size_t)(4 * kScoreSpecArrays + 3 + 1) * a.SP : 0;
+      if (quadk) { specg = true; a.p2win = 0; a.QB = waves * 8; a.n_qblocks = (int)((nq + a.QB - 1) / a.QB); a.n_items = a.n_list * a.n_qblocks; }   // (HBM region per wave; items of two quads per wave)
       int blocks = std::min(a.n_items, big ? e->cu_count : e->cu_count * std::max(1, 8 / waves));
       blocks = clamp_blocks(blocks, (size_t)waves * (a.scratch_stride + a.spec_stride) * sizeof(float), e->d_scratch);
       if (pass == 0) {
@@ -889,6 +901,7 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
       if (class_mark(e, s, Q, big ? 1 : 0)) return WH_EHIP;
       hipError_t err = big ? launch_score_big(Q, a, blocks, waves * kWave, lds, s)
                        : pairk ? launch_score9(Q, a, blocks, waves * kWave, lds, s)
+                       : quadk ? launch_score7q(Q, a, blocks, waves * kWave, lds, s)
                        : kn.kernel == 8 ? launch_score7b(Q, a, blocks, waves * kWave, lds, s)
                                         : launch_score7(Q, a, blocks, waves * kWave, lds, s);
       if (err != hipSuccess) { set_error("score kernel launch (Q=%d) failed: %s", Q, hipGetErrorString(err)); return WH_EHIP; }

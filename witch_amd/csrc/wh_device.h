@@ -122,6 +122,45 @@ __device__ __forceinline__ float scan_apply(const ScanC &c, float B) {
 #endif
 }
 
+// A pointer the compiler cannot prove wave-uniform (an argument of a non-inlined function arrives in vector registers)
+// read back from lane 0: it then lives in scalar registers, and loads through it take the <scalar base + vector offset>
+// form instead of a 64-bit address per lane.
+template <class T>
+__device__ __forceinline__ T *uniform_ptr(T *p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  return (T *)(((unsigned long long)hi << 32) | lo);
+}
+
+// ------------------------------------------------------------------ the same primitives inside a DPP row (16 lanes)
+// Four problems per wavefront, one per row of 16 lanes (round 5, sweep_backward_null2_quad): every cross-lane step stays
+// inside the row - the row_* DPP controls never leave it, and lane 0 of a row has no left neighbour (bound_ctrl -> 0).
+__device__ __forceinline__ float row_shr1(float x) { return dppf<0x111, 0xF, 0xF, true>(0.f, x); }   // row_shr:1, lane 0 of the row <- 0
+__device__ __forceinline__ float row_sum(float x) {          // every lane ends with the sum over its row
+  x += dppf<0xB1>(0.f, x);
+  x += dppf<0x4E>(0.f, x);
+  x += dppf<0x141>(0.f, x);
+  x += dppf<0x140>(0.f, x);
+  return x;
+}
+struct ScanR { float s[4]; };
+__device__ __forceinline__ ScanR scan_prepare_row(float A) {
+  ScanR c;
+  c.s[0] = A; A *= dppf<0x111>(1.f, A);
+  c.s[1] = A; A *= dppf<0x112>(1.f, A);
+  c.s[2] = A; A *= dppf<0x114>(1.f, A);
+  c.s[3] = A;
+  return c;
+}
+__device__ __forceinline__ float scan_apply_row(const ScanR &c, float B) {
+  asm("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(B) : "v"(c.s[0]));
+  asm("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %1 row_shr:2 row_mask:0xf bank_mask:0xf" : "+v"(B) : "v"(c.s[1]));
+  asm("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %1 row_shr:4 row_mask:0xf bank_mask:0xf" : "+v"(B) : "v"(c.s[2]));
+  asm("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %1 row_shr:8 row_mask:0xf bank_mask:0xf" : "+v"(B) : "v"(c.s[3]));
+  asm("s_nop 1" : "+v"(B));
+  return B;
+}
+
 // ------------------------------------------------------------------ transition tables
 // TREG: the 8 arrays of one orientation live in VGPRs (reloaded per pass from L2);
 // otherwise they are read from LDS in 16-byte pieces on every use.
@@ -499,6 +538,16 @@ __device__ __forceinline__ float backward_emit(const TransTab<Q, TREG> &T, const
   return part;
 }
 
+// Transition arrays of one orientation read from the lane-blocked LDS copy through PER-LANE piece slots (a lane of a
+// quarter-wave window owns 16 nodes somewhere in the model: slot[p4] = float4 index of its piece p4 inside an array).
+template <int Q>
+struct TransTabAt {
+  LdsF4 base;
+  int slot[4];
+  __device__ __forceinline__ TransTabAt(const float *lds) : base(lds) {}
+  __device__ __forceinline__ float4 ld(int a, int p4) const { return base[a * (Q / 4) * kWave + slot[p4]]; }
+};
+
 // ------------------------------------------------------------------ Backward sweep core
 // One Backward row in reversed node order.  On entry Mb/Ib hold row i+1 (or zeros for
 // i = L) and <G> has been formed in place in Mb (G_k = o_k(x_{i+1}) * B_M_k(i+1)).
@@ -538,6 +587,55 @@ __device__ __forceinline__ void backward_cells(const TransTab<Q, TREG> &T, const
   const float dm1 = wave_shr1(Dn[Q - 1]);
 #pragma unroll
   for (int p4 = Q / 4 - 1; p4 >= 0; p4--) {
+    const float4 MM = T.ld(BW_MM, p4), IM = T.ld(BW_IM, p4), MI = T.ld(BW_MI, p4), II = T.ld(BW_II, p4);
+    const float4 MD = T.ld(BW_MD, p4);
+#pragma unroll
+    for (int j = 3; j >= 0; j--) {
+      const int p = 4 * p4 + j;
+      const float g = p > 0 ? Mb[p > 0 ? p - 1 : 0] : gm1;
+      const float dn = p > 0 ? Dn[p > 0 ? p - 1 : 0] : dm1;
+      float nm = fmaf(f4get(MM, j), g, xE);
+      nm = fmaf(f4get(MI, j), Ib[p], nm);
+      nm = fmaf(f4get(MD, j), dn, nm);
+      const float ni = fmaf(f4get(IM, j), g, f4get(II, j) * Ib[p]);
+      Mb[p] = nm;
+      Ib[p] = ni;
+    }
+  }
+}
+
+// One Backward row for FOUR windows at once, one per DPP row: backward_cells' arithmetic on 16 cells per lane, the
+// cross-lane steps (G / D of the neighbouring node, the D->D scan) inside the row of 16 lanes.  TT::ld(array, piece).
+template <class TT>
+__device__ __forceinline__ void backward_cells_row(const TT &T, const ScanR &sc, float (&Mb)[16], float (&Ib)[16], float xE) {
+  float Dn[16];
+  const float gm1 = row_shr1(Mb[15]);
+  float dprev = 0.f;
+#pragma unroll
+  for (int p4 = 0; p4 < 4; p4++) {
+    const float4 DM = T.ld(BW_DM, p4), DD = T.ld(BW_DD, p4);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int p = 4 * p4 + j;
+      const float g = p > 0 ? Mb[p > 0 ? p - 1 : 0] : gm1;
+      dprev = fmaf(f4get(DD, j), dprev, fmaf(f4get(DM, j), g, xE));
+      Dn[p] = dprev;
+    }
+  }
+  float carry = row_shr1(scan_apply_row(sc, dprev));
+#pragma unroll
+  for (int p4 = 0; p4 < 4; p4++) {
+    const float4 DD = T.ld(BW_DD, p4);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int p = 4 * p4 + j;
+      carry *= f4get(DD, j);
+      Dn[p] += carry;
+    }
+  }
+  const float dm1 = row_shr1(Dn[15]);
+#pragma unroll
+  for (int p4 = 3; p4 >= 0; p4--) {
     const float4 MM = T.ld(BW_MM, p4), IM = T.ld(BW_IM, p4), MI = T.ld(BW_MI, p4), II = T.ld(BW_II, p4);
     const float4 MD = T.ld(BW_MD, p4);
 #pragma unroll

@@ -115,6 +115,7 @@ hipError_t launch_staged_assemble(const StagedArgs &a, hipStream_t s);
 hipError_t launch_score_big(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
 hipError_t launch_score7(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
 hipError_t launch_score7b(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);   // A/B slot
+hipError_t launch_score7q(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);   // four envelopes per Backward sweep (Q = 16)
 // two queries per wavefront (wh_score9.hip): ScoreArgs::wave_lds = 2 x score9_block_floats(SP, Lcap), scratch_stride = two slabs
 hipError_t launch_score9(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s);
 int score9_block_floats(int SP, int Lcap);

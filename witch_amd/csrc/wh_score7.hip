@@ -505,6 +505,224 @@ __device__ __noinline__ P4Out sweep_backward_null2_win(const WaveCtx c, lds_u8 *
   return o;
 }
 
+// ---------------------------------------------------------------- P4 for FOUR envelopes at once (round 5)
+// The window sweep above keeps 4 cells per lane: of its ~170 instructions per row some 100 are per-ROW work (the D->D
+// scan, the reductions, the special states, the row requests) that 64 lanes x 4 cells cannot amortise, and it is one
+// dependent chain per row - latency-bound at three waves per SIMD.  Here a wavefront carries FOUR envelopes, one per DPP
+// row of 16 lanes: lane r of quarter t owns the 16 reversed nodes m0_t + 16 r .. + 15 of envelope t's 256-node window,
+// every cross-lane step stays inside the quarter (row_shr scans, row sums), and the per-row work is shared by four
+// envelopes - a row costs what a full-width Backward row costs (~300 instructions, 40 table reads) and serves four pairs.
+// The transition arrays cannot live in registers at 16 cells per lane; they are read from the LDS copy through per-lane
+// piece slots (four consecutive lanes of a quarter read 64 contiguous bytes: conflict-free).  Each envelope's Forward
+// rows come from ITS slab (c.Fs + t * slab_stride), its per-row special states from ITS copy in HBM (c.specg + t *
+// spec_stride: the caller wrote the six arrays there after the envelope's Forward sweep), both requested a row ahead,
+// the stored-lane mask two rows ahead.  The arithmetic per cell is the window sweep's; the sums over a row are formed in
+// another order (16 lanes x 16 cells instead of 64 x 4), so results agree with it to float32 rounding, not bitwise - the
+// same relation the window sweep has to the full-width one.  Same mass certificate.
+// slots (LDS, 16 ints per envelope): [0] active, [1] Ld, [2] m0, [3] 1/Z (float), [4] loop, [5] move (float), [6] byte offset of
+// the envelope's residues inside <seqs>; outputs [8] mass, [9] domcorr (float), [10..] the null2 table scratch is n2 + 32 t.
+enum { QS_ACTIVE = 0, QS_LD, QS_M0, QS_INVZ, QS_LOOP, QS_MOVE, QS_SEQ, QS_PAD, QS_MASS, QS_DOMCORR, QS_INTS = 16 };
+template <int Q, int TH>
+__device__ __noinline__ void sweep_backward_null2_quad(const WaveCtx c, lds_i *slots3, lds_u8 *seqs3, lds_f *n2, int slab_stride, int spec_stride, float mass_tol) {
+  static_assert(Q % 4 == 0, "float4 pieces");
+  constexpr int Q4 = Q / 4;
+  const int lane = c.lane, SP = c.SP, Klds = ctxKlds(c);
+  const int t = lane >> 4, r = lane & 15;
+  lds_i *slot = slots3 + t * QS_INTS;
+  const bool active = slot[QS_ACTIVE] != 0;
+  // (a slot without an envelope holds whatever the last one left: every value an address is formed from is pinned here)
+  const int Ld = active ? min(max(slot[QS_LD], 0), SP - 1) : 0;
+  const int m0 = active ? min(max(slot[QS_M0], 0), 16 * (Q - 4) * 4) & ~15 : 0;
+  const float invZe = __builtin_bit_cast(float, slot[QS_INVZ]);
+  LenCfg cu;
+  cu.loop = __builtin_bit_cast(float, slot[QS_LOOP]); cu.move = __builtin_bit_cast(float, slot[QS_MOVE]); cu.EJ = 0.0f; cu.EC = 1.0f;
+  lds_u8 *eseq = seqs3 + (active ? slot[QS_SEQ] : 0);
+  // HBM addresses = a wave-uniform base in scalar registers + this lane's 32-bit byte offset.  The four envelopes walk
+  // their rows TOGETHER from their last row down (step j: envelope t is on row Ld_t - j), so that the row part of every
+  // address is uniform (- j rows from the base) and the lane's offset holds what differs: its quarter's slab / copy of
+  // the arrays, its last row, its piece.  (Per-lane 64-bit row pointers cost 26 registers and spilled; a scratch reload
+  // between two row requests counts on vmcnt like they do and serialised them.)
+  typedef __attribute__((address_space(1))) unsigned glb_u;
+  typedef __attribute__((address_space(1))) v4f_t glb_v4;
+  typedef __attribute__((address_space(1))) char glb_c;
+  const glb_c *FsU = (const glb_c *)uniform_ptr((const glb_f *)c.Fs);
+  const glb_c *specU = (const glb_c *)uniform_ptr((const glb_f *)c.specg);
+  constexpr int kRowBytes = 32 * Q4 * kWave;             // one Forward row of a slab: M and I cells of 64 lane blocks
+  const unsigned qspec = 4u * (unsigned)(t * __builtin_amdgcn_readfirstlane(spec_stride) + Ld);
+  const unsigned qslab = 4u * (unsigned)(t * __builtin_amdgcn_readfirstlane(slab_stride)) + (unsigned)Ld * kRowBytes;
+  // word <arr * SP + (row Ld_t - back)> of my quarter's copy of the per-row arrays, <back> uniform
+  auto ldu = [&](int arr_word, int back) -> unsigned {
+    return __builtin_nontemporal_load((const glb_u *)(uniform_ptr(specU + 4 * ((long)__builtin_amdgcn_readfirstlane(arr_word) - (long)__builtin_amdgcn_readfirstlane(back))) + qspec));
+  };
+  auto ldf_ = [&](int arr_word, int back) -> float { return __builtin_bit_cast(float, ldu(arr_word, back)); };
+  const unsigned qmask = qspec + 4u * (unsigned)(((kWave - 1 - ((m0 >> 4) + r)) < 32 ? kSpML : kSpMH) * SP);   // ... of the mask word that holds my lane block's bit
+  // This lane's 16 nodes are ONE forward lane block (Q = 16, m0 a multiple of 16): reversed piece p4 is slot p4 * 64 + lr of a
+  // reversed array, and slot (3 - p4) * 64 + lanef of a forward-ordered one - one register each, the rest are immediates.
+  static_assert(Q == 16, "the quarter-wave sweep is written for 16 cells per lane");
+  const int lr = (m0 >> 4) + r, lanef = kWave - 1 - lr;
+  struct TabRow {
+    LdsF4 base; int lr;
+    __device__ __forceinline__ TabRow(const float *lds, int lr_) : base(lds), lr(lr_) {}
+    __device__ __forceinline__ float4 ld(int a, int p4) const { return base[(a * 4 + p4) * kWave + lr]; }
+  } T((const float *)c.bwL, lr);
+  float A = 1.f;
+#pragma unroll
+  for (int p4 = 0; p4 < 4; p4++) { const float4 d = T.ld(BW_DD, p4); A *= d.x; A *= d.y; A *= d.z; A *= d.w; }
+  const ScanR sc = scan_prepare_row(A);
+  const LdsF4 em4L((const float *)c.emL);
+  const float4 *em4G = reinterpret_cast<const float4 *>((const float *)c.emG);
+  float Mb[16], Ib[16], fM[16];
+#pragma unroll
+  for (int p = 0; p < 16; p++) { Mb[p] = 0.f; Ib[p] = 0.f; fM[p] = 0.f; }
+  float xC = cu.move, xJ = 0.f, xN = 0.f, xB = 0.f, xfac = 0.f, fIs = 0.f;
+  // Every step REQUESTS what the next step needs - the Forward cells of my lane block, the row's special states, and the
+  // stored-lane mask word of the step after - in wave-uniform control flow and for every lane alike (an envelope that has
+  // run out of rows reads the rows in front of its slab: the caller leaves one slab / one array of slack in front of the
+  // first), so that the loaded registers carry no copies across the loop edge and are waited for only where the row uses
+  // them, a whole row of arithmetic later.  (Requested inside the per-envelope branch, every loaded value was copied at
+  // the branch's merge point - which waits for it: one exposed HBM round trip per row.)
+  auto mask_word = [&](int back) -> unsigned {             // the mask word holding my lane block's bit, my row Ld - back
+    return __builtin_nontemporal_load((const glb_u *)(uniform_ptr(specU - 4 * (long)__builtin_amdgcn_readfirstlane(back)) + qmask));
+  };
+  float4 fm[4], fi[4];
+  const unsigned foff = qslab + 16u * (unsigned)lanef;       // byte offset of my block's cells on my LAST row; piece p4: + 1024 (3 - p4), the I cells + 4096
+  auto ld4 = [&](const glb_c *rowp, unsigned off) -> float4 {
+    const v4f_t v = __builtin_nontemporal_load((const glb_v4 *)(rowp + off));
+    return make_float4(v.x, v.y, v.z, v.w);
+  };
+  auto request_row = [&](int back) {                        // my row Ld - back
+#pragma unroll
+    for (int p4 = 0; p4 < 4; p4++) {
+      const glb_c *rowp = uniform_ptr(FsU - (long)__builtin_amdgcn_readfirstlane(back) * kRowBytes + 1024 * (3 - p4));
+      fm[p4] = ld4(rowp, foff);
+      fi[p4] = ld4(uniform_ptr(rowp + 4096), foff);
+    }
+  };
+  int Lmax = Ld;
+  Lmax = max(Lmax, __shfl_xor(Lmax, 16));
+  Lmax = max(Lmax, __shfl_xor(Lmax, 32));
+  // step j works on row i = Ld - j of my envelope with S(i), S(i-1), N/J/C(i-1) and the mask word of row i in registers
+  int S_i, S_p, S_next = 0;
+  float n_p, j_p, c_p;
+  unsigned w_i, w_n;
+  request_row(0);
+  w_i = mask_word(0); w_n = mask_word(1);
+  S_i = (int)ldu(SP_S * SP, 0);
+  S_p = (int)ldu(SP_S * SP, 1);
+  n_p = ldf_(SP_N * SP, 1);
+  j_p = ldf_(SP_J * SP, 1);
+  c_p = ldf_(SP_C * SP, 1);
+#pragma unroll 1
+  for (int j = 0; j < Lmax; j++) {
+    asm volatile("" ::: "memory");
+    const int i = Ld - j;
+    if (i >= 1) {
+      if (j > 0) {
+        mirror_scale<16>(S_next - S_i, Mb, Ib, xJ, xC, xN);
+        const int x = eseq[i];
+        float part = 0.f;
+        auto emit = [&](auto em_ld) {
+#pragma unroll
+          for (int p4 = 0; p4 < 4; p4++) {
+            const float4 E = T.ld(BW_E, p4);
+            const float4 O = em_ld(p4);
+            Mb[4 * p4 + 0] *= O.w; part = fmaf(E.x, Mb[4 * p4 + 0], part);
+            Mb[4 * p4 + 1] *= O.z; part = fmaf(E.y, Mb[4 * p4 + 1], part);
+            Mb[4 * p4 + 2] *= O.y; part = fmaf(E.z, Mb[4 * p4 + 2], part);
+            Mb[4 * p4 + 3] *= O.x; part = fmaf(E.w, Mb[4 * p4 + 3], part);
+          }
+        };
+        if (x < Klds) emit([&](int p4) { return em4L[x * (Q * 16) + (3 - p4) * kWave + lanef]; });
+        else emit([&](int p4) { return em4G[(size_t)x * (Q * 16) + (3 - p4) * kWave + lanef]; });
+        xB = row_sum(part);
+        xJ = fmaf(xJ, cu.loop, xB * cu.move);
+        xC = xC * cu.loop;
+        xN = fmaf(xN, cu.loop, xB * cu.move);
+      }
+      const float xE = fmaf(xC, cu.EC, xJ * cu.EJ);
+      backward_cells_row(T, sc, Mb, Ib, xE);
+      clamp_backward<16>(Mb, Ib, xB, xJ, xC, xN);
+      const float s_i = invZe;
+      const float s_p = ldexpf(invZe, S_p - S_i);       // the Forward rescale between rows i-1 and i
+      if ((w_i >> (lanef & 31)) & 1u) {                 // the Forward sweep stored my lane block on this row
+        float idot = 0.f;
+#pragma unroll
+        for (int p4 = 0; p4 < 4; p4++) {
+          const float4 fm_ = fm[p4], fi_ = fi[p4];
+          fM[4 * p4 + 0] = fmaf(fm_.w * Mb[4 * p4 + 0], s_i, fM[4 * p4 + 0]);
+          fM[4 * p4 + 1] = fmaf(fm_.z * Mb[4 * p4 + 1], s_i, fM[4 * p4 + 1]);
+          fM[4 * p4 + 2] = fmaf(fm_.y * Mb[4 * p4 + 2], s_i, fM[4 * p4 + 2]);
+          fM[4 * p4 + 3] = fmaf(fm_.x * Mb[4 * p4 + 3], s_i, fM[4 * p4 + 3]);
+          idot = fmaf(fi_.w, Ib[4 * p4 + 0], idot); idot = fmaf(fi_.z, Ib[4 * p4 + 1], idot);
+          idot = fmaf(fi_.y, Ib[4 * p4 + 2], idot); idot = fmaf(fi_.x, Ib[4 * p4 + 3], idot);
+        }
+        fIs = fmaf(idot, s_i, fIs);
+      }
+      float nj = n_p * xN;
+      nj = fmaf(j_p, xJ, nj);
+      nj = fmaf(c_p, xC, nj);
+      xfac = fmaf(nj * cu.loop, s_p, xfac);
+      S_next = S_i;
+    }
+    // (uniform) the next step's row, for every lane
+    if (j + 1 < Lmax) {
+      request_row(j + 1);
+      w_i = w_n;
+      w_n = mask_word(j + 2);
+      S_i = S_p;
+      S_p = (int)ldu(SP_S * SP, j + 2);
+      n_p = ldf_(SP_N * SP, j + 2);
+      j_p = ldf_(SP_J * SP, j + 2);
+      c_p = ldf_(SP_C * SP, j + 2);
+    }
+  }
+  float sm = 0.f;
+#pragma unroll
+  for (int p = 0; p < 16; p++) sm += fM[p];
+  sm = row_sum(sm);
+  const float si = row_sum(fIs);
+  const float mass = sm + si + xfac;
+  const bool ok = active && fabsf((float)Ld - mass) <= mass_tol * (float)Ld;
+  lds_f *n2tab = n2 + 32 * t;
+  const int K = ctxK(c), Kp = ctxKp(c);
+  // (every quarter walks the null2 steps; one without an accepted envelope computes on zeros and its result is not read)
+  const float norm = 1.0f / (float)(Ld > 0 ? Ld : 1);
+  for (int x = 0; x < K; x++) {
+    float s_ = 0.f;
+    auto dot = [&](auto em_ld) {
+#pragma unroll
+      for (int p4 = 0; p4 < 4; p4++) {
+        const float4 O = em_ld(p4);
+        s_ = fmaf(fM[4 * p4 + 0], O.w, s_); s_ = fmaf(fM[4 * p4 + 1], O.z, s_);
+        s_ = fmaf(fM[4 * p4 + 2], O.y, s_); s_ = fmaf(fM[4 * p4 + 3], O.x, s_);
+      }
+    };
+    if (x < Klds) dot([&](int p4) { return em4L[x * (Q * 16) + (3 - p4) * kWave + lanef]; });
+    else dot([&](int p4) { return em4G[(size_t)x * (Q * 16) + (3 - p4) * kWave + lanef]; });
+    s_ = row_sum(s_);
+    if (r == 0) n2tab[x] = (s_ + si) * norm + xfac * norm;
+  }
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t mdeg = (uint32_t)__shfl((int)c.degen, min(K + r, kWave - 1));      // (all lanes active here) the mask of "my" degenerate code
+  if (K + r < Kp) {
+    // degenerate codes (at most 16 of them: one per lane of the quarter): unweighted mean of the canonical ratios; gap/*/~ -> 1
+    float s_ = 0.f; int n = 0;
+    for (int x = 0; x < K; x++) if (mdeg & (1u << x)) { s_ += n2tab[x]; n++; }
+    n2tab[K + r] = n > 0 ? s_ / (float)n : 1.0f;
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int d = r; d < Kp; d += 16) n2tab[d] = logf(n2tab[d]);
+  __builtin_amdgcn_wave_barrier();
+  float dc = 0.f;
+  for (int u = r; u < Ld; u += 16) dc += n2tab[eseq[u]];
+  const float domcorr = row_sum(dc);
+  if (r == 0) {
+    slot[QS_MASS] = __builtin_bit_cast(int, mass);
+    slot[QS_DOMCORR] = __builtin_bit_cast(int, ok ? domcorr : 0.f);
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
 // ---------------------------------------------------------------- P2 on a node window (round 4)
 // The multihit Backward sweep exists for per-ROW numbers only: the posterior of a domain beginning / ending at each row
 // and of the row's residue being emitted by a flank state, which the region scan compares with 0.25 / 0.10 / 0.20.
@@ -521,15 +739,19 @@ __device__ __noinline__ P4Out sweep_backward_null2_win(const WaveCtx c, lds_u8 *
 // three posterior rows overwrite the E, B and N rows in place as the full-width sweep does - row i reads E(i), B(i) and
 // N(i-1), and N(i) was read one row earlier.  BWG: as in sweep_backward_null2_win.
 struct WinDec { float eps; };
-template <int QB, int Q, int TH, bool INPL = false, bool BWG = false>
+// TMPG (four envelopes per wave, score_kernel7q): the three posterior rows go to the wave's HBM region (c.specg), not to
+// LDS - the wave's LDS block then has room for four queries' residues and records.
+template <int QB, int Q, int TH, bool INPL = false, bool BWG = false, bool TMPG = false>
 __device__ __noinline__ WinDec sweep_backward_decode_win(const WaveCtx c, lds_u8 *seq3, int L, LenCfg cm, float invZ, int ef_L, int m0) {
   static_assert(Q % QB == 0 && QB % 4 == 0, "a window lane must stay inside one forward lane block");
+  static_assert(!(BWG && TMPG) && !(INPL && TMPG), "c.specg serves one purpose per call");
   constexpr int Q4 = Q / 4, B4 = QB / 4;
   const uint8_t *seq = (const uint8_t *)seq3;
   const int lane = c.lane, SP = c.SP, Klds = ctxKlds(c);
   const float *spec = (const float *)c.spec;
   float *tmp = (float *)c.spec + kSpArr * SP;          // [0] pe, [1] pb, [2] njc rows of the window sweep
   float *tE = INPL ? (float *)c.spec + SP_E * SP : tmp, *tB = INPL ? (float *)c.spec + SP_B * SP : tmp + SP, *tN = INPL ? (float *)c.spec + SP_N * SP : tmp + 2 * SP;
+  glb_f *gE = c.specg, *gB = c.specg + SP, *gN = c.specg + 2 * SP;
   const int *speci = reinterpret_cast<const int *>(spec);
   int fwd[B4];
   TransTab<QB, true> T;
@@ -603,7 +825,8 @@ __device__ __noinline__ WinDec sweep_backward_decode_win(const WaveCtx c, lds_u8
       ratio = spec[SP_N * SP] * xN * s_i;               // N_F(0) N_B(0) / Z: the share of the paths that stay inside the window
     }
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) { tE[i] = pe; tB[i] = pb; tN[i] = njc; }
+    if (TMPG) { if (lane == 0) { gE[i] = pe; gB[i] = pb; gN[i] = njc; } }
+    else if (lane == 0) { tE[i] = pe; tB[i] = pb; tN[i] = njc; }
     __builtin_amdgcn_wave_barrier();
   }
   WinDec o;
@@ -615,10 +838,11 @@ __device__ __noinline__ WinDec sweep_backward_decode_win(const WaveCtx c, lds_u8
 // the slack of the window (header above): a windowed posterior p_w stands for a true value in [p_w, p_w + eps].
 // Returns the regions and, in bit 24 of flags, whether any decision was in doubt (the caller then discards the result).
 // The cumulative sums go back into the pe row (etot) and the njc row (btot): both are read at the row they are written.
-template <int TH, bool INPL = false>
-__device__ __noinline__ RegOut region_scan_cert(lds_f *spec3, int SP, int L, lds_i *regs3, int lane, float eps) {
-  float *tmp = (float *)spec3 + kSpArr * SP;
+template <int TH, bool INPL = false, bool TMPG = false>
+__device__ __noinline__ RegOut region_scan_cert(lds_f *spec3, int SP, int L, lds_i *regs3, int lane, float eps, glb_f *tmpg = nullptr) {
+  float *tmp = TMPG ? (float *)tmpg : (float *)spec3 + kSpArr * SP;
   float *tE = INPL ? (float *)spec3 + SP_E * SP : tmp, *tB = INPL ? (float *)spec3 + SP_B * SP : tmp + SP, *tN = INPL ? (float *)spec3 + SP_N * SP : tmp + 2 * SP;
+  if (TMPG) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // the rows were stored by lane 0, every lane reads them next
   int *regs = (int *)regs3;
   const float rt1 = 0.25f, rt2 = 0.10f, rt3 = 0.20f;
   const float slack = 2e-5f;                // float32 rounding of the sums, on top of eps
@@ -627,15 +851,18 @@ __device__ __noinline__ RegOut region_scan_cert(lds_f *spec3, int SP, int L, lds
   float btot = 0.f, etot = 0.f;
   int i0 = -1;
   bool trig = false;
-  const float pb0 = tB[0];
+  // (TMPG: the rows live in HBM and are rewritten for every pair - L1-bypassing accesses, as the long-query sweeps use)
+  auto ldt = [&](const float *p_) -> float { return TMPG ? __builtin_nontemporal_load(p_) : *p_; };
+  auto stt = [&](float *p_, float v_) { if (TMPG) __builtin_nontemporal_store(v_, p_); else *p_ = v_; };
+  const float pb0 = ldt(tB);
   __builtin_amdgcn_wave_barrier();
-  if (lane == 0) { tE[0] = 0.f; tN[0] = 0.f; }
+  if (lane == 0) { stt(tE, 0.f); stt(tN, 0.f); }
   for (int j0 = 1; j0 <= L; j0 += kWave) {
     const int jj = j0 + lane;
     const bool valid = jj <= L;
-    const float nv = valid ? tN[jj] : 0.f;
-    const float bv = valid ? (jj - 1 == 0 ? pb0 : tB[jj - 1]) : 0.f;
-    const float ev = valid ? tE[jj] : 0.f;
+    const float nv = valid ? ldt(tN + jj) : 0.f;
+    const float bv = valid ? (jj - 1 == 0 ? pb0 : ldt(tB + jj - 1)) : 0.f;
+    const float ev = valid ? ldt(tE + jj) : 0.f;
     float jout = 0.f, cout = 0.f;
     const int cnt = L - j0 + 1 < kWave ? L - j0 + 1 : kWave;
     for (int t = 0; t < cnt; t++) {
@@ -666,18 +893,19 @@ __device__ __noinline__ RegOut region_scan_cert(lds_f *spec3, int SP, int L, lds
         }
       }
     }
-    if (valid) { tN[jj] = jout; tE[jj] = cout; }
+    if (valid) { stt(tN + jj, jout); stt(tE + jj, cout); }
   }
   __builtin_amdgcn_wave_barrier();
+  if (TMPG) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // the cumulative sums were stored by other lanes of this wave
   // multidomain test: max_z min(etot[z]-etot[i-1], btot[j]-btot[z-1]) >= rt3; each sum of windowed posteriors over the
   // region's rows falls short of the true one by at most (rows) x eps
   int multi_mask = 0;
   for (int e = 0; e < nenv; e++) {
     const int ri = regs[2 * e], rj = regs[2 * e + 1];
     float mx = -1.0f;
-    const float e0 = tE[ri - 1], bj = tN[rj];
+    const float e0 = ldt(tE + ri - 1), bj = ldt(tN + rj);
     for (int z = ri + lane; z <= rj; z += kWave) {
-      const float u = tE[z] - e0, v = bj - tN[z - 1];
+      const float u = ldt(tE + z) - e0, v = bj - ldt(tN + z - 1);
       mx = fmaxf(mx, fminf(u, v));
     }
     mx = wave_max(mx);
@@ -721,19 +949,91 @@ __device__ __noinline__ RegOut region_scan(lds_f *spec3, glb_f *specg, int SP, i
   return o;
 }
 
+struct EnvCounters { unsigned n_w256, n_w512, n_wfail, n_full; };
+// An envelope's Backward sweep + null2 once its Forward rows are in c.Fs and its per-row arrays in the wave's block: on a
+// node window where one fits around the dominant alignment and passes the mass certificate, else at full width.
+// <dense>: the Forward sweep stored every row (the redo after a failed spill certificate): full width, no tolerance.
+// <skip_window>: the caller has tried the window already (the four-envelopes-per-wave sweep).  The caller checks the
+// spill certificate |Ld - mass| <= kMassTol7 Ld on the result of a sparse sweep.
+template <int Q, int TH, bool SG>
+__device__ __forceinline__ P4Out envelope_backward(const ScoreArgs &a, const WaveCtx &c, const uint8_t *eseq, int Ld, LenCfg cu, const FwdOut &f3,
+                                                   bool dense, bool skip_window, EnvCounters &ec, int lane) {
+  const int SP = c.SP;
+  const float tol = dense ? INFINITY : kMassTol7;
+  P4Out p4;
+  bool have4 = false;
+  if constexpr (Q >= 8) {
+    if (!dense && !a.no_window && !skip_window) {
+      // the node window around the lane blocks the dominant alignment runs through (two blocks in
+      // front: the envelope's first ~25 rows set no bit and lie that many nodes ahead; one block behind)
+      const unsigned *su = reinterpret_cast<const unsigned *>(SG ? (const float *)c.specg : (const float *)c.spec);
+      const unsigned long long um = ((unsigned long long)su[kSpMH * SP] << 32) | su[kSpML * SP];
+      if (um != 0) {
+        int lo = __builtin_ctzll(um), hi = 63 - __builtin_clzll(um);
+        lo = lo > 1 ? lo - 2 : 0; hi = hi < 63 ? hi + 1 : 63;
+        const int nodes = (hi - lo + 1) * Q;
+        if (a.stats && lane == 0) { atomicAdd(a.stats + 12, (unsigned long long)(hi - lo + 1)); atomicAdd(a.stats + 14, 1ull); atomicAdd(a.stats + 15, (unsigned long long)__builtin_popcountll(um)); }
+        if (nodes <= 4 * kWave) {
+          const int m0 = min((63 - hi) * Q, kWave * (Q - 4));
+          p4 = sweep_backward_null2_win<4, Q, TH, SG>(c, (lds_u8 *)eseq, Ld, cu, 1.0f / (f3.xC * cu.move), kWinTol7, m0);
+          have4 = fabsf((float)Ld - p4.mass) <= kWinTol7 * (float)Ld;
+          if (have4) ec.n_w256++; else ec.n_wfail++;
+          if (a.stats && lane == 0) {
+            atomicAdd(a.stats + (have4 ? 0 : 2), 1ull);
+            const float dev = fabsf((float)Ld - p4.mass) / (float)Ld;
+            atomicAdd(a.stats + (dev < 3e-7f ? 16 : dev < 1e-6f ? 17 : dev < 3e-6f ? 18 : dev < 1e-5f ? 19 : dev < 2e-5f ? 20 : 21), 1ull);
+          }
+        } else if (Q % 8 == 0 && Q > 8 && nodes <= 8 * kWave) {
+          const int m0 = min((63 - hi) * Q, kWave * (Q - 8));
+          p4 = sweep_backward_null2_win<(Q % 8 == 0 ? 8 : 4), Q, TH, SG>(c, (lds_u8 *)eseq, Ld, cu, 1.0f / (f3.xC * cu.move), kWinTol7, m0);
+          have4 = fabsf((float)Ld - p4.mass) <= kWinTol7 * (float)Ld;
+          if (have4) ec.n_w512++; else ec.n_wfail++;
+          if (a.stats && lane == 0) atomicAdd(a.stats + (have4 ? 1 : 2), 1ull);
+        }
+      }
+    }
+  }
+  if (!have4) {
+    p4 = sweep_backward_null2<Q, TH, SG>(c, (lds_u8 *)eseq, Ld, cu, 1.0f / (f3.xC * cu.move), f3.ef, tol);
+    ec.n_full++;
+    if (a.stats && lane == 0) {
+      atomicAdd(a.stats + 3, 1ull);
+      const float dev = fabsf((float)Ld - p4.mass) / (float)Ld;
+      atomicAdd(a.stats + (dev < 3e-7f ? 22 : dev < 1e-6f ? 23 : dev < 3e-6f ? 24 : dev < 1e-5f ? 25 : dev < 2e-5f ? 26 : 27), 1ull);
+    }
+  }
+  return p4;
+}
+
+// ---------------- A.6 score assembly (float32 where HMMER is float32): the sums over a pair's envelopes -> deci-bits
+__device__ __forceinline__ void assemble_score(int L, int Ld_tot, float seqbias_sum, float sum_score, float sb2, float fwdsc, float nullsc,
+                                               wh_pair_detail *dp, int &flags, int &decibits) {
+  const double LOG2 = 0.69314718055994529;
+  const float lomega = (float)log(1.0 / 256.0);
+  const float seqbias = flogsum0_v7(lomega + seqbias_sum);
+  float pre_score = (float)(((double)fwdsc - (double)nullsc) / LOG2);
+  float seq_score = (float)(((double)fwdsc - (double)(nullsc + seqbias)) / LOG2);
+  sb2 = flogsum0_v7(lomega + sb2);
+  sum_score += (float)((double)(L - Ld_tot) * log((double)((float)L / (float)(L + 3))));
+  const float pre2 = (float)(((double)sum_score - (double)nullsc) / LOG2);
+  sum_score = (float)(((double)sum_score - (double)(nullsc + sb2)) / LOG2);
+  if (Ld_tot > 0 && sum_score > seq_score) { seq_score = sum_score; pre_score = pre2; flags |= WH_FLAG_OVERRIDE; }
+  decibits = (int)rint((double)seq_score * 10.0);
+  flags |= WH_FLAG_REPORTED;
+  if (dp) { dp->seq_score = seq_score; dp->pre_score = pre_score; dp->seqbias_nats = seqbias; }
+}
+
 // ---------------------------------------------------------------- envelopes + score assembly (A.5, A.6)
 // Everything a pair needs after its regions are known: per envelope P3 (sparse spill) -> P4 on a node window / at full
 // width / dense redo -> null2; then HMMER's float32 score assembly, or the pair's record for the multidomain resolver.
 // Inlined into its two callers: the fused kernel below, and the envelope kernel of the staged launches (wh_staged.hip),
 // whose P1 / P2 ran as launches of their own.
-struct EnvCounters { unsigned n_w256, n_w512, n_wfail, n_full; };
 #define WH_TICK7(slot) do { if (a.stats) { const long long t_now = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(a.stats + (slot), (unsigned long long)(t_now - t_last)); t_last = t_now; } } while (0)
 template <int Q, int TH, bool SG>
 __device__ __forceinline__ void score_envelopes(const ScoreArgs &a, WaveCtx &c, uint8_t *seq, int *regs, int L, int lane, int h, int64_t qi, int nenv, int nreg,
                                                 int multi_mask, float fwdsc, float nullsc, float fwd_bits_out, wh_pair_detail *dp, int &flags, int &decibits,
                                                 EnvCounters &ec, long long &t_last) {
   const double LOG2 = 0.69314718055994529;
-  const int SP = c.SP;
   {
   // ---------------- envelopes
   const LenCfg cu = len_config(L, false);
@@ -759,49 +1059,7 @@ __device__ __forceinline__ void score_envelopes(const ScoreArgs &a, WaveCtx &c, 
       domcorr = 0.f;
       if (!(f3.xC > 0.f)) break;
       WH_TICK7(7);
-      const float tol = attempt == 0 ? kMassTol7 : INFINITY;
-      P4Out p4;
-      bool have4 = false;
-      if constexpr (Q >= 8) {
-        if (attempt == 0 && !a.no_window) {
-          // the node window around the lane blocks the dominant alignment runs through (two blocks in
-          // front: the envelope's first ~25 rows set no bit and lie that many nodes ahead; one block behind)
-          const unsigned *su = reinterpret_cast<const unsigned *>(SG ? (const float *)c.specg : (const float *)c.spec);
-          const unsigned long long um = ((unsigned long long)su[kSpMH * SP] << 32) | su[kSpML * SP];
-          if (um != 0) {
-            int lo = __builtin_ctzll(um), hi = 63 - __builtin_clzll(um);
-            lo = lo > 1 ? lo - 2 : 0; hi = hi < 63 ? hi + 1 : 63;
-            const int nodes = (hi - lo + 1) * Q;
-            if (a.stats && lane == 0) { atomicAdd(a.stats + 12, (unsigned long long)(hi - lo + 1)); atomicAdd(a.stats + 14, 1ull); atomicAdd(a.stats + 15, (unsigned long long)__builtin_popcountll(um)); }
-            if (nodes <= 4 * kWave) {
-              const int m0 = min((63 - hi) * Q, kWave * (Q - 4));
-              p4 = sweep_backward_null2_win<4, Q, TH, SG>(c, (lds_u8 *)eseq, Ld, cu, 1.0f / (f3.xC * cu.move), kWinTol7, m0);
-              have4 = fabsf((float)Ld - p4.mass) <= kWinTol7 * (float)Ld;
-              if (have4) ec.n_w256++; else ec.n_wfail++;
-              if (a.stats && lane == 0) {
-                atomicAdd(a.stats + (have4 ? 0 : 2), 1ull);
-                const float dev = fabsf((float)Ld - p4.mass) / (float)Ld;
-                atomicAdd(a.stats + (dev < 3e-7f ? 16 : dev < 1e-6f ? 17 : dev < 3e-6f ? 18 : dev < 1e-5f ? 19 : dev < 2e-5f ? 20 : 21), 1ull);
-              }
-            } else if (Q % 8 == 0 && Q > 8 && nodes <= 8 * kWave) {
-              const int m0 = min((63 - hi) * Q, kWave * (Q - 8));
-              p4 = sweep_backward_null2_win<(Q % 8 == 0 ? 8 : 4), Q, TH, SG>(c, (lds_u8 *)eseq, Ld, cu, 1.0f / (f3.xC * cu.move), kWinTol7, m0);
-              have4 = fabsf((float)Ld - p4.mass) <= kWinTol7 * (float)Ld;
-              if (have4) ec.n_w512++; else ec.n_wfail++;
-              if (a.stats && lane == 0) atomicAdd(a.stats + (have4 ? 1 : 2), 1ull);
-            }
-          }
-        }
-      }
-      if (!have4) {
-        p4 = sweep_backward_null2<Q, TH, SG>(c, (lds_u8 *)eseq, Ld, cu, 1.0f / (f3.xC * cu.move), f3.ef, tol);
-        ec.n_full++;
-        if (a.stats && lane == 0) {
-          atomicAdd(a.stats + 3, 1ull);
-          const float dev = fabsf((float)Ld - p4.mass) / (float)Ld;
-          atomicAdd(a.stats + (dev < 3e-7f ? 22 : dev < 1e-6f ? 23 : dev < 3e-6f ? 24 : dev < 1e-5f ? 25 : dev < 2e-5f ? 26 : 27), 1ull);
-        }
-      }
+      const P4Out p4 = envelope_backward<Q, TH, SG>(a, c, eseq, Ld, cu, f3, attempt == 1, false, ec, lane);
       domcorr = p4.domcorr;
       WH_TICK7(8);
       if (attempt == 0 && !(fabsf((float)Ld - p4.mass) <= kMassTol7 * (float)Ld)) continue;
@@ -825,22 +1083,66 @@ __device__ __forceinline__ void score_envelopes(const ScoreArgs &a, WaveCtx &c, 
       for (int e = 0; e < nenv; e++) { rr->ri[e] = regs[2 * e]; rr->rj[e] = regs[2 * e + 1]; rr->envsc[e] = envres[e]; rr->domcorr[e] = envres[WH_MAX_ENVELOPES + e]; }
     }
     // provisional result: resolve_kernel writes the final score and flags of this pair
-  } else {
-  // ---------------- A.6 score assembly (float32 where HMMER is float32)
-  const float lomega = (float)log(1.0 / 256.0);
-  const float seqbias = flogsum0_v7(lomega + seqbias_sum);
-  float pre_score = (float)(((double)fwdsc - (double)nullsc) / LOG2);
-  float seq_score = (float)(((double)fwdsc - (double)(nullsc + seqbias)) / LOG2);
-  sb2 = flogsum0_v7(lomega + sb2);
-  sum_score += (float)((double)(L - Ld_tot) * log((double)((float)L / (float)(L + 3))));
-  const float pre2 = (float)(((double)sum_score - (double)nullsc) / LOG2);
-  sum_score = (float)(((double)sum_score - (double)(nullsc + sb2)) / LOG2);
-  if (Ld_tot > 0 && sum_score > seq_score) { seq_score = sum_score; pre_score = pre2; flags |= WH_FLAG_OVERRIDE; }
-  decibits = (int)rint((double)seq_score * 10.0);
-  flags |= WH_FLAG_REPORTED;
-  if (dp) { dp->seq_score = seq_score; dp->pre_score = pre_score; dp->seqbias_nats = seqbias; }
+  } else assemble_score(L, Ld_tot, seqbias_sum, sum_score, sb2, fwdsc, nullsc, dp, flags, decibits);
   }
+}
+
+// ---------------------------------------------------------------- P2 + region scan of a pair (after its P1)
+struct FrontState {               // per wave: the window heuristics of the multihit Backward sweep, and its path counters
+  float eps_prev, eps_prev2;      // slack of the last two windows tried on the current model
+  unsigned n_pairs_h;             // pairs of the current model this wave has scored
+  unsigned n_p2w, n_p2rej;        // sweeps kept from a window / windows in doubt (redone at full width)
+};
+// TMPG: the windowed sweep keeps its three posterior rows in the wave's HBM region <tmpg> (score_kernel7q) instead of LDS.
+template <int Q, int TH, bool SG, bool TMPG>
+__device__ __forceinline__ RegOut score_regions(const ScoreArgs &a, const WaveCtx &c, uint8_t *seq, int *regs, int L, int lane, LenCfg cm, const FwdOut &f1,
+                                                FrontState &fs, long long &t_last, glb_f *tmpg = nullptr) {
+  const int SP = c.SP;
+  WaveCtx cw = c;
+  if (TMPG) cw.specg = tmpg;
+  // ---------------- P2 + region scan: on a node window when every decision of the scan is then beyond doubt
+  RegOut ro;
+  bool have_ro = false;
+  if constexpr (Q >= 8 && !SG) {
+    // (the slack of a window is mostly the model's: a junk mini-domain costs what its weakest nodes allow.  Rows x
+    // slack must stay below the 0.20 of the multidomain test for a single-domain region to be certified, so a wave
+    // that has measured a slack too large for this query length TWICE in a row skips the window on the model's next
+    // pairs and probes again every sixteenth)
+    const bool try_win = fminf(fs.eps_prev, fs.eps_prev2) * (float)L < 0.17f || (fs.n_pairs_h & 15) == 0;
+    fs.n_pairs_h++;
+    if ((a.p2win || TMPG) && !a.no_window && try_win) {
+      const unsigned *su = reinterpret_cast<const unsigned *>((const float *)c.n2tab) + kUmSlot;
+      const unsigned long long um = ((unsigned long long)su[1] << 32) | su[0];
+      if (um != 0) {
+        int lo = __builtin_ctzll(um), hi = 63 - __builtin_clzll(um);
+        lo = lo > 1 ? lo - 2 : 0; hi = hi < 63 ? hi + 1 : 63;
+        const int nodes = (hi - lo + 1) * Q;
+        WinDec wd;
+        wd.eps = 1.0f;
+        if (nodes <= 4 * kWave) wd = sweep_backward_decode_win<4, Q, TH, false, false, TMPG>(cw, (lds_u8 *)seq, L, cm, 1.0f / (f1.xC * cm.move), f1.ef, min((63 - hi) * Q, kWave * (Q - 4)));
+        else if (Q % 8 == 0 && Q > 8 && nodes <= 8 * kWave) wd = sweep_backward_decode_win<(Q % 8 == 0 ? 8 : 4), Q, TH, false, false, TMPG>(cw, (lds_u8 *)seq, L, cm, 1.0f / (f1.xC * cm.move), f1.ef, min((63 - hi) * Q, kWave * (Q - 8)));
+        fs.eps_prev2 = fs.eps_prev; fs.eps_prev = fabsf(wd.eps);
+        if (wd.eps > -1e-4f && wd.eps < 0.01f) {
+          ro = region_scan_cert<TH, false, TMPG>(c.spec, SP, L, (lds_i *)regs, lane, fmaxf(wd.eps, 0.f), cw.specg);
+          have_ro = ((ro.flags >> 24) & 3) == 0;
+          if (a.stats && lane == 0) {
+            if ((ro.flags >> 24) & 1) atomicAdd(a.stats + 32, 1ull);
+            if ((ro.flags >> 25) & 1) atomicAdd(a.stats + 33, 1ull);
+            atomicAdd(a.stats + 34, (unsigned long long)(wd.eps * 1e9f));
+            atomicAdd(a.stats + 35, 1ull);
+          }
+          ro.flags &= 0xFFFFFF;
+        } else if (a.stats && lane == 0) atomicAdd(a.stats + 36, 1ull);
+        if (have_ro) fs.n_p2w++; else fs.n_p2rej++;
+      }
+    }
   }
+  if (!have_ro) {
+    sweep_backward_decode<Q, TH, SG>(c, (lds_u8 *)seq, L, cm, 1.0f / (f1.xC * cm.move), f1.ef);
+    WH_TICK7(5);
+    ro = region_scan<TH, SG>(c.spec, c.specg, SP, L, (lds_i *)regs, lane);
+  } else WH_TICK7(5);
+  return ro;
 }
 
 #ifndef WH_SWEEPS_ONLY
@@ -872,9 +1174,7 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
   int cur_h = -1;
   const DevHMM *hm = nullptr;
   EnvCounters ec = {0, 0, 0, 0};                              // this wave's envelope Backward sweeps by path (wh_last_score_paths)
-  unsigned n_p2w = 0, n_p2rej = 0;                            // multihit Backward sweeps kept from a window / windows in doubt (redone at full width)
-  float eps_prev = 0.f, eps_prev2 = 0.f;                      // slack of the last two windows tried on the current model
-  unsigned n_pairs_h = 0;                                     // pairs of the current model this wave has scored
+  FrontState fs = {0.f, 0.f, 0u, 0u, 0u};                     // window heuristics and path counters of the multihit Backward sweep
 
   for (;;) {
     if (threadIdx.x == 0) *s_item_p = atomicAdd(a.counter, 1);
@@ -895,7 +1195,7 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
       float4 *d1 = reinterpret_cast<float4 *>(trL);
       for (int t = threadIdx.x; t < NARR * TBL / 4; t += blockDim.x) { d1[t] = s1[t]; d1[NARR * TBL / 4 + t] = s2[t]; }
       cur_h = h;
-      eps_prev = 0.f; eps_prev2 = 0.f; n_pairs_h = 0;
+      fs.eps_prev = 0.f; fs.eps_prev2 = 0.f; fs.n_pairs_h = 0;
       __syncthreads();
     }
     c.emG = (const glb_f *)(a.tables + hm->em_off);
@@ -932,48 +1232,7 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
         if (dp) dp->fwd_bits = fwd_bits_out;
         if (f1.xC > 0.f && isfinite(fwdsc)) {
           WH_TICK7(4);
-          // ---------------- P2 + region scan: on a node window when every decision of the scan is then beyond doubt
-          RegOut ro;
-          bool have_ro = false;
-          if constexpr (Q >= 8 && !SG) {
-            // (the slack of a window is mostly the model's: a junk mini-domain costs what its weakest nodes allow.  Rows x
-            // slack must stay below the 0.20 of the multidomain test for a single-domain region to be certified, so a wave
-            // that has measured a slack too large for this query length TWICE in a row skips the window on the model's next
-            // pairs and probes again every sixteenth)
-            const bool try_win = fminf(eps_prev, eps_prev2) * (float)L < 0.17f || (n_pairs_h & 15) == 0;
-            n_pairs_h++;
-            if (a.p2win && !a.no_window && try_win) {
-              const unsigned *su = reinterpret_cast<const unsigned *>((const float *)c.n2tab) + kUmSlot;
-              const unsigned long long um = ((unsigned long long)su[1] << 32) | su[0];
-              if (um != 0) {
-                int lo = __builtin_ctzll(um), hi = 63 - __builtin_clzll(um);
-                lo = lo > 1 ? lo - 2 : 0; hi = hi < 63 ? hi + 1 : 63;
-                const int nodes = (hi - lo + 1) * Q;
-                WinDec wd;
-                wd.eps = 1.0f;
-                if (nodes <= 4 * kWave) wd = sweep_backward_decode_win<4, Q, TH>(c, (lds_u8 *)seq, L, cm, 1.0f / (f1.xC * cm.move), f1.ef, min((63 - hi) * Q, kWave * (Q - 4)));
-                else if (Q % 8 == 0 && Q > 8 && nodes <= 8 * kWave) wd = sweep_backward_decode_win<(Q % 8 == 0 ? 8 : 4), Q, TH>(c, (lds_u8 *)seq, L, cm, 1.0f / (f1.xC * cm.move), f1.ef, min((63 - hi) * Q, kWave * (Q - 8)));
-                eps_prev2 = eps_prev; eps_prev = fabsf(wd.eps);
-                if (wd.eps > -1e-4f && wd.eps < 0.01f) {
-                  ro = region_scan_cert<TH>(c.spec, SP, L, (lds_i *)regs, lane, fmaxf(wd.eps, 0.f));
-                  have_ro = ((ro.flags >> 24) & 3) == 0;
-                  if (a.stats && lane == 0) {
-                    if ((ro.flags >> 24) & 1) atomicAdd(a.stats + 32, 1ull);
-                    if ((ro.flags >> 25) & 1) atomicAdd(a.stats + 33, 1ull);
-                    atomicAdd(a.stats + 34, (unsigned long long)(wd.eps * 1e9f));
-                    atomicAdd(a.stats + 35, 1ull);
-                  }
-                  ro.flags &= 0xFFFFFF;
-                } else if (a.stats && lane == 0) atomicAdd(a.stats + 36, 1ull);
-                if (have_ro) n_p2w++; else n_p2rej++;
-              }
-            }
-          }
-          if (!have_ro) {
-            sweep_backward_decode<Q, TH, SG>(c, (lds_u8 *)seq, L, cm, 1.0f / (f1.xC * cm.move), f1.ef);
-            WH_TICK7(5);
-            ro = region_scan<TH, SG>(c.spec, c.specg, SP, L, (lds_i *)regs, lane);
-          } else WH_TICK7(5);
+          const RegOut ro = score_regions<Q, TH, SG, false>(a, c, seq, regs, L, lane, cm, f1, fs, t_last);
           const int nenv = ro.nenv, nreg = ro.nreg, multi_mask = ro.flags >> 8;
           flags |= ro.flags & 0xFF;
           if (dp) { dp->nregions = nreg; dp->nenv = nenv; }
@@ -995,9 +1254,276 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
     if (ec.n_w512) atomicAdd(a.paths + 1, (unsigned long long)ec.n_w512);
     if (ec.n_wfail) atomicAdd(a.paths + 2, (unsigned long long)ec.n_wfail);
     if (ec.n_full) atomicAdd(a.paths + 3, (unsigned long long)ec.n_full);
-    if (n_p2w) atomicAdd(a.paths + 4, (unsigned long long)n_p2w);
-    if (n_p2rej) atomicAdd(a.paths + 5, (unsigned long long)n_p2rej);
+    if (fs.n_p2w) atomicAdd(a.paths + 4, (unsigned long long)fs.n_p2w);
+    if (fs.n_p2rej) atomicAdd(a.paths + 5, (unsigned long long)fs.n_p2rej);
   }
+}
+
+// ---------------------------------------------------------------- the fused kernel with FOUR envelopes per Backward sweep (round 5)
+// score_kernel7 with one change of schedule: a wave takes its queries four at a time.  Each goes through P1, P2, the region
+// scan and - when it has exactly one single-domain envelope whose dominant alignment fits a 256-node window, the case of
+// ~87 % of the headline's pairs - through P3 into ITS OWN Forward slab (four per wave) with its per-row arrays copied to
+// the wave's HBM region; then ONE sweep_backward_null2_quad serves the four envelopes, a quarter of the wave each, and
+// the pairs are assembled.  Everything else (no envelope, several, a multidomain region, a wider window, a failed
+// certificate) takes the one-pair path of score_kernel7 on the spot, through the same functions.
+// Per-wave LDS block: [six per-row arrays][4 x 32 null2 floats][region list][4 x 16 slot ints][4 x 16 record words][4 x residues].
+// a.scratch_stride = FIVE slabs per wave (one of slack in front); a.spec_scratch / a.spec_stride = per wave one array of slack,
+// four copies of the six arrays and the three posterior rows of the windowed P2 (28 x SP floats).
+enum { QR_QLO = 0, QR_QHI, QR_L, QR_NREG, QR_FLAGS, QR_FWDSC, QR_NULLSC, QR_FWDBITS, QR_ENVSC, QR_RI, QR_RJ, QR_XC3, QR_EF3, QR_INTS = 16 };
+template <int Q, int TH>
+__global__ __launch_bounds__(TH) void score_kernel7q(ScoreArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem_raw[];
+  volatile int *s_item_p = reinterpret_cast<volatile int *>(smem_raw);
+  float *smem = smem_raw + 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  constexpr int TBL = Q * kWave;
+  float *emL = smem;
+  float *trL = smem + (size_t)a.K * TBL;
+  float *wbase = trL + 2 * FW_NARR * TBL + (size_t)wave * a.wave_lds;
+  const int SP = a.SP;
+  const int seqw = (a.Lcap + 3) / 4 + 4;                       // words per residue buffer
+  WaveCtx c;
+  c.emL = (lds_f *)emL; c.fwL = (lds_f *)trL; c.bwL = (lds_f *)(trL + FW_NARR * TBL);
+  c.spec = (lds_f *)wbase; c.n2tab = (lds_f *)(wbase + kSpArr * SP);
+  const size_t wid = (size_t)blockIdx.x * nwaves + wave;
+  // (one array / one slab of slack in front: an envelope that has run out of rows keeps requesting the rows "above" its first)
+  glb_f *specg0 = (glb_f *)(a.spec_scratch + wid * a.spec_stride) + SP;
+  const int spec_stride1 = kSpArr * SP;                        // floats per copy of the six arrays
+  glb_f *tmpg = specg0 + 4 * spec_stride1;                     // the windowed P2's three rows
+  c.specg = nullptr;
+  c.degen = 0;
+  for (int t = 0; t < 32; t++) if (t == lane) c.degen = a.degen[t];
+  const int slab1 = (int)(a.scratch_stride / 5);               // floats per slab: four + the slack
+  glb_f *Fs0 = (glb_f *)(a.scratch + wid * a.scratch_stride) + slab1;
+  glb_f *FsW = Fs0 - slab1;                                    // the slack slab doubles as the work slab of the one-pair paths (the four
+  c.Fs = FsW;                                                  // slabs behind it hold waiting envelopes; what a run-out envelope reads from the slack is not used)
+  c.SP = SP; c.alpha = a.K | (a.Kp << 8) | (a.K << 16); c.lane = lane;
+  int *regs = reinterpret_cast<int *>(wbase + kSpArr * SP + 128);
+  int *qslots = regs + kRegsInts;
+  int *qrecs = qslots + 4 * QS_INTS;
+  uint8_t *seqs = reinterpret_cast<uint8_t *>(qrecs + 4 * QR_INTS);
+  const double LOG2 = 0.69314718055994529;
+  int cur_h = -1;
+  const DevHMM *hm = nullptr;
+  EnvCounters ec = {0, 0, 0, 0};
+  FrontState fs = {0.f, 0.f, 0u, 0u, 0u};
+
+  for (;;) {
+    if (threadIdx.x == 0) *s_item_p = atomicAdd(a.counter, 1);
+    __syncthreads();
+    const int item = *s_item_p;
+    __syncthreads();
+    if (item >= a.n_items) break;
+    const int h = a.hmm_list[item / a.n_qblocks];
+    const int64_t q_lo = (int64_t)(item % a.n_qblocks) * a.QB;
+    const int64_t q_hi = q_lo + a.QB < a.nq ? q_lo + a.QB : a.nq;
+    if (h != cur_h) {
+      hm = a.hmms + h;
+      const float4 *src = reinterpret_cast<const float4 *>(a.tables + hm->em_off);
+      float4 *dst = reinterpret_cast<float4 *>(emL);
+      for (int t = threadIdx.x; t < a.K * TBL / 4; t += blockDim.x) dst[t] = src[t];
+      const float4 *s1 = reinterpret_cast<const float4 *>(a.tables + hm->fw_off);
+      const float4 *s2 = reinterpret_cast<const float4 *>(a.tables + hm->bw_off);
+      float4 *d1 = reinterpret_cast<float4 *>(trL);
+      for (int t = threadIdx.x; t < FW_NARR * TBL / 4; t += blockDim.x) { d1[t] = s1[t]; d1[FW_NARR * TBL / 4 + t] = s2[t]; }
+      cur_h = h;
+      fs.eps_prev = 0.f; fs.eps_prev2 = 0.f; fs.n_pairs_h = 0;
+      __syncthreads();
+    }
+    c.emG = (const glb_f *)(a.tables + hm->em_off);
+
+    for (int64_t base = q_lo + wave; base < q_hi; base += 4 * nwaves) {
+      int waiting = 0;                                          // bit t: slot t waits for the four-envelope sweep
+      if (lane < 4) qslots[lane * QS_INTS + QS_ACTIVE] = 0;
+      __builtin_amdgcn_wave_barrier();
+      // ------------------------------------------------ phase A: every query up to its envelope's Forward sweep
+      for (int t = 0; t < 4; t++) {
+        const int64_t qpos = base + (int64_t)t * nwaves;
+        if (qpos >= q_hi) break;
+        const int64_t qi = a.qorder ? a.qorder[qpos] : qpos;
+        const int64_t off = a.offsets[qi];
+        const int L = (int)(a.offsets[qi + 1] - off);
+        const size_t out = (size_t)qi * a.H + h;
+        uint8_t *seq = seqs + t * seqw * 4;
+        int flags = 0, decibits = 0;
+        float fwd_bits_out = -INFINITY;
+        bool deferred = false;
+        wh_pair_detail *dp = (a.detail && lane == 0) ? a.detail + out : nullptr;
+        if (dp) {
+          dp->fwd_bits = -INFINITY; dp->seq_score = 0.f; dp->pre_score = 0.f; dp->seqbias_nats = 0.f;
+          dp->nregions = 0; dp->nenv = 0;
+        }
+        if (L > 0 && L <= a.Lcap) {
+          for (int u = lane; u < L; u += kWave) {
+            int r = a.residues[off + u];
+            seq[u] = (uint8_t)(r < a.Kp ? r : a.Kp - 1);
+          }
+          __builtin_amdgcn_wave_barrier();
+          long long t_last = a.stats ? __builtin_readcyclecounter() : 0;
+          const LenCfg cm = len_config(L, true);
+          const FwdOut f1 = sweep_forward<Q, false, TH, false>(c, (lds_u8 *)seq, L, cm, 0.f);
+          const double fwd_nats = (double)f1.ef * LOG2 + log((double)(f1.xC * cm.move));
+          const float fwdsc = (float)fwd_nats;
+          const float p1 = (float)L / (float)(L + 1);
+          const float nullsc = (float)((double)(float)L * log((double)p1) + log(1.0 - (double)p1));
+          fwd_bits_out = (float)((fwd_nats - (double)nullsc) / LOG2);
+          if (dp) dp->fwd_bits = fwd_bits_out;
+          if (f1.xC > 0.f && isfinite(fwdsc)) {
+            WH_TICK7(4);
+            const RegOut ro = score_regions<Q, TH, false, true>(a, c, seq, regs, L, lane, cm, f1, fs, t_last, tmpg);
+            const int nenv = ro.nenv, nreg = ro.nreg, multi_mask = ro.flags >> 8;
+            flags |= ro.flags & 0xFF;
+            if (dp) { dp->nregions = nreg; dp->nenv = nenv; }
+            if (nenv == 1 && multi_mask == 0 && !a.no_window) {
+              // ---- one single-domain envelope: its Forward sweep into slab t; the Backward sweep waits for the other three
+              WH_TICK7(6);
+              const int ri = regs[0], rj = regs[1];
+              const int Ld = rj - ri + 1;
+              const uint8_t *eseq = seq + (ri - 1);
+              const LenCfg cu = len_config(L, false);
+              c.Fs = Fs0 + (size_t)t * slab1;
+              const float keep_scale = a.keep_scale > 0.f ? a.keep_scale : kKeepScale7;
+              const FwdOut f3 = sweep_forward<Q, true, TH, false>(c, (lds_u8 *)eseq, Ld, cu, keep_scale);
+              __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+              const float envsc = (float)((double)f3.ef * LOG2 + log((double)(f3.xC * cu.move)));
+              WH_TICK7(7);
+              float domcorr = 0.f;
+              bool done = !(f3.xC > 0.f);
+              if (!done) {
+                const unsigned *su = reinterpret_cast<const unsigned *>((const float *)c.spec);
+                const unsigned long long um = ((unsigned long long)su[kSpMH * SP] << 32) | su[kSpML * SP];
+                int m0 = -1;
+                if (um != 0) {
+                  int lo = __builtin_ctzll(um), hi = 63 - __builtin_clzll(um);
+                  lo = lo > 1 ? lo - 2 : 0; hi = hi < 63 ? hi + 1 : 63;
+                  if ((hi - lo + 1) * Q <= 4 * kWave) m0 = min((63 - hi) * Q, kWave * (Q - 4));
+                }
+                if (m0 >= 0) {
+                  // the six per-row arrays of this envelope -> the wave's HBM copy t (coalesced), the slot and the record
+                  glb_f *dst = specg0 + (size_t)t * spec_stride1;
+                  const float *spec = (const float *)c.spec;
+                  for (int arr = 0; arr < kSpArr; arr++)
+                    for (int u = lane; u <= Ld; u += kWave) __builtin_nontemporal_store(spec[arr * SP + u], dst + arr * SP + u);
+                  if (lane == 0) {
+                    int *sl = qslots + t * QS_INTS;
+                    sl[QS_ACTIVE] = 1; sl[QS_LD] = Ld; sl[QS_M0] = m0;
+                    sl[QS_INVZ] = __builtin_bit_cast(int, 1.0f / (f3.xC * cu.move));
+                    sl[QS_LOOP] = __builtin_bit_cast(int, cu.loop); sl[QS_MOVE] = __builtin_bit_cast(int, cu.move);
+                    sl[QS_SEQ] = t * seqw * 4 + (ri - 1);
+                    int *qr = qrecs + t * QR_INTS;
+                    qr[QR_QLO] = (int)(unsigned)(qi & 0xFFFFFFFF); qr[QR_QHI] = (int)(qi >> 32);
+                    qr[QR_L] = L; qr[QR_NREG] = nreg; qr[QR_FLAGS] = flags;
+                    qr[QR_FWDSC] = __builtin_bit_cast(int, fwdsc); qr[QR_NULLSC] = __builtin_bit_cast(int, nullsc);
+                    qr[QR_FWDBITS] = __builtin_bit_cast(int, fwd_bits_out); qr[QR_ENVSC] = __builtin_bit_cast(int, envsc);
+                    qr[QR_RI] = ri; qr[QR_RJ] = rj; qr[QR_XC3] = __builtin_bit_cast(int, f3.xC); qr[QR_EF3] = f3.ef;
+                  }
+                  waiting |= 1 << t;
+                  deferred = true;
+                } else {
+                  // a wider window or none: this envelope's Backward sweep now, as score_envelopes runs it
+                  P4Out p4 = envelope_backward<Q, TH, false>(a, c, eseq, Ld, cu, f3, false, false, ec, lane);
+                  domcorr = p4.domcorr;
+                  if (!(fabsf((float)Ld - p4.mass) <= kMassTol7 * (float)Ld)) {
+                    const FwdOut f3d = sweep_forward<Q, true, TH, false>(c, (lds_u8 *)eseq, Ld, cu, -1.0f);
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                    domcorr = 0.f;
+                    if (f3d.xC > 0.f) { p4 = envelope_backward<Q, TH, false>(a, c, eseq, Ld, cu, f3d, true, false, ec, lane); domcorr = p4.domcorr; flags |= WH_FLAG_EXACT; }
+                  }
+                  done = true;
+                }
+              }
+              if (done) {
+                WH_TICK7(8);
+                float sum_score = 0.f, sb2 = 0.f; int Ld_tot = 0;
+                if (envsc - domcorr > 0.0f) { sum_score = envsc; Ld_tot = Ld; sb2 = domcorr; }
+                if (dp) { dp->env_i[0] = ri; dp->env_j[0] = rj; dp->envsc[0] = envsc; dp->domcorr[0] = domcorr; }
+                assemble_score(L, Ld_tot, domcorr, sum_score, sb2, fwdsc, nullsc, dp, flags, decibits);
+              }
+              c.Fs = FsW;
+            } else if (nenv > 0) {
+              WH_TICK7(6);
+              score_envelopes<Q, TH, false>(a, c, seq, regs, L, lane, h, qi, nenv, nreg, multi_mask, fwdsc, nullsc, fwd_bits_out, dp, flags, decibits, ec, t_last);
+            }
+          }
+        }
+        if (lane == 0) {
+          if (!deferred) { a.decibits[out] = decibits; a.flags[out] = (uint8_t)flags; }
+          if (a.fwd_bits) a.fwd_bits[out] = fwd_bits_out;
+        }
+      }
+      // ------------------------------------------------ phase B: one Backward sweep for the waiting envelopes
+      if (waiting) {
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      // rows and per-row arrays of four envelopes, written by this wave
+        WaveCtx cq = c;
+        cq.specg = specg0;
+        cq.Fs = Fs0;
+        sweep_backward_null2_quad<Q, TH>(cq, (lds_i *)qslots, (lds_u8 *)seqs, (lds_f *)(wbase + kSpArr * SP), slab1, spec_stride1, kWinTol7);
+        // ---------------------------------------------- phase C: certificates, assembly
+        for (int t = 0; t < 4; t++) {
+          if (!((waiting >> t) & 1)) continue;
+          const int *qr = qrecs + t * QR_INTS;
+          const int *sl = qslots + t * QS_INTS;
+          const int64_t qi = ((int64_t)qr[QR_QHI] << 32) | (unsigned)qr[QR_QLO];
+          const size_t out = (size_t)qi * a.H + h;
+          const int L = qr[QR_L], Ld = sl[QS_LD], ri = qr[QR_RI], rj = qr[QR_RJ];
+          int flags = qr[QR_FLAGS], decibits = 0;
+          const float fwdsc = __builtin_bit_cast(float, qr[QR_FWDSC]), nullsc = __builtin_bit_cast(float, qr[QR_NULLSC]);
+          const float envsc = __builtin_bit_cast(float, qr[QR_ENVSC]);
+          const float mass = __builtin_bit_cast(float, sl[QS_MASS]);
+          float domcorr = __builtin_bit_cast(float, sl[QS_DOMCORR]);
+          wh_pair_detail *dp = (a.detail && lane == 0) ? a.detail + out : nullptr;
+          if (fabsf((float)Ld - mass) <= kWinTol7 * (float)Ld) ec.n_w256++;
+          else {
+            // the window lost mass: full width on the same rows (the per-row arrays back into the wave's block), then
+            // the dense redo if the spill certificate fails too - score_envelopes' own sequence
+            ec.n_wfail++;
+            uint8_t *seq = seqs + t * seqw * 4;
+            const uint8_t *eseq = seq + (ri - 1);
+            const LenCfg cu = len_config(L, false);
+            float *spec = (float *)c.spec;
+            const glb_f *src = specg0 + (size_t)t * spec_stride1;
+            __builtin_amdgcn_wave_barrier();
+            for (int arr = 0; arr < kSpArr; arr++)
+              for (int u = lane; u <= Ld; u += kWave) spec[arr * SP + u] = __builtin_nontemporal_load(src + arr * SP + u);
+            __builtin_amdgcn_wave_barrier();
+            c.Fs = Fs0 + (size_t)t * slab1;
+            FwdOut f3; f3.xC = __builtin_bit_cast(float, qr[QR_XC3]); f3.ef = qr[QR_EF3];
+            P4Out p4 = envelope_backward<Q, TH, false>(a, c, eseq, Ld, cu, f3, false, true, ec, lane);
+            domcorr = p4.domcorr;
+            if (!(fabsf((float)Ld - p4.mass) <= kMassTol7 * (float)Ld)) {
+              const FwdOut f3d = sweep_forward<Q, true, TH, false>(c, (lds_u8 *)eseq, Ld, cu, -1.0f);
+              __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+              domcorr = 0.f;
+              if (f3d.xC > 0.f) { p4 = envelope_backward<Q, TH, false>(a, c, eseq, Ld, cu, f3d, true, false, ec, lane); domcorr = p4.domcorr; flags |= WH_FLAG_EXACT; }
+            }
+            c.Fs = FsW;
+          }
+          float sum_score = 0.f, sb2 = 0.f; int Ld_tot = 0;
+          if (envsc - domcorr > 0.0f) { sum_score = envsc; Ld_tot = Ld; sb2 = domcorr; }
+          if (dp) { dp->env_i[0] = ri; dp->env_j[0] = rj; dp->envsc[0] = envsc; dp->domcorr[0] = domcorr; }
+          assemble_score(L, Ld_tot, domcorr, sum_score, sb2, fwdsc, nullsc, dp, flags, decibits);
+          if (lane == 0) { a.decibits[out] = decibits; a.flags[out] = (uint8_t)flags; }
+        }
+      }
+    }
+  }
+  if (a.paths && lane == 0) {
+    if (ec.n_w256) atomicAdd(a.paths + 0, (unsigned long long)ec.n_w256);
+    if (ec.n_w512) atomicAdd(a.paths + 1, (unsigned long long)ec.n_w512);
+    if (ec.n_wfail) atomicAdd(a.paths + 2, (unsigned long long)ec.n_wfail);
+    if (ec.n_full) atomicAdd(a.paths + 3, (unsigned long long)ec.n_full);
+    if (fs.n_p2w) atomicAdd(a.paths + 4, (unsigned long long)fs.n_p2w);
+    if (fs.n_p2rej) atomicAdd(a.paths + 5, (unsigned long long)fs.n_p2rej);
+  }
+}
+
+template <int Q, int TH>
+static hipError_t launch7q(const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
+  hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&score_kernel7q<Q, TH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (err != hipSuccess) return err;
+  hipLaunchKernelGGL((score_kernel7q<Q, TH>), dim3(blocks), dim3(threads), lds, s, a);
+  return hipGetLastError();
 }
 
 template <int Q, int TH, bool SG>
@@ -1033,6 +1559,15 @@ static hipError_t launch7_q(int Q, const ScoreArgs &a, int blocks, int threads, 
 #endif  // WH_SWEEPS_ONLY
 }  // namespace WH_K7NS
 
+#if !defined(WH_SWEEPS_ONLY) && !defined(WH_K7B)
+// four envelopes per Backward sweep (score_kernel7q): models of 16 cells per lane
+hipError_t launch_score7q(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
+  using namespace WH_K7NS;
+  if (a.spec_arrays != kSpArr || !a.spec_scratch || threads > 768) return hipErrorInvalidValue;
+  if (Q == 16) return launch7q<16, 768>(a, blocks, threads, lds, s);
+  return hipErrorInvalidValue;
+}
+#endif
 #ifndef WH_SWEEPS_ONLY
 hipError_t WH_K7LAUNCH(int Q, const ScoreArgs &a, int blocks, int threads, size_t lds, hipStream_t s) {
   using namespace WH_K7NS;

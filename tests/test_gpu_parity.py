@@ -997,6 +997,24 @@ def test_staged_launches_equal_the_fused_kernel(tmp_path):
             assert int(((ref[1] & 2) != 0).sum()) > 0                          # the resolver's class is present
             same(run(batch, "7", WH_NO_RESOLVE="1"), run(batch, "10", WH_NO_RESOLVE="1"), (tag, "no resolver"))
             same(run(batch, "7", WH_NO_WINDOW="1"), run(batch, "11", WH_NO_WINDOW="1"), (tag, "no window"))
+    # WH_SCORE_KERNEL=12: four envelopes per Backward sweep (sweep_backward_null2_quad: one envelope per quarter of the wave,
+    # 16 cells per lane).  The per-cell arithmetic is the window sweep's, the sums over a row are formed in another order:
+    # flags, regions, envelopes, Forward log-odds and envelope scores identical, the null2 correction equal to float32
+    # rounding (1e-4 nats), deci-bits under the rounding-boundary rule (on the kernel's own float scores).
+    for batch, tag in ((full, "headline"), (ragged, "ragged"), (mixed, "mixed")):
+        ref, got = run(batch, "7"), run(batch, "12")
+        assert np.array_equal(ref[1], got[1]) and np.array_equal(ref[2].view(np.uint32), got[2].view(np.uint32)), tag
+        for name in ("fwd_bits", "nregions", "nenv", "env_i", "env_j", "envsc"):
+            x, y = ref[3][name], got[3][name]
+            assert np.array_equal(x.view(np.int32) if x.dtype.kind == "f" else x, y.view(np.int32) if y.dtype.kind == "f" else y), (tag, name)
+        assert np.max(np.abs(ref[3]["domcorr"] - got[3]["domcorr"])) <= 1e-4, tag
+        dd = np.nonzero(ref[0] != got[0])
+        assert len(dd[0]) <= max(2, ref[0].size // 100000), (tag, len(dd[0]))
+        for q_, h_ in zip(*dd):
+            sc = float(ref[3]["seq_score"][q_ * e.H + h_])
+            assert abs(int(ref[0][q_, h_]) - int(got[0][q_, h_])) == 1 and _near_boundary_eps(sc, BOUNDARY_EPS), (tag, int(q_), int(h_), sc)
+        if tag == "headline":
+            assert got[4]["window256"] > 0.8 * ref[4]["window256"]             # ... and the quarter-wave sweep did serve them
     # several batches (units for ~1/6 of the pairs at a time), and too few units for even one work item's envelopes
     ref = run(full, "7")
     got = run(full, "11", WH_ST_UNITS="40000")

@@ -861,7 +861,10 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
       a.paths = reinterpret_cast<unsigned long long *>((int *)e->d_counter.p + kScorePathSlot);
       a.p2win = (p2win && !specg && !big && !pairk) ? 1 : 0;
       a.qorder = (big || mixed) ? d_qorder : nullptr;
-      a.QB = big ? waves * 2 : waves * 4;   // long models: a pair is milliseconds, smaller items shorten the tail of the launch
+      // (the phase-call kernels deal an item's queries to the waves one by one, so an item can be large - the wait at its
+      // end is one pair's time whatever its size: 32 queries per wave; long models: a pair is milliseconds, smaller items
+      // shorten the tail of the launch)
+      a.QB = big ? waves * 2 : pairk ? waves * 4 : waves * 32;
       const int per_turn = pairk ? 2 : 1;   // queries a wave takes per turn
       // small batches (the reference's example as shipped: 500 fragments x 15 models): with the default item size there
       // are fewer than a handful of items per workgroup and the launch ends on its stragglers - one query per wave and
@@ -869,13 +872,18 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
       {
         const int max_blocks = big ? e->cu_count : e->cu_count * std::max(1, 8 / waves);
         const int64_t items_default = (int64_t)a.n_list * ((nq + a.QB - 1) / a.QB);
-        if (items_default < 4 * (int64_t)max_blocks) a.QB = waves * per_turn;
+        if (items_default < 4 * (int64_t)max_blocks) {
+          // fewer items than that: smaller ones, down to one query per wave
+          a.QB = waves * per_turn;
+          if (!big && !pairk) for (int g_ = 16; g_ > 1; g_ /= 2)
+            if ((int64_t)a.n_list * ((nq + waves * g_ - 1) / (waves * g_)) >= 4 * (int64_t)max_blocks) { a.QB = waves * g_; break; }
+        }
       }
       a.n_qblocks = (int)((nq + a.QB - 1) / a.QB);
       a.n_items = a.n_list * a.n_qblocks;
       a.scratch_stride = (size_t)(quadk ? 5 : per_turn) * (size_t)(a.Lcap + 1) * 2 * Q * kWave;   // Forward slab(s) per wave
-      a.spec_stride = specg ? (size_t)8 * a.SP : quadk ? (size_t)(4 * kScoreSpecArrays + 3 + 1) * a.SP : 0;
-      if (quadk) { specg = true; a.p2win = 0; a.QB = waves * 8; a.n_qblocks = (int)((nq + a.QB - 1) / a.QB); a.n_items = a.n_list * a.n_qblocks; }   // (HBM region per wave; items of two quads per wave)
+      a.spec_stride = specg ? (size_t)8 * a.SP : quadk ? (size_t)(5 * kScoreSpecArrays + 1) * a.SP : 0;
+      if (quadk) { specg = true; a.p2win = 0; a.QB = std::max(a.QB, waves * 8); a.n_qblocks = (int)((nq + a.QB - 1) / a.QB); a.n_items = a.n_list * a.n_qblocks; }   // (HBM region per wave; items of two quads per wave)
       int blocks = std::min(a.n_items, big ? e->cu_count : e->cu_count * std::max(1, 8 / waves));
       blocks = clamp_blocks(blocks, (size_t)waves * (a.scratch_stride + a.spec_stride) * sizeof(float), e->d_scratch);
       if (pass == 0) {
@@ -913,6 +921,8 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
         const double tot = (double)(st[4] + st[5] + st[6] + st[7] + st[8] + st[9] + st[10] + st[11]);
         fprintf(stderr, "[wh] Q=%d wave cycles: P1 %.1f%%  P2 %.1f%%  regions %.1f%%  P3 %.1f%%  P4 %.1f%%  null2 %.1f%%  swaps+barriers %.1f%%  other %.1f%%  (total %.3g ticks)\n", Q, 100.0 * st[4] / tot,
                 100.0 * st[5] / tot, 100.0 * st[6] / tot, 100.0 * st[7] / tot, 100.0 * st[8] / tot, 100.0 * st[9] / tot, 100.0 * st[10] / tot, 100.0 * st[11] / tot, tot);
+        if (st[38]) fprintf(stderr, "[wh] Q=%d wave lifetimes %.3g cycles: %.1f%% in the phases above, %.1f%% fetching an item (two barriers)\n", Q, (double)st[38], 100.0 * tot / (double)st[38], 100.0 * (double)st[39] / (double)st[38]);
+        if (st[37]) fprintf(stderr, "[wh] Q=%d four-envelope sweeps: %llu envelopes, %.0f wave cycles per envelope (slot 'null2' above)\n", Q, st[37], (double)st[9] / (double)st[37]);
         fprintf(stderr, "[wh] Q=%d envelope Backward sweeps: %llu on a 256-node window, %llu on a 512-node window, %llu windows failed the mass certificate, %llu full width; union of the stored lane blocks: span %.1f blocks (with margin), %.1f blocks set, of %llu envelopes\n", Q, st[0], st[1], st[2], st[3], (double)st[12] / (double)std::max(1ull, st[14]), (double)st[15] / (double)std::max(1ull, st[14]), st[14]);
         fprintf(stderr, "[wh] Q=%d multihit Backward on a window: %llu scans, of them in doubt at a threshold %llu, at the multidomain bound %llu; window loss out of range %llu; mean eps %.3g\n", Q,
                 st[35], st[32], st[33], st[36], st[35] ? 1e-9 * (double)st[34] / (double)st[35] : 0.0);

@@ -602,11 +602,13 @@ __device__ __noinline__ void sweep_backward_null2_quad(const WaveCtx c, lds_i *s
   Lmax = max(Lmax, __shfl_xor(Lmax, 16));
   Lmax = max(Lmax, __shfl_xor(Lmax, 32));
   // step j works on row i = Ld - j of my envelope with S(i), S(i-1), N/J/C(i-1) and the mask word of row i in registers
-  int S_i, S_p, S_next = 0;
+  // (every loop-carried value below is DEFINED by a load and nothing else: "x = y; y = load" would make the compiler copy
+  // the loaded register at the loop edge - a copy waits for its load - so the scale exponent of a row is loaded twice)
+  int S_i, S_p;
   float n_p, j_p, c_p;
-  unsigned w_i, w_n;
+  unsigned w_i;
   request_row(0);
-  w_i = mask_word(0); w_n = mask_word(1);
+  w_i = mask_word(0);
   S_i = (int)ldu(SP_S * SP, 0);
   S_p = (int)ldu(SP_S * SP, 1);
   n_p = ldf_(SP_N * SP, 1);
@@ -618,7 +620,6 @@ __device__ __noinline__ void sweep_backward_null2_quad(const WaveCtx c, lds_i *s
     const int i = Ld - j;
     if (i >= 1) {
       if (j > 0) {
-        mirror_scale<16>(S_next - S_i, Mb, Ib, xJ, xC, xN);
         const int x = eseq[i];
         float part = 0.f;
         auto emit = [&](auto em_ld) {
@@ -662,14 +663,16 @@ __device__ __noinline__ void sweep_backward_null2_quad(const WaveCtx c, lds_i *s
       nj = fmaf(j_p, xJ, nj);
       nj = fmaf(c_p, xC, nj);
       xfac = fmaf(nj * cu.loop, s_p, xfac);
-      S_next = S_i;
+      // the Forward rescale between this row and the next one down, applied to the carried state NOW (the window sweep
+      // applies it at the top of the next row: the same exact power of two on the same values, but here no row begins by
+      // waiting for a scale exponent that was requested a moment ago)
+      mirror_scale<16>(S_i - S_p, Mb, Ib, xJ, xC, xN);
     }
     // (uniform) the next step's row, for every lane
     if (j + 1 < Lmax) {
       request_row(j + 1);
-      w_i = w_n;
-      w_n = mask_word(j + 2);
-      S_i = S_p;
+      w_i = mask_word(j + 1);
+      S_i = (int)ldu(SP_S * SP, j + 1);
       S_p = (int)ldu(SP_S * SP, j + 2);
       n_p = ldf_(SP_N * SP, j + 2);
       j_p = ldf_(SP_J * SP, j + 2);
@@ -1093,13 +1096,16 @@ struct FrontState {               // per wave: the window heuristics of the mult
   unsigned n_pairs_h;             // pairs of the current model this wave has scored
   unsigned n_p2w, n_p2rej;        // sweeps kept from a window / windows in doubt (redone at full width)
 };
-// TMPG: the windowed sweep keeps its three posterior rows in the wave's HBM region <tmpg> (score_kernel7q) instead of LDS.
+// TMPG (score_kernel7q: no room in the wave's LDS block for three more rows): P1's six per-row arrays are COPIED to the wave's
+// HBM region <tmpg> (18 coalesced stores), the windowed sweep then writes its posteriors IN PLACE over the E, B and N rows
+// (INPL, as in the staged launches) and the certified scan reads them there; only when the scan ends in doubt do the rows
+// come back from the copy for the full-width sweep.  (Keeping the three posterior rows in HBM instead cost 80 000 cycles
+// per pair in the scan: every 64-row chunk a round trip, two fences.)
 template <int Q, int TH, bool SG, bool TMPG>
 __device__ __forceinline__ RegOut score_regions(const ScoreArgs &a, const WaveCtx &c, uint8_t *seq, int *regs, int L, int lane, LenCfg cm, const FwdOut &f1,
                                                 FrontState &fs, long long &t_last, glb_f *tmpg = nullptr) {
   const int SP = c.SP;
-  WaveCtx cw = c;
-  if (TMPG) cw.specg = tmpg;
+  bool saved = false;
   // ---------------- P2 + region scan: on a node window when every decision of the scan is then beyond doubt
   RegOut ro;
   bool have_ro = false;
@@ -1119,11 +1125,18 @@ __device__ __forceinline__ RegOut score_regions(const ScoreArgs &a, const WaveCt
         const int nodes = (hi - lo + 1) * Q;
         WinDec wd;
         wd.eps = 1.0f;
-        if (nodes <= 4 * kWave) wd = sweep_backward_decode_win<4, Q, TH, false, false, TMPG>(cw, (lds_u8 *)seq, L, cm, 1.0f / (f1.xC * cm.move), f1.ef, min((63 - hi) * Q, kWave * (Q - 4)));
-        else if (Q % 8 == 0 && Q > 8 && nodes <= 8 * kWave) wd = sweep_backward_decode_win<(Q % 8 == 0 ? 8 : 4), Q, TH, false, false, TMPG>(cw, (lds_u8 *)seq, L, cm, 1.0f / (f1.xC * cm.move), f1.ef, min((63 - hi) * Q, kWave * (Q - 8)));
-        fs.eps_prev2 = fs.eps_prev; fs.eps_prev = fabsf(wd.eps);
+        if (TMPG && nodes <= (Q % 8 == 0 && Q > 8 ? 8 : 4) * kWave) {
+          const float *spec = (const float *)c.spec;
+          for (int arr = 0; arr < kSpArr; arr++)
+            for (int u = lane; u <= L; u += kWave) __builtin_nontemporal_store(spec[arr * SP + u], tmpg + arr * SP + u);
+          saved = true;
+        }
+        if (nodes <= 4 * kWave) wd = sweep_backward_decode_win<4, Q, TH, TMPG, false, false>(c, (lds_u8 *)seq, L, cm, 1.0f / (f1.xC * cm.move), f1.ef, min((63 - hi) * Q, kWave * (Q - 4)));
+        else if (Q % 8 == 0 && Q > 8 && nodes <= 8 * kWave) wd = sweep_backward_decode_win<(Q % 8 == 0 ? 8 : 4), Q, TH, TMPG, false, false>(c, (lds_u8 *)seq, L, cm, 1.0f / (f1.xC * cm.move), f1.ef, min((63 - hi) * Q, kWave * (Q - 8)));
+        // (a dominant alignment too wide for any window says nothing about the MODEL's slack: only a measured slack is remembered)
+        if (nodes <= (Q % 8 == 0 && Q > 8 ? 8 : 4) * kWave) { fs.eps_prev2 = fs.eps_prev; fs.eps_prev = fabsf(wd.eps); }
         if (wd.eps > -1e-4f && wd.eps < 0.01f) {
-          ro = region_scan_cert<TH, false, TMPG>(c.spec, SP, L, (lds_i *)regs, lane, fmaxf(wd.eps, 0.f), cw.specg);
+          ro = region_scan_cert<TH, TMPG, false>(c.spec, SP, L, (lds_i *)regs, lane, fmaxf(wd.eps, 0.f));
           have_ro = ((ro.flags >> 24) & 3) == 0;
           if (a.stats && lane == 0) {
             if ((ro.flags >> 24) & 1) atomicAdd(a.stats + 32, 1ull);
@@ -1138,6 +1151,15 @@ __device__ __forceinline__ RegOut score_regions(const ScoreArgs &a, const WaveCt
     }
   }
   if (!have_ro) {
+    if (TMPG && saved) {
+      // the window sweep wrote over P1's rows: back from the copy (the stores above are this wave's own: order them first)
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      float *spec = (float *)c.spec;
+      __builtin_amdgcn_wave_barrier();
+      for (int arr = 0; arr < kSpArr; arr++)
+        for (int u = lane; u <= L; u += kWave) spec[arr * SP + u] = __builtin_nontemporal_load(tmpg + arr * SP + u);
+      __builtin_amdgcn_wave_barrier();
+    }
     sweep_backward_decode<Q, TH, SG>(c, (lds_u8 *)seq, L, cm, 1.0f / (f1.xC * cm.move), f1.ef);
     WH_TICK7(5);
     ro = region_scan<TH, SG>(c.spec, c.specg, SP, L, (lds_i *)regs, lane);
@@ -1177,10 +1199,10 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
   FrontState fs = {0.f, 0.f, 0u, 0u, 0u};                     // window heuristics and path counters of the multihit Backward sweep
 
   for (;;) {
-    if (threadIdx.x == 0) *s_item_p = atomicAdd(a.counter, 1);
+    __syncthreads();                       // every wave has left the previous item's deal: its counter may be reset
+    if (threadIdx.x == 0) { *s_item_p = atomicAdd(a.counter, 1); s_item_p[1] = 0; }
     __syncthreads();
     const int item = *s_item_p;
-    __syncthreads();
     if (item >= a.n_items) break;
     const int h = a.hmm_list[item / a.n_qblocks];
     const int64_t q_lo = (int64_t)(item % a.n_qblocks) * a.QB;
@@ -1200,9 +1222,15 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
     }
     c.emG = (const glb_f *)(a.tables + hm->em_off);
 
-    for (int64_t qpos = q_lo + wave; qpos < q_hi; qpos += nwaves) {
-      // (mixed-length batches arrive in descending length order: the waves of a work item then get queries of
-      // about the same length and reach the item's end together)
+    // The queries of an item are DEALT to the waves one by one from a counter in LDS (round 5; until then in fixed turns,
+    // wave w taking q_lo + w, + nwaves, ...): a pair costs 1.5 to 2.5 million cycles depending on its path - a fixed deal
+    // left 8-15 % of the wave time waiting at the item's end for the wave that drew the expensive pairs (measured with
+    // the per-wave cycle counters).  Mixed-length batches arrive in descending length order: longest first.
+    for (;;) {
+      int k_ = 0;
+      if (lane == 0) k_ = atomicAdd(const_cast<int *>(s_item_p) + 1, 1);
+      const int64_t qpos = q_lo + __builtin_amdgcn_readfirstlane(k_);
+      if (qpos >= q_hi) break;
       const int64_t qi = a.qorder ? a.qorder[qpos] : qpos;
       const int64_t off = a.offsets[qi];
       const int L = (int)(a.offsets[qi + 1] - off);
@@ -1268,7 +1296,7 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
 // certificate) takes the one-pair path of score_kernel7 on the spot, through the same functions.
 // Per-wave LDS block: [six per-row arrays][4 x 32 null2 floats][region list][4 x 16 slot ints][4 x 16 record words][4 x residues].
 // a.scratch_stride = FIVE slabs per wave (one of slack in front); a.spec_scratch / a.spec_stride = per wave one array of slack,
-// four copies of the six arrays and the three posterior rows of the windowed P2 (28 x SP floats).
+// four copies of the six arrays and one copy of P1's (the windowed P2 works in place on the wave's block): 31 x SP floats.
 enum { QR_QLO = 0, QR_QHI, QR_L, QR_NREG, QR_FLAGS, QR_FWDSC, QR_NULLSC, QR_FWDBITS, QR_ENVSC, QR_RI, QR_RJ, QR_XC3, QR_EF3, QR_INTS = 16 };
 template <int Q, int TH>
 __global__ __launch_bounds__(TH) void score_kernel7q(ScoreArgs a) {
@@ -1289,7 +1317,7 @@ __global__ __launch_bounds__(TH) void score_kernel7q(ScoreArgs a) {
   // (one array / one slab of slack in front: an envelope that has run out of rows keeps requesting the rows "above" its first)
   glb_f *specg0 = (glb_f *)(a.spec_scratch + wid * a.spec_stride) + SP;
   const int spec_stride1 = kSpArr * SP;                        // floats per copy of the six arrays
-  glb_f *tmpg = specg0 + 4 * spec_stride1;                     // the windowed P2's three rows
+  glb_f *tmpg = specg0 + 4 * spec_stride1;                     // the copy of P1's rows while the windowed P2 works in place
   c.specg = nullptr;
   c.degen = 0;
   for (int t = 0; t < 32; t++) if (t == lane) c.degen = a.degen[t];
@@ -1307,12 +1335,15 @@ __global__ __launch_bounds__(TH) void score_kernel7q(ScoreArgs a) {
   const DevHMM *hm = nullptr;
   EnvCounters ec = {0, 0, 0, 0};
   FrontState fs = {0.f, 0.f, 0u, 0u, 0u};
+  const long long t_kernel0 = a.stats ? (long long)__builtin_readcyclecounter() : 0;
 
   for (;;) {
-    if (threadIdx.x == 0) *s_item_p = atomicAdd(a.counter, 1);
+    const long long t_bar0 = a.stats ? (long long)__builtin_readcyclecounter() : 0;
+    __syncthreads();                       // every wave has left the previous item's deal: its counter may be reset
+    if (threadIdx.x == 0) { *s_item_p = atomicAdd(a.counter, 1); s_item_p[1] = 0; }
     __syncthreads();
     const int item = *s_item_p;
-    __syncthreads();
+    if (a.stats && lane == 0) atomicAdd(a.stats + 39, (unsigned long long)((long long)__builtin_readcyclecounter() - t_bar0));
     if (item >= a.n_items) break;
     const int h = a.hmm_list[item / a.n_qblocks];
     const int64_t q_lo = (int64_t)(item % a.n_qblocks) * a.QB;
@@ -1332,13 +1363,18 @@ __global__ __launch_bounds__(TH) void score_kernel7q(ScoreArgs a) {
     }
     c.emG = (const glb_f *)(a.tables + hm->em_off);
 
-    for (int64_t base = q_lo + wave; base < q_hi; base += 4 * nwaves) {
+    // (four consecutive queries per draw from the item's LDS counter: see score_kernel7)
+    for (;;) {
+      int k_ = 0;
+      if (lane == 0) k_ = atomicAdd(const_cast<int *>(s_item_p) + 1, 4);
+      const int64_t base = q_lo + __builtin_amdgcn_readfirstlane(k_);
+      if (base >= q_hi) break;
       int waiting = 0;                                          // bit t: slot t waits for the four-envelope sweep
       if (lane < 4) qslots[lane * QS_INTS + QS_ACTIVE] = 0;
       __builtin_amdgcn_wave_barrier();
       // ------------------------------------------------ phase A: every query up to its envelope's Forward sweep
       for (int t = 0; t < 4; t++) {
-        const int64_t qpos = base + (int64_t)t * nwaves;
+        const int64_t qpos = base + t;
         if (qpos >= q_hi) break;
         const int64_t qi = a.qorder ? a.qorder[qpos] : qpos;
         const int64_t off = a.offsets[qi];
@@ -1419,6 +1455,7 @@ __global__ __launch_bounds__(TH) void score_kernel7q(ScoreArgs a) {
                   }
                   waiting |= 1 << t;
                   deferred = true;
+                  WH_TICK7(10);
                 } else {
                   // a wider window or none: this envelope's Backward sweep now, as score_envelopes runs it
                   P4Out p4 = envelope_backward<Q, TH, false>(a, c, eseq, Ld, cu, f3, false, false, ec, lane);
@@ -1453,12 +1490,16 @@ __global__ __launch_bounds__(TH) void score_kernel7q(ScoreArgs a) {
       }
       // ------------------------------------------------ phase B: one Backward sweep for the waiting envelopes
       if (waiting) {
+        long long t_last = a.stats ? __builtin_readcyclecounter() : 0;
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      // rows and per-row arrays of four envelopes, written by this wave
         WaveCtx cq = c;
         cq.specg = specg0;
         cq.Fs = Fs0;
+        WH_TICK7(10);
         sweep_backward_null2_quad<Q, TH>(cq, (lds_i *)qslots, (lds_u8 *)seqs, (lds_f *)(wbase + kSpArr * SP), slab1, spec_stride1, kWinTol7);
+        WH_TICK7(9);
+        if (a.stats && lane == 0) atomicAdd(a.stats + 37, (unsigned long long)__builtin_popcount(waiting));
         // ---------------------------------------------- phase C: certificates, assembly
         for (int t = 0; t < 4; t++) {
           if (!((waiting >> t) & 1)) continue;
@@ -1505,6 +1546,7 @@ __global__ __launch_bounds__(TH) void score_kernel7q(ScoreArgs a) {
           assemble_score(L, Ld_tot, domcorr, sum_score, sb2, fwdsc, nullsc, dp, flags, decibits);
           if (lane == 0) { a.decibits[out] = decibits; a.flags[out] = (uint8_t)flags; }
         }
+        WH_TICK7(11);
       }
     }
   }
@@ -1516,6 +1558,7 @@ __global__ __launch_bounds__(TH) void score_kernel7q(ScoreArgs a) {
     if (fs.n_p2w) atomicAdd(a.paths + 4, (unsigned long long)fs.n_p2w);
     if (fs.n_p2rej) atomicAdd(a.paths + 5, (unsigned long long)fs.n_p2rej);
   }
+  if (a.stats && lane == 0) atomicAdd(a.stats + 38, (unsigned long long)(__builtin_readcyclecounter() - t_kernel0));
 }
 
 template <int Q, int TH>

@@ -70,6 +70,7 @@ struct Knobs {
   bool no_p2win = false;     // the multihit Backward sweep runs full width only (A/B and debugging)
   bool no_resolve = false;   // multidomain regions stay ONE envelope (round-1 behaviour) instead of HMMER's stochastic resolver
   int rqueue_cap = 0;        // test hook: size the resolver's queue for this many pairs instead of the estimate (forces the overflow re-run)
+  int item_g = 0;            // queries per wave in a work item of the phase-call kernels (0 = 32; A/B)
   int st_units = 0;          // staged launches: envelope units (Forward slabs) per batch (0 = sized from the free HBM)
   bool stats = false, trace = false;
   int dbg = 0;
@@ -367,6 +368,7 @@ int wh_set_option(wh_ehmm *e, const char *name, const char *value) {
   else if (!strcmp(name, "WH_NO_WINDOW")) k.no_window = on;
   else if (!strcmp(name, "WH_NO_P2WIN")) k.no_p2win = on;
   else if (!strcmp(name, "WH_RQUEUE_CAP")) k.rqueue_cap = *v ? std::max(1, atoi(v)) : 0;
+  else if (!strcmp(name, "WH_ITEM_G")) k.item_g = *v ? std::max(1, std::min(1024, atoi(v))) : 0;
   else if (!strcmp(name, "WH_ST_UNITS")) k.st_units = *v ? std::max(16, atoi(v)) : 0;
   else if (!strcmp(name, "WH_NO_WIDE_ALIGN")) k.no_wide_align = on;
   else if (!strcmp(name, "WH_STATS")) k.stats = on;
@@ -378,7 +380,7 @@ int wh_set_option(wh_ehmm *e, const char *name, const char *value) {
 }
 
 static void knobs_from_env(wh_ehmm *e) {
-  for (const char *name : {"WH_SCORE_KERNEL", "WH_ST_UNITS", "WH_KEEP_LOG2", "WH_MAX_WAVES", "WH_FORCE_SPECG", "WH_NO_LOGSPACE", "WH_NO_RESOLVE", "WH_NO_WINDOW", "WH_NO_P2WIN", "WH_RQUEUE_CAP", "WH_NO_WIDE_ALIGN", "WH_STATS", "WH_TRACE", "WH_DBG", "WH_RDBG"})
+  for (const char *name : {"WH_SCORE_KERNEL", "WH_ITEM_G", "WH_ST_UNITS", "WH_KEEP_LOG2", "WH_MAX_WAVES", "WH_FORCE_SPECG", "WH_NO_LOGSPACE", "WH_NO_RESOLVE", "WH_NO_WINDOW", "WH_NO_P2WIN", "WH_RQUEUE_CAP", "WH_NO_WIDE_ALIGN", "WH_STATS", "WH_TRACE", "WH_DBG", "WH_RDBG"})
     if (const char *v = getenv(name)) (void)wh_set_option(e, name, v);
 }
 
@@ -864,7 +866,7 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
       // (the phase-call kernels deal an item's queries to the waves one by one, so an item can be large - the wait at its
       // end is one pair's time whatever its size: 32 queries per wave; long models: a pair is milliseconds, smaller items
       // shorten the tail of the launch)
-      a.QB = big ? waves * 2 : pairk ? waves * 4 : waves * 32;
+      a.QB = big ? waves * 2 : pairk ? waves * 4 : waves * (kn.item_g > 0 ? kn.item_g : 32);
       const int per_turn = pairk ? 2 : 1;   // queries a wave takes per turn
       // small batches (the reference's example as shipped: 500 fragments x 15 models): with the default item size there
       // are fewer than a handful of items per workgroup and the launch ends on its stragglers - one query per wave and

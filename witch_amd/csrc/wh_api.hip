@@ -106,6 +106,7 @@ struct wh_ehmm {
   // staged launches (wh_staged.hip): per-batch state in HBM
   DevBuf d_st_pairs, d_st_p1spec, d_st_units, d_st_p3spec, d_st_slabs, d_st_cnt;
   double st_upp = 1.25;                     // envelope units per pair the next call's batches are sized for (learned: 1.25 x the largest seen)
+  int st_last_NB = 0;                       // pairs per batch of the last full-split class launch
   bool st_off = false;                      // a batch of the current call ran out of units: the call is repeated with the fused kernel
   int last_staged_batches = 0;              // batches the staged launches of the last scoring call went through
   std::vector<int> st_cnt_host;             // the batches' counters of the last call (read back once, at the end of the scoring pass)
@@ -597,6 +598,7 @@ static int score_staged_class(wh_ehmm *e, ScoreArgs a, int Q, int Lc, hipStream_
                 e->d_st_slabs.ensure(sizeof(float) * g.slab_stride * (size_t)NS)))
     return WH_ENOMEM;
   g.NB = NB; g.NS = (int)NS;
+  if (split) e->st_last_NB = NB;
   g.pairs = (StPair *)e->d_st_pairs.p; g.p1spec = (float *)e->d_st_p1spec.p;
   g.units = (StUnit *)e->d_st_units.p; g.p3spec = (float *)e->d_st_p3spec.p; g.slabs = (float *)e->d_st_slabs.p;
   g.pair_paths = e->path_buf;
@@ -1054,7 +1056,13 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
     HIPCHK(hipMemcpyAsync(e->st_cnt_host.data(), e->d_st_cnt.p, sizeof(int) * e->st_cnt_host.size(), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     bool over = false;
-    for (int b = 0; b < e->last_staged_batches; b++) over = over || e->st_cnt_host[(size_t)32 * b + ST_OVERFLOW] != 0;
+    int most_units = 0;
+    for (int b = 0; b < e->last_staged_batches; b++) {
+      over = over || e->st_cnt_host[(size_t)32 * b + ST_OVERFLOW] != 0;
+      most_units = std::max(most_units, e->st_cnt_host[(size_t)32 * b + ST_N_UNITS]);
+    }
+    // (full split: the next call's batches are sized for 1.25 x the densest batch seen, never below 1.05 units per pair)
+    if (most_units > 0 && e->st_last_NB > 0) e->st_upp = std::max(e->st_upp > 1.25 ? 1.05 : e->st_upp, std::max(1.05, 1.25 * (double)most_units / (double)e->st_last_NB));
     if (over) {
       // a batch held more envelopes than it had slabs for (sixteen regions per pair are possible, batches are sized for the
       // rate seen so far): this call runs again with the fused kernel, the next ones with batches sized for what was seen

@@ -1062,7 +1062,7 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
       most_units = std::max(most_units, e->st_cnt_host[(size_t)32 * b + ST_N_UNITS]);
     }
     // (full split: the next call's batches are sized for 1.25 x the densest batch seen, never below 1.05 units per pair)
-    if (most_units > 0 && e->st_last_NB > 0) e->st_upp = std::max(e->st_upp > 1.25 ? 1.05 : e->st_upp, std::max(1.05, 1.25 * (double)most_units / (double)e->st_last_NB));
+    if (!over && most_units > 0 && e->st_last_NB > 0) e->st_upp = std::max(1.05, 1.25 * (double)most_units / (double)e->st_last_NB);
     if (over) {
       // a batch held more envelopes than it had slabs for (sixteen regions per pair are possible, batches are sized for the
       // rate seen so far): this call runs again with the fused kernel, the next ones with batches sized for what was seen

@@ -987,7 +987,10 @@ def test_staged_launches_equal_the_fused_kernel(tmp_path):
         assert [a[4][t] for t in env] == [b[4][t] for t in env], (what, a[4], b[4])
 
     full = [s_.astype(np.uint8) for s_ in seqs]
-    for batch, tag in ((full, "headline"), (ragged, "ragged"), (mixed, "mixed")):
+    # (queries of 300-900 nt: too long for the staged kernels' LDS plans at this model size - the class is then left to the
+    # fused kernel without an error - or served by them where they fit; the same results either way)
+    longq = [np.concatenate([s_] * int(rng.integers(2, 7))).astype(np.uint8) for s_ in seqs[:48]]
+    for batch, tag in ((full, "headline"), (ragged, "ragged"), (mixed, "mixed"), (longq, "long")):
         ref = run(batch, "7")
         for kern in ("10", "11"):
             got = run(batch, kern)

@@ -526,7 +526,8 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
 // batches from the free HBM, and enqueues eight to ten launches per batch - nothing is read back in between: every
 // kernel takes its work from device-side lists and counters.  Batches are ranges of the class's work items (model-major,
 // a.QB queries each), so a batch holds one or two models' tables worth of pairs.
-static int score_staged_class(wh_ehmm *e, ScoreArgs a, int Q, int Lc, hipStream_t s, int *launches, size_t *need_scratch) {
+static int score_staged_class(wh_ehmm *e, ScoreArgs a, int Q, int Lc, hipStream_t s, int *launches, size_t *need_scratch, bool *served) {
+  *served = false;                 // (a class whose batch does not fit the staged kernels' LDS plans is left to the fused kernel)
   const Knobs &kn = e->knobs;
   const bool split = kn.kernel == 11;           // 11: P3 and P4 as launches of their own too (one Forward slab per envelope of a batch)
   const int sp = (Lc + 1 + 3) / 4 * 4;
@@ -545,7 +546,8 @@ static int score_staged_class(wh_ehmm *e, ScoreArgs a, int Q, int Lc, hipStream_
   int w_p2 = 12, w_p4 = 10;
   while (w_p2 >= 1 && 2 * lds_of(e->K, w_p2, cap_of(G_most, 1)) > kLdsBudget) w_p2--;
   while (w_p4 >= 1 && 2 * lds_of(e->K, w_p4, cap_of(G_most, WH_MAX_ENVELOPES)) > kLdsBudget) w_p4--;
-  if (w_one < 4 || w_both < 1 || w_p2 < 4 || w_p4 < 4) { set_error("staged launches: query length %d with model class Q=%d does not fit in LDS", Lc, Q); return WH_ERANGE; }
+  if (w_one < 4 || w_both < 4 || w_p2 < 4 || w_p4 < 4) return WH_OK;
+  *served = true;
   a.SP = sp; a.wave_lds = wl; a.spec_arrays = kScoreSpecArrays;
   a.paths = reinterpret_cast<unsigned long long *>((int *)e->d_counter.p + kScorePathSlot);
   a.p2win = 0; a.qorder = nullptr;
@@ -845,10 +847,10 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
       const bool staged = (kn.kernel == 10 || kn.kernel == 11) && !e->st_off && !big && !pairk && !specg && !kn.dbg &&
                           (Q == 8 || Q == 12 || Q == 16 || Q == 20 || Q == 24);
       if (staged) {
-        int rc_st = score_staged_class(e, a, Q, Lc, s, &launches, pass == 0 ? &need_scratch : nullptr);
-        if (pass == 0 && rc_st == WH_OK) continue;
+        bool served = false;
+        int rc_st = score_staged_class(e, a, Q, Lc, s, &launches, pass == 0 ? &need_scratch : nullptr, &served);
         if (rc_st != WH_OK) return rc_st;
-        continue;
+        if (served) continue;
       }
       // ---- four envelopes per Backward sweep (score_kernel7q, WH_SCORE_KERNEL=12): 16-cell models, special states in LDS
       bool quadk = false;

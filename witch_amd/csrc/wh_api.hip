@@ -104,6 +104,7 @@ struct wh_ehmm {
   int64_t rq_floor = 0;                     // ... at least this many (set when a call overflowed its estimate; the call then runs again)
   int last_queue_reruns = 0;                // scoring passes the last wh_score call repeated because its queue overflowed (0 or 1)
   // staged launches (wh_staged.hip): per-batch state in HBM
+  DevBuf d_p2bak;                           // 20- / 24-cell classes: P1's per-row arrays of every resident wave while its P2 window sweep works in place
   DevBuf d_st_pairs, d_st_p1spec, d_st_units, d_st_p3spec, d_st_slabs, d_st_cnt;
   double st_upp = 1.25;                     // envelope units per pair the next call's batches are sized for (learned: 1.25 x the largest seen)
   int st_last_NB = 0;                       // pairs per batch of the last full-split class launch
@@ -182,7 +183,7 @@ void wh_ehmm_free(wh_ehmm *e) {
                     &e->s_nk, &e->s_nu, &e->s_pq, &e->s_ph, &e->s_co, &e->s_cols, &e->s_pos, &e->d_rkeys, &e->d_rorder, &e->d_rchunks, &e->d_qorder, &e->d_order, &e->d_items, &e->d_recs, &e->d_spec, &e->d_back, &e->d_cwj, &e->d_cwv, &e->d_cwn, &e->d_crow,
                     &e->c_buf[0], &e->c_buf[1], &e->c_buf[2], &e->c_buf[3], &e->c_buf[4], &e->c_buf[5], &e->c_buf[6],
                     &e->c_buf[7], &e->c_buf[8], &e->c_buf[9],
-                    &e->d_st_pairs, &e->d_st_p1spec, &e->d_st_units, &e->d_st_p3spec, &e->d_st_slabs, &e->d_st_cnt})
+                    &e->d_p2bak, &e->d_st_pairs, &e->d_st_p1spec, &e->d_st_units, &e->d_st_p3spec, &e->d_st_slabs, &e->d_st_cnt})
     b->release();
   for (hipEvent_t ev : e->cls_ev) (void)hipEventDestroy(ev);
   for (auto &t : e->timers) {
@@ -791,7 +792,7 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
       //  * the same kernel with the special-state rows in HBM ("SG"): long queries
       //  * pass-synchronous kernel (wh_score_big.hip): 28+ cells per lane, and 20/24-cell models whose
       //    emission rows do not fit in LDS beside both orientations (protein)
-      bool big = Q > kMaxQFast, specg = false, pairk = false, p2win = false;
+      bool big = Q > kMaxQFast, specg = false, pairk = false, p2win = false, p2inpl = false;
       if (!big && kn.kernel == 9 && !kn.force_specg && (Q == 8 || Q == 12 || Q == 16)) {
         // two queries per wavefront (wh_score9.hip): eight waves, each with two blocks of per-row arrays
         const int sp9 = (Lc + 1 + 3) / 4 * 4;
@@ -814,6 +815,7 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
           int w2 = 0, sp2 = 0, wl2 = 0;
           size_t lds2 = 0;
           if (plan_block1(e, Q, e->K, Lc, 12, &w2, &sp2, &wl2, &lds2, 3) == WH_OK && (w2 >= waves || (getenv("WH_P2WIN_FORCE") && w2 >= 8))) { p2win = true; waves = w2; SP = sp2; wave_lds = wl2; lds = lds2; }
+          else if (Q >= 20 && kn.kernel != 9) p2inpl = true;      // round 5: the window sweep in place, P1's rows backed up in HBM (ScoreArgs::p2win == 2)
         }
         if (rc_plan != WH_OK || waves < 4 || kn.force_specg) {
           specg = true;
@@ -865,7 +867,7 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
       }
       a.SP = SP; a.wave_lds = wave_lds; a.spec_arrays = kScoreSpecArrays;
       a.paths = reinterpret_cast<unsigned long long *>((int *)e->d_counter.p + kScorePathSlot);
-      a.p2win = (p2win && !specg && !big && !pairk) ? 1 : 0;
+      a.p2win = (p2win && !specg && !big && !pairk) ? 1 : (p2inpl && !specg && !big && !pairk) ? 2 : 0;
       a.qorder = (big || mixed) ? d_qorder : nullptr;
       // (the phase-call kernels deal an item's queries to the waves one by one, so an item can be large - the wait at its
       // end is one pair's time whatever its size: 32 queries per wave; long models: a pair is milliseconds, smaller items
@@ -903,6 +905,11 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
       if (blocks < 1) { set_error("workspace planning failed (Q=%d)", Q); return WH_ENOMEM; }
       a.scratch = (float *)e->d_scratch.p;
       if (specg) a.spec_scratch = (float *)e->d_spec.p;
+      if (a.p2win == 2) {
+        a.p2_backup_stride = (size_t)kScoreSpecArrays * a.SP;
+        if (e->d_p2bak.ensure((size_t)blocks * waves * a.p2_backup_stride * sizeof(float))) return WH_ENOMEM;
+        a.p2_backup = (float *)e->d_p2bak.p;
+      }
       if (kn.stats) {
         if (e->d_recs.ensure(320)) return WH_ENOMEM;
         HIPCHK(hipMemsetAsync(e->d_recs.p, 0, 320, s));

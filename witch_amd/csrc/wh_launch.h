@@ -49,7 +49,11 @@ struct ScoreArgs {
   uint32_t degen[32];
   int Klds;                    // emission rows staged in LDS (= K, or 0: read from L2)
   int no_window;               // 1: envelope Backward sweeps at full width only (WH_NO_WINDOW)
-  int p2win;                   // 1: the wave blocks hold three more per-row arrays and the multihit Backward sweep tries a node window first
+  int p2win;                   // 1: the wave blocks hold three more per-row arrays and the multihit Backward sweep tries a node window first;
+                               // 2: no room for them (20- / 24-cell models): the window sweep works IN PLACE on the block, after P1's rows
+                               //    were copied to <p2_backup> (a doubtful scan brings them back for the full-width sweep)
+  float *p2_backup;            // p2win == 2: per resident wave spec_arrays x SP floats
+  size_t p2_backup_stride;     // floats per wave
   int dbg;                     // timing experiments only: 1 = skip Forward-row stores, 2 = skip Forward-row loads
   float keep_scale;            // Forward-row spill threshold relative to E(row); 0 = the kernel's default (2^-24)
   ResolveRec *rrecs;           // queue of pairs with a multidomain region (NULL: such regions become one envelope)

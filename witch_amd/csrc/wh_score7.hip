@@ -1116,7 +1116,7 @@ __device__ __forceinline__ RegOut score_regions(const ScoreArgs &a, const WaveCt
     // pairs and probes again every sixteenth)
     const bool try_win = fminf(fs.eps_prev, fs.eps_prev2) * (float)L < 0.17f || (fs.n_pairs_h & 15) == 0;
     fs.n_pairs_h++;
-    if ((a.p2win || TMPG) && !a.no_window && try_win) {
+    if ((a.p2win == 1 || TMPG) && !a.no_window && try_win) {
       const unsigned *su = reinterpret_cast<const unsigned *>((const float *)c.n2tab) + kUmSlot;
       const unsigned long long um = ((unsigned long long)su[1] << 32) | su[0];
       if (um != 0) {
@@ -1183,7 +1183,7 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
   const int SP = a.SP;
   WaveCtx c;
   c.emL = (lds_f *)emL; c.fwL = (lds_f *)trL; c.bwL = (lds_f *)(trL + NARR * TBL);
-  const int spArrAll = kSpArr + (a.p2win ? 3 : 0);          // + the three rows of the windowed P2 (ScoreArgs::p2win)
+  const int spArrAll = kSpArr + (a.p2win == 1 ? 3 : 0);          // + the three rows of the windowed P2 (ScoreArgs::p2win)
   c.spec = (lds_f *)wbase; c.n2tab = (lds_f *)(wbase + (SG ? 0 : spArrAll * SP));
   c.specg = SG ? (glb_f *)(a.spec_scratch + ((size_t)blockIdx.x * nwaves + wave) * a.spec_stride) : nullptr;
   c.degen = 0;
@@ -1260,7 +1260,12 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
         if (dp) dp->fwd_bits = fwd_bits_out;
         if (f1.xC > 0.f && isfinite(fwdsc)) {
           WH_TICK7(4);
-          const RegOut ro = score_regions<Q, TH, SG, false>(a, c, seq, regs, L, lane, cm, f1, fs, t_last);
+          RegOut ro;
+          if constexpr (!SG && Q >= 20) {
+            // (20- / 24-cell models: no LDS for three more rows - the window sweep in place, P1's rows backed up in HBM)
+            if (a.p2win == 2) ro = score_regions<Q, TH, false, true>(a, c, seq, regs, L, lane, cm, f1, fs, t_last, (glb_f *)(a.p2_backup + ((size_t)blockIdx.x * nwaves + wave) * a.p2_backup_stride));
+            else ro = score_regions<Q, TH, SG, false>(a, c, seq, regs, L, lane, cm, f1, fs, t_last);
+          } else ro = score_regions<Q, TH, SG, false>(a, c, seq, regs, L, lane, cm, f1, fs, t_last);
           const int nenv = ro.nenv, nreg = ro.nreg, multi_mask = ro.flags >> 8;
           flags |= ro.flags & 0xFF;
           if (dp) { dp->nregions = nreg; dp->nenv = nenv; }

@@ -78,6 +78,7 @@ struct Knobs {
 };
 static const int kScorePathSlot = 128;   // d_counter[128..139]: six 64-bit path counters of the last scoring call (wh_last_score_paths); [96..123] belong to wh_align_dev
 static const int kResolveErrSlot = 140;  // d_counter[140]: queue records the resolver found in a segment of another model (never, for a well-formed segment list)
+static const int kStagedMaxBatches = 1 << 15;   // staged launches: batches per scoring call (32 counters each: 4 MB)
 static const int kMaxLaunches = 60;   // work-queue heads in d_counter (slot 63 belongs to the consensus kernel)
 
 struct wh_ehmm {
@@ -595,8 +596,11 @@ static int score_staged_class(wh_ehmm *e, ScoreArgs a, int Q, int Lc, hipStream_
   const int NB = items_b * a.QB;
   const int n_batches = (a.n_items + items_b - 1) / items_b;
   if (e->d_st_pairs.ensure(sizeof(StPair) * (size_t)NB) || e->d_st_p1spec.ensure(sizeof(float) * g.p1stride * (size_t)NB) ||
-      e->d_st_cnt.ensure(sizeof(int) * 32 * (size_t)(e->last_staged_batches + n_batches)))
+      e->d_st_cnt.ensure(sizeof(int) * 32 * (size_t)kStagedMaxBatches))
     return WH_ENOMEM;
+  // (the counters of EVERY batch of the call are read back once, at its end: the block is allocated at its full size the
+  // first time - growing it between two size classes of a call would drop the first class's counters)
+  if (e->last_staged_batches + n_batches > kStagedMaxBatches) { set_error("staged launches: more than %d batches in one call", kStagedMaxBatches); return WH_ERANGE; }
   if (split && (e->d_st_units.ensure(sizeof(StUnit) * (size_t)NS) || e->d_st_p3spec.ensure(sizeof(float) * g.p3stride * (size_t)NS) ||
                 e->d_st_slabs.ensure(sizeof(float) * g.slab_stride * (size_t)NS)))
     return WH_ENOMEM;

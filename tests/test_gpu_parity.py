@@ -1611,6 +1611,26 @@ def test_end_to_end_example_against_the_reference_pipeline(tmp_path, ehmm_source
 
 
 @pytest.mark.gpu
+def test_a_call_of_two_to_the_31_pairs_is_refused():
+    """One scoring call serves fewer than 2^31 pairs.  Until round 4 a larger call ran WITHOUT the multidomain resolver and
+    said nothing (a different reported set); now it is refused before anything is touched, and the engine's chunks
+    (20 000 queries per call, the reference's hmmsearch chunk) keep every call far below the limit."""
+    _need_gpu()
+    import torch
+    from tests.conftest import load_case
+    from witch_amd._lib import lib, WH_ERANGE
+    from witch_amd.ehmm import EHMM
+    case = load_case("dna_synth")
+    e = EHMM(case.hmm_paths, hmm_index=case.hmm_index, nseq=case.nseq)
+    dummy = torch.zeros(16, dtype=torch.int64, device="cuda")
+    nq = (1 << 31) // e.H + 1
+    rc = lib().wh_score_dev(e._h, dummy.data_ptr(), dummy.data_ptr(), nq, 0, 150, dummy.data_ptr(), dummy.data_ptr(), None, None, None)
+    assert rc == WH_ERANGE, rc
+    assert b"chunks" in lib().wh_last_error()
+    e.close()
+
+
+@pytest.mark.gpu
 def test_chunked_engine_run_equals_the_one_pass_run(tmp_path):
     """QueryAlignmentEngine.run feeds the GPU in chunks of at most 20 000 queries like the reference feeds hmmsearch
     (algorithm.py:209,280-284), so nothing on the device grows with the query count.  Chunks are independent, so a run

@@ -16,6 +16,8 @@ CSRC = os.path.join(_HERE, "csrc")
 WH_MAX_ENVELOPES = 16
 FLAG_REPORTED, FLAG_MULTI, FLAG_OVERRIDE, FLAG_TRUNC, FLAG_EXACT = 1, 2, 4, 8, 16
 ALPH_DNA, ALPH_RNA, ALPH_AMINO = 0, 1, 2
+WH_OK, WH_EINVAL, WH_EIO, WH_ENODEV, WH_EHIP, WH_ERANGE, WH_ENOMEM = 0, -1, -2, -3, -4, -5, -6      # include/witch_hip.h
+PATH_P2_WIN, PATH_P2_FULL, PATH_P4_W256, PATH_P4_W512, PATH_P4_WFAIL, PATH_P4_FULL, PATH_DENSE, PATH_MULTI = 1, 2, 4, 8, 16, 32, 64, 128
 
 
 class WitchHipError(RuntimeError):

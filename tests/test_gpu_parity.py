@@ -1318,7 +1318,8 @@ def test_config2_dna_1k_x10_at_its_stated_size(orc, tmp_path):
     e.close()
 
 
-def test_config5_shape_all_500_hmms(orc, tmp_path):
+@pytest.mark.parametrize("block", [0, 1])
+def test_config5_shape_all_500_hmms(orc, tmp_path, block):
     """BASELINE.json configs[4] shape (aa_50k_x500): ALL 500 protein HMMs (more than 256 candidates per
     query: the multi-slot path of the top-k kernel) x 256 mixed-length queries (50-2000 residues) against
     the oracle, then the structural properties of the top-k table and the aligned columns at 2 000 queries
@@ -1331,9 +1332,10 @@ def test_config5_shape_all_500_hmms(orc, tmp_path):
     assert len(se.paths) == 500 and k == 10
     seqs = [s_.astype(np.uint8) for s_ in seqs]
     e = EHMM(se.paths, hmm_index=se.index, nseq=se.nseq)
-    # ---- 256 queries x 500 HMMs against the oracle (round 5: 64 until then)
-    NSUB = 256
-    sub = seqs[:NSUB]
+    # ---- 256 queries x 500 HMMs against the oracle (round 5: 64 until then), in two blocks of 128: the float64 oracle needs
+    # ~200 s per block on the box's cores, and a test that prints nothing for seven minutes is taken for hung
+    NSUB = 128
+    sub = seqs[block * NSUB:(block + 1) * NSUB]
     assert min(len(s_) for s_ in sub) < 400 and max(len(s_) for s_ in sub) > 1500
     res, offs = pack_queries(sub)
     deci, flags, fwd = e.score(res, offs, want_fwd=True)
@@ -1357,8 +1359,12 @@ def test_config5_shape_all_500_hmms(orc, tmp_path):
     cols, co = e.align(res, offs, pq, ph)
     ocols, oco = orc.align_batch(ohm, res, offs, pq, ph, nthreads=os.cpu_count() or 16)
     assert np.array_equal(cols, ocols), int((cols != ocols).sum())
-    print("\n[aa_50k_x500] 256 x 500 pairs: %d single-domain pairs one deci-bit off (boundary), %d multidomain pairs, %d pairs aligned identically"
+    print("\n[aa_50k_x500] block %d, 128 x 500 pairs:" % block, end=" ")
+    print(" %d single-domain pairs one deci-bit off (boundary), %d multidomain pairs, %d pairs aligned identically"
           % (n_off, int(((of & 2) != 0).sum()), len(pq)))
+    if block != 0:
+        e.close()
+        return
     # ---- 2 000 queries x 500 HMMs: size-independent properties
     res, offs = pack_queries(seqs)
     res_t, off_t = torch.from_numpy(res).cuda(), torch.from_numpy(offs).cuda()
@@ -1366,7 +1372,7 @@ def test_config5_shape_all_500_hmms(orc, tmp_path):
     d1, f1 = e.score_t(res_t, off_t, maxlen)
     d2, f2 = e.score_t(res_t, off_t, maxlen)
     assert torch.equal(d1, d2) and torch.equal(f1, f2)
-    assert torch.equal(d1[:NSUB].cpu(), torch.from_numpy(deci)) and torch.equal(f1[:NSUB].cpu(), torch.from_numpy(flags))   # batch-size independent
+    assert torch.equal(d1[:NSUB].cpu(), torch.from_numpy(deci)) and torch.equal(f1[:NSUB].cpu(), torch.from_numpy(flags))   # batch-size independent (block 0)
     idx, w, nk, nu = [t.cpu().numpy() for t in e.topk_t(d1, f1, k)]
     fl = f1.cpu().numpy()
     assert (fl & 8).sum() == 0                                            # nor at 2 000 queries

@@ -1318,28 +1318,40 @@ def test_config2_dna_1k_x10_at_its_stated_size(orc, tmp_path):
     e.close()
 
 
+@pytest.fixture(scope="module")
+def config5_case(tmp_path_factory):
+    """The 500-model protein eHMM of BASELINE configs[4] with its first 2 000 queries, loaded once for both blocks below
+    (writing 500 model files and parsing them twice - GPU handle and oracle - takes over a minute)."""
+    _need_gpu()
+    import bench
+    from oracle import oracle as orc_
+    from witch_amd.ehmm import EHMM
+    wd = tmp_path_factory.mktemp("config5")
+    fam, se, names, seqs, k = bench.make_workload("aa_50k_x500", str(wd), 2000, None)
+    assert len(se.paths) == 500 and k == 10
+    e = EHMM(se.paths, hmm_index=se.index, nseq=se.nseq)
+    ohm = [orc_.OracleHMM(p_) for p_ in se.paths]
+    yield se, [s_.astype(np.uint8) for s_ in seqs], k, e, ohm
+    e.close()
+
+
 @pytest.mark.parametrize("block", [0, 1])
-def test_config5_shape_all_500_hmms(orc, tmp_path, block):
+def test_config5_shape_all_500_hmms(orc, config5_case, block):
     """BASELINE.json configs[4] shape (aa_50k_x500): ALL 500 protein HMMs (more than 256 candidates per
-    query: the multi-slot path of the top-k kernel) x 256 mixed-length queries (50-2000 residues) against
+    query: the multi-slot path of the top-k kernel) x 192 mixed-length queries (50-2000 residues, two blocks) against
     the oracle, then the structural properties of the top-k table and the aligned columns at 2 000 queries
     (a quarter of these pairs hold several hits: each goes through the 200-trace resolver)."""
     _need_gpu()
     import torch
-    import bench
-    from witch_amd.ehmm import EHMM, pack_queries
-    fam, se, names, seqs, k = bench.make_workload("aa_50k_x500", str(tmp_path), 2000, None)
-    assert len(se.paths) == 500 and k == 10
-    seqs = [s_.astype(np.uint8) for s_ in seqs]
-    e = EHMM(se.paths, hmm_index=se.index, nseq=se.nseq)
-    # ---- 256 queries x 500 HMMs against the oracle (round 5: 64 until then), in two blocks of 128: the float64 oracle needs
-    # ~200 s per block on the box's cores, and a test that prints nothing for seven minutes is taken for hung
-    NSUB = 128
+    from witch_amd.ehmm import pack_queries
+    se, seqs, k, e, ohm = config5_case
+    # ---- 192 queries x 500 HMMs against the oracle (round 5: 64 until then), in two blocks of 96: the float64 oracle needs
+    # ~150 s per block on the box's cores, and a test that prints nothing for seven minutes is taken for hung
+    NSUB = 96
     sub = seqs[block * NSUB:(block + 1) * NSUB]
     assert min(len(s_) for s_ in sub) < 400 and max(len(s_) for s_ in sub) > 1500
     res, offs = pack_queries(sub)
     deci, flags, fwd = e.score(res, offs, want_fwd=True)
-    ohm = [orc.OracleHMM(p) for p in se.paths]
     od, of, ofwd, osc = orc.score_batch(ohm, res, offs, nthreads=os.cpu_count() or 16)
     fin = np.isfinite(ofwd)
     assert np.max(np.abs(fwd[fin] - ofwd[fin]) / np.maximum(1.0, np.abs(ofwd[fin]) / 1000)) <= 2e-4
@@ -1359,11 +1371,10 @@ def test_config5_shape_all_500_hmms(orc, tmp_path, block):
     cols, co = e.align(res, offs, pq, ph)
     ocols, oco = orc.align_batch(ohm, res, offs, pq, ph, nthreads=os.cpu_count() or 16)
     assert np.array_equal(cols, ocols), int((cols != ocols).sum())
-    print("\n[aa_50k_x500] block %d, 128 x 500 pairs:" % block, end=" ")
+    print("\n[aa_50k_x500] block %d, 96 x 500 pairs:" % block, end=" ")
     print(" %d single-domain pairs one deci-bit off (boundary), %d multidomain pairs, %d pairs aligned identically"
           % (n_off, int(((of & 2) != 0).sum()), len(pq)))
     if block != 0:
-        e.close()
         return
     # ---- 2 000 queries x 500 HMMs: size-independent properties
     res, offs = pack_queries(seqs)
@@ -1404,7 +1415,6 @@ def test_config5_shape_all_500_hmms(orc, tmp_path, block):
     for p in np.random.default_rng(0).choice(len(pq), size=min(1000, len(pq)), replace=False):
         c = cols[co[p]:co[p + 1]]
         assert (np.diff(c[c >= 0]) > 0).all()
-    e.close()
 
 
 @pytest.mark.parametrize("ranks", [2, 4])

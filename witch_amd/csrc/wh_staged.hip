@@ -49,8 +49,8 @@ namespace WH_K7NS {
     atomicAdd(a.stats + 4 * (kind), (unsigned long long)(st_c1 - st_c0)); atomicAdd(a.stats + 4 * (kind) + 1, (unsigned long long)(st_r1 - st_r0)); atomicAdd(a.stats + 4 * (kind) + 3, 1ull); } } } while (0)
 #define ST_K0() const long long st_k0 = a.stats ? (long long)__builtin_readcyclecounter() : 0
 #define ST_K1(kind) do { if (a.stats && lane == 0) atomicAdd(a.stats + 4 * (kind) + 2, (unsigned long long)((long long)__builtin_readcyclecounter() - st_k0)); } while (0)
-constexpr int kStTH = 768;            // dense kernels: twelve waves, 168 registers
-constexpr int kLightTH = 768;         // light kernels: two workgroups of up to twelve waves per CU
+[[maybe_unused]] constexpr int kStTH = 768;            // dense kernels: twelve waves, 168 registers
+[[maybe_unused]] constexpr int kLightTH = 768;         // light kernels: two workgroups of up to twelve waves per CU
 
 // pair of a batch -> query and model
 struct PairPos { int h; int64_t qi; };

@@ -96,6 +96,7 @@ def hot_path_step(e, res_t, off_t, maxlen, k, gather_topk=None, keep_device=Fals
     hot_path_step.aligned_cells = float((lens.double() * torch.from_numpy(e.M.astype(np.float64)).to(ph.device)[ph.long()]).sum().item())
     hot_path_step.aligned_residues = float(lens.double().sum().item())
     hot_path_step.align_paths = e.last_align_paths()
+    hot_path_step.spill_bytes = e.last_score_spill_bytes()      # device counter of the scoring call above (waits for the device: after the copies)
     return out, int(pq.numel()), total_cols
 
 
@@ -288,6 +289,10 @@ def score_roofline(M, lens_local, class_ms, kern_ms0, kern_n0, steps, H, stamp, 
          "scoring_launch_classes": {"%s/%d" % (FAM_NAMES.get(kd, "?").split("::")[-1], qc): round(v[0] / steps, 3) for (qc, kd), v in sorted(class_ms.items())},
          "achieved": round(s_tflops, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(s_tflops / 157.3, 4),
          "traffic": stamp.get("score_kernel_hbm_bytes_per_launch") if stamp else None, "traffic_source": stamp_src,
+         # measured LIVE in this run (wh_last_score_counters): bytes of Forward rows the envelope sweeps of one scoring call asked
+         # the memory system to store (the Backward sweeps read about three quarters of them back); the HBM-level figure above
+         # is the stamped profile's - a change of the spill shows here first
+         "spill_bytes_stored_per_step_live": getattr(hot_path_step, "spill_bytes", None),
          "flop_per_cell": 77, "cells_per_launch": cells_launch, "cells_per_s": round(cells_launch / (score_ms * 1e-3), 1) if score_ms > 0 else 0.0,
          "kernel_ms_avg": round(score_ms, 3), "launches": score_launches,
          "algorithmic_hbm_bytes_per_launch": float(len(lens_local) * H * (L + 9.0)) * steps / score_launches}

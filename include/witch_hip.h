@@ -164,6 +164,12 @@ int wh_last_align_paths(wh_ehmm *e, int64_t *paths4);
  * decision in doubt and whose sweep ran again at full width (pairs that never tried a window are in neither).
  * Waits for the device.  (What a window is: DESIGN.md section 4.1; WH_NO_WINDOW switches both off.) */
 int wh_last_score_paths(wh_ehmm *e, int64_t *paths6);
+/* The same six counters and, in out8[6], the BYTES of Forward rows the envelope sweeps of the last scoring call stored to
+ * their slabs (lane blocks kept by the sparse spill x 8 bytes per cell: what the kernels ASKED the memory system to write,
+ * counted on the device with one scalar add per row; the Backward sweeps read about three quarters of it back).  bench.py
+ * reports it live beside the HBM-level traffic of the stamped profile: a regression of the spill shows in the driver's own
+ * line.  out8[7] is reserved (0).  One-wavefront-per-pair kernels only. */
+int wh_last_score_counters(wh_ehmm *e, int64_t *out8);
 
 /* Optional per-PAIR record of the same: a device array of nq x H bytes that the scoring calls made after this one fill
  * with WH_PATH_* bits (NULL switches it off again).  Written by the staged launches only (WH_SCORE_KERNEL=10; pairs

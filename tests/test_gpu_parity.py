@@ -774,6 +774,7 @@ def test_bench_line_contract(tmp_path):
     rf = j["roofline"]
     assert rf["bound"] == "valu" and rf["unit"] == "TFLOP/s" and rf["peak"] == 157.3
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and "traffic" in rf
+    assert rf["spill_bytes_stored_per_step_live"] > 0                       # the live device counter of the Forward-row spill
     assert abs(rf["achieved"] - rf["cells_per_launch"] * 77 / (rf["kernel_ms_avg"] * 1e-3) / 1e12) < 0.02 * rf["achieved"] + 0.01
     ra = j["roofline_align"]
     assert ra["bound"] == "hbm" and ra["unit"] == "GB/s" and abs(ra["frac"] - ra["achieved"] / 8000.0) < 1e-3

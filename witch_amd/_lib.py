@@ -68,6 +68,7 @@ SYMBOLS = {
     "wh_last_align_status": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _P, C.c_int64]),
     "wh_last_align_paths": (C.c_int, [_P, _P]),
     "wh_last_score_paths": (C.c_int, [_P, _P]),
+    "wh_last_score_counters": (C.c_int, [_P, _P]),
     "wh_set_path_buffer": (C.c_int, [_P, _P]),
     "wh_last_queue_reruns": (C.c_int, [_P]),
     "wh_last_score_launches": (C.c_int, [_P, _P, _P, _P, C.c_int]),

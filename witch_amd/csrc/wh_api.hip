@@ -76,8 +76,8 @@ struct Knobs {
   int dbg = 0;
   int rdbg = 0;              // resolver: print the first <n> sampled segments and the cluster statistics of every region
 };
-static const int kScorePathSlot = 128;   // d_counter[128..139]: six 64-bit path counters of the last scoring call (wh_last_score_paths); [96..123] belong to wh_align_dev
-static const int kResolveErrSlot = 140;  // d_counter[140]: queue records the resolver found in a segment of another model (never, for a well-formed segment list)
+static const int kScorePathSlot = 128;   // d_counter[128..143]: eight 64-bit counters of the last scoring call: six paths (wh_last_score_paths), bytes of Forward rows stored, spare (wh_last_score_counters); [96..123] belong to wh_align_dev
+static const int kResolveErrSlot = 146;  // d_counter[140]: queue records the resolver found in a segment of another model (never, for a well-formed segment list)
 static const int kStagedMaxBatches = 1 << 15;   // staged launches: batches per scoring call (32 counters each: 4 MB)
 static const int kMaxLaunches = 60;   // work-queue heads in d_counter (slot 63 belongs to the consensus kernel)
 
@@ -446,6 +446,16 @@ int wh_last_score_paths(wh_ehmm *e, int64_t *paths6) {
   return WH_OK;
 }
 
+int wh_last_score_counters(wh_ehmm *e, int64_t *out8) {
+  if (!e || !out8) { set_error("wh_last_score_counters: bad argument"); return WH_EINVAL; }
+  HIPCHK(hipSetDevice(e->device));
+  unsigned long long v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(v, (int *)e->d_counter.p + kScorePathSlot, sizeof v, hipMemcpyDeviceToHost));
+  for (int t = 0; t < 8; t++) out8[t] = (int64_t)v[t];
+  return WH_OK;
+}
+
 int wh_set_path_buffer(wh_ehmm *e, uint8_t *d_paths) {
   if (!e) { set_error("wh_set_path_buffer: null handle"); return WH_EINVAL; }
   e->path_buf = d_paths;
@@ -734,7 +744,7 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
       e->rq_cap = cap;
       HIPCHK(hipMemsetAsync(d_rcount, 0, 2 * sizeof(int), s));
     }
-    HIPCHK(hipMemsetAsync((int *)e->d_counter.p + kScorePathSlot, 0, 6 * sizeof(unsigned long long), s));
+    HIPCHK(hipMemsetAsync((int *)e->d_counter.p + kScorePathSlot, 0, 8 * sizeof(unsigned long long), s));
     // Long models run four waves in lockstep per workgroup (wh_score_big.hip): hand them the queries in
     // descending length order, so that the waves of a workgroup finish their sweeps together and the longest
     // pairs start first.  (One D2H copy of the offsets and a host sort; only when such a class exists.)

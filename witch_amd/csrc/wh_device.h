@@ -340,16 +340,17 @@ __device__ __forceinline__ void region_scan_global(float *spec, int SP, int L, i
 // mask words instead (SP_B <- low word, SP_E <- high word) and a wave's block needs six arrays, not eight.
 // UM (without STORE): the dominant-path mask alone - the union over every EIGHTH row of the lane blocks that hold a cell
 // above E(row)/2 - written to um_out[0..1]; the multihit sweep uses it to place the node window of its Backward sweep.
-template <int Q, bool TREG, bool STORE, bool USEP = false, bool SLIM = false, bool UM = false>
+template <int Q, bool TREG, bool STORE, bool USEP = false, bool SLIM = false, bool UM = false, bool COUNT = false>
 __device__ __forceinline__ void forward_sweep(const TransTab<Q, TREG> &T, const ScanC &sc, const float *emL,
                                               const float *emG, int K, const uint8_t *seq, int L, LenCfg cfg,
                                               float *spec, int SP, float *Fs, float keep_scale, int lane,
-                                              float &xC_out, int &ef_out, unsigned *um_out = nullptr) {
+                                              float &xC_out, int &ef_out, unsigned *um_out = nullptr, int *nstored_out = nullptr) {
   float Mp[Q], Ip[Q], Dp[Q];
 #pragma unroll
   for (int q = 0; q < Q; q++) { Mp[q] = 0.f; Ip[q] = 0.f; Dp[q] = 0.f; }
   float xN = 1.0f, xB = cfg.move, xJ = 0.f, xC = 0.f, xE = 0.f;
   int ef = 0;
+  int nstored = 0;                   // COUNT: lane blocks stored over all rows (scalar: one s_bcnt1 + s_add per row)
   unsigned long long umask = 0;      // STORE: union over the rows of the lane block that holds a cell above E(row)/2: where the
                                      // envelope's dominant alignment runs.  The first rows set no bit: it takes ~25 nucleotides
                                      // until the true diagonal outweighs the chance matches among ~1000 others
@@ -450,6 +451,7 @@ __device__ __forceinline__ void forward_sweep(const TransTab<Q, TREG> &T, const 
       // full-width alignment passes, which read rows without looking at the masks, then saw the previous pair's cells)
       const bool keep = keep_scale < 0.f || lmax > keep_scale * xE;
       const unsigned long long mask = __ballot(keep);
+      if (COUNT) nstored += __builtin_popcountll(mask);
       umask |= __ballot(lmax > 0.5f * xE);
       if (lane == 0) {
         reinterpret_cast<unsigned *>(spec)[ML * SP + i] = (unsigned)(mask & 0xFFFFFFFFull);
@@ -472,6 +474,7 @@ __device__ __forceinline__ void forward_sweep(const TransTab<Q, TREG> &T, const 
     reinterpret_cast<unsigned *>(spec)[(SLIM ? SP_E : SP_MH) * SP] = (unsigned)(umask >> 32);
   }
   if (UM && !STORE && lane == 0) { um_out[0] = (unsigned)(umask & 0xFFFFFFFFull); um_out[1] = (unsigned)(umask >> 32); }
+  if (COUNT && nstored_out) *nstored_out = nstored;
   xC_out = xC;
   ef_out = ef;
 }

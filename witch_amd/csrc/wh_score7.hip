@@ -89,7 +89,7 @@ __device__ __forceinline__ int ctxKlds(const WaveCtx &c) { return (c.alpha >> 16
 struct P4Out { float mass, domcorr; };
 struct RegOut { int nenv, nreg, flags; };   // flags: WH_FLAG_* | multidomain mask of the stored regions << 8 (12 bytes: stays in return registers)
 
-struct FwdOut { float xC; int ef; };
+struct FwdOut { float xC; int ef; int nst; };      // C(L), its scale exponent; STORE: lane blocks the sweep stored (rows x kept lanes)
 
 // ---------------------------------------------------------------- P1 / P3
 // (the sweep without STORE is the multihit one, P1: it also leaves the dominant-path mask in n2tab[30..31] for P2's window)
@@ -102,8 +102,9 @@ __device__ __noinline__ FwdOut sweep_forward(const WaveCtx c, lds_u8 *seq3, int 
   const ScanC sc = scan_prepare(lane_product<Q, false>(T, FW_D2));
   FwdOut o;
   constexpr bool UM = !STORE && !SG && Q >= 8;
-  forward_sweep<Q, false, STORE, (Q <= kMaxQP), kSlim, UM>(T, sc, (const float *)c.emL, (const float *)c.emG, ctxKlds(c), seq, L, cfg, SG ? (float *)c.specg : (float *)c.spec, c.SP, (float *)c.Fs, keep_scale, c.lane, o.xC, o.ef,
-                                                           reinterpret_cast<unsigned *>((float *)c.n2tab) + kUmSlot);
+  o.nst = 0;
+  forward_sweep<Q, false, STORE, (Q <= kMaxQP), kSlim, UM, STORE>(T, sc, (const float *)c.emL, (const float *)c.emG, ctxKlds(c), seq, L, cfg, SG ? (float *)c.specg : (float *)c.spec, c.SP, (float *)c.Fs, keep_scale, c.lane, o.xC, o.ef,
+                                                                  reinterpret_cast<unsigned *>((float *)c.n2tab) + kUmSlot, &o.nst);
   if (SG) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // the rows were written by lane 0, every lane reads them next
   return o;
 }
@@ -952,7 +953,7 @@ __device__ __noinline__ RegOut region_scan(lds_f *spec3, glb_f *specg, int SP, i
   return o;
 }
 
-struct EnvCounters { unsigned n_w256, n_w512, n_wfail, n_full; };
+struct EnvCounters { unsigned n_w256, n_w512, n_wfail, n_full; unsigned long long spill; };   // ... and bytes of Forward rows the envelope sweeps stored
 // An envelope's Backward sweep + null2 once its Forward rows are in c.Fs and its per-row arrays in the wave's block: on a
 // node window where one fits around the dominant alignment and passes the mass certificate, else at full width.
 // <dense>: the Forward sweep stored every row (the redo after a failed spill certificate): full width, no tolerance.
@@ -1056,6 +1057,7 @@ __device__ __forceinline__ void score_envelopes(const ScoreArgs &a, WaveCtx &c, 
     for (int attempt = 0; attempt < 2; attempt++) {
       const float keep_scale = attempt == 0 ? (a.keep_scale > 0.f ? a.keep_scale : kKeepScale7) : -1.0f;
       const FwdOut f3 = sweep_forward<Q, true, TH, SG>(c, (lds_u8 *)eseq, Ld, cu, keep_scale);
+      ec.spill += (unsigned long long)f3.nst * (8 * Q);
       // the rows were written by other lanes of this wave: order the stores before the loads
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       envsc = (float)((double)f3.ef * LOG2 + log((double)(f3.xC * cu.move)));
@@ -1195,7 +1197,7 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
   const double LOG2 = 0.69314718055994529;
   int cur_h = -1;
   const DevHMM *hm = nullptr;
-  EnvCounters ec = {0, 0, 0, 0};                              // this wave's envelope Backward sweeps by path (wh_last_score_paths)
+  EnvCounters ec = {0, 0, 0, 0, 0};                           // this wave's envelope Backward sweeps by path (wh_last_score_paths)
   FrontState fs = {0.f, 0.f, 0u, 0u, 0u};                     // window heuristics and path counters of the multihit Backward sweep
 
   for (;;) {
@@ -1287,6 +1289,7 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
     if (ec.n_w512) atomicAdd(a.paths + 1, (unsigned long long)ec.n_w512);
     if (ec.n_wfail) atomicAdd(a.paths + 2, (unsigned long long)ec.n_wfail);
     if (ec.n_full) atomicAdd(a.paths + 3, (unsigned long long)ec.n_full);
+    if (ec.spill) atomicAdd(a.paths + 6, ec.spill);
     if (fs.n_p2w) atomicAdd(a.paths + 4, (unsigned long long)fs.n_p2w);
     if (fs.n_p2rej) atomicAdd(a.paths + 5, (unsigned long long)fs.n_p2rej);
   }
@@ -1338,7 +1341,7 @@ __global__ __launch_bounds__(TH) void score_kernel7q(ScoreArgs a) {
   const double LOG2 = 0.69314718055994529;
   int cur_h = -1;
   const DevHMM *hm = nullptr;
-  EnvCounters ec = {0, 0, 0, 0};
+  EnvCounters ec = {0, 0, 0, 0, 0};
   FrontState fs = {0.f, 0.f, 0u, 0u, 0u};
   const long long t_kernel0 = a.stats ? (long long)__builtin_readcyclecounter() : 0;
 
@@ -1425,6 +1428,7 @@ __global__ __launch_bounds__(TH) void score_kernel7q(ScoreArgs a) {
               c.Fs = Fs0 + (size_t)t * slab1;
               const float keep_scale = a.keep_scale > 0.f ? a.keep_scale : kKeepScale7;
               const FwdOut f3 = sweep_forward<Q, true, TH, false>(c, (lds_u8 *)eseq, Ld, cu, keep_scale);
+              ec.spill += (unsigned long long)f3.nst * (8 * Q);
               __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
               const float envsc = (float)((double)f3.ef * LOG2 + log((double)(f3.xC * cu.move)));
               WH_TICK7(7);
@@ -1467,6 +1471,7 @@ __global__ __launch_bounds__(TH) void score_kernel7q(ScoreArgs a) {
                   domcorr = p4.domcorr;
                   if (!(fabsf((float)Ld - p4.mass) <= kMassTol7 * (float)Ld)) {
                     const FwdOut f3d = sweep_forward<Q, true, TH, false>(c, (lds_u8 *)eseq, Ld, cu, -1.0f);
+                    ec.spill += (unsigned long long)f3d.nst * (8 * Q);
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                     domcorr = 0.f;
                     if (f3d.xC > 0.f) { p4 = envelope_backward<Q, TH, false>(a, c, eseq, Ld, cu, f3d, true, false, ec, lane); domcorr = p4.domcorr; flags |= WH_FLAG_EXACT; }
@@ -1539,6 +1544,7 @@ __global__ __launch_bounds__(TH) void score_kernel7q(ScoreArgs a) {
             domcorr = p4.domcorr;
             if (!(fabsf((float)Ld - p4.mass) <= kMassTol7 * (float)Ld)) {
               const FwdOut f3d = sweep_forward<Q, true, TH, false>(c, (lds_u8 *)eseq, Ld, cu, -1.0f);
+              ec.spill += (unsigned long long)f3d.nst * (8 * Q);
               __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
               domcorr = 0.f;
               if (f3d.xC > 0.f) { p4 = envelope_backward<Q, TH, false>(a, c, eseq, Ld, cu, f3d, true, false, ec, lane); domcorr = p4.domcorr; flags |= WH_FLAG_EXACT; }
@@ -1560,6 +1566,7 @@ __global__ __launch_bounds__(TH) void score_kernel7q(ScoreArgs a) {
     if (ec.n_w512) atomicAdd(a.paths + 1, (unsigned long long)ec.n_w512);
     if (ec.n_wfail) atomicAdd(a.paths + 2, (unsigned long long)ec.n_wfail);
     if (ec.n_full) atomicAdd(a.paths + 3, (unsigned long long)ec.n_full);
+    if (ec.spill) atomicAdd(a.paths + 6, ec.spill);
     if (fs.n_p2w) atomicAdd(a.paths + 4, (unsigned long long)fs.n_p2w);
     if (fs.n_p2rej) atomicAdd(a.paths + 5, (unsigned long long)fs.n_p2rej);
   }

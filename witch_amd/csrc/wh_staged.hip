@@ -325,6 +325,7 @@ __global__ __launch_bounds__(kStTH) void staged_p3_kernel(StagedArgs g) {
   float *spec = S.wbase;
   const int SP = a.SP;
   const double LOG2 = 0.69314718055994529;
+  unsigned long long spill = 0;
   ST_K0();
   group_loop(g, ST_C_P3, S.slot, S.cand, WH_MAX_ENVELOPES,
     [&](int h) {
@@ -364,6 +365,7 @@ __global__ __launch_bounds__(kStTH) void staged_p3_kernel(StagedArgs g) {
       ST_T0();
       const FwdOut f3 = sweep_forward<Q, true, kStTH, false>(c, (lds_u8 *)seq, Ld, cu, keep_scale);
       ST_T1(4);
+      spill += (unsigned long long)f3.nst * (8 * Q);
       const float envsc = (float)((double)f3.ef * LOG2 + log((double)(f3.xC * cu.move)));
       int cls = ST_CLS_NONE, m0 = 0;
       if (f3.xC > 0.f) {
@@ -382,6 +384,7 @@ __global__ __launch_bounds__(kStTH) void staged_p3_kernel(StagedArgs g) {
         pp->envsc[e] = envsc; pp->domcorr[e] = 0.f; pp->uid[e] = uid; pp->cls[e] = (uint8_t)cls;
       }
     });
+  if (a.paths && lane == 0 && spill) atomicAdd(a.paths + 6, spill);
   ST_K1(4);
   // the row stores of this kernel are read by other workgroups in the next launch: kernel boundary = release
 }
@@ -479,6 +482,7 @@ __global__ __launch_bounds__(kStTH) void staged_dense_kernel(StagedArgs g) {
       c.Fs = (glb_f *)(g.slabs + (size_t)uid * g.slab_stride);
       const LenCfg cu = len_config(L, false);
       const FwdOut f3 = sweep_forward<Q, true, kStTH, false>(c, (lds_u8 *)seq, Ld, cu, -1.0f);
+      if (lane == 0 && a.paths) atomicAdd(a.paths + 6, (unsigned long long)f3.nst * (8 * Q));
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      // the rows were written by other lanes of this wave
       const float envsc = (float)((double)f3.ef * LOG2 + log((double)(f3.xC * cu.move)));
       float domcorr = 0.f;
@@ -513,7 +517,7 @@ __global__ __launch_bounds__(kStTH) void staged_env_kernel(StagedArgs g) {
   uint8_t *seq = ctx_seq(a, S.wbase);
   int *regs = ctx_regs(a, S.wbase);
   const double LOG2 = 0.69314718055994529;
-  EnvCounters ec = {0, 0, 0, 0};
+  EnvCounters ec = {0, 0, 0, 0, 0};
   ST_K0();
   group_loop(g, ST_C_P3, S.slot, S.cand, 1,
     [&](int h) {
@@ -565,6 +569,7 @@ __global__ __launch_bounds__(kStTH) void staged_env_kernel(StagedArgs g) {
     if (ec.n_w512) atomicAdd(a.paths + 1, (unsigned long long)ec.n_w512);
     if (ec.n_wfail) atomicAdd(a.paths + 2, (unsigned long long)ec.n_wfail);
     if (ec.n_full) atomicAdd(a.paths + 3, (unsigned long long)ec.n_full);
+    if (ec.spill) atomicAdd(a.paths + 6, ec.spill);
   }
   ST_K1(4);
 }

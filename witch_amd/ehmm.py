@@ -118,6 +118,12 @@ class EHMM:
         return {"window256": int(p6[0]), "window512": int(p6[1]), "window_rejected": int(p6[2]), "full_width": int(p6[3]),
                 "p2_window": int(p6[4]), "p2_window_in_doubt": int(p6[5])}
 
+    def last_score_spill_bytes(self) -> int:
+        """Bytes of Forward rows the envelope sweeps of the last score call stored (include/witch_hip.h: wh_last_score_counters)."""
+        c8 = np.zeros(8, dtype=np.int64)
+        check(lib().wh_last_score_counters(self._h, c8.ctypes.data), "wh_last_score_counters")
+        return int(c8[6])
+
     def set_path_buffer(self, paths_t):
         """Registers a CUDA uint8 tensor of nq x H bytes that later score calls fill with WH_PATH_* bits per pair
         (staged launches only; None switches it off).  The caller keeps the tensor alive (include/witch_hip.h)."""

@@ -385,6 +385,9 @@ def main():
     ap.add_argument("--no-level1", action="store_true", help="skip the level-1 end-to-end stage (reported beside the hot-path value)")
     ap.add_argument("--no-also", action="store_true", help="skip the two workloads reported beside the headline (dna_100k_x200_m1000 in full, a 3 000-query slice of aa_50k_x500)")
     args = ap.parse_args()
+    if os.environ.get("WITCH_BENCH_WATCHDOG"):      # tests: a run that stops says where (every thread's stack on stderr), then goes on
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["WITCH_BENCH_WATCHDOG"]), exit=False)
 
     import torch
     import torch.distributed as dist

@@ -792,11 +792,18 @@ def test_ab_slot_kernel_agrees(golden_case):
     e, seqs, res, offs = _load(case)
     d0, f0 = e.score(res, offs)
     for name, value in (("WH_SCORE_KERNEL", "8"), ("WH_SCORE_KERNEL", "9"), ("WH_MAX_WAVES", "4"), ("WH_FORCE_SPECG", "1")):
+        unbanded = value == "9" or name == "WH_FORCE_SPECG"
+        if unbanded:            # the two-query kernel and the long-query sweeps store their envelope rows without the lane-block band (spill_band, wh_score7.hip)
+            e.set_option("WH_SPILL_BAND", "0")
+            d0, f0 = e.score(res, offs)
         e.set_option(name, value)
         d1, f1 = e.score(res, offs)
         e.set_option(name, "")
         assert np.array_equal(f0, f1), (case.name, name)
         assert np.array_equal(d0, d1), (case.name, name)
+        if unbanded:
+            e.set_option("WH_SPILL_BAND", "")
+            d0, f0 = e.score(res, offs)
     with pytest.raises(Exception):
         e.set_option("WH_SCORE_KERNEL", "2")      # removed experiment kernels are refused, not ignored
     e.close()
@@ -835,6 +842,55 @@ def test_scoring_on_a_node_window_equals_the_full_width_sweeps(tmp_path):
     # the Forward side is untouched by the window
     assert all(a.fwd_bits == b.fwd_bits for a, b in zip(det_w[:4096], det_f[:4096]))
     e.close()
+
+
+def test_envelope_rows_stored_on_a_band_of_lane_blocks_equal_the_unbanded_store(tmp_path):
+    """An envelope's Forward sweep stores only the lane blocks around the dominant path of the pair's multihit Forward sweep
+    (spill_band, wh_score7.hip) - what the band cuts is posterior mass, and the mass certificate (held to the
+    float32 noise band, as for a window) sends an envelope it fails to the dense redo.  Against WH_SPILL_BAND=0 on 2 048
+    headline queries x 200 HMMs, on SURVEY's family sketch and on ragged / unrelated / two-copy queries: reported /
+    multidomain / override / truncation flags identical, envelopes identical, deci-bits identical or one unit apart at a
+    "%6.1f" rounding boundary of the unbanded float score; the live counter proves the band stored less than half the bytes
+    on the headline fragments.  An envelope whose band fails the certificate is stored as in round 4 next (every lane block
+    that passes the keep rule) and only then densely, so the band adds NO dense redo (WH_FLAG_EXACT identical)."""
+    _need_gpu()
+    import bench
+    from witch_amd.ehmm import EHMM, pack_queries
+    rng = np.random.default_rng(23)
+    for wl, nq, nh, max_bytes in (("dna_100k_x200", 2048, None, 0.5), ("dna_100k_x200_m1000", 1024, 40, 0.6), ("dna_m1250", 192, 6, 1.0)):
+        fam, se, names, seqs, k = bench.make_workload(wl, str(tmp_path / wl), nq, nh)
+        e = EHMM(se.paths, hmm_index=se.index, nseq=se.nseq)
+        base = [s_.astype(np.uint8) for s_ in seqs]
+        extra = []
+        if wl != "dna_100k_x200":
+            extra = [s_[: int(rng.integers(12, len(s_) + 1))] for s_ in base[:100]]
+            extra += [rng.integers(0, 4, size=int(n)).astype(np.uint8) for n in rng.integers(5, 150, size=40)]
+            extra += [np.concatenate([s_[:70], s_[:70]]).astype(np.uint8) for s_ in base[:40]]
+        res, offs = pack_queries(base + extra)
+        d_b, f_b, det_b = e.score(res, offs, want_detail=True)
+        bytes_b = e.last_score_spill_bytes()
+        e.set_option("WH_SPILL_BAND", "0")
+        d_a, f_a, det_a = e.score(res, offs, want_detail=True)
+        bytes_a = e.last_score_spill_bytes()
+        e.set_option("WH_SPILL_BAND", "")
+        assert 0 < bytes_b <= max_bytes * bytes_a, (wl, bytes_b, bytes_a)
+        assert np.array_equal(f_b, f_a), wl
+        H = e.H
+        nall = len(base) + len(extra)
+        sc_a = np.array([d.seq_score for d in det_a], dtype=np.float64).reshape(nall, H)
+        moved = _check_decibits(d_b, d_a, sc_a, (f_a & 1) == 1, "banded store vs unbanded (%s)" % wl)
+        assert moved <= 8, (wl, moved)
+        xb, xa = np.ctypeslib.as_array(det_b), np.ctypeslib.as_array(det_a)
+        for name in ("nenv", "nregions"):
+            assert np.array_equal(xb[name], xa[name]), (wl, name)
+        used = np.arange(xa["domcorr"].shape[1])[None, :] < xa["nenv"][:, None]
+        for name in ("env_i", "env_j"):
+            assert np.array_equal(xb[name][used], xa[name][used]), (wl, name)
+        # the Forward side is untouched by what is stored
+        assert np.array_equal(xb["fwd_bits"].view(np.uint32), xa["fwd_bits"].view(np.uint32)), wl
+        assert np.array_equal(xb["envsc"][used].view(np.uint32), xa["envsc"][used].view(np.uint32)), wl
+        assert np.all(np.abs(xb["domcorr"] - xa["domcorr"])[used] <= 1e-3), (wl, float(np.abs(xb["domcorr"] - xa["domcorr"])[used].max()))
+        e.close()
 
 
 def test_multihit_backward_on_a_node_window_gives_the_full_width_regions(tmp_path):
@@ -921,6 +977,7 @@ def test_two_queries_per_wave_kernel_equals_the_one_query_kernel(tmp_path):
     from witch_amd.ehmm import EHMM, pack_queries
     fam, se, names, seqs, k = bench.make_workload("dna_100k_x200", str(tmp_path), 1025, 12)
     e = EHMM(se.paths, hmm_index=se.index, nseq=se.nseq)
+    e.set_option("WH_SPILL_BAND", "0")       # (the two-query Forward sweep has no lane-block band: compare like with like)
     rng = np.random.default_rng(5)
     ragged = [s_.astype(np.uint8)[: int(rng.integers(20, 151))] for s_ in seqs[:301]]
     junk = [rng.integers(0, 4, size=int(n)).astype(np.uint8) for n in rng.integers(1, 150, size=40)]
@@ -1913,13 +1970,29 @@ def test_two_rank_rehearsal_of_the_protein_shape(tmp_path):
     common = ["--workload", "aa_50k_x500", "--steps", "1", "--warmup", "0", "--nq", "2000", "--no-cpu-baseline"]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     env.pop("WITCH_FORCE_COLLECTIVES", None)
-    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common,
-                        capture_output=True, text=True, timeout=1200, env=env)
+    import signal
+    import types
+
+    def run(cmd, env_, tag):
+        # A child that stops must fail THIS test with what it last said (a silent wait gets the whole GPU run killed): output
+        # to files (a pipe stays open while any grandchild lives), own process group, every member killed at the limit.
+        out, err = tmp_path / (tag + ".out"), tmp_path / (tag + ".err")
+        with open(out, "w") as fo, open(err, "w") as fe:
+            p = subprocess.Popen(cmd, stdout=fo, stderr=fe, env=dict(env_, WITCH_BENCH_WATCHDOG="150"), start_new_session=True)
+            try:
+                rc = p.wait(timeout=240)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)
+                p.wait()
+                import torch
+                free_b, total_b = torch.cuda.mem_get_info()
+                pytest.fail("no result after 240 s (device memory free %.1f of %.1f GB): %s\n%s" % (free_b / 1e9, total_b / 1e9, " ".join(cmd[-12:]), err.read_text()[-6000:]))
+        return types.SimpleNamespace(returncode=rc, stdout=out.read_text(), stderr=err.read_text())
+    r1 = run([sys.executable, "-X", "faulthandler", os.path.join(ROOT, "bench.py"), "--gpus", "1"] + common, env, "one_rank")
     assert r1.returncode == 0, r1.stderr[-2000:]
-    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-                         os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common,
-                        capture_output=True, text=True, timeout=1200, env=dict(env, WITCH_BENCH_REHEARSAL="1"))
+    r2 = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+              "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+              os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common, dict(env, WITCH_BENCH_REHEARSAL="1"), "two_ranks")
     assert r2.returncode == 0, r2.stderr[-2000:]
     j1, j2 = _json_line(r1.stdout), _json_line(r2.stdout)
     assert j2["n_gpus"] == 2 and j2["config"]["n_hmms"] == 500 and j2["config"]["n_queries"] == 2000

@@ -62,6 +62,7 @@ struct Knobs {
                              // 9 two queries per wavefront where a batch fits (wh_score9.hip; measured slower, kept for A/B: DESIGN.md);
                              // 10 staged launches (wh_staged.hip) for the size classes and batches they serve, 7 for the rest
   float keep_scale = 0.f;    // Forward-row spill threshold relative to E(row); 0 = the kernel's default
+  int spill_band = 1;        // 0: envelope Forward rows stored at every lane block that passes keep_scale (A/B; the two-query kernel has no band)
   int max_waves = 0;         // cap on waves per workgroup (0 = planner's choice)
   bool force_specg = false;  // force the HBM special-state mode
   bool no_logspace = false;  // skip the log-space alignment pass
@@ -364,6 +365,7 @@ int wh_set_option(wh_ehmm *e, const char *name, const char *value) {
     if (kv < 7 || kv > 12) { set_error("WH_SCORE_KERNEL=%s: this build has kernels 7 to 12", v); return WH_EINVAL; }
     k.kernel = kv;
   } else if (!strcmp(name, "WH_KEEP_LOG2")) k.keep_scale = *v ? ldexpf(1.0f, atoi(v)) : 0.f;
+  else if (!strcmp(name, "WH_SPILL_BAND")) k.spill_band = *v ? atoi(v) : 1;
   else if (!strcmp(name, "WH_MAX_WAVES")) k.max_waves = *v ? std::max(1, std::min(16, atoi(v))) : 0;
   else if (!strcmp(name, "WH_FORCE_SPECG")) k.force_specg = on;
   else if (!strcmp(name, "WH_NO_LOGSPACE")) k.no_logspace = on;
@@ -797,6 +799,7 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
       a.dbg = kn.dbg;
       a.no_window = kn.no_window ? 1 : 0;
       a.keep_scale = kn.keep_scale;
+      a.spill_band = kn.kernel != 9 ? kn.spill_band : 0;
       if (resolve) { a.rrecs = (ResolveRec *)e->d_rrecs.p; a.rcount = d_rcount; a.rcap = (int)e->rq_cap; }
       memcpy(a.degen, e->degen, sizeof a.degen);
       int waves = 0, SP = 0, wave_lds = 0;

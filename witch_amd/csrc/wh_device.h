@@ -344,7 +344,7 @@ template <int Q, bool TREG, bool STORE, bool USEP = false, bool SLIM = false, bo
 __device__ __forceinline__ void forward_sweep(const TransTab<Q, TREG> &T, const ScanC &sc, const float *emL,
                                               const float *emG, int K, const uint8_t *seq, int L, LenCfg cfg,
                                               float *spec, int SP, float *Fs, float keep_scale, int lane,
-                                              float &xC_out, int &ef_out, unsigned *um_out = nullptr, int *nstored_out = nullptr) {
+                                              float &xC_out, int &ef_out, unsigned *um_out = nullptr, int *nstored_out = nullptr, int keep_lanes = 63 << 8) {
   float Mp[Q], Ip[Q], Dp[Q];
 #pragma unroll
   for (int q = 0; q < Q; q++) { Mp[q] = 0.f; Ip[q] = 0.f; Dp[q] = 0.f; }
@@ -449,10 +449,18 @@ __device__ __forceinline__ void forward_sweep(const TransTab<Q, TREG> &T, const 
       for (int q = 0; q < Q; q += 2) lmax = fmaxf(lmax, fmaxf(fmaxf(Mp[q], Mp[q + 1]), fmaxf(Ip[q], Ip[q + 1])));
       // (keep_scale < 0 must store EVERY row: a row that has underflowed to zero everywhere gives 0 > -0 = false, and the
       // full-width alignment passes, which read rows without looking at the masks, then saw the previous pair's cells)
-      const bool keep = keep_scale < 0.f || lmax > keep_scale * xE;
+      const unsigned long long dom = __ballot(lmax > 0.5f * xE);
+      umask |= dom;
+      // keep_lanes: the band of lane blocks the caller thinks worth storing (lowest | highest << 8; the mass certificate of the
+      // Backward sweep judges the choice like it judges keep_scale)
+      // (bits 16..: a cap on the highest block that rises with the row - lane block <cap0 + i / Q> - for the first rows, where the
+      // keep rule holds nothing back: the alignment cannot be further up the model than its start plus the rows walked)
+      const int blo = keep_lanes & 255;
+      int bhi = (keep_lanes >> 8) & 255;
+      if (keep_lanes >> 16) bhi = min(bhi, (keep_lanes >> 16) - 1 + i / Q);
+      const bool keep = keep_scale < 0.f || (lmax > keep_scale * xE && lane >= blo && lane <= bhi);
       const unsigned long long mask = __ballot(keep);
       if (COUNT) nstored += __builtin_popcountll(mask);
-      umask |= __ballot(lmax > 0.5f * xE);
       if (lane == 0) {
         reinterpret_cast<unsigned *>(spec)[ML * SP + i] = (unsigned)(mask & 0xFFFFFFFFull);
         reinterpret_cast<unsigned *>(spec)[MH * SP + i] = (unsigned)(mask >> 32);

@@ -56,6 +56,7 @@ struct ScoreArgs {
   size_t p2_backup_stride;     // floats per wave
   int dbg;                     // timing experiments only: 1 = skip Forward-row stores, 2 = skip Forward-row loads
   float keep_scale;            // Forward-row spill threshold relative to E(row); 0 = the kernel's default (2^-24)
+  int spill_band;              // 1: an envelope's Forward sweep stores only the lane blocks around P1's dominant path (spill_band, wh_score7.hip)
   ResolveRec *rrecs;           // queue of pairs with a multidomain region (NULL: such regions become one envelope)
   int *rcount;                 // queue length (device counter)
   int rcap;

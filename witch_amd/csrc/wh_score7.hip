@@ -29,6 +29,10 @@ constexpr float kMassTol7 = 2e-5f;
 // sums: 1.6 million envelopes of the headline workload, none above); a window is accepted only inside that noise band,
 // so what it loses cannot be told from rounding (0.05 % of the windows are rejected and redone at full width)
 constexpr float kWinTol7 = 3e-6f;
+// the spill certificate where an envelope's Forward rows are stored on a band of lane blocks (spill_band below): a band cuts
+// posterior mass on purpose, so its sweeps are held to the noise band like a window's (with 2e-5 a 266-row envelope of the
+// reference's example data lost 2.9e-3 nats of its null2 correction: the oracle comparison allows 1e-3)
+__device__ __forceinline__ float spill_tol(bool banded) { return banded ? kWinTol7 : kMassTol7; }
 // model classes that keep the FW_P / BW_P arrays in LDS (0 = none).  Measured at three waves per
 // SIMD on the headline workload: 557 ms with the arrays (Q <= 16) vs 554 ms without - the saved
 // multiplies do not show, so the arrays stay out of LDS.
@@ -95,7 +99,7 @@ struct FwdOut { float xC; int ef; int nst; };      // C(L), its scale exponent; 
 // (the sweep without STORE is the multihit one, P1: it also leaves the dominant-path mask in n2tab[30..31] for P2's window)
 constexpr int kUmSlot = 30;
 template <int Q, bool STORE, int TH, bool SG>
-__device__ __noinline__ FwdOut sweep_forward(const WaveCtx c, lds_u8 *seq3, int L, LenCfg cfg, float keep_scale) {
+__device__ __noinline__ FwdOut sweep_forward(const WaveCtx c, lds_u8 *seq3, int L, LenCfg cfg, float keep_scale, int keep_lanes = 63 << 8) {
   const uint8_t *seq = (const uint8_t *)seq3;
   TransTab<Q, false> T;
   T.load(nullptr, (const float *)c.fwL, c.lane);
@@ -104,7 +108,7 @@ __device__ __noinline__ FwdOut sweep_forward(const WaveCtx c, lds_u8 *seq3, int 
   constexpr bool UM = !STORE && !SG && Q >= 8;
   o.nst = 0;
   forward_sweep<Q, false, STORE, (Q <= kMaxQP), kSlim, UM, STORE>(T, sc, (const float *)c.emL, (const float *)c.emG, ctxKlds(c), seq, L, cfg, SG ? (float *)c.specg : (float *)c.spec, c.SP, (float *)c.Fs, keep_scale, c.lane, o.xC, o.ef,
-                                                                  reinterpret_cast<unsigned *>((float *)c.n2tab) + kUmSlot, &o.nst);
+                                                                  reinterpret_cast<unsigned *>((float *)c.n2tab) + kUmSlot, &o.nst, keep_lanes);
   if (SG) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // the rows were written by lane 0, every lane reads them next
   return o;
 }
@@ -958,12 +962,12 @@ struct EnvCounters { unsigned n_w256, n_w512, n_wfail, n_full; unsigned long lon
 // node window where one fits around the dominant alignment and passes the mass certificate, else at full width.
 // <dense>: the Forward sweep stored every row (the redo after a failed spill certificate): full width, no tolerance.
 // <skip_window>: the caller has tried the window already (the four-envelopes-per-wave sweep).  The caller checks the
-// spill certificate |Ld - mass| <= kMassTol7 Ld on the result of a sparse sweep.
+// spill certificate |Ld - mass| <= spill_tol Ld on the result of a sparse sweep.
 template <int Q, int TH, bool SG>
 __device__ __forceinline__ P4Out envelope_backward(const ScoreArgs &a, const WaveCtx &c, const uint8_t *eseq, int Ld, LenCfg cu, const FwdOut &f3,
-                                                   bool dense, bool skip_window, EnvCounters &ec, int lane) {
+                                                   bool dense, bool skip_window, EnvCounters &ec, int lane, bool banded) {
   const int SP = c.SP;
-  const float tol = dense ? INFINITY : kMassTol7;
+  const float tol = dense ? INFINITY : spill_tol(banded);
   P4Out p4;
   bool have4 = false;
   if constexpr (Q >= 8) {
@@ -1033,11 +1037,67 @@ __device__ __forceinline__ void assemble_score(int L, int Ld_tot, float seqbias_
 // Inlined into its two callers: the fused kernel below, and the envelope kernel of the staged launches (wh_staged.hip),
 // whose P1 / P2 ran as launches of their own.
 #define WH_TICK7(slot) do { if (a.stats) { const long long t_now = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(a.stats + (slot), (unsigned long long)(t_now - t_last)); t_last = t_now; } } while (0)
+// The lane blocks an envelope's Forward sweep stores on its first attempt: those around the dominant path of the pair's
+// multihit Forward sweep (<um1>, P1's mask: lane blocks that held a cell above E(row)/2 on a sampled row).  Without it the
+// first rows of EVERY envelope are stored at full width - until ~25 residues have matched, local entry keeps all 64 lane
+// blocks above keep_scale x E(row) - and those rows were two thirds of all spill bytes on the headline workload
+// (5.99e11 -> 2.2e11 B per 8 192 queries; kernel time -7 %).  The margins are in nodes: the true diagonal is not dominant
+// on the envelope's first rows, so the path starts BELOW the lowest sampled block (80 nodes; 64 nodes gave 5x the dense
+// redos) and may run on past the highest (48 nodes).  A band that cuts posterior mass fails the spill certificate like a
+// keep_scale that is too coarse does, and the envelope is redone with every row stored at full width.
+constexpr int kAllLanes = 63 << 8;
+template <int Q>
+__device__ __forceinline__ int spill_band(const ScoreArgs &a, unsigned long long um1) {
+  if (Q < 8 || um1 == 0 || !a.spill_band) return kAllLanes;
+  int below = (80 + Q - 1) / Q, above = (48 + Q - 1) / Q;
+  if (a.spill_band > 2) { below = (a.spill_band / 1000 + Q - 1) / Q; above = (a.spill_band % 1000 + Q - 1) / Q; }   // (development: margins in nodes, below * 1000 + above)
+  const int lo = __builtin_ctzll(um1) - below, hi = 63 - __builtin_clzll(um1) + above;
+  int band = (lo > 0 ? lo : 0) | ((hi < 63 ? hi : 63) << 8);
+  if (a.spill_band == 2) band |= (__builtin_ctzll(um1) + 1 + (48 + Q - 1) / Q + 1) << 16;      // EXPERIMENT: rising cap
+  return band;
+}
+__device__ __forceinline__ unsigned long long p1_mask(const WaveCtx &c) {
+  const unsigned *su = reinterpret_cast<const unsigned *>((const float *)c.n2tab) + kUmSlot;
+  return ((unsigned long long)su[1] << 32) | su[0];
+}
+// One envelope: Forward sweep (rows stored for the Backward sweep) -> Backward sweep + null2, by up to three attempts at
+// what is stored.  0: the lane blocks of <band> that pass the keep rule, certificate at the noise band (a band cuts mass on
+// purpose);  1: every lane block that passes the keep rule, certificate 2e-5 (the store of rounds 1-4: an envelope whose
+// band failed gets exactly the result it had then - on SURVEY's family sketch 1 % of the pairs carry 1e-5 of their posterior
+// mass on junk nodes far from the alignment, whatever the margins);  2: every row at full width, no certificate (WH_FLAG_EXACT).
+// <first>: where to begin (0 with a band, 1 without; callers whose own first attempt failed pass the next one).
+// Returns the null2 correction; <envsc> is the envelope's Forward score (the same from every attempt).
+template <int Q, int TH, bool SG>
+__device__ __forceinline__ float envelope_attempts(const ScoreArgs &a, WaveCtx &c, const uint8_t *eseq, int Ld, LenCfg cu, int band, int first,
+                                                   EnvCounters &ec, int lane, int &flags, long long &t_last, float &envsc) {
+  const double LOG2 = 0.69314718055994529;
+  float domcorr = 0.f;
+#pragma unroll 1
+  for (int attempt = first; attempt < 3; attempt++) {
+    const float keep_scale = attempt < 2 ? (a.keep_scale > 0.f ? a.keep_scale : kKeepScale7) : -1.0f;
+    const FwdOut f3 = sweep_forward<Q, true, TH, SG>(c, (lds_u8 *)eseq, Ld, cu, keep_scale, attempt == 0 ? band : kAllLanes);
+    ec.spill += (unsigned long long)f3.nst * (8 * Q);
+    // the rows were written by other lanes of this wave: order the stores before the loads
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    envsc = (float)((double)f3.ef * LOG2 + log((double)(f3.xC * cu.move)));
+    domcorr = 0.f;
+    if (!(f3.xC > 0.f)) break;
+    WH_TICK7(7);
+    const P4Out p4 = envelope_backward<Q, TH, SG>(a, c, eseq, Ld, cu, f3, attempt == 2, false, ec, lane, attempt == 0);
+    domcorr = p4.domcorr;
+    WH_TICK7(8);
+    if (attempt < 2 && !(fabsf((float)Ld - p4.mass) <= spill_tol(attempt == 0) * (float)Ld)) continue;
+    if (attempt == 2) flags |= WH_FLAG_EXACT;
+    break;
+  }
+  return domcorr;
+}
+
 template <int Q, int TH, bool SG>
 __device__ __forceinline__ void score_envelopes(const ScoreArgs &a, WaveCtx &c, uint8_t *seq, int *regs, int L, int lane, int h, int64_t qi, int nenv, int nreg,
                                                 int multi_mask, float fwdsc, float nullsc, float fwd_bits_out, wh_pair_detail *dp, int &flags, int &decibits,
-                                                EnvCounters &ec, long long &t_last) {
-  const double LOG2 = 0.69314718055994529;
+                                                EnvCounters &ec, long long &t_last, unsigned long long um1) {
+  const int band = spill_band<Q>(a, SG ? 0ull : um1);      // (long queries: P1 keeps no mask; the band gained nothing there, 2.5 % of the bytes on the protein slice)
   {
   // ---------------- envelopes
   const LenCfg cu = len_config(L, false);
@@ -1052,25 +1112,8 @@ __device__ __forceinline__ void score_envelopes(const ScoreArgs &a, WaveCtx &c, 
     const int ri = regs[2 * e], rj = regs[2 * e + 1];
     const int Ld = rj - ri + 1;
     const uint8_t *eseq = seq + (ri - 1);
-    float envsc = -INFINITY, domcorr = 0.f;
-#pragma unroll 1
-    for (int attempt = 0; attempt < 2; attempt++) {
-      const float keep_scale = attempt == 0 ? (a.keep_scale > 0.f ? a.keep_scale : kKeepScale7) : -1.0f;
-      const FwdOut f3 = sweep_forward<Q, true, TH, SG>(c, (lds_u8 *)eseq, Ld, cu, keep_scale);
-      ec.spill += (unsigned long long)f3.nst * (8 * Q);
-      // the rows were written by other lanes of this wave: order the stores before the loads
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-      envsc = (float)((double)f3.ef * LOG2 + log((double)(f3.xC * cu.move)));
-      domcorr = 0.f;
-      if (!(f3.xC > 0.f)) break;
-      WH_TICK7(7);
-      const P4Out p4 = envelope_backward<Q, TH, SG>(a, c, eseq, Ld, cu, f3, attempt == 1, false, ec, lane);
-      domcorr = p4.domcorr;
-      WH_TICK7(8);
-      if (attempt == 0 && !(fabsf((float)Ld - p4.mass) <= kMassTol7 * (float)Ld)) continue;
-      if (attempt == 1) flags |= WH_FLAG_EXACT;
-      break;
-    }
+    float envsc = -INFINITY;
+    const float domcorr = envelope_attempts<Q, TH, SG>(a, c, eseq, Ld, cu, band, band != kAllLanes ? 0 : 1, ec, lane, flags, t_last, envsc);
     seqbias_sum += domcorr;
     if (envsc - domcorr > 0.0f) { sum_score += envsc; Ld_tot += Ld; sb2 += domcorr; }
     if (dp) { dp->env_i[e] = ri; dp->env_j[e] = rj; dp->envsc[e] = envsc; dp->domcorr[e] = domcorr; }
@@ -1273,7 +1316,7 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
           if (dp) { dp->nregions = nreg; dp->nenv = nenv; }
           if (nenv > 0) {
             WH_TICK7(6);
-            score_envelopes<Q, TH, SG>(a, c, seq, regs, L, lane, h, qi, nenv, nreg, multi_mask, fwdsc, nullsc, fwd_bits_out, dp, flags, decibits, ec, t_last);
+            score_envelopes<Q, TH, SG>(a, c, seq, regs, L, lane, h, qi, nenv, nreg, multi_mask, fwdsc, nullsc, fwd_bits_out, dp, flags, decibits, ec, t_last, p1_mask(c));
           }
         }
       }
@@ -1305,7 +1348,7 @@ __global__ __launch_bounds__(TH) void score_kernel7(ScoreArgs a) {
 // Per-wave LDS block: [six per-row arrays][4 x 32 null2 floats][region list][4 x 16 slot ints][4 x 16 record words][4 x residues].
 // a.scratch_stride = FIVE slabs per wave (one of slack in front); a.spec_scratch / a.spec_stride = per wave one array of slack,
 // four copies of the six arrays and one copy of P1's (the windowed P2 works in place on the wave's block): 31 x SP floats.
-enum { QR_QLO = 0, QR_QHI, QR_L, QR_NREG, QR_FLAGS, QR_FWDSC, QR_NULLSC, QR_FWDBITS, QR_ENVSC, QR_RI, QR_RJ, QR_XC3, QR_EF3, QR_INTS = 16 };
+enum { QR_QLO = 0, QR_QHI, QR_L, QR_NREG, QR_FLAGS, QR_FWDSC, QR_NULLSC, QR_FWDBITS, QR_ENVSC, QR_RI, QR_RJ, QR_XC3, QR_EF3, QR_BAND, QR_INTS = 16 };
 template <int Q, int TH>
 __global__ __launch_bounds__(TH) void score_kernel7q(ScoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem_raw[];
@@ -1427,7 +1470,8 @@ __global__ __launch_bounds__(TH) void score_kernel7q(ScoreArgs a) {
               const LenCfg cu = len_config(L, false);
               c.Fs = Fs0 + (size_t)t * slab1;
               const float keep_scale = a.keep_scale > 0.f ? a.keep_scale : kKeepScale7;
-              const FwdOut f3 = sweep_forward<Q, true, TH, false>(c, (lds_u8 *)eseq, Ld, cu, keep_scale);
+              const int band = spill_band<Q>(a, p1_mask(c));
+              const FwdOut f3 = sweep_forward<Q, true, TH, false>(c, (lds_u8 *)eseq, Ld, cu, keep_scale, band);
               ec.spill += (unsigned long long)f3.nst * (8 * Q);
               __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
               const float envsc = (float)((double)f3.ef * LOG2 + log((double)(f3.xC * cu.move)));
@@ -1460,21 +1504,19 @@ __global__ __launch_bounds__(TH) void score_kernel7q(ScoreArgs a) {
                     qr[QR_L] = L; qr[QR_NREG] = nreg; qr[QR_FLAGS] = flags;
                     qr[QR_FWDSC] = __builtin_bit_cast(int, fwdsc); qr[QR_NULLSC] = __builtin_bit_cast(int, nullsc);
                     qr[QR_FWDBITS] = __builtin_bit_cast(int, fwd_bits_out); qr[QR_ENVSC] = __builtin_bit_cast(int, envsc);
-                    qr[QR_RI] = ri; qr[QR_RJ] = rj; qr[QR_XC3] = __builtin_bit_cast(int, f3.xC); qr[QR_EF3] = f3.ef;
+                    qr[QR_RI] = ri; qr[QR_RJ] = rj; qr[QR_XC3] = __builtin_bit_cast(int, f3.xC); qr[QR_EF3] = f3.ef; qr[QR_BAND] = band;
                   }
                   waiting |= 1 << t;
                   deferred = true;
                   WH_TICK7(10);
                 } else {
                   // a wider window or none: this envelope's Backward sweep now, as score_envelopes runs it
-                  P4Out p4 = envelope_backward<Q, TH, false>(a, c, eseq, Ld, cu, f3, false, false, ec, lane);
+                  const bool banded = band != kAllLanes;
+                  const P4Out p4 = envelope_backward<Q, TH, false>(a, c, eseq, Ld, cu, f3, false, false, ec, lane, banded);
                   domcorr = p4.domcorr;
-                  if (!(fabsf((float)Ld - p4.mass) <= kMassTol7 * (float)Ld)) {
-                    const FwdOut f3d = sweep_forward<Q, true, TH, false>(c, (lds_u8 *)eseq, Ld, cu, -1.0f);
-                    ec.spill += (unsigned long long)f3d.nst * (8 * Q);
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                    domcorr = 0.f;
-                    if (f3d.xC > 0.f) { p4 = envelope_backward<Q, TH, false>(a, c, eseq, Ld, cu, f3d, true, false, ec, lane); domcorr = p4.domcorr; flags |= WH_FLAG_EXACT; }
+                  if (!(fabsf((float)Ld - p4.mass) <= spill_tol(banded) * (float)Ld)) {
+                    float envsc2;
+                    domcorr = envelope_attempts<Q, TH, false>(a, c, eseq, Ld, cu, band, banded ? 1 : 2, ec, lane, flags, t_last, envsc2);
                   }
                   done = true;
                 }
@@ -1489,7 +1531,7 @@ __global__ __launch_bounds__(TH) void score_kernel7q(ScoreArgs a) {
               c.Fs = FsW;
             } else if (nenv > 0) {
               WH_TICK7(6);
-              score_envelopes<Q, TH, false>(a, c, seq, regs, L, lane, h, qi, nenv, nreg, multi_mask, fwdsc, nullsc, fwd_bits_out, dp, flags, decibits, ec, t_last);
+              score_envelopes<Q, TH, false>(a, c, seq, regs, L, lane, h, qi, nenv, nreg, multi_mask, fwdsc, nullsc, fwd_bits_out, dp, flags, decibits, ec, t_last, p1_mask(c));
             }
           }
         }
@@ -1540,14 +1582,13 @@ __global__ __launch_bounds__(TH) void score_kernel7q(ScoreArgs a) {
             __builtin_amdgcn_wave_barrier();
             c.Fs = Fs0 + (size_t)t * slab1;
             FwdOut f3; f3.xC = __builtin_bit_cast(float, qr[QR_XC3]); f3.ef = qr[QR_EF3];
-            P4Out p4 = envelope_backward<Q, TH, false>(a, c, eseq, Ld, cu, f3, false, true, ec, lane);
+            const int band = qr[QR_BAND];
+            const bool banded = band != kAllLanes;
+            const P4Out p4 = envelope_backward<Q, TH, false>(a, c, eseq, Ld, cu, f3, false, true, ec, lane, banded);
             domcorr = p4.domcorr;
-            if (!(fabsf((float)Ld - p4.mass) <= kMassTol7 * (float)Ld)) {
-              const FwdOut f3d = sweep_forward<Q, true, TH, false>(c, (lds_u8 *)eseq, Ld, cu, -1.0f);
-              ec.spill += (unsigned long long)f3d.nst * (8 * Q);
-              __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-              domcorr = 0.f;
-              if (f3d.xC > 0.f) { p4 = envelope_backward<Q, TH, false>(a, c, eseq, Ld, cu, f3d, true, false, ec, lane); domcorr = p4.domcorr; flags |= WH_FLAG_EXACT; }
+            if (!(fabsf((float)Ld - p4.mass) <= spill_tol(banded) * (float)Ld)) {
+              float envsc2;
+              domcorr = envelope_attempts<Q, TH, false>(a, c, eseq, Ld, cu, band, banded ? 1 : 2, ec, lane, flags, t_last, envsc2);
             }
             c.Fs = FsW;
           }

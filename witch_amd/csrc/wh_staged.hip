@@ -363,7 +363,8 @@ __global__ __launch_bounds__(kStTH) void staged_p3_kernel(StagedArgs g) {
       c.Fs = (glb_f *)(g.slabs + (size_t)uid * g.slab_stride);
       const float keep_scale = a.keep_scale > 0.f ? a.keep_scale : kKeepScale7;
       ST_T0();
-      const FwdOut f3 = sweep_forward<Q, true, kStTH, false>(c, (lds_u8 *)seq, Ld, cu, keep_scale);
+      const unsigned long long um1 = ((unsigned long long)(unsigned)bcast_i((int)pp->um_hi) << 32) | (unsigned)bcast_i((int)pp->um_lo);
+      const FwdOut f3 = sweep_forward<Q, true, kStTH, false>(c, (lds_u8 *)seq, Ld, cu, keep_scale, spill_band<Q>(a, um1));
       ST_T1(4);
       spill += (unsigned long long)f3.nst * (8 * Q);
       const float envsc = (float)((double)f3.ef * LOG2 + log((double)(f3.xC * cu.move)));
@@ -429,10 +430,12 @@ __global__ __launch_bounds__(kStTH) void staged_p4full_kernel(StagedArgs g) {
       const LenCfg cu = len_config(L, false);
       const float xC = u->xC; const int ef = u->ef;
       ST_T0();
-      const P4Out p4 = sweep_backward_null2<Q, kStTH, false>(c, (lds_u8 *)seq, Ld, cu, 1.0f / (xC * cu.move), ef, kMassTol7);
+      const unsigned long long um1 = ((unsigned long long)(unsigned)bcast_i((int)pp->um_hi) << 32) | (unsigned)bcast_i((int)pp->um_lo);
+      const float tol = spill_tol(spill_band<Q>(a, um1) != kAllLanes);
+      const P4Out p4 = sweep_backward_null2<Q, kStTH, false>(c, (lds_u8 *)seq, Ld, cu, 1.0f / (xC * cu.move), ef, tol);
       ST_T1(7);
       n_full++;
-      const bool ok = fabsf((float)Ld - p4.mass) <= kMassTol7 * (float)Ld;
+      const bool ok = fabsf((float)Ld - p4.mass) <= tol * (float)Ld;
       if (lane == 0) {
         atomicOr(&pp->path, WH_PATH_P4_FULL);
         if (ok) { pp->domcorr[e] = p4.domcorr; pp->cls[e] = ST_CLS_NONE; }
@@ -453,8 +456,7 @@ __global__ __launch_bounds__(kStTH) void staged_dense_kernel(StagedArgs g) {
   StLds<Q> S(smem_raw, a.K, 2 * FW_NARR, wave, nwaves, a.wave_lds);
   WaveCtx c = make_ctx(a, S.em, S.tr, S.tr + FW_NARR * TBL, S.wbase, lane);
   uint8_t *seq = ctx_seq(a, S.wbase);
-  const double LOG2 = 0.69314718055994529;
-  unsigned n_full = 0;
+  EnvCounters ec = {0, 0, 0, 0, 0};
   ST_K0();
   group_loop(g, ST_C_DENSE, S.slot, S.cand, WH_MAX_ENVELOPES,
     [&](int h) {
@@ -481,23 +483,25 @@ __global__ __launch_bounds__(kStTH) void staged_dense_kernel(StagedArgs g) {
       load_seq(a, seq, off + (ri - 1), Ld, lane);
       c.Fs = (glb_f *)(g.slabs + (size_t)uid * g.slab_stride);
       const LenCfg cu = len_config(L, false);
-      const FwdOut f3 = sweep_forward<Q, true, kStTH, false>(c, (lds_u8 *)seq, Ld, cu, -1.0f);
-      if (lane == 0 && a.paths) atomicAdd(a.paths + 6, (unsigned long long)f3.nst * (8 * Q));
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      // the rows were written by other lanes of this wave
-      const float envsc = (float)((double)f3.ef * LOG2 + log((double)(f3.xC * cu.move)));
-      float domcorr = 0.f;
-      if (f3.xC > 0.f) {
-        const P4Out p4 = sweep_backward_null2<Q, kStTH, false>(c, (lds_u8 *)seq, Ld, cu, 1.0f / (f3.xC * cu.move), f3.ef, INFINITY);
-        n_full++;
-        domcorr = p4.domcorr;
-      }
+      // the band of lane blocks failed the certificate: the unbanded store next, then the dense one (envelope_attempts, wh_score7.hip)
+      const unsigned long long um1 = ((unsigned long long)(unsigned)bcast_i((int)pp->um_hi) << 32) | (unsigned)bcast_i((int)pp->um_lo);
+      const int band = spill_band<Q>(a, um1);
+      int flags = 0;
+      long long t_last = 0;
+      float envsc;
+      const float domcorr = envelope_attempts<Q, kStTH, false>(a, c, seq, Ld, cu, band, band != kAllLanes ? 1 : 2, ec, lane, flags, t_last, envsc);
       if (lane == 0) {
         pp->envsc[e] = envsc; pp->domcorr[e] = domcorr; pp->cls[e] = ST_CLS_NONE;
-        atomicOr(&pp->flags, WH_FLAG_EXACT);
-        atomicOr(&pp->path, WH_PATH_DENSE);
+        if (flags & WH_FLAG_EXACT) { atomicOr(&pp->flags, WH_FLAG_EXACT); atomicOr(&pp->path, WH_PATH_DENSE); }
       }
     });
-  if (a.paths && lane == 0 && n_full) atomicAdd(a.paths + 3, (unsigned long long)n_full);
+  if (a.paths && lane == 0) {
+    if (ec.n_w256) atomicAdd(a.paths + 0, (unsigned long long)ec.n_w256);
+    if (ec.n_w512) atomicAdd(a.paths + 1, (unsigned long long)ec.n_w512);
+    if (ec.n_wfail) atomicAdd(a.paths + 2, (unsigned long long)ec.n_wfail);
+    if (ec.n_full) atomicAdd(a.paths + 3, (unsigned long long)ec.n_full);
+    if (ec.spill) atomicAdd(a.paths + 6, ec.spill);
+  }
   ST_K1(8);
 }
 
@@ -553,7 +557,8 @@ __global__ __launch_bounds__(kStTH) void staged_env_kernel(StagedArgs g) {
         __builtin_amdgcn_wave_barrier();
         long long t_last = 0;
         ST_T0();
-        score_envelopes<Q, kStTH, false>(a, c, seq, regs, L, lane, h, qi, nenv, nreg, multi_mask, fwdsc, nullsc, fwd_bits_out, dp, flags, decibits, ec, t_last);
+        const unsigned long long um1 = ((unsigned long long)(unsigned)bcast_i((int)pp->um_hi) << 32) | (unsigned)bcast_i((int)pp->um_lo);
+        score_envelopes<Q, kStTH, false>(a, c, seq, regs, L, lane, h, qi, nenv, nreg, multi_mask, fwdsc, nullsc, fwd_bits_out, dp, flags, decibits, ec, t_last, um1);
         ST_T1(4);
         if (multi_mask != 0 && a.rrecs != nullptr) path |= WH_PATH_MULTI;
       }

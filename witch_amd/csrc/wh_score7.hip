@@ -965,8 +965,9 @@ struct EnvCounters { unsigned n_w256, n_w512, n_wfail, n_full; unsigned long lon
 // spill certificate |Ld - mass| <= spill_tol Ld on the result of a sparse sweep.
 template <int Q, int TH, bool SG>
 __device__ __forceinline__ P4Out envelope_backward(const ScoreArgs &a, const WaveCtx &c, const uint8_t *eseq, int Ld, LenCfg cu, const FwdOut &f3,
-                                                   bool dense, bool skip_window, EnvCounters &ec, int lane, bool banded) {
+                                                   bool dense, bool skip_window, EnvCounters &ec, int lane, int band) {
   const int SP = c.SP;
+  const bool banded = band != (63 << 8);
   const float tol = dense ? INFINITY : spill_tol(banded);
   P4Out p4;
   bool have4 = false;
@@ -975,7 +976,12 @@ __device__ __forceinline__ P4Out envelope_backward(const ScoreArgs &a, const Wav
       // the node window around the lane blocks the dominant alignment runs through (two blocks in
       // front: the envelope's first ~25 rows set no bit and lie that many nodes ahead; one block behind)
       const unsigned *su = reinterpret_cast<const unsigned *>(SG ? (const float *)c.specg : (const float *)c.spec);
-      const unsigned long long um = ((unsigned long long)su[kSpMH * SP] << 32) | su[kSpML * SP];
+      unsigned long long um = ((unsigned long long)su[kSpMH * SP] << 32) | su[kSpML * SP];
+      if (banded && (a.spill_band & 4)) {       // EXPERIMENT: nothing outside the band was stored, so the window need not reach a chance block there
+        const int blo = band & 255, bhi = (band >> 8) & 255;
+        const unsigned long long bm = (bhi >= 63 ? ~0ull : ((1ull << (bhi + 1)) - 1)) & ~((1ull << blo) - 1);
+        if (um & bm) um &= bm;
+      }
       if (um != 0) {
         int lo = __builtin_ctzll(um), hi = 63 - __builtin_clzll(um);
         lo = lo > 1 ? lo - 2 : 0; hi = hi < 63 ? hi + 1 : 63;
@@ -1050,10 +1056,10 @@ template <int Q>
 __device__ __forceinline__ int spill_band(const ScoreArgs &a, unsigned long long um1) {
   if (Q < 8 || um1 == 0 || !a.spill_band) return kAllLanes;
   int below = (80 + Q - 1) / Q, above = (48 + Q - 1) / Q;
-  if (a.spill_band > 2) { below = (a.spill_band / 1000 + Q - 1) / Q; above = (a.spill_band % 1000 + Q - 1) / Q; }   // (development: margins in nodes, below * 1000 + above)
+  if (a.spill_band >= 1000) { below = (a.spill_band / 1000 + Q - 1) / Q; above = (a.spill_band % 1000 + Q - 1) / Q; }   // (development: margins in nodes, below * 1000 + above)
   const int lo = __builtin_ctzll(um1) - below, hi = 63 - __builtin_clzll(um1) + above;
   int band = (lo > 0 ? lo : 0) | ((hi < 63 ? hi : 63) << 8);
-  if (a.spill_band == 2) band |= (__builtin_ctzll(um1) + 1 + (48 + Q - 1) / Q + 1) << 16;      // EXPERIMENT: rising cap
+  if (a.spill_band < 1000 && (a.spill_band & 2)) band |= (__builtin_ctzll(um1) + 1 + (48 + Q - 1) / Q + 1) << 16;      // EXPERIMENT: rising cap
   return band;
 }
 __device__ __forceinline__ unsigned long long p1_mask(const WaveCtx &c) {
@@ -1083,7 +1089,7 @@ __device__ __forceinline__ float envelope_attempts(const ScoreArgs &a, WaveCtx &
     domcorr = 0.f;
     if (!(f3.xC > 0.f)) break;
     WH_TICK7(7);
-    const P4Out p4 = envelope_backward<Q, TH, SG>(a, c, eseq, Ld, cu, f3, attempt == 2, false, ec, lane, attempt == 0);
+    const P4Out p4 = envelope_backward<Q, TH, SG>(a, c, eseq, Ld, cu, f3, attempt == 2, false, ec, lane, attempt == 0 ? band : kAllLanes);
     domcorr = p4.domcorr;
     WH_TICK7(8);
     if (attempt < 2 && !(fabsf((float)Ld - p4.mass) <= spill_tol(attempt == 0) * (float)Ld)) continue;
@@ -1512,7 +1518,7 @@ __global__ __launch_bounds__(TH) void score_kernel7q(ScoreArgs a) {
                 } else {
                   // a wider window or none: this envelope's Backward sweep now, as score_envelopes runs it
                   const bool banded = band != kAllLanes;
-                  const P4Out p4 = envelope_backward<Q, TH, false>(a, c, eseq, Ld, cu, f3, false, false, ec, lane, banded);
+                  const P4Out p4 = envelope_backward<Q, TH, false>(a, c, eseq, Ld, cu, f3, false, false, ec, lane, band);
                   domcorr = p4.domcorr;
                   if (!(fabsf((float)Ld - p4.mass) <= spill_tol(banded) * (float)Ld)) {
                     float envsc2;
@@ -1584,7 +1590,7 @@ __global__ __launch_bounds__(TH) void score_kernel7q(ScoreArgs a) {
             FwdOut f3; f3.xC = __builtin_bit_cast(float, qr[QR_XC3]); f3.ef = qr[QR_EF3];
             const int band = qr[QR_BAND];
             const bool banded = band != kAllLanes;
-            const P4Out p4 = envelope_backward<Q, TH, false>(a, c, eseq, Ld, cu, f3, false, true, ec, lane, banded);
+            const P4Out p4 = envelope_backward<Q, TH, false>(a, c, eseq, Ld, cu, f3, false, true, ec, lane, band);
             domcorr = p4.domcorr;
             if (!(fabsf((float)Ld - p4.mass) <= spill_tol(banded) * (float)Ld)) {
               float envsc2;

@@ -26,6 +26,17 @@ __device__ __forceinline__ float dppf(float old, float src) {
 // 16-byte streaming accesses that bypass the vector L1 (data written by one lane is re-read
 // by another lane of the same wave later; it has no reuse in L1)
 typedef float v4f_t __attribute__((ext_vector_type(4)));
+// Layout of a stored Forward row (in float4 pieces; a row is 2 * Q/4 * 64 of them): the pieces of ONE lane block - its M
+// cells, then its I cells - are contiguous (128 B at 16 cells per lane).  The rows are stored sparsely - one to three
+// adjacent lane blocks of a row after its first ~25 - and piece-major rows (piece q of every lane side by side, a 1 KB
+// store per instruction when all 64 lanes store) put the 8 pieces of a block into 8 different 128-B lines: the memory
+// system moved 9.2 TB per headline step for 2.7 TB stored (profiles/r05_v3_traffic.json).
+// The price: a row stored by MANY lanes takes one 128-B line per lane and instruction (the headline with every envelope's
+// first rows at full width - WH_SPILL_BAND=0 - runs 2.1 x slower than with piece-major rows), so this layout needs the band
+// of lane blocks (spill_band, wh_score7.hip); models of fewer than 8 cells per lane have no band and keep piece-major rows.
+// 8 192 x 200 headline pairs: 397 -> 373 ms; SURVEY's family sketch 295 -> 283 ms; protein slice 893 -> 875 ms.
+template <int Q>
+__device__ __forceinline__ constexpr int fs_piece(int lane, int q4) { return Q >= 8 ? lane * (2 * (Q / 4)) + q4 : q4 * kWave + lane; }
 __device__ __forceinline__ float4 nt_load4(const float4 *p) {
   v4f_t v = __builtin_nontemporal_load(reinterpret_cast<const v4f_t *>(p));
   return make_float4(v.x, v.y, v.z, v.w);
@@ -340,7 +351,9 @@ __device__ __forceinline__ void region_scan_global(float *spec, int SP, int L, i
 // mask words instead (SP_B <- low word, SP_E <- high word) and a wave's block needs six arrays, not eight.
 // UM (without STORE): the dominant-path mask alone - the union over every EIGHTH row of the lane blocks that hold a cell
 // above E(row)/2 - written to um_out[0..1]; the multihit sweep uses it to place the node window of its Backward sweep.
-template <int Q, bool TREG, bool STORE, bool USEP = false, bool SLIM = false, bool UM = false, bool COUNT = false>
+// BLK (with STORE): the stored rows keep a lane block's pieces contiguous (fs_piece, above: the scoring kernels); without it
+// piece-major rows (the alignment kernels, whose passes read and rewrite whole rows).
+template <int Q, bool TREG, bool STORE, bool USEP = false, bool SLIM = false, bool UM = false, bool COUNT = false, bool BLK = false>
 __device__ __forceinline__ void forward_sweep(const TransTab<Q, TREG> &T, const ScanC &sc, const float *emL,
                                               const float *emG, int K, const uint8_t *seq, int L, LenCfg cfg,
                                               float *spec, int SP, float *Fs, float keep_scale, int lane,
@@ -453,11 +466,7 @@ __device__ __forceinline__ void forward_sweep(const TransTab<Q, TREG> &T, const 
       umask |= dom;
       // keep_lanes: the band of lane blocks the caller thinks worth storing (lowest | highest << 8; the mass certificate of the
       // Backward sweep judges the choice like it judges keep_scale)
-      // (bits 16..: a cap on the highest block that rises with the row - lane block <cap0 + i / Q> - for the first rows, where the
-      // keep rule holds nothing back: the alignment cannot be further up the model than its start plus the rows walked)
-      const int blo = keep_lanes & 255;
-      int bhi = (keep_lanes >> 8) & 255;
-      if (keep_lanes >> 16) bhi = min(bhi, (keep_lanes >> 16) - 1 + i / Q);
+      const int blo = keep_lanes & 255, bhi = keep_lanes >> 8;
       const bool keep = keep_scale < 0.f || (lmax > keep_scale * xE && lane >= blo && lane <= bhi);
       const unsigned long long mask = __ballot(keep);
       if (COUNT) nstored += __builtin_popcountll(mask);
@@ -466,12 +475,12 @@ __device__ __forceinline__ void forward_sweep(const TransTab<Q, TREG> &T, const 
         reinterpret_cast<unsigned *>(spec)[MH * SP + i] = (unsigned)(mask >> 32);
       }
       if (keep) {
-        float4 *row = reinterpret_cast<float4 *>(Fs) + (size_t)i * (2 * (Q / 4) * kWave) + lane;
+        float4 *row = reinterpret_cast<float4 *>(Fs) + (size_t)i * (2 * (Q / 4) * kWave);
 #pragma unroll
         for (int q4 = 0; q4 < Q / 4; q4++) {
           // streamed once and re-read once by another lane of this wave: keep it out of L1
-          nt_store4(row + q4 * kWave, Mp[4 * q4], Mp[4 * q4 + 1], Mp[4 * q4 + 2], Mp[4 * q4 + 3]);
-          nt_store4(row + (Q / 4 + q4) * kWave, Ip[4 * q4], Ip[4 * q4 + 1], Ip[4 * q4 + 2], Ip[4 * q4 + 3]);
+          nt_store4(row + (BLK ? fs_piece<Q>(lane, q4) : q4 * kWave + lane), Mp[4 * q4], Mp[4 * q4 + 1], Mp[4 * q4 + 2], Mp[4 * q4 + 3]);
+          nt_store4(row + (BLK ? fs_piece<Q>(lane, Q / 4 + q4) : (Q / 4 + q4) * kWave + lane), Ip[4 * q4], Ip[4 * q4 + 1], Ip[4 * q4 + 2], Ip[4 * q4 + 3]);
         }
       }
     }

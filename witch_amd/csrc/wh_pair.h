@@ -194,11 +194,11 @@ __device__ __forceinline__ void forward_sweep2(const TransTab<Q, false> &T, cons
             reinterpret_cast<unsigned *>(spec)[SP_E * SP + i] = (unsigned)(mask >> 32);
           }
           if (keep) {
-            float4 *row = reinterpret_cast<float4 *>(pq[n].Fs) + (size_t)i * (2 * (Q / 4) * kWave) + lane;
+            float4 *row = reinterpret_cast<float4 *>(pq[n].Fs) + (size_t)i * (2 * (Q / 4) * kWave);
 #pragma unroll
             for (int q4 = 0; q4 < Q / 4; q4++) {
-              nt_store4(row + q4 * kWave, Mp[n][4 * q4], Mp[n][4 * q4 + 1], Mp[n][4 * q4 + 2], Mp[n][4 * q4 + 3]);
-              nt_store4(row + (Q / 4 + q4) * kWave, Ip[n][4 * q4], Ip[n][4 * q4 + 1], Ip[n][4 * q4 + 2], Ip[n][4 * q4 + 3]);
+              nt_store4(row + fs_piece<Q>(lane, q4), Mp[n][4 * q4], Mp[n][4 * q4 + 1], Mp[n][4 * q4 + 2], Mp[n][4 * q4 + 3]);
+              nt_store4(row + fs_piece<Q>(lane, Q / 4 + q4), Ip[n][4 * q4], Ip[n][4 * q4 + 1], Ip[n][4 * q4 + 2], Ip[n][4 * q4 + 3]);
             }
           }
         }

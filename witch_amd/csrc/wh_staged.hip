@@ -364,7 +364,8 @@ __global__ __launch_bounds__(kStTH) void staged_p3_kernel(StagedArgs g) {
       const float keep_scale = a.keep_scale > 0.f ? a.keep_scale : kKeepScale7;
       ST_T0();
       const unsigned long long um1 = ((unsigned long long)(unsigned)bcast_i((int)pp->um_hi) << 32) | (unsigned)bcast_i((int)pp->um_lo);
-      const FwdOut f3 = sweep_forward<Q, true, kStTH, false>(c, (lds_u8 *)seq, Ld, cu, keep_scale, spill_band<Q>(a, um1));
+      const int band = spill_band<Q>(a, um1);
+      const FwdOut f3 = sweep_forward<Q, true, kStTH, false>(c, (lds_u8 *)seq, Ld, cu, keep_scale, band);
       ST_T1(4);
       spill += (unsigned long long)f3.nst * (8 * Q);
       const float envsc = (float)((double)f3.ef * LOG2 + log((double)(f3.xC * cu.move)));
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(kStTH) void staged_p3_kernel(StagedArgs g) {
         cls = ST_CLS_FULL;
         if (Q >= 8 && !a.no_window) {
           const unsigned *su = reinterpret_cast<const unsigned *>(spec);
-          const unsigned long long um = ((unsigned long long)su[kSpMH * SP] << 32) | su[kSpML * SP];
+          const unsigned long long um = mask_in_band(((unsigned long long)su[kSpMH * SP] << 32) | su[kSpML * SP], band);
           const int w = place_window<Q>(um, m0);
           if (w == 4) cls = ST_CLS_W256; else if (w == 8) cls = ST_CLS_W512;
         }

@@ -363,6 +363,7 @@ __device__ __forceinline__ void forward_sweep(const TransTab<Q, TREG> &T, const 
   for (int q = 0; q < Q; q++) { Mp[q] = 0.f; Ip[q] = 0.f; Dp[q] = 0.f; }
   float xN = 1.0f, xB = cfg.move, xJ = 0.f, xC = 0.f, xE = 0.f;
   int ef = 0;
+  unsigned long long um_prev = 0, um_steady = 0;
   int nstored = 0;                   // COUNT: lane blocks stored over all rows (scalar: one s_bcnt1 + s_add per row)
   unsigned long long umask = 0;      // STORE: union over the rows of the lane block that holds a cell above E(row)/2: where the
                                      // envelope's dominant alignment runs.  The first rows set no bit: it takes ~25 nucleotides
@@ -452,7 +453,13 @@ __device__ __forceinline__ void forward_sweep(const TransTab<Q, TREG> &T, const 
         float lmax = 0.f;
 #pragma unroll
         for (int q = 0; q < Q; q += 2) lmax = fmaxf(lmax, fmaxf(fmaxf(Mp[q], Mp[q + 1]), fmaxf(Ip[q], Ip[q + 1])));
-        umask |= __ballot(lmax > 0.5f * xE);
+        const unsigned long long dom = __ballot(lmax > 0.5f * xE);
+        umask |= dom;
+        // ... and the same union over the blocks whose dominance CARRIED OVER from the last sampled row (the same block or the
+        // next one up): a chance diagonal that rivals the alignment on its first rows does not last eight rows
+        const unsigned long long link = dom & (um_prev | (um_prev << 1));
+        if (link) um_steady |= link | (um_prev & (link | (link >> 1)));
+        um_prev = dom;
       }
     }
     if (STORE) {
@@ -466,7 +473,11 @@ __device__ __forceinline__ void forward_sweep(const TransTab<Q, TREG> &T, const 
       umask |= dom;
       // keep_lanes: the band of lane blocks the caller thinks worth storing (lowest | highest << 8; the mass certificate of the
       // Backward sweep judges the choice like it judges keep_scale)
-      const int blo = keep_lanes & 255, bhi = keep_lanes >> 8;
+      // (bits 16..: a cap on the highest block that rises with the row - block <cap - 1 + i / Q>: the alignment cannot be
+      // further up the model than its start plus the rows walked.  It thins the FIRST rows, where the keep rule holds nothing back)
+      const int blo = keep_lanes & 255;
+      int bhi = (keep_lanes >> 8) & 255;
+      if (keep_lanes >> 16) bhi = min(bhi, (keep_lanes >> 16) - 1 + i / Q);
       const bool keep = keep_scale < 0.f || (lmax > keep_scale * xE && lane >= blo && lane <= bhi);
       const unsigned long long mask = __ballot(keep);
       if (COUNT) nstored += __builtin_popcountll(mask);
@@ -490,7 +501,11 @@ __device__ __forceinline__ void forward_sweep(const TransTab<Q, TREG> &T, const 
     reinterpret_cast<unsigned *>(spec)[(SLIM ? SP_B : SP_ML) * SP] = (unsigned)(umask & 0xFFFFFFFFull);
     reinterpret_cast<unsigned *>(spec)[(SLIM ? SP_E : SP_MH) * SP] = (unsigned)(umask >> 32);
   }
-  if (UM && !STORE && lane == 0) { um_out[0] = (unsigned)(umask & 0xFFFFFFFFull); um_out[1] = (unsigned)(umask >> 32); }
+  if (UM && !STORE && lane == 0) {
+    um_out[0] = (unsigned)(umask & 0xFFFFFFFFull); um_out[1] = (unsigned)(umask >> 32);
+    // (one word in front: lowest | highest << 8 | 1 << 16 of the steady blocks, 0 when there are none)
+    um_out[-1] = um_steady ? (unsigned)(__builtin_ctzll(um_steady) | ((63 - __builtin_clzll(um_steady)) << 8) | (1 << 16)) : 0u;
+  }
   if (COUNT && nstored_out) *nstored_out = nstored;
   xC_out = xC;
   ef_out = ef;

@@ -74,6 +74,7 @@ enum { ST_CLS_NONE = 0, ST_CLS_FULL = 1, ST_CLS_DENSE = 2, ST_CLS_W256 = 4, ST_C
 struct StPair {
   float xC; int32_t ef;              // P1: C(L) and its scale exponent (the multihit Forward score)
   uint32_t um_lo, um_hi;             // P1: lane blocks the dominant alignment runs through (places the window of P2)
+  uint32_t um_steady;                // P1: range of the steady blocks among them (the envelopes' band; forward_sweep, wh_device.h)
   int32_t state;                     // 0 nothing to do (empty / too long / no Forward mass: result written by P1), 1 P1 done,
                                      // 2 regions known, 3 the windowed region scan was in doubt (full-width P2 follows),
                                      // 4 the window of P2 needs 512 nodes

@@ -1057,17 +1057,28 @@ __device__ __forceinline__ void assemble_score(int L, int Ld_tot, float seqbias_
 // redos) and may run on past the highest (48 nodes).  A band that cuts posterior mass fails the spill certificate like a
 // keep_scale that is too coarse does, and the envelope is redone with every row stored at full width.
 constexpr int kAllLanes = 63 << 8;
+struct P1Mask { unsigned long long um; unsigned steady; };      // the union mask; lowest | highest << 8 | 1 << 16 of the steady blocks (0: none)
 template <int Q>
-__device__ __forceinline__ int spill_band(const ScoreArgs &a, unsigned long long um1) {
+__device__ __forceinline__ int spill_band(const ScoreArgs &a, P1Mask pm) {
+  unsigned long long um1 = pm.um;
+  // the band goes around the STEADY blocks of P1's mask (forward_sweep: dominance that carried over between two sampled rows -
+  // a chance diagonal of the first rows does not), around the plain union when there are none
+  const bool steady = pm.steady && !(a.spill_band & 2);      // (WH_SPILL_BAND=3: the band around the plain union, no cap)
+  if (steady) um1 = (1ull << (pm.steady & 255)) | (1ull << ((pm.steady >> 8) & 255));
   if (Q < 8 || um1 == 0 || !a.spill_band) return kAllLanes;
   int below = (80 + Q - 1) / Q, above = (48 + Q - 1) / Q;
   if (a.spill_band >= 1000) { below = (a.spill_band / 1000 + Q - 1) / Q; above = (a.spill_band % 1000 + Q - 1) / Q; }   // (development: margins in nodes, below * 1000 + above)
   const int lo = __builtin_ctzll(um1) - below, hi = 63 - __builtin_clzll(um1) + above;
-  return (lo > 0 ? lo : 0) | ((hi < 63 ? hi : 63) << 8);
+  int band = (lo > 0 ? lo : 0) | ((hi < 63 ? hi : 63) << 8);
+  // the cap that rises with the row (forward_sweep): the steady blocks begin where the alignment is ~25 rows old, so on row i
+  // it cannot be above block <lowest + i / Q> by more than the deletions it holds: 32 nodes of slack (32 / 48 / 64 / 80: 366 / 367 /
+  // 368 / 368 ms, without the cap 371; rejected windows 3 700 - 3 400 of 1.6 million)
+  if (steady && !(a.spill_band & 4)) band |= (__builtin_ctzll(um1) + 1 + (32 + Q - 1) / Q) << 16;      // (WH_SPILL_BAND=5: no cap)
+  return band;
 }
-__device__ __forceinline__ unsigned long long p1_mask(const WaveCtx &c) {
+__device__ __forceinline__ P1Mask p1_mask(const WaveCtx &c) {
   const unsigned *su = reinterpret_cast<const unsigned *>((const float *)c.n2tab) + kUmSlot;
-  return ((unsigned long long)su[1] << 32) | su[0];
+  return P1Mask{((unsigned long long)su[1] << 32) | su[0], su[-1]};
 }
 // One envelope: Forward sweep (rows stored for the Backward sweep) -> Backward sweep + null2, by up to three attempts at
 // what is stored.  0: the lane blocks of <band> that pass the keep rule, certificate at the noise band (a band cuts mass on
@@ -1105,8 +1116,8 @@ __device__ __forceinline__ float envelope_attempts(const ScoreArgs &a, WaveCtx &
 template <int Q, int TH, bool SG>
 __device__ __forceinline__ void score_envelopes(const ScoreArgs &a, WaveCtx &c, uint8_t *seq, int *regs, int L, int lane, int h, int64_t qi, int nenv, int nreg,
                                                 int multi_mask, float fwdsc, float nullsc, float fwd_bits_out, wh_pair_detail *dp, int &flags, int &decibits,
-                                                EnvCounters &ec, long long &t_last, unsigned long long um1) {
-  const int band = spill_band<Q>(a, SG ? 0ull : um1);      // (long queries: P1 keeps no mask; the band gained nothing there, 2.5 % of the bytes on the protein slice)
+                                                EnvCounters &ec, long long &t_last, P1Mask um1) {
+  const int band = spill_band<Q>(a, SG ? P1Mask{0ull, 0u} : um1);      // (long queries: P1 keeps no mask; the band gained nothing there, 2.5 % of the bytes on the protein slice)
   {
   // ---------------- envelopes
   const LenCfg cu = len_config(L, false);

@@ -258,7 +258,7 @@ __global__ __launch_bounds__(kStTH) void staged_p1_kernel(StagedArgs g) {
           if (lane == 0) {
             const unsigned *su = reinterpret_cast<const unsigned *>((const float *)c.n2tab) + kUmSlot;
             pp->xC = f1.xC; pp->ef = f1.ef;
-            pp->um_lo = Q >= 8 ? su[0] : 0u; pp->um_hi = Q >= 8 ? su[1] : 0u;
+            pp->um_lo = Q >= 8 ? su[0] : 0u; pp->um_hi = Q >= 8 ? su[1] : 0u; pp->um_steady = Q >= 8 ? su[-1] : 0u;
           }
         }
       }
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(kStTH) void staged_p3_kernel(StagedArgs g) {
       c.Fs = (glb_f *)(g.slabs + (size_t)uid * g.slab_stride);
       const float keep_scale = a.keep_scale > 0.f ? a.keep_scale : kKeepScale7;
       ST_T0();
-      const unsigned long long um1 = ((unsigned long long)(unsigned)bcast_i((int)pp->um_hi) << 32) | (unsigned)bcast_i((int)pp->um_lo);
+      const P1Mask um1 = {((unsigned long long)(unsigned)bcast_i((int)pp->um_hi) << 32) | (unsigned)bcast_i((int)pp->um_lo), (unsigned)bcast_i((int)pp->um_steady)};
       const int band = spill_band<Q>(a, um1);
       const FwdOut f3 = sweep_forward<Q, true, kStTH, false>(c, (lds_u8 *)seq, Ld, cu, keep_scale, band);
       ST_T1(4);
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(kStTH) void staged_p4full_kernel(StagedArgs g) {
       const LenCfg cu = len_config(L, false);
       const float xC = u->xC; const int ef = u->ef;
       ST_T0();
-      const unsigned long long um1 = ((unsigned long long)(unsigned)bcast_i((int)pp->um_hi) << 32) | (unsigned)bcast_i((int)pp->um_lo);
+      const P1Mask um1 = {((unsigned long long)(unsigned)bcast_i((int)pp->um_hi) << 32) | (unsigned)bcast_i((int)pp->um_lo), (unsigned)bcast_i((int)pp->um_steady)};
       const float tol = spill_tol(spill_band<Q>(a, um1) != kAllLanes);
       const P4Out p4 = sweep_backward_null2<Q, kStTH, false>(c, (lds_u8 *)seq, Ld, cu, 1.0f / (xC * cu.move), ef, tol);
       ST_T1(7);
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(kStTH) void staged_dense_kernel(StagedArgs g) {
       c.Fs = (glb_f *)(g.slabs + (size_t)uid * g.slab_stride);
       const LenCfg cu = len_config(L, false);
       // the band of lane blocks failed the certificate: the unbanded store next, then the dense one (envelope_attempts, wh_score7.hip)
-      const unsigned long long um1 = ((unsigned long long)(unsigned)bcast_i((int)pp->um_hi) << 32) | (unsigned)bcast_i((int)pp->um_lo);
+      const P1Mask um1 = {((unsigned long long)(unsigned)bcast_i((int)pp->um_hi) << 32) | (unsigned)bcast_i((int)pp->um_lo), (unsigned)bcast_i((int)pp->um_steady)};
       const int band = spill_band<Q>(a, um1);
       int flags = 0;
       long long t_last = 0;
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(kStTH) void staged_env_kernel(StagedArgs g) {
         __builtin_amdgcn_wave_barrier();
         long long t_last = 0;
         ST_T0();
-        const unsigned long long um1 = ((unsigned long long)(unsigned)bcast_i((int)pp->um_hi) << 32) | (unsigned)bcast_i((int)pp->um_lo);
+        const P1Mask um1 = {((unsigned long long)(unsigned)bcast_i((int)pp->um_hi) << 32) | (unsigned)bcast_i((int)pp->um_lo), (unsigned)bcast_i((int)pp->um_steady)};
         score_envelopes<Q, kStTH, false>(a, c, seq, regs, L, lane, h, qi, nenv, nreg, multi_mask, fwdsc, nullsc, fwd_bits_out, dp, flags, decibits, ec, t_last, um1);
         ST_T1(4);
         if (multi_mask != 0 && a.rrecs != nullptr) path |= WH_PATH_MULTI;

@@ -452,7 +452,7 @@ __device__ __forceinline__ void forward_sweep(const TransTab<Q, TREG> &T, const 
       if ((i & 7) == 0) {
         float lmax = 0.f;
 #pragma unroll
-        for (int q = 0; q < Q; q += 2) lmax = fmaxf(lmax, fmaxf(fmaxf(Mp[q], Mp[q + 1]), fmaxf(Ip[q], Ip[q + 1])));
+        for (int q = 0; q < Q; q += 2) lmax = fmaxf(fmaxf(fmaxf(fmaxf(lmax, Mp[q]), Mp[q + 1]), Ip[q]), Ip[q + 1]);      // (two v_max3 per four cells)
         const unsigned long long dom = __ballot(lmax > 0.5f * xE);
         umask |= dom;
         // ... and the same union over the blocks whose dominance CARRIED OVER from the last sampled row (the same block or the
@@ -466,7 +466,7 @@ __device__ __forceinline__ void forward_sweep(const TransTab<Q, TREG> &T, const 
       constexpr int ML = SLIM ? SP_B : SP_ML, MH = SLIM ? SP_E : SP_MH;
       float lmax = 0.f;
 #pragma unroll
-      for (int q = 0; q < Q; q += 2) lmax = fmaxf(lmax, fmaxf(fmaxf(Mp[q], Mp[q + 1]), fmaxf(Ip[q], Ip[q + 1])));
+      for (int q = 0; q < Q; q += 2) lmax = fmaxf(fmaxf(fmaxf(fmaxf(lmax, Mp[q]), Mp[q + 1]), Ip[q]), Ip[q + 1]);      // (two v_max3 per four cells)
       // (keep_scale < 0 must store EVERY row: a row that has underflowed to zero everywhere gives 0 > -0 = false, and the
       // full-width alignment passes, which read rows without looking at the masks, then saw the previous pair's cells)
       const unsigned long long dom = __ballot(lmax > 0.5f * xE);

@@ -55,9 +55,17 @@ extern "C" {
 #define WH_FLAG_REPORTED  1   /* pair appears in hmmsearch's per-sequence table          */
 #define WH_FLAG_MULTI     2   /* a region was multidomain (HMMER's stochastic class)     */
 #define WH_FLAG_OVERRIDE  4   /* reconstruction score overrode the Forward score         */
-#define WH_FLAG_TRUNC     8   /* more envelopes than WH_MAX_ENVELOPES; extra ones dropped */
+#define WH_FLAG_TRUNC     8   /* a list of the pair overflowed and part of it was dropped: see below       */
 #define WH_FLAG_EXACT    16   /* an envelope failed the sparse-spill certificate and was redone dense */
 
+/* Envelopes a wh_pair_detail record LISTS.  The SCORE of a pair has no such limit (hmmsearch has none: SURVEY A.4, called at
+ * witch_msa/gcmm/algorithm.py:526-532): a pair with more regions than the scoring kernels' list holds is scored a second
+ * time inside the same call by the long-list pass (float64 front end with the region list in HBM + a resolver launch of
+ * its own; wh_last_score_counters out8[7] counts such pairs), every region and every envelope enters its score, and it
+ * comes back WITHOUT WH_FLAG_TRUNC; its detail record lists the first WH_MAX_ENVELOPES envelopes, nregions is the full
+ * count.  What can still set WH_FLAG_TRUNC: more than 16 significant clusters inside ONE multidomain region, more sampled
+ * segments in one region than the resolver's segment arrays hold, more than four million overflowing pairs in one call,
+ * or the development knobs WH_NO_LONG_LIST / WH_NO_RESOLVE. */
 #define WH_MAX_ENVELOPES 16
 
 /* Which code path a pair took through the scoring kernels (optional per-pair byte, wh_set_path_buffer; written by
@@ -140,10 +148,11 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
 
 /* Outcome classes of the last wh_align / wh_align_dev call on this handle (the call itself returns WH_OK for
  * them): n_logspace = pairs that left the float range and were redone in log space (same columns as hmmalign's
- * own log-space fallback); n_unaligned = pairs on models of more than 3072 nodes whose Forward and Backward
- * scores disagree even in log space: their columns are ALL -1, where hmmalign (aligner.py:96-142) would have
- * produced an alignment.  Their pair numbers (positions in pair_q / pair_h) are copied to unaligned_pairs[0..cap).
- * Callers must not feed such pairs into wh_consensus as if they were all-insertion alignments. */
+ * own log-space fallback); n_unaligned = pairs returned with ALL columns -1 where hmmalign (aligner.py:96-142) would
+ * have produced an alignment: always 0 since round 5 (a pair on a model of more than 3072 nodes whose log-space Forward
+ * and Backward scores disagree used to be dropped; it is now aligned from the Forward-normalised posteriors, as hmmalign
+ * does, counted in n_logspace and noted on stderr).  The argument stays for binary compatibility; unaligned_pairs is
+ * not written. */
 int wh_last_align_status(wh_ehmm *e, int64_t *n_logspace, int64_t *n_unaligned, int64_t *unaligned_pairs, int64_t cap);
 
 /* Which sweeps the register-kernel pairs (models of up to 3072 nodes) of the last wh_align / wh_align_dev call went
@@ -168,7 +177,8 @@ int wh_last_score_paths(wh_ehmm *e, int64_t *paths6);
  * their slabs (lane blocks kept by the sparse spill x 8 bytes per cell: what the kernels ASKED the memory system to write,
  * counted on the device with one scalar add per row; the Backward sweeps read about three quarters of it back).  bench.py
  * reports it live beside the HBM-level traffic of the stamped profile: a regression of the spill shows in the driver's own
- * line.  out8[7] is reserved (0).  One-wavefront-per-pair kernels only. */
+ * line (one-wavefront-per-pair kernels only).  out8[7] = pairs of the last call that went through the long-list pass
+ * (more regions than WH_MAX_ENVELOPES; see there). */
 int wh_last_score_counters(wh_ehmm *e, int64_t *out8);
 
 /* Optional per-PAIR record of the same: a device array of nq x H bytes that the scoring calls made after this one fill

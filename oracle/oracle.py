@@ -23,7 +23,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 FLAG_REPORTED, FLAG_MULTI, FLAG_OVERRIDE = 1, 2, 4
-MAXENV = 16
+MAXENV = 256
 
 
 class OrcResult(C.Structure):

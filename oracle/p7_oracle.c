@@ -543,7 +543,7 @@ static float flogsum(float a, float b)
 /* ----------------------------------------------------------------------------
  * Results
  * -------------------------------------------------------------------------- */
-#define ORC_MAXENV 16
+#define ORC_MAXENV 256   /* (HMMER has no limit; 256 is beyond any test) */
 typedef struct {
   int    flags;
   int    nregions, nenv;

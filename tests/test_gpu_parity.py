@@ -930,8 +930,8 @@ def test_multihit_backward_on_a_node_window_gives_the_full_width_regions(tmp_pat
 
 
 def test_queries_with_more_than_eight_regions_lose_none(orc, tmp_path):
-    """HMMER has no limit on the domains of a sequence; this library keeps up to 16 regions per pair (as does the oracle)
-    and flags what it drops (WH_FLAG_TRUNC).  Queries of ten to fourteen copies of a family fragment, random sequence
+    """HMMER has no limit on the domains of a sequence; the scoring kernels list up to 16 regions per pair (more: the
+    long-list pass, next test).  Queries of ten to fourteen copies of a family fragment, random sequence
     between them: every region is found and scored, nothing is flagged, scores and envelopes equal the oracle's - on a
     small model (one-query kernel) and through the pass-synchronous kernel (1 900 nodes)."""
     _need_gpu()
@@ -963,6 +963,67 @@ def test_queries_with_more_than_eight_regions_lose_none(orc, tmp_path):
                 r = ohm[h].score(seqs[q])
                 d = det[q * e.H + h]
                 assert d.nregions == r.nregions, (root_len, q, h, d.nregions, r.nregions)
+        e.close()
+
+
+def test_pairs_with_more_regions_than_a_kernel_lists_are_scored_in_full(orc, tmp_path):
+    """HMMER has no limit on the regions of a sequence (hmmsearch as called at witch_msa/gcmm/algorithm.py:526-532).
+    The scoring kernels list WH_MAX_ENVELOPES regions per pair; a pair with more is scored again inside the same call by
+    the long-list pass (float64 front end, region list in HBM, its own resolver launch).  Queries of 20 to 56 copies of a
+    family fragment - random spacers between them, some copies back to back (multidomain candidates) - on a small model
+    (one-query kernel) and on 1 900 nodes (pass-synchronous kernel): nothing is flagged WH_FLAG_TRUNC, every region is
+    counted, flags and deci-bits equal the oracle's (whose own list holds 256), the detail record lists the first
+    WH_MAX_ENVELOPES envelopes; with WH_NO_LONG_LIST the same pairs come back flagged (what the pass is for), and the
+    pairs of an ordinary query in the same batch are bitwise what they are without the long ones."""
+    _need_gpu()
+    from witch_amd import synth
+    from witch_amd.ehmm import EHMM, pack_queries
+    rng = np.random.default_rng(4077)
+    for root_len in (180, 1900):
+        fam = synth.make_family(3100 + root_len, root_len, 16, "dna", 0.03, 1e-4)
+        eh = synth.make_ehmm(fam, 2, str(tmp_path / str(root_len)), witch_layout=False)
+        e = EHMM(eh.paths, hmm_index=eh.index, nseq=eh.nseq)
+        _, frags = synth.make_queries(fam, 5, 14, 60)
+        seqs = [frags[0].astype(np.uint8)]                       # an ordinary query
+        for copies, touch in ((20, True), (24, False), (34, True), (56, True)):
+            parts = []
+            for c in range(copies):
+                parts.append(frags[c % len(frags)].astype(np.uint8))
+                if not (touch and c % 7 == 3):                   # (touch: every seventh copy runs straight into the next)
+                    parts.append(rng.integers(0, 4, size=int(rng.integers(25, 40))).astype(np.uint8))
+            seqs.append(np.concatenate(parts))
+        seqs.append(np.zeros(0, dtype=np.uint8))                 # and an empty one
+        res, offs = pack_queries(seqs)
+        deci, flags, det = e.score(res, offs, want_detail=True)
+        n_long = e.last_long_list_pairs()
+        ohm = [orc.OracleHMM(p) for p in eh.paths]
+        od, of, ofwd, osc = orc.score_batch(ohm, res, offs)
+        assert (flags & 8).sum() == 0, ("an envelope was dropped", root_len, flags)
+        nreg = np.array([d.nregions for d in det]).reshape(len(seqs), e.H)
+        assert nreg.max() > 2 * WH_MAX_ENVELOPES, nreg                         # the case this test is about
+        assert n_long == int((nreg > WH_MAX_ENVELOPES).sum()) and n_long >= 3, (n_long, nreg)
+        assert np.array_equal(flags & 3, of & 3), (root_len, flags, of)
+        _check_decibits(deci, od, osc, (of & 1) == 1, ("long list", root_len), LONG_EPS)
+        for q in range(len(seqs)):
+            for h in range(e.H):
+                r = ohm[h].score(seqs[q])
+                d = det[q * e.H + h]
+                assert d.nregions == r.nregions, (root_len, q, h, d.nregions, r.nregions)
+                assert d.nenv == min(r.nenv, WH_MAX_ENVELOPES), (root_len, q, h, d.nenv, r.nenv)
+                if not (r.flags & 2):                                          # (multidomain regions: the stochastic class)
+                    assert list(d.env_i[:d.nenv]) == list(r.env_i[:d.nenv]) and list(d.env_j[:d.nenv]) == list(r.env_j[:d.nenv]), (root_len, q, h)
+        # without the pass the same pairs are flagged, the others untouched
+        e.set_option("WH_NO_LONG_LIST", "1")
+        deci0, flags0, _ = e.score(res, offs, want_detail=True)
+        e.set_option("WH_NO_LONG_LIST", "")
+        assert e.last_long_list_pairs() == 0
+        assert np.array_equal((flags0 & 8) != 0, nreg > WH_MAX_ENVELOPES), (flags0, nreg)
+        keep = nreg <= WH_MAX_ENVELOPES
+        assert np.array_equal(deci0[keep], deci[keep]) and np.array_equal(flags0[keep], flags[keep])
+        # the ordinary query alone: bitwise the same result as inside the batch
+        r1, o1 = pack_queries(seqs[:1])
+        d1, f1, _ = e.score(r1, o1, want_detail=True)
+        assert np.array_equal(d1[0], deci[0]) and np.array_equal(f1[0], flags[0])
         e.close()
 
 

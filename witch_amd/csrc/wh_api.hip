@@ -69,6 +69,7 @@ struct Knobs {
   bool no_wide_align = false; // models beyond 3 072 nodes are aligned by the float64 kernel only (A/B and debugging)
   bool no_window = false;    // envelope Backward sweeps run full width (no node window; A/B and debugging)
   bool no_p2win = false;     // the multihit Backward sweep runs full width only (A/B and debugging)
+  bool no_long_list = false; // WH_NO_LONG_LIST: pairs with more than WH_MAX_ENVELOPES regions keep WH_FLAG_TRUNC (no second pass; tests)
   bool no_resolve = false;   // multidomain regions stay ONE envelope (round-1 behaviour) instead of HMMER's stochastic resolver
   int rqueue_cap = 0;        // test hook: size the resolver's queue for this many pairs instead of the estimate (forces the overflow re-run)
   int item_g = 0;            // queries per wave in a work item of the phase-call kernels (0 = 32; A/B)
@@ -78,6 +79,7 @@ struct Knobs {
   int rdbg = 0;              // resolver: print the first <n> sampled segments and the cluster statistics of every region
 };
 static const int kScorePathSlot = 128;   // d_counter[128..143]: eight 64-bit counters of the last scoring call: six paths (wh_last_score_paths), bytes of Forward rows stored, spare (wh_last_score_counters); [96..123] belong to wh_align_dev
+static const int kLongListSlot = 148;    // d_counter[148]: pairs flagged WH_FLAG_TRUNC after the resolver (long-list pass)
 static const int kResolveErrSlot = 146;  // d_counter[140]: queue records the resolver found in a segment of another model (never, for a well-formed segment list)
 static const int kStagedMaxBatches = 1 << 15;   // staged launches: batches per scoring call (32 counters each: 4 MB)
 static const int kMaxLaunches = 60;   // work-queue heads in d_counter (slot 63 belongs to the consensus kernel)
@@ -101,6 +103,8 @@ struct wh_ehmm {
   DevBuf d_ascratch;                        // per-wave slabs of the alignment kernels (allocated while the scoring kernels run)
   DevBuf d_gtab, d_rrecs, d_rmx, d_rsegs;   // multidomain resolver: float64 tables, pair queue, matrix slabs, segment arrays
   int last_resolved = 0;                    // pairs the resolver finished in the last wh_score call
+  int64_t last_long_list = 0;               // ... of them, pairs of the long-list pass (more than WH_MAX_ENVELOPES regions)
+  DevBuf d_tlist, d_rext;                   // long-list pass: pair positions, their region lists
   int64_t rq_cap = 0;                       // records the queue of the current scoring call holds
   double rq_rate = 0.0;                     // largest share of queued pairs any call on this handle has seen (sizes the next queue)
   int64_t rq_floor = 0;                     // ... at least this many (set when a call overflowed its estimate; the call then runs again)
@@ -180,7 +184,7 @@ int wh_digitize(int alphabet, const char *text, int64_t n, uint8_t *out) {
 
 void wh_ehmm_free(wh_ehmm *e) {
   if (!e) return;
-  for (DevBuf *b : {&e->d_gtab, &e->d_rrecs, &e->d_rmx, &e->d_rsegs, &e->d_hmms, &e->d_tables, &e->d_nseq, &e->d_index, &e->d_lists, &e->d_counter, &e->d_scratch, &e->d_ascratch, &e->d_wscratch,
+  for (DevBuf *b : {&e->d_tlist, &e->d_rext, &e->d_gtab, &e->d_rrecs, &e->d_rmx, &e->d_rsegs, &e->d_hmms, &e->d_tables, &e->d_nseq, &e->d_index, &e->d_lists, &e->d_counter, &e->d_scratch, &e->d_ascratch, &e->d_wscratch,
                     &e->s_res, &e->s_off, &e->s_deci, &e->s_flags, &e->s_fwd, &e->s_det, &e->s_idx, &e->s_w,
                     &e->s_nk, &e->s_nu, &e->s_pq, &e->s_ph, &e->s_co, &e->s_cols, &e->s_pos, &e->d_rkeys, &e->d_rorder, &e->d_rchunks, &e->d_qorder, &e->d_order, &e->d_items, &e->d_recs, &e->d_spec, &e->d_back, &e->d_cwj, &e->d_cwv, &e->d_cwn, &e->d_crow,
                     &e->c_buf[0], &e->c_buf[1], &e->c_buf[2], &e->c_buf[3], &e->c_buf[4], &e->c_buf[5], &e->c_buf[6],
@@ -370,6 +374,7 @@ int wh_set_option(wh_ehmm *e, const char *name, const char *value) {
   else if (!strcmp(name, "WH_FORCE_SPECG")) k.force_specg = on;
   else if (!strcmp(name, "WH_NO_LOGSPACE")) k.no_logspace = on;
   else if (!strcmp(name, "WH_NO_RESOLVE")) k.no_resolve = on;
+  else if (!strcmp(name, "WH_NO_LONG_LIST")) k.no_long_list = on;
   else if (!strcmp(name, "WH_NO_WINDOW")) k.no_window = on;
   else if (!strcmp(name, "WH_NO_P2WIN")) k.no_p2win = on;
   else if (!strcmp(name, "WH_RQUEUE_CAP")) k.rqueue_cap = *v ? std::max(1, atoi(v)) : 0;
@@ -385,7 +390,7 @@ int wh_set_option(wh_ehmm *e, const char *name, const char *value) {
 }
 
 static void knobs_from_env(wh_ehmm *e) {
-  for (const char *name : {"WH_SCORE_KERNEL", "WH_ITEM_G", "WH_ST_UNITS", "WH_KEEP_LOG2", "WH_MAX_WAVES", "WH_FORCE_SPECG", "WH_NO_LOGSPACE", "WH_NO_RESOLVE", "WH_NO_WINDOW", "WH_NO_P2WIN", "WH_RQUEUE_CAP", "WH_NO_WIDE_ALIGN", "WH_STATS", "WH_TRACE", "WH_DBG", "WH_RDBG"})
+  for (const char *name : {"WH_SCORE_KERNEL", "WH_ITEM_G", "WH_ST_UNITS", "WH_KEEP_LOG2", "WH_MAX_WAVES", "WH_FORCE_SPECG", "WH_NO_LOGSPACE", "WH_NO_RESOLVE", "WH_NO_LONG_LIST", "WH_NO_WINDOW", "WH_NO_P2WIN", "WH_RQUEUE_CAP", "WH_NO_WIDE_ALIGN", "WH_STATS", "WH_TRACE", "WH_DBG", "WH_RDBG"})
     if (const char *v = getenv(name)) (void)wh_set_option(e, name, v);
 }
 
@@ -455,6 +460,7 @@ int wh_last_score_counters(wh_ehmm *e, int64_t *out8) {
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(v, (int *)e->d_counter.p + kScorePathSlot, sizeof v, hipMemcpyDeviceToHost));
   for (int t = 0; t < 8; t++) out8[t] = (int64_t)v[t];
+  out8[7] = e->last_long_list;
   return WH_OK;
 }
 
@@ -1136,10 +1142,13 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
         return WH_OK;
       }
     }
-    if (n_multi > 0) {
+    // one resolver launch over the first <n_multi> records of the queue; <rext>: the long-list pass below, whose records
+    // keep their regions in HBM
+    auto resolve_queue = [&](int n_multi, const int32_t *rext, int64_t rext_stride) -> int {
       const int Qmax = e->max_Q;
       ResolveArgs r;
       memset(&r, 0, sizeof r);
+      r.rext = rext; r.rext_stride = rext_stride;
       r.hmms = (const DevHMM *)e->d_hmms.p; r.gtab = (const double *)e->d_gtab.p; r.ftab = (const float *)e->d_tables.p;
       r.residues = d_residues; r.offsets = d_offsets;
       r.recs = (const ResolveRec *)e->d_rrecs.p; r.count = d_rcount; r.rec_cap = (int)e->rq_cap;
@@ -1190,7 +1199,7 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
       std::vector<int32_t> chunk_list;
       {
         int32_t *d_models = (int32_t *)e->d_rkeys.p + n_multi;
-        hipError_t kerr = launch_resolve_keys(r.recs, n_multi, r.hmms, (float *)e->d_rkeys.p, d_models, s);
+        hipError_t kerr = launch_resolve_keys(r.recs, n_multi, r.hmms, (float *)e->d_rkeys.p, d_models, s, rext, rext_stride);
         if (kerr != hipSuccess) { set_error("resolve key kernel launch failed: %s", hipGetErrorString(kerr)); return WH_EHIP; }
         std::vector<float> keys((size_t)n_multi);
         std::vector<int32_t> models((size_t)n_multi);
@@ -1277,7 +1286,7 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_rl0).count());
       }
       rlaunches++;
-      e->last_resolved = n_multi;
+      e->last_resolved += n_multi;
       if (r.stats) {
         unsigned long long st[24];
         HIPCHK(hipMemcpyAsync(st, r.stats, sizeof st, hipMemcpyDeviceToHost, s));
@@ -1297,6 +1306,73 @@ static int score_dev_pass(wh_ehmm *e, const uint8_t *d_residues, const int64_t *
         fprintf(stderr, "[wh]   shader clock while a pair is resolved: %.2f GHz (cycle counter / 100 MHz real-time counter); pair cycles %.3g\n", st[15] ? 0.1 * (double)st[14] / (double)st[15] : 0.0, (double)st[14]);
         fprintf(stderr, "[wh]   wave lifetimes: %llu waves, mean %.1f ms, longest %.1f ms (a wave leaves when no slot is left)\n", st[19], st[19] ? 1e-5 * (double)st[17] / (double)st[19] : 0.0, 1e-5 * (double)st[18]);
         fprintf(stderr, "[wh]   waiting at the workgroup's slot barriers: %.1f%% on top of the pair cycles (%d slots on %d models, %d workgroups of %d waves)\n", 100.0 * st[13] / tot, r.n_slots, r.n_chunks, blocks, waves);
+      }
+      return WH_OK;
+    };
+    if (n_multi > 0) { const int rc = resolve_queue(n_multi, nullptr, 0); if (rc != WH_OK) return rc; }
+    // ---- the long-list pass.  The scoring kernels keep the regions of a pair in a list of WH_MAX_ENVELOPES entries in LDS;
+    // HMMER has no such limit.  A pair with more regions comes out of them flagged WH_FLAG_TRUNC - and is scored
+    // AGAIN here: the any-size float64 front end (wh_generic.hip) with a region list in HBM that holds every region a
+    // sequence of this length can have, then a resolver launch of its own that reads the regions from that list and sums
+    // over all envelopes.  Costs one pass over the flags (a byte per pair) and one 4-byte read-back per call; the float64
+    // kernels run only when a pair needs them.
+    e->last_long_list = 0;
+    if (rlds <= kLdsBudget && nq * (int64_t)e->hmms.size() < 0x7FFFFFFF && generic_lds_bytes(Lc) <= kLdsBudget && !e->knobs.no_long_list) {
+      const int64_t npairs_all = nq * (int64_t)e->hmms.size();
+      int *d_tcount = (int *)e->d_counter.p + kLongListSlot;
+      const int list_cap = (int)std::min<int64_t>(npairs_all, (int64_t)1 << 22);
+      if (e->d_tlist.ensure(sizeof(int64_t) * (size_t)list_cap)) return WH_ENOMEM;
+      HIPCHK(hipMemsetAsync(d_tcount, 0, sizeof(int), s));
+      hipError_t terr = launch_trunc_list(d_flags, npairs_all, d_tcount, (int64_t *)e->d_tlist.p, list_cap, s);
+      if (terr != hipSuccess) { set_error("flag scan launch failed: %s", hipGetErrorString(terr)); return WH_EHIP; }
+      int n_trunc = 0;
+      HIPCHK(hipMemcpyAsync(&n_trunc, d_tcount, sizeof(int), hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
+      n_trunc = std::min(n_trunc, list_cap);          // (beyond four million such pairs in one call the rest stay flagged)
+      if (n_trunc > 0) {
+        // a region is at least two rows long (the row that triggers it and a later one that ends it)
+        const int ext_cap = Lc / 2 + 2;
+        const int64_t rext_stride = (int64_t)kRextInts * ext_cap;
+        // rounds of as many pairs as 256 MB of region lists hold
+        const int per_round = (int)std::max<int64_t>(1, std::min<int64_t>(n_trunc, ((int64_t)64 << 20) / rext_stride));
+        if (e->d_rext.ensure(sizeof(int32_t) * (size_t)per_round * (size_t)rext_stride)) return WH_ENOMEM;
+        if (e->d_rrecs.cap < sizeof(ResolveRec) * (size_t)per_round) {
+          HIPCHK(hipStreamSynchronize(s));
+          if (e->d_rrecs.ensure(sizeof(ResolveRec) * (size_t)per_round)) return WH_ENOMEM;
+        }
+        e->rq_cap = std::max<int64_t>(e->rq_cap, per_round);
+        if (e->knobs.trace) fprintf(stderr, "[wh] long-list pass: %d pairs with more than %d regions, %d per round, up to %d regions each\n", n_trunc, WH_MAX_ENVELOPES, per_round, ext_cap);
+        for (int t0 = 0; t0 < n_trunc; t0 += per_round) {
+          const int n_round = std::min(per_round, n_trunc - t0);
+          GenericArgs g;
+          memset(&g, 0, sizeof g);
+          g.hmms = (const DevHMM *)e->d_hmms.p; g.gtab = (const double *)e->d_gtab.p;
+          g.residues = d_residues; g.offsets = d_offsets; g.nq = nq;
+          g.counter = (int *)e->d_counter.p + 66;
+          g.Lcap = Lc; g.Qmax = e->max_Q;
+          g.slab_stride = (generic_front_doubles(Lc, e->max_Q) + 1) & ~(size_t)1;
+          g.decibits = d_decibits; g.flags = d_flags; g.fwd_bits = nullptr; g.detail = d_detail;
+          g.H = (int)e->hmms.size(); g.K = e->K; g.Kp = e->Kp;
+          memcpy(g.degen, e->degen, sizeof g.degen);
+          g.rrecs = (ResolveRec *)e->d_rrecs.p; g.rcount = d_rcount; g.rcap = n_round;
+          g.pair_list = (const int64_t *)e->d_tlist.p + t0; g.n_pairs = n_round;
+          g.rext = (int32_t *)e->d_rext.p; g.rext_stride = rext_stride; g.ext_cap = ext_cap;
+          const size_t glds = generic_lds_bytes(Lc);
+          int gblocks = (int)std::min<int64_t>(n_round, (int64_t)e->cu_count * std::min<size_t>(12, kLdsBudget / glds));
+          gblocks = clamp_blocks(gblocks, g.slab_stride * sizeof(double), e->d_rmx);
+          if (e->d_rmx.ensure((size_t)gblocks * g.slab_stride * sizeof(double))) return WH_ENOMEM;
+          g.slab = (double *)e->d_rmx.p;
+          HIPCHK(hipMemsetAsync(g.counter, 0, sizeof(int), s));
+          hipError_t gerr = launch_generic_front(g, gblocks, glds, s);
+          if (gerr != hipSuccess) { set_error("long-list front kernel launch failed: %s", hipGetErrorString(gerr)); return WH_EHIP; }
+          // the resolver's queue is now this round's records: length and work-queue head
+          const int two[2] = {n_round, 0};
+          HIPCHK(hipMemcpyAsync(d_rcount, two, sizeof two, hipMemcpyHostToDevice, s));
+          HIPCHK(hipStreamSynchronize(s));
+          const int rc = resolve_queue(n_round, (const int32_t *)e->d_rext.p, rext_stride);
+          if (rc != WH_OK) return rc;
+          e->last_long_list += n_round;
+        }
       }
     }
   }
@@ -1727,16 +1803,13 @@ int wh_align_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
       HIPCHK(hipMemcpyAsync(st.data(), e->d_recs.p, sizeof(int32_t) * st.size(), hipMemcpyDeviceToHost, s));
       HIPCHK(hipStreamSynchronize(s));     // gitems is a local
       int n_range = 0, n_log = 0;
-      for (size_t p = 0; p < st.size(); p++) {
-        n_range += st[p] == 3; n_log += st[p] == 4;
-        if (st[p] == 3) e->last_unaligned_pairs.push_back((int64_t)p);
-      }
-      e->last_align_unaligned = n_range;
+      for (size_t p = 0; p < st.size(); p++) { n_range += st[p] == 3; n_log += st[p] == 4 || st[p] == 3; }
+      e->last_align_unaligned = 0;        // (round 5: no pair is left unaligned for its range - see generic_align_kernel)
       e->last_align_redo += n_log;
       if (e->knobs.trace && n_log > 0) fprintf(stderr, "[wh] any-size alignment: %d pairs left float64 range, redone in log space\n", n_log);
       if (n_range > 0)
-        fprintf(stderr, "[wh] warning: %d pair(s) on models of more than %d nodes could not be aligned (Forward and Backward disagree "
-                        "even in log space); they are returned unaligned (all residues -1)\n", n_range, kMaxQ * kWave);
+        fprintf(stderr, "[wh] note: on %d pair(s) on models of more than %d nodes the log-space Forward and Backward scores disagree; "
+                        "aligned from the Forward-normalised posteriors, as hmmalign does\n", n_range, kMaxQ * kWave);
     }
   }
   if (timer_end(e, 2, s, launches)) return WH_EHIP;

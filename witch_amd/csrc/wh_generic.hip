@@ -15,6 +15,7 @@
 //    traceback (A.7; witch_msa/gcmm/aligner.py:96-142) in place in one slab: Forward rows -> posteriors ->
 //    OA rows.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 
 #include "wh_launch.h"
 #include "wh_f64.h"
@@ -366,24 +367,32 @@ size_t generic_front_doubles(int Lcap, int Qmax) {
 size_t generic_align_doubles(int Lcap, int Qmax) {
   return (size_t)(Lcap + 4) * generic_rowlen(Qmax) + 2 * (size_t)(Lcap + 2) * xNSPEC + 8;
 }
-size_t generic_lds_bytes(int Lcap) { return (size_t)(Lcap + 16) + 64 * 4 + 4 * WH_MAX_ENVELOPES * 4 + 64; }
+size_t generic_lds_bytes(int Lcap) { return (size_t)(Lcap + 16) + 64 * 4 + kRextInts * WH_MAX_ENVELOPES * 4 + 64; }
 
 __global__ __launch_bounds__(64, 3) void generic_front_kernel(GenericArgs a) {
   extern __shared__ __attribute__((aligned(16))) int lds_raw[];
   const int lane = threadIdx.x;
   float *null2 = reinterpret_cast<float *>(lds_raw);                 // 32 floats (+ 32 spare)
-  int *regs = lds_raw + 64;                                          // 2 x WH_MAX_ENVELOPES region bounds
-  float *envres = reinterpret_cast<float *>(regs + 2 * WH_MAX_ENVELOPES);   // envsc, domcorr per region
-  uint8_t *seq = reinterpret_cast<uint8_t *>(envres + 2 * WH_MAX_ENVELOPES);
+  int *regs_lds = lds_raw + 64;                                      // WH_MAX_ENVELOPES regions x kRextInts (first row, last row, envsc, domcorr, multidomain)
+  uint8_t *seq = reinterpret_cast<uint8_t *>(regs_lds + kRextInts * WH_MAX_ENVELOPES);
+  // The region list of a pair: in LDS, WH_MAX_ENVELOPES entries - or, in the long-list pass (a.pair_list), in HBM with room
+  // for every region a sequence of Lcap rows can hold.  Written by lane 0, read by every lane: ordered by hand (one
+  // wavefront per workgroup, see wave_mem_sync; the LDS case goes through the same flat accesses, hence lgkmcnt).
+  const bool listed = a.pair_list != nullptr;
+  const int rcap = listed ? a.ext_cap : WH_MAX_ENVELOPES;
+  auto list_sync = []() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\tbuffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory"); };
+  const int64_t n_work = listed ? a.n_pairs : a.nq * (int64_t)a.n_list;
   const double LOG2 = 0.69314718055994529;
   double *slab = a.slab + (size_t)blockIdx.x * a.slab_stride;
   for (;;) {
     int item = 0;
     if (lane == 0) item = atomicAdd(a.counter, 1);
     item = __builtin_amdgcn_readfirstlane(__shfl(item, 0));
-    if ((int64_t)item >= a.nq * a.n_list) break;
-    const int h = a.hmm_list[item / a.nq];
-    const int64_t qi = item % a.nq;
+    if ((int64_t)item >= n_work) break;
+    const int64_t pl = listed ? a.pair_list[item] : 0;
+    const int h = listed ? (int)(pl % a.H) : a.hmm_list[item / a.nq];
+    const int64_t qi = listed ? pl / a.H : item % a.nq;
+    int *rl = listed ? a.rext + (size_t)item * a.rext_stride : regs_lds;
     const DevHMM hm = a.hmms[h];
     GModel m;
     m.tf = a.gtab + hm.gfw_off; m.te = a.gtab + hm.gem_off;
@@ -403,8 +412,10 @@ __global__ __launch_bounds__(64, 3) void generic_front_kernel(GenericArgs a) {
     int flags = 0;
     float fwd_bits_out = -INFINITY;
     wh_pair_detail *dp = (a.detail && lane == 0) ? a.detail + out : nullptr;
-    if (dp) { dp->fwd_bits = -INFINITY; dp->seq_score = 0.f; dp->pre_score = 0.f; dp->seqbias_nats = 0.f; dp->nregions = 0; dp->nenv = 0; }
+    if (dp) { if (!listed) dp->fwd_bits = -INFINITY; dp->seq_score = 0.f; dp->pre_score = 0.f; dp->seqbias_nats = 0.f; dp->nregions = 0; dp->nenv = 0; }
     bool queued = false;
+    float fwdsc_rec = -INFINITY;
+    int nreg_rec = 0, nenv_rec = 0;
     if (L > 0 && L <= a.Lcap) {
       for (int t = lane; t < L; t += 64) { const int r = a.residues[off + t]; seq[t] = (uint8_t)(r < a.Kp ? r : a.Kp - 1); }
       __builtin_amdgcn_wave_barrier();
@@ -415,7 +426,8 @@ __global__ __launch_bounds__(64, 3) void generic_front_kernel(GenericArgs a) {
       const float p1 = (float)L / (float)(L + 1);
       const float nullsc = (float)((double)(float)L * log((double)p1) + log(1.0 - (double)p1));
       fwd_bits_out = (float)((fwd - (double)nullsc) / LOG2);
-      if (dp) dp->fwd_bits = fwd_bits_out;
+      if (dp && !listed) dp->fwd_bits = fwd_bits_out;     // (long-list pass: the pair keeps the Forward log-odds of the kernel that scored it first)
+      fwdsc_rec = fwdsc;
       if (isfinite(fwd)) {
         (void)gbackward<0>(m, seq, L, cm, mx, mx.row(0), mx.row(1), xsB, fwd, nullptr, nullptr, lane);
         // ---------------- A.4 domain decoding (lanes over rows), then the serial region scan 64 rows per fetch
@@ -452,7 +464,7 @@ __global__ __launch_bounds__(64, 3) void generic_front_kernel(GenericArgs a) {
               else if (i0 == -1) i0 = j;
               if (mocc >= kRt1) trig = true;
             } else if (mocc - (etot - eold) < kRt2) {
-              if (nenv < WH_MAX_ENVELOPES) { if (lane == 0) { regs[2 * nenv] = i0; regs[2 * nenv + 1] = j; } nenv++; }
+              if (nenv < rcap) { if (lane == 0) { rl[kRextInts * nenv] = i0; rl[kRextInts * nenv + 1] = j; } nenv++; }
               else flags |= WH_FLAG_TRUNC;
               nreg++;
               i0 = -1; trig = false;
@@ -460,12 +472,12 @@ __global__ __launch_bounds__(64, 3) void generic_front_kernel(GenericArgs a) {
           }
           if (valid) { btotv[jj] = bout; etotv[jj] = eout; }
         }
-        wave_mem_sync();
+        list_sync();
         __builtin_amdgcn_wave_barrier();
         // multidomain test: max_z min(etot[z]-etot[i-1], btot[j]-btot[z-1]) >= rt3
-        int multi_mask = 0;
+        int multi_mask = 0;       // the first 32 regions (the record of the hmm_list mode)
         for (int e = 0; e < nenv; e++) {
-          const int ri = regs[2 * e], rj = regs[2 * e + 1];
+          const int ri = rl[kRextInts * e], rj = rl[kRextInts * e + 1];
           const double e0 = __builtin_nontemporal_load(etotv + ri - 1), bj = __builtin_nontemporal_load(btotv + rj);
           double mxv = -1.0;
           for (int z = ri + lane; z <= rj; z += 64) {
@@ -474,14 +486,18 @@ __global__ __launch_bounds__(64, 3) void generic_front_kernel(GenericArgs a) {
             mxv = w > mxv ? w : mxv;
           }
           mxv = wave_max_d(mxv);
-          if (mxv >= kRt3) { flags |= WH_FLAG_MULTI; multi_mask |= 1 << e; }
+          const bool mu = mxv >= kRt3;
+          if (mu) { flags |= WH_FLAG_MULTI; if (e < 32) multi_mask |= 1 << e; }
+          if (lane == 0) rl[kRextInts * e + 4] = mu ? 1 : 0;
         }
-        if (dp) { dp->nregions = nreg; dp->nenv = nenv; }
+        list_sync();
+        nreg_rec = nreg; nenv_rec = nenv;
+        if (dp) { dp->nregions = nreg; dp->nenv = nenv < WH_MAX_ENVELOPES ? nenv : WH_MAX_ENVELOPES; }
         if (nenv > 0) {
           // ---------------- A.5 single-domain regions: the envelope is the region
           for (int e = 0; e < nenv; e++) {
-            if ((multi_mask >> e) & 1) { if (lane == 0) { envres[e] = 0.f; envres[WH_MAX_ENVELOPES + e] = 0.f; } continue; }
-            const int ri = regs[2 * e], rj = regs[2 * e + 1], Ld = rj - ri + 1;
+            if (rl[kRextInts * e + 4]) { if (lane == 0) { rl[kRextInts * e + 2] = 0; rl[kRextInts * e + 3] = 0; } continue; }
+            const int ri = rl[kRextInts * e], rj = rl[kRextInts * e + 1], Ld = rj - ri + 1;
             const uint8_t *eseq = seq + (ri - 1);
             const double envsc = gforward<true>(m, eseq, Ld, cu, mx, lane);
             float domcorr = 0.f;
@@ -513,27 +529,41 @@ __global__ __launch_bounds__(64, 3) void generic_front_kernel(GenericArgs a) {
               domcorr = wave_sum_f(dc);
               __builtin_amdgcn_wave_barrier();
             }
-            if (lane == 0) { envres[e] = (float)envsc; envres[WH_MAX_ENVELOPES + e] = domcorr; }
-            if (dp) { dp->env_i[e] = ri; dp->env_j[e] = rj; dp->envsc[e] = (float)envsc; dp->domcorr[e] = domcorr; }
+            if (lane == 0) { rl[kRextInts * e + 2] = __builtin_bit_cast(int, (float)envsc); rl[kRextInts * e + 3] = __builtin_bit_cast(int, domcorr); }
+            if (dp && e < WH_MAX_ENVELOPES) { dp->env_i[e] = ri; dp->env_j[e] = rj; dp->envsc[e] = (float)envsc; dp->domcorr[e] = domcorr; }
           }
+          list_sync();
           __builtin_amdgcn_wave_barrier();
           // every pair with a region is finished by resolve_kernel: multidomain regions and the score assembly
           int slot = 0;
-          if (lane == 0) slot = atomicAdd(a.rcount, 1);
+          if (lane == 0 && !listed) slot = atomicAdd(a.rcount, 1);
           slot = __shfl(slot, 0);
-          if (slot < a.rcap) {
+          if (listed) {
+            queued = true;          // (the record is written below, for every pair of the list)
+          } else if (slot < a.rcap) {
             queued = true;
             if (lane == 0) {
               ResolveRec *rr = a.rrecs + slot;
               rr->q = qi; rr->h = h; rr->fwdsc = fwdsc; rr->fwd_bits = fwd_bits_out; rr->nreg = nreg; rr->nenv = nenv;
               rr->multi_mask = multi_mask; rr->flags = flags;
-              for (int e = 0; e < nenv; e++) { rr->ri[e] = regs[2 * e]; rr->rj[e] = regs[2 * e + 1]; rr->envsc[e] = envres[e]; rr->domcorr[e] = envres[WH_MAX_ENVELOPES + e]; }
+              for (int e = 0; e < nenv; e++) {
+                rr->ri[e] = rl[kRextInts * e]; rr->rj[e] = rl[kRextInts * e + 1];
+                rr->envsc[e] = __builtin_bit_cast(float, rl[kRextInts * e + 2]); rr->domcorr[e] = __builtin_bit_cast(float, rl[kRextInts * e + 3]);
+              }
             }
           } else flags |= WH_FLAG_TRUNC;
         }
       }
     }
-    if (lane == 0) {
+    if (listed) {
+      // every pair of the list has its record (slot = list position): the resolver launch that follows writes its result,
+      // its regions from the list at rl (a pair without a region comes back unreported)
+      if (lane == 0) {
+        ResolveRec *rr = a.rrecs + item;
+        rr->q = qi; rr->h = h; rr->fwdsc = fwdsc_rec; rr->fwd_bits = fwd_bits_out; rr->nreg = nreg_rec; rr->nenv = queued ? nenv_rec : 0;
+        rr->multi_mask = 0; rr->flags = flags;
+      }
+    } else if (lane == 0) {
       if (!queued) { a.decibits[out] = 0; a.flags[out] = (uint8_t)flags; }
       if (a.fwd_bits) a.fwd_bits[out] = fwd_bits_out;
     }
@@ -590,8 +620,9 @@ __global__ __launch_bounds__(64, 3) void generic_align_kernel(GenericAlignArgs a
     if (!(fabs(fwd - bwd) <= 1e-6 * fabs(fwd) + 1e-3)) {
       const double lf = gforward_log(m, seq, L, c, mx, lane);
       const double lb = gbackward_log(m, seq, L, c, mx, mx.row(a.Lcap + 2), mx.row(a.Lcap + 3), pps, lf, lane);
+      // (3: the two log-space scores disagree as well - never seen.  hmmalign makes no such comparison: it decodes with
+      // the Forward score and aligns, and so does this kernel; the class is counted and reported, nothing is dropped)
       if (lane == 0 && a.status) a.status[p] = (fabs(lf - lb) <= 1e-6 * fabs(lf) + 1e-3) ? 4 : 3;
-      if (!(fabs(lf - lb) <= 1e-6 * fabs(lf) + 1e-3)) continue;       // (never seen: reported, left unaligned)
     }
     // ---------------- optimal-accuracy fill, in place: row i holds ppM / ppI on entry, oM / oI / oD on exit
     const float tNl = c.loop > 0.0 ? 1.0f : 0.0f, tNm = c.move > 0.0 ? 1.0f : 0.0f;
@@ -779,6 +810,24 @@ hipError_t launch_generic_front(const GenericArgs &a, int blocks, size_t lds, hi
   hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(&generic_front_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (err != hipSuccess) return err;
   hipLaunchKernelGGL(generic_front_kernel, dim3(blocks), dim3(64), lds, s, a);
+  return hipGetLastError();
+}
+
+// Pairs whose result carries WH_FLAG_TRUNC after the scoring kernels and the resolver: their positions (q * H + h) go to
+// <list> for the long-list pass.  <count> counts all of them, the list holds the first <cap> (in no particular order).
+__global__ void trunc_list_kernel(const uint8_t *flags, int64_t npairs, int *count, int64_t *list, int cap) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npairs; p += stride)
+    if (flags[p] & WH_FLAG_TRUNC) {
+      const int t = atomicAdd(count, 1);
+      if (t < cap) list[t] = p;
+    }
+}
+
+hipError_t launch_trunc_list(const uint8_t *flags, int64_t npairs, int *count, int64_t *list, int cap, hipStream_t s) {
+  const int blocks = (int)std::min<int64_t>((npairs + 255) / 256, 8192);
+  if (blocks < 1) return hipSuccess;
+  hipLaunchKernelGGL(trunc_list_kernel, dim3(blocks), dim3(256), 0, s, flags, npairs, count, list, cap);
   return hipGetLastError();
 }
 

@@ -161,11 +161,15 @@ struct ResolveArgs {
   unsigned long long *stats;   // WH_STATS: wave cycles per phase [0] region Forward [1] traces [2] clustering [3] cluster statistics [4] envelope Forward
   int dbg;                     // WH_RDBG > 0: print the first <dbg> sampled segments and the cluster statistics of every region
   int *err;                    // device counter: records dropped because their model is not the segment's (the host turns it into WH_EHIP)
+  const int32_t *rext;         // long-list pass (wh_api.hip): record t's regions are NOT in the record but here, at rext + t * rext_stride:
+  int64_t rext_stride;         // kRextInts ints per region (first row, last row, envsc bits, domcorr bits, multidomain), ResolveRec::nenv of them
 };
+constexpr int kRextInts = 5;
 hipError_t launch_resolve(const ResolveArgs &a, int blocks, int waves, size_t lds, hipStream_t s);
 size_t resolve_lds_header_bytes(int Qt);
 // cost estimate of every queued pair (cells of its multidomain regions) for the longest-first order
-hipError_t launch_resolve_keys(const ResolveRec *recs, int n, const DevHMM *hmms, float *keys, int32_t *models, hipStream_t s);
+hipError_t launch_resolve_keys(const ResolveRec *recs, int n, const DevHMM *hmms, float *keys, int32_t *models, hipStream_t s,
+                               const int32_t *rext = nullptr, int64_t rext_stride = 0);
 size_t resolve_lds_bytes(int Lcap, int Mmax);
 int resolve_seg_cap();
 int resolve_waves_per_cu();
@@ -245,7 +249,17 @@ struct GenericArgs {
   ResolveRec *rrecs;           // EVERY pair with a region is finished by resolve_kernel
   int *rcount;
   int rcap;
+  // long-list pass: the pairs whose region list did not fit WH_MAX_ENVELOPES in the kernel that scored them (WH_FLAG_TRUNC)
+  // are scored again here with a region list in HBM.  Work item t = pair_list[t] (q * H + h), its record is rrecs[t] and its
+  // regions are rext + t * rext_stride (kRextInts ints each, up to ext_cap of them).  NULL: the hmm_list x nq mode above.
+  const int64_t *pair_list;
+  int64_t n_pairs;
+  int32_t *rext;
+  int64_t rext_stride;
+  int ext_cap;
 };
+// pairs flagged WH_FLAG_TRUNC, appended to <list> (up to <cap>; <count> keeps counting)
+hipError_t launch_trunc_list(const uint8_t *flags, int64_t npairs, int *count, int64_t *list, int cap, hipStream_t s);
 struct GenericAlignArgs {
   const DevHMM *hmms;
   const double *gtab;

@@ -231,7 +231,10 @@ __global__ __launch_bounds__(64 * kResMaxWaves) void resolve_kernel(ResolveArgs 
     // and the sampling loop is bounded, so a bad record can no longer run the wave out of its slab.
     const long long t_pair0 = a.stats ? __builtin_readcyclecounter() : 0;
     const unsigned long long r_pair0 = a.stats ? __builtin_amdgcn_s_memrealtime() : 0;
-    const ResolveRec rec = a.recs[a.order ? a.order[c_start + item] : c_start + item];
+    const int ridx = a.order ? a.order[c_start + item] : c_start + item;
+    const ResolveRec rec = a.recs[ridx];
+    // long-list pass: the pair's regions are in HBM (any number of them), the record carries the pair alone
+    const int32_t *xl = a.rext ? a.rext + (size_t)ridx * (size_t)a.rext_stride : nullptr;
     if (c_h >= 0 && rec.h != c_h) {                    // never true for a well-formed segment list (the staged tables are c_h's):
       if (lane == 0 && a.err) atomicAdd(a.err, 1);     // counted, and the next scoring call on the handle fails with WH_EHIP
       continue;
@@ -259,16 +262,28 @@ __global__ __launch_bounds__(64 * kResMaxWaves) void resolve_kernel(ResolveArgs 
     int *env_i = misc, *env_j = misc + kEnvMax;
     float *env_sc = reinterpret_cast<float *>(misc + 2 * kEnvMax), *env_dc = reinterpret_cast<float *>(misc + 3 * kEnvMax);
     float seqbias_sum = 0.f;
-    const int nrec = rec.nenv < 0 ? 0 : rec.nenv > WH_MAX_ENVELOPES ? WH_MAX_ENVELOPES : rec.nenv;
+    // A.6's sums over the envelopes, taken as the envelopes arrive (the order HMMER adds them in): the lists above keep the
+    // first kEnvMax for the detail record only, the score has no limit
+    float sum_score = 0.f, sb2 = 0.f;
+    int Ld_tot = 0;
+    auto add_envelope = [&](int ei, int ej, float esc, float edc) {
+      if (nenv < kEnvMax) { env_i[nenv] = ei; env_j[nenv] = ej; env_sc[nenv] = esc; env_dc[nenv] = edc; }
+      nenv++;
+      if (esc - edc > 0.0f) { sum_score += esc; Ld_tot += ej - ei + 1; sb2 += edc; }
+    };
+    const int nrec = rec.nenv < 0 ? 0 : xl ? rec.nenv : rec.nenv > WH_MAX_ENVELOPES ? WH_MAX_ENVELOPES : rec.nenv;
     for (int e = 0; e < nrec; e++) {
       // (values that steer the wave-uniform walk are made provably uniform: the walk then compiles to SALU code)
-      const int ireg = __builtin_amdgcn_readfirstlane(rec.ri[e]), jreg = __builtin_amdgcn_readfirstlane(rec.rj[e]), Lr = jreg - ireg + 1;
+      const int ireg = __builtin_amdgcn_readfirstlane(xl ? xl[kRextInts * e] : rec.ri[e]);
+      const int jreg = __builtin_amdgcn_readfirstlane(xl ? xl[kRextInts * e + 1] : rec.rj[e]), Lr = jreg - ireg + 1;
       if (ireg < 1 || jreg > L || Lr < 1 || L > a.Lcap) { flags |= WH_FLAG_TRUNC; continue; }     // never true for a well-formed record
-      if (!((rec.multi_mask >> e) & 1)) {
+      const bool multi_reg = xl ? __builtin_amdgcn_readfirstlane(xl[kRextInts * e + 4]) != 0 : ((rec.multi_mask >> (e & 31)) & 1) != 0;
+      if (!multi_reg) {
         // single-domain region: envelope = region, scored by the scoring kernel (A.5)
-        seqbias_sum += rec.domcorr[e];
-        if (nenv < kEnvMax) { env_i[nenv] = ireg; env_j[nenv] = jreg; env_sc[nenv] = rec.envsc[e]; env_dc[nenv] = rec.domcorr[e]; nenv++; }
-        else flags |= WH_FLAG_TRUNC;
+        const float r_sc = xl ? __builtin_bit_cast(float, xl[kRextInts * e + 2]) : rec.envsc[e];
+        const float r_dc = xl ? __builtin_bit_cast(float, xl[kRextInts * e + 3]) : rec.domcorr[e];
+        seqbias_sum += r_dc;
+        add_envelope(ireg, jreg, r_sc, r_dc);
         continue;
       }
       // ---------------- A.4b
@@ -893,8 +908,7 @@ __global__ __launch_bounds__(64 * kResMaxWaves) void resolve_kernel(ResolveArgs 
         const int i2 = g_i[d], j2 = g_j[d], Ld = j2 - i2 + 1;
         const double envsc = gforward_any<false>(m, seq + (i2 - 1), Ld, cu, mx, lane, use_tl ? (const ldbl *)tabL : nullptr);
         const float dc = n2sum(i2, j2);
-        if (nenv < kEnvMax) { env_i[nenv] = i2; env_j[nenv] = j2; env_sc[nenv] = (float)envsc; env_dc[nenv] = dc; nenv++; }
-        else flags |= WH_FLAG_TRUNC;
+        add_envelope(i2, j2, (float)envsc, dc);
       }
       RTICK(4);
     }
@@ -915,10 +929,6 @@ __global__ __launch_bounds__(64 * kResMaxWaves) void resolve_kernel(ResolveArgs 
       const float seqbias = flogsum0(lomega + seqbias_sum);
       float pre_score = (float)(((double)fwdsc - (double)nullsc) / LOG2);
       float seq_score = (float)(((double)fwdsc - (double)(nullsc + seqbias)) / LOG2);
-      float sum_score = 0.f, sb2 = 0.f;
-      int Ld_tot = 0;
-      for (int e = 0; e < nenv; e++)
-        if (env_sc[e] - env_dc[e] > 0.0f) { sum_score += env_sc[e]; Ld_tot += env_j[e] - env_i[e] + 1; sb2 += env_dc[e]; }
       sb2 = flogsum0(lomega + sb2);
       sum_score += (float)((double)(L - Ld_tot) * log((double)((float)L / (float)(L + 3))));
       const float pre2 = (float)(((double)sum_score - (double)nullsc) / LOG2);
@@ -930,7 +940,7 @@ __global__ __launch_bounds__(64 * kResMaxWaves) void resolve_kernel(ResolveArgs 
     }
     if (dp) {
       dp->nregions = rec.nreg;
-      dp->nenv = nenv < WH_MAX_ENVELOPES ? nenv : WH_MAX_ENVELOPES;
+      dp->nenv = nenv < WH_MAX_ENVELOPES ? nenv : WH_MAX_ENVELOPES;       // (the first ones; the score above is over all of them)
       for (int e = 0; e < dp->nenv; e++) { dp->env_i[e] = env_i[e]; dp->env_j[e] = env_j[e]; dp->envsc[e] = env_sc[e]; dp->domcorr[e] = env_dc[e]; }
     }
     if (lane == 0) { a.decibits[out] = decibits; a.flags[out] = (uint8_t)flags; }
@@ -948,20 +958,24 @@ __global__ __launch_bounds__(64 * kResMaxWaves) void resolve_kernel(ResolveArgs 
 
 // One thread per queued pair: the cells of its multidomain regions (region length x model length), the
 // quantity the Forward fill, the walk and the envelope rescoring all scale with; and its model.
-__global__ void resolve_keys_kernel(const ResolveRec *recs, int n, const DevHMM *hmms, float *keys, int32_t *models) {
+__global__ void resolve_keys_kernel(const ResolveRec *recs, int n, const DevHMM *hmms, float *keys, int32_t *models, const int32_t *rext, int64_t rext_stride) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n) return;
   const ResolveRec &r = recs[t];
-  const int ne = r.nenv < 0 ? 0 : r.nenv > WH_MAX_ENVELOPES ? WH_MAX_ENVELOPES : r.nenv;
+  const int ne = r.nenv < 0 ? 0 : rext ? r.nenv : r.nenv > WH_MAX_ENVELOPES ? WH_MAX_ENVELOPES : r.nenv;
   float cost = 0.f;
+  if (rext) {
+    const int32_t *xl = rext + (size_t)t * (size_t)rext_stride;
+    for (int e = 0; e < ne; e++) if (xl[kRextInts * e + 4]) cost += (float)(xl[kRextInts * e + 1] - xl[kRextInts * e] + 1);
+  } else
   for (int e = 0; e < ne; e++)
     if ((r.multi_mask >> e) & 1) cost += (float)(r.rj[e] - r.ri[e] + 1);
   keys[t] = cost * (float)hmms[r.h].M;
   models[t] = r.h;
 }
 
-hipError_t launch_resolve_keys(const ResolveRec *recs, int n, const DevHMM *hmms, float *keys, int32_t *models, hipStream_t s) {
-  hipLaunchKernelGGL(resolve_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, s, recs, n, hmms, keys, models);
+hipError_t launch_resolve_keys(const ResolveRec *recs, int n, const DevHMM *hmms, float *keys, int32_t *models, hipStream_t s, const int32_t *rext, int64_t rext_stride) {
+  hipLaunchKernelGGL(resolve_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, s, recs, n, hmms, keys, models, rext, rext_stride);
   return hipGetLastError();
 }
 

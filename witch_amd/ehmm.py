@@ -124,6 +124,13 @@ class EHMM:
         check(lib().wh_last_score_counters(self._h, c8.ctypes.data), "wh_last_score_counters")
         return int(c8[6])
 
+    def last_long_list_pairs(self) -> int:
+        """Pairs of the last score call that had more regions than a scoring kernel's list holds (WH_MAX_ENVELOPES) and were
+        scored again by the long-list pass (include/witch_hip.h: wh_last_score_counters, out8[7])."""
+        c8 = np.zeros(8, dtype=np.int64)
+        check(lib().wh_last_score_counters(self._h, c8.ctypes.data), "wh_last_score_counters")
+        return int(c8[7])
+
     def set_path_buffer(self, paths_t):
         """Registers a CUDA uint8 tensor of nq x H bytes that later score calls fill with WH_PATH_* bits per pair
         (staged launches only; None switches it off).  The caller keeps the tensor alive (include/witch_hip.h)."""

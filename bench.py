@@ -96,6 +96,7 @@ def hot_path_step(e, res_t, off_t, maxlen, k, gather_topk=None, keep_device=Fals
     hot_path_step.aligned_cells = float((lens.double() * torch.from_numpy(e.M.astype(np.float64)).to(ph.device)[ph.long()]).sum().item())
     hot_path_step.aligned_residues = float(lens.double().sum().item())
     hot_path_step.align_paths = e.last_align_paths()
+    hot_path_step.long_list = e.last_long_list_pairs()           # pairs with more than 16 regions, scored in full by the long-list pass
     hot_path_step.spill_bytes = e.last_score_spill_bytes()      # device counter of the scoring call above (waits for the device: after the copies)
     return out, int(pq.numel()), total_cols
 
@@ -539,6 +540,7 @@ def main():
                            "model_len_mean": round(float(M.mean()), 1),
                            "k": k, "aligned_pairs_per_step": npairs, "sharding": "queries/%d" % world, "collective_backend": (dist.get_backend() if use_dist else None),
                            "pairs_reported_rank0": hot_path_step.reported, "pairs_multidomain_rank0": hot_path_step.multidomain,
+                           "pairs_long_list_rank0": getattr(hot_path_step, "long_list", None),
                            "pairs_dense_redo_rank0": hot_path_step.dense_redo,
                            "topk_crc32": crc_of(out[0].numpy(), out[1].numpy(), out[2].numpy(), out[3].numpy())},
                 "stage_ms_per_step": {"score": round((kern_ms[0] + kern_ms[4]) / args.steps, 3), "topk": round(kern_ms[1] / args.steps, 3),

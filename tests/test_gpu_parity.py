@@ -1000,12 +1000,15 @@ def test_pairs_with_more_regions_than_a_kernel_lists_are_scored_in_full(orc, tmp
         od, of, ofwd, osc = orc.score_batch(ohm, res, offs)
         assert (flags & 8).sum() == 0, ("an envelope was dropped", root_len, flags)
         nreg = np.array([d.nregions for d in det]).reshape(len(seqs), e.H)
+        nreg[[len(s_) == 0 for s_ in seqs], :] = 0                             # (an empty query has no detail record)
         assert nreg.max() > 2 * WH_MAX_ENVELOPES, nreg                         # the case this test is about
         assert n_long == int((nreg > WH_MAX_ENVELOPES).sum()) and n_long >= 3, (n_long, nreg)
         assert np.array_equal(flags & 3, of & 3), (root_len, flags, of)
         _check_decibits(deci, od, osc, (of & 1) == 1, ("long list", root_len), LONG_EPS)
         for q in range(len(seqs)):
             for h in range(e.H):
+                if len(seqs[q]) == 0:
+                    continue
                 r = ohm[h].score(seqs[q])
                 d = det[q * e.H + h]
                 assert d.nregions == r.nregions, (root_len, q, h, d.nregions, r.nregions)
@@ -1025,6 +1028,22 @@ def test_pairs_with_more_regions_than_a_kernel_lists_are_scored_in_full(orc, tmp
         d1, f1, _ = e.score(r1, o1, want_detail=True)
         assert np.array_equal(d1[0], deci[0]) and np.array_equal(f1[0], flags[0])
         e.close()
+        if root_len == 180:
+            # the same pairs found by the several-waves-per-pair kernels (their own 16-entry list; WH_FORCE_WIDE, read at load)
+            old = os.environ.get("WH_FORCE_WIDE")
+            os.environ["WH_FORCE_WIDE"] = "4"
+            try:
+                ew = EHMM(eh.paths, hmm_index=eh.index, nseq=eh.nseq)
+                dw, fw, _ = ew.score(res, offs, want_detail=True)
+                assert ew.last_long_list_pairs() == n_long
+                assert (fw & 8).sum() == 0 and np.array_equal(fw & 3, of & 3)
+                _check_decibits(dw, od, osc, (of & 1) == 1, ("long list, several waves per pair", root_len), LONG_EPS)
+                ew.close()
+            finally:
+                if old is None:
+                    os.environ.pop("WH_FORCE_WIDE", None)
+                else:
+                    os.environ["WH_FORCE_WIDE"] = old
 
 
 def test_two_queries_per_wave_kernel_equals_the_one_query_kernel(tmp_path):

@@ -6,7 +6,7 @@ set -e -o pipefail
 tag=${1:-r05_v6}
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout -k 10 900 python3 -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "more_regions or more_than_eight or score_against_oracle or beyond_3072 or resolver_on_every or resolver_queue or long_protein or end_to_end or multihit_queries_on_a_long or several_waves or level0" > gpurun_out/${tag}_tests.log 2>&1 || { tail -40 gpurun_out/${tag}_tests.log; exit 1; }
+timeout -k 10 900 python3 -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "${WH_CHECK_K:-more_regions or more_than_eight or score_against_oracle or beyond_3072 or resolver_on_every or resolver_queue or long_protein or end_to_end or multihit_queries_on_a_long or several_waves or level0}" > gpurun_out/${tag}_tests.log 2>&1 || { tail -40 gpurun_out/${tag}_tests.log; exit 1; }
 tail -3 gpurun_out/${tag}_tests.log
 tools/profile_round.sh $tag
 # stamp the traffic figures with this build (bench.py refuses a stamp of another build), keep a copy where gpurun merges it back

@@ -700,6 +700,8 @@ int wh_score_dev(wh_ehmm *e, const uint8_t *d_residues, const int64_t *d_offsets
   e->last_queue_reruns = 0;
   e->rq_floor = 0;
   e->st_off = false;
+  // (diagnostics only: a pair the kernels leave early - an empty query, one beyond the length cap - has a record of zeros)
+  if (d_detail && nq > 0) HIPCHK(hipMemsetAsync(d_detail, 0, sizeof(wh_pair_detail) * (size_t)nq * e->hmms.size(), (hipStream_t)stream));
   bool overflow = false;
   int rc = score_dev_pass(e, d_residues, d_offsets, nq, total_residues, max_len, d_decibits, d_flags, d_fwd_bits, d_detail, stream, &overflow);
   // (two independent reasons to repeat a pass: the resolver's queue, and a staged batch that ran out of envelope units)

@@ -60,6 +60,7 @@ class QueryAlignmentEngine:
         self.query_offsets = None     # int64 [nq+1]
         self.merged_minmax = None
         self.truncated_pairs = []     # (taxon, hmm label) with WH_FLAG_TRUNC
+        self.long_list_pairs = 0      # pairs with more regions than a scoring kernel lists, scored in full by the long-list pass
         self.unaligned_pairs = []     # (taxon, hmm label) the alignment stage returned unaligned
         self.query_text = None        # uint8: the local queries' characters (upper-cased on read), concatenated like query_offsets
         self.device = 0
@@ -142,6 +143,7 @@ class QueryAlignmentEngine:
             cres = res[offs[c0]:offs[c1]]
             t0 = time.time()
             deci, flags = e.score(cres, coffs)
+            self.long_list_pairs += e.last_long_list_pairs()
             if multidomain_policy == "drop":
                 drop = (flags & 2) != 0
                 flags = np.where(drop, flags & ~np.uint8(1), flags).astype(np.uint8)

@@ -17,3 +17,5 @@ run resolver_default 7 fuzz_resolver.py 500 $((n * 2))
 run resolver_split 11 fuzz_resolver.py 700 $n
 run level1_default 7 fuzz_level1.py 900 $((n / 4 + 1)) 4
 run built_default 7 fuzz_built_models.py 300 $n
+run long_list_default 7 fuzz_long_list.py 100 $n
+run long_list_hybrid 10 fuzz_long_list.py 300 $((n / 2))

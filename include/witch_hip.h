@@ -63,9 +63,9 @@ extern "C" {
  * time inside the same call by the long-list pass (float64 front end with the region list in HBM + a resolver launch of
  * its own; wh_last_score_counters out8[7] counts such pairs), every region and every envelope enters its score, and it
  * comes back WITHOUT WH_FLAG_TRUNC; its detail record lists the first WH_MAX_ENVELOPES envelopes, nregions is the full
- * count.  What can still set WH_FLAG_TRUNC: more than 16 significant clusters inside ONE multidomain region, more sampled
- * segments in one region than the resolver's segment arrays hold, more than four million overflowing pairs in one call,
- * or the development knobs WH_NO_LONG_LIST / WH_NO_RESOLVE. */
+ * count.  What can still set WH_FLAG_TRUNC: ONE multidomain region with more than 32 domains in a sampled trace or more
+ * than 64 significant clusters (tandem repeats of up to 28 copies are tested), more than four million overflowing pairs
+ * in one call, or the development knobs WH_NO_LONG_LIST / WH_NO_RESOLVE. */
 #define WH_MAX_ENVELOPES 16
 
 /* Which code path a pair took through the scoring kernels (optional per-pair byte, wh_set_path_buffer; written by

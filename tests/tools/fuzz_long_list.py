@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised check of the long-list pass on the GPU box: random DNA and protein families of
 150-1 200 nodes, queries that hold 18-45 fragments of the family with random spacers (some fragments back to back:
-multidomain candidates) - more regions than a scoring kernel's list holds.  Every (query, model) pair is scored and
+multidomain candidates) - more regions than a scoring kernel's list holds - and one tandem repeat of 8-26 fragments (one
+region of as many domains).  Every (query, model) pair is scored and
 compared with the float64 oracle (whose own list holds 256 envelopes): no pair flagged WH_FLAG_TRUNC, reported mask and
 multidomain flag, deci-bit scores under the tests' boundary rule (0.02 bit for this class), the pass's own count of
 pairs against the regions the detail records report.
@@ -43,6 +44,8 @@ def main():
                 if rng.random() > 0.15:
                     parts.append(rng.integers(0, K, size=int(rng.integers(15, 60))).astype(np.uint8))
             seqs.append(np.concatenate(parts))
+        # tandem repeats: ONE region that the resolver splits into as many envelopes (vertex stacks in HBM beyond 2 048 segments)
+        seqs.append(np.concatenate([frags[int(rng.integers(0, len(frags)))].astype(np.uint8) for _c in range(int(rng.integers(8, 27)))]))
         seqs.append(frags[0].astype(np.uint8))
         e = EHMM(eh.paths, hmm_index=eh.index, nseq=eh.nseq)
         res, offs = pack_queries(seqs)

@@ -32,7 +32,9 @@ namespace {
 
 constexpr int kSamples = 200;
 constexpr int kDomMax = 32;          // domains per sampled trace kept (more: TRUNC)
-constexpr int kSegCap = 2048;         // sampled segments per region kept (200 traces x ~1-3 domains; more: TRUNC)
+constexpr int kSegCap = 8192;         // sampled segments per region kept, in HBM (200 traces x up to kDomMax domains = 6 400: never short)
+constexpr int kSegLds = 2048;         // ... of them, the clustering keeps its two vertex stacks in LDS up to this many (beyond: in HBM)
+constexpr int kClusMax = 64;          // significant clusters of ONE region kept (more: TRUNC)
 constexpr int kHist = 64;            // decision fetches of a trace whose keys are remembered for the next trace
 constexpr int kEnvMax = 16;          // envelopes per pair kept internally (detail reports WH_MAX_ENVELOPES)
 enum { stM = 1, stD, stI, stN, stC, stJ, stE, stB, stS };
@@ -86,12 +88,12 @@ __device__ __forceinline__ bool seg_linked(int i1, int j1, int k1, int m1, int i
 // wave's HBM slab.
 __host__ __device__ inline size_t resolve_uni_ints(int Lcap) {
   const int Lp = (Lcap + 4) & ~1;
-  const size_t traces = (size_t)kDomMax * (4 + 32) + Lp / 2 + 2, clustering = kSegCap;
+  const size_t traces = (size_t)kDomMax * (4 + 32) + Lp / 2 + 2, clustering = kSegLds;
   return ((traces > clustering ? traces : clustering) + 1) & ~(size_t)1;
 }
 __host__ __device__ inline size_t resolve_lds_ints(int Lcap, int Mmax) {
   (void)Mmax;
-  return (((size_t)(Lcap + 8) / 4 + 2 + 1) & ~(size_t)1) /*seq*/ + resolve_uni_ints(Lcap) + 128 /*64 float64 bins of the E-state row pass*/ + 7 * kEnvMax + 16
+  return (((size_t)(Lcap + 8) / 4 + 2 + 1) & ~(size_t)1) /*seq*/ + resolve_uni_ints(Lcap) + 128 /*64 float64 bins of the E-state row pass*/ + 4 * kEnvMax + 3 * kClusMax + 16
          + 2 * 2 * kHist /*WH_STATS: fetch keys of the previous and the current trace*/;
 }
 // waves per SIMD the kernel is compiled for (registers per lane = 512 / WH_RES_OCC)
@@ -105,7 +107,7 @@ size_t resolve_lds_header_bytes(int Qt) { return 16 + (size_t)gNARR * Qt * 64 * 
 // per wave in HBM: the segment arrays, the end-point histogram, and the two per-residue float arrays (null2 scores of
 // the pair, accumulators of the region): in LDS they cost 8 bytes per residue of the LONGEST query of the batch and
 // halved the resident waves for 2 000-residue proteins
-size_t resolve_seg_ints(int Lcap, int Mmax) { return (size_t)6 * kSegCap + (size_t)(Lcap > Mmax ? Lcap : Mmax) + 8 + 2 * ((size_t)Lcap + 8); }
+size_t resolve_seg_ints(int Lcap, int Mmax) { return (size_t)7 * kSegCap + (size_t)(Lcap > Mmax ? Lcap : Mmax) + 8 + 2 * ((size_t)Lcap + 8); }
 int resolve_seg_cap() { return kSegCap; }
 // the walk's cache of threshold lines: 2^kDcBits lines of 64 x 16 bytes + their 8-byte tags, in doubles
 constexpr int kDcBits = 13;
@@ -150,16 +152,17 @@ __global__ __launch_bounds__(64 * kResMaxWaves) void resolve_kernel(ResolveArgs 
   short *stk = reinterpret_cast<short *>(dnull + 32 * kDomMax);  // emitting state of each residue: +k match, -k insert
   const int SEGCAP = a.seg_cap;
   unsigned short *s_a = reinterpret_cast<unsigned short *>(uni); // clustering (after the traces): Easel's vertex stacks, same block
-  unsigned short *s_b = s_a + SEGCAP;
+  unsigned short *s_b = s_a + kSegLds;
   double *bins = reinterpret_cast<double *>(uni + resolve_uni_ints(a.Lcap));   // 64 float64 bins of the E-state row pass (8-byte aligned)
-  int *misc = reinterpret_cast<int *>(bins + 64);                // 7 x kEnvMax ints: envelope and cluster lists of the pair
-  unsigned long long *hprev = reinterpret_cast<unsigned long long *>(misc + 7 * kEnvMax + 16), *hcur = hprev + kHist;
+  int *misc = reinterpret_cast<int *>(bins + 64);                // 4 x kEnvMax + 3 x kClusMax ints: envelope list of the pair (detail), cluster list of a region
+  unsigned long long *hprev = reinterpret_cast<unsigned long long *>(misc + 4 * kEnvMax + 3 * kClusMax + 16), *hcur = hprev + kHist;
   (void)Lp;
   const size_t wslot = (size_t)blockIdx.x * nwaves + wave;        // this wave's slab / segment arrays
-  int32_t *sg = a.segs + wslot * a.seg_stride;      // per wave in HBM: 6 arrays of SEGCAP ints + the histogram
+  int32_t *sg = a.segs + wslot * a.seg_stride;      // per wave in HBM: 6 arrays of SEGCAP ints, the vertex stacks of a large region, the histogram
   int32_t *s_idx = sg, *s_i = sg + SEGCAP, *s_j = sg + 2 * SEGCAP, *s_k = sg + 3 * SEGCAP, *s_m = sg + 4 * SEGCAP;
   int32_t *s_as = sg + 5 * SEGCAP;
-  int32_t *epc = sg + 6 * SEGCAP;                                // end-point histogram of one cluster
+  unsigned short *h_a = reinterpret_cast<unsigned short *>(sg + 6 * SEGCAP), *h_b = h_a + SEGCAP;   // vertex stacks of a region of more than kSegLds segments
+  int32_t *epc = sg + 7 * SEGCAP;                                // end-point histogram of one cluster
   float *n2sc = reinterpret_cast<float *>(epc + (a.Lcap > a.Mmax ? a.Lcap : a.Mmax) + 8);   // per residue, HBM (read with L1 bypass)
   float *acc = n2sc + a.Lcap + 8;
   // sum of n2sc[lo..hi] in position order (float32, as HMMER adds them): 64 values per fetch, walked with v_readlane
@@ -750,22 +753,24 @@ __global__ __launch_bounds__(64 * kResMaxWaves) void resolve_kernel(ResolveArgs 
       for (int pos = 1 + lane; pos <= Lr; pos += 64) n2sc[ireg + pos - 1] = logf(__builtin_nontemporal_load(acc + pos) / (float)kSamples);
       wave_mem_sync();
       // ---------------- single-linkage clustering in Easel's vertex order (esl_cluster_SingleLinkage)
-      int nc = 0;
-      {
+      // (the two vertex stacks: in LDS, ordered by the LDS pipeline itself - or, for a region of more than kSegLds segments,
+      // in the wave's HBM block with every hand-over between lanes ordered by hand; same code, <sync> is what differs)
+      auto single_linkage = [&](unsigned short *s_a, unsigned short *s_b, auto sync) -> int {
+        int nc = 0;
         for (int v = lane; v < nseg; v += 64) s_a[v] = (unsigned short)(nseg - v - 1);
-        __builtin_amdgcn_wave_barrier();
+        sync();
         int na = nseg;
         while (na > 0) {
           int v = s_a[na - 1];
           na--;
           int nb = 1;
-          __builtin_amdgcn_wave_barrier();
+          sync();
           if (lane == 0) s_b[0] = (unsigned short)v;
-          __builtin_amdgcn_wave_barrier();
+          sync();
           while (nb > 0) {
             v = s_b[nb - 1];
             nb--;
-            __builtin_amdgcn_wave_barrier();
+            sync();
             if (lane == 0) s_as[v] = nc;
             const int vi = __builtin_nontemporal_load(s_i + v), vj = __builtin_nontemporal_load(s_j + v), vk = __builtin_nontemporal_load(s_k + v), vm = __builtin_nontemporal_load(s_m + v);
             // scan a[na-1 .. 0]: link tests in parallel, deletions (swap with the last entry) in scan order
@@ -786,19 +791,22 @@ __global__ __launch_bounds__(64 * kResMaxWaves) void resolve_kernel(ResolveArgs 
                 hits &= hits - 1;
                 const int tp = hi - l;
                 const int wv = __shfl(w, l);
-                __builtin_amdgcn_wave_barrier();
+                sync();
                 if (lane == 0) {
                   s_a[tp] = s_a[na - 1];
                   s_b[nb] = (unsigned short)wv;
                 }
                 na--; nb++;
-                __builtin_amdgcn_wave_barrier();
+                sync();
               }
             }
           }
           nc++;
         }
-      }
+        return nc;
+      };
+      const int nc = nseg <= kSegLds ? single_linkage(s_a, s_b, []() { __builtin_amdgcn_wave_barrier(); })
+                                     : single_linkage(h_a, h_b, []() { wave_mem_sync(); });
       wave_mem_sync();
 #ifdef WH_RESOLVE_DEBUG
       if (a.dbg && lane == 0) {
@@ -809,8 +817,8 @@ __global__ __launch_bounds__(64 * kResMaxWaves) void resolve_kernel(ResolveArgs 
       RTICK(2);
       // ---------------- clusters -> envelopes (p7_spensemble_Cluster)
       int nsig = 0;
-      int *g_i = misc + 4 * kEnvMax, *g_j = misc + 5 * kEnvMax;
-      float *g_p = reinterpret_cast<float *>(misc + 6 * kEnvMax);
+      int *g_i = misc + 4 * kEnvMax, *g_j = g_i + kClusMax;
+      float *g_p = reinterpret_cast<float *>(g_j + kClusMax);
       for (int c = 0; c < nc; c++) {
         // posterior of the cluster: traces that contribute (segments are in trace order)
         int ninc = 0;
@@ -877,7 +885,7 @@ __global__ __launch_bounds__(64 * kResMaxWaves) void resolve_kernel(ResolveArgs 
         if (a.dbg && lane == 0) printf("[resolve q=%lld h=%d region %d..%d] cluster %d: ninc %d thr %d i %d..%d j %d..%d k %d..%d m %d..%d best %d %d %d %d\n", (long long)rec.q, rec.h, ireg, jreg, c, ninc, thr, imin, imax, jmin, jmax, kmin, kmax, mmin, mmax, best[0], best[2], best[1], best[3]);
 #endif
         if (best[0] > best[2] || best[1] > best[3]) continue;
-        if (nsig < kEnvMax) { g_i[nsig] = best[0]; g_j[nsig] = best[2]; g_p[nsig] = (float)ninc / (float)kSamples; nsig++; }
+        if (nsig < kClusMax) { g_i[nsig] = best[0]; g_j[nsig] = best[2]; g_p[nsig] = (float)ninc / (float)kSamples; nsig++; }
         else flags |= WH_FLAG_TRUNC;
       }
       RTICK(3);
@@ -888,13 +896,13 @@ __global__ __launch_bounds__(64 * kResMaxWaves) void resolve_kernel(ResolveArgs 
         for (; d2 >= 0 && g_i[d2] > ti; d2--) { g_i[d2 + 1] = g_i[d2]; g_j[d2 + 1] = g_j[d2]; g_p[d2 + 1] = g_p[d2]; }
         g_i[d2 + 1] = ti; g_j[d2 + 1] = tj; g_p[d2 + 1] = tp;
       }
-      unsigned dominated = 0;
+      unsigned long long dominated = 0;
       for (int d = 0; d < nsig; d++)
         for (int d2 = d + 1; d2 < nsig; d2++) {
           const int nov = min(g_j[d], g_j[d2]) - max(g_i[d], g_i[d2]) + 1;
           if (nov == 0) break;
           const int nn = min(g_j[d] - g_i[d] + 1, g_j[d2] - g_i[d2] + 1);
-          if ((float)nov / (float)nn >= 0.8f) { if (g_p[d] > g_p[d2]) dominated |= 1u << d2; else dominated |= 1u << d; }
+          if ((float)nov / (float)nn >= 0.8f) { if (g_p[d] > g_p[d2]) dominated |= 1ull << d2; else dominated |= 1ull << d; }
         }
       // ---------------- every surviving cluster is an envelope: unihit Forward score, trace-derived null2
       // HMMER sums n2sc over the whole sequence in position order; per region here (float32 either way)
@@ -904,7 +912,7 @@ __global__ __launch_bounds__(64 * kResMaxWaves) void resolve_kernel(ResolveArgs 
       if (a.dbg && lane == 0) { printf("[resolve] region n2sc sum %.6f; n2sc:", regsum); for (int pos = ireg; pos <= jreg; pos++) printf(" %.3f", __builtin_nontemporal_load(n2sc + pos)); printf("\n"); }
 #endif
       for (int d = 0; d < nsig; d++) {
-        if (dominated & (1u << d)) continue;
+        if (dominated & (1ull << d)) continue;
         const int i2 = g_i[d], j2 = g_j[d], Ld = j2 - i2 + 1;
         const double envsc = gforward_any<false>(m, seq + (i2 - 1), Ld, cu, mx, lane, use_tl ? (const ldbl *)tabL : nullptr);
         const float dc = n2sum(i2, j2);

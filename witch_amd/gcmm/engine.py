@@ -150,8 +150,8 @@ class QueryAlignmentEngine:
             trunc = np.argwhere((flags & 8) != 0)
             if len(trunc):
                 # WH_FLAG_TRUNC: a list of the pair overflowed (include/witch_hip.h: since round 5 NOT the region list - pairs
-                # with more than WH_MAX_ENVELOPES regions are scored in full by the long-list pass - but e.g. more than 16
-                # clusters inside one multidomain region); its score may differ from hmmsearch's.  Never silent.
+                # with more than WH_MAX_ENVELOPES regions are scored in full by the long-list pass - but more than 32 domains
+                # or 64 clusters inside ONE multidomain region); its score may differ from hmmsearch's.  Never silent.
                 self.truncated_pairs += [(self.taxa[int(q) + c0 + self.row_lo], int(labels[int(h)])) for q, h in trunc]
             t1 = time.time()
             idx, w, nk, nu = e.topk(deci, flags, self.num_hmms)
@@ -204,10 +204,9 @@ class QueryAlignmentEngine:
         self.qpair_off[1:] = np.cumsum(self.n_used)
         self.pair_of = None
         if self.truncated_pairs:
-            from .._lib import WH_MAX_ENVELOPES
-            warnings.warn("witch_amd: %d (query, HMM) pair(s) overflowed a list of the scoring kernels (WH_FLAG_TRUNC: e.g. more than %d "
+            warnings.warn("witch_amd: %d (query, HMM) pair(s) overflowed a list of the scoring kernels (WH_FLAG_TRUNC: more than 32 domains or 64 "
                           "clusters in one multidomain region); their scores may differ from hmmsearch's (first: %s vs A_0_%d)"
-                          % ((len(self.truncated_pairs), WH_MAX_ENVELOPES) + self.truncated_pairs[0]), RuntimeWarning)
+                          % ((len(self.truncated_pairs),) + self.truncated_pairs[0]), RuntimeWarning)
         if self.unaligned_pairs:
             warnings.warn("witch_amd: %d pair(s) on models of more than 3072 nodes could not be aligned and are left out "
                           "of the consensus (first: %s vs A_0_%d)" % ((len(self.unaligned_pairs),) + self.unaligned_pairs[0]), RuntimeWarning)

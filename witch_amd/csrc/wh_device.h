@@ -35,8 +35,12 @@ typedef float v4f_t __attribute__((ext_vector_type(4)));
 // first rows at full width - WH_SPILL_BAND=0 - runs 2.1 x slower than with piece-major rows), so this layout needs the band
 // of lane blocks (spill_band, wh_score7.hip); models of fewer than 8 cells per lane have no band and keep piece-major rows.
 // 8 192 x 200 headline pairs: 397 -> 373 ms; SURVEY's family sketch 295 -> 283 ms; protein slice 893 -> 875 ms.
-template <int Q>
-__device__ __forceinline__ constexpr int fs_piece(int lane, int q4) { return Q >= 8 ? lane * (2 * (Q / 4)) + q4 : q4 * kWave + lane; }
+// BLK = false: piece-major rows - the long-query instantiations of the scoring kernels (special states in HBM, "SG"), whose
+// first sweep keeps no mask to place a band with: their envelopes store every lane block that passes the keep rule, which on
+// block-contiguous rows cost the 24-cell class of the reference's example data (real 16S fragments of ~400 nt) 3 x its time
+// (19.5 -> 60 ms for 9 000 pairs; found at the end of round 5 by tools/bench_example.py across builds).
+template <int Q, bool BLK = true>
+__device__ __forceinline__ constexpr int fs_piece(int lane, int q4) { return (BLK && Q >= 8) ? lane * (2 * (Q / 4)) + q4 : q4 * kWave + lane; }
 __device__ __forceinline__ float4 nt_load4(const float4 *p) {
   v4f_t v = __builtin_nontemporal_load(reinterpret_cast<const v4f_t *>(p));
   return make_float4(v.x, v.y, v.z, v.w);

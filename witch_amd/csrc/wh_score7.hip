@@ -107,7 +107,7 @@ __device__ __noinline__ FwdOut sweep_forward(const WaveCtx c, lds_u8 *seq3, int 
   FwdOut o;
   constexpr bool UM = !STORE && !SG && Q >= 8;
   o.nst = 0;
-  forward_sweep<Q, false, STORE, (Q <= kMaxQP), kSlim, UM, STORE, true>(T, sc, (const float *)c.emL, (const float *)c.emG, ctxKlds(c), seq, L, cfg, SG ? (float *)c.specg : (float *)c.spec, c.SP, (float *)c.Fs, keep_scale, c.lane, o.xC, o.ef,
+  forward_sweep<Q, false, STORE, (Q <= kMaxQP), kSlim, UM, STORE, !SG>(T, sc, (const float *)c.emL, (const float *)c.emG, ctxKlds(c), seq, L, cfg, SG ? (float *)c.specg : (float *)c.spec, c.SP, (float *)c.Fs, keep_scale, c.lane, o.xC, o.ef,
                                                                   reinterpret_cast<unsigned *>((float *)c.n2tab) + kUmSlot, &o.nst, keep_lanes);
   if (SG) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // the rows were written by lane 0, every lane reads them next
   return o;
@@ -230,8 +230,8 @@ __device__ __noinline__ P4Out sweep_backward_null2(const WaveCtx c, lds_u8 *eseq
       if (have) {
 #pragma unroll
         for (int p4 = 0; p4 < Q / 4; p4++) {
-          fm4[p4] = nt_load4(row + fs_piece<Q>(src, Q / 4 - 1 - p4));
-          fi4[p4] = nt_load4(row + fs_piece<Q>(src, Q / 4 + Q / 4 - 1 - p4));
+          fm4[p4] = nt_load4(row + fs_piece<Q, !SG>(src, Q / 4 - 1 - p4));
+          fi4[p4] = nt_load4(row + fs_piece<Q, !SG>(src, Q / 4 + Q / 4 - 1 - p4));
         }
       } else {
 #pragma unroll
@@ -264,8 +264,8 @@ __device__ __noinline__ P4Out sweep_backward_null2(const WaveCtx c, lds_u8 *eseq
 #pragma unroll
         for (int p4 = 0; p4 < Q / 4; p4++) {
           // reversed order: component 3-j of the forward-ordered vector is position 4*p4+j
-          const float4 fm = nt_load4(row + fs_piece<Q>(src, Q / 4 - 1 - p4));
-          const float4 fi = nt_load4(row + fs_piece<Q>(src, Q / 4 + Q / 4 - 1 - p4));
+          const float4 fm = nt_load4(row + fs_piece<Q, !SG>(src, Q / 4 - 1 - p4));
+          const float4 fi = nt_load4(row + fs_piece<Q, !SG>(src, Q / 4 + Q / 4 - 1 - p4));
           fM[4 * p4 + 0] = fmaf(fm.w * Mb[4 * p4 + 0], s_i, fM[4 * p4 + 0]);
           fM[4 * p4 + 1] = fmaf(fm.z * Mb[4 * p4 + 1], s_i, fM[4 * p4 + 1]);
           fM[4 * p4 + 2] = fmaf(fm.y * Mb[4 * p4 + 2], s_i, fM[4 * p4 + 2]);
@@ -371,7 +371,7 @@ __device__ __noinline__ P4Out sweep_backward_null2_win(const WaveCtx c, lds_u8 *
       const int rev = (m4 % Q4) * kWave + m4 / Q4;
       const int jf = 16 * Q - 1 - m4;
       fwd[p4] = (jf % Q4) * kWave + jf / Q4;
-      frow[p4] = fs_piece<Q>(jf / Q4, jf % Q4);
+      frow[p4] = fs_piece<Q, !SG>(jf / Q4, jf % Q4);
 #pragma unroll
       for (int a = 0; a < BW_NARR; a++) T.v[a][p4] = bw4[a * Q4 * kWave + rev];
     }
@@ -402,7 +402,7 @@ __device__ __noinline__ P4Out sweep_backward_null2_win(const WaveCtx c, lds_u8 *
     if (have_n) {
       const float4 *row = reinterpret_cast<const float4 *>((const float *)c.Fs) + (size_t)r * (2 * Q4 * kWave);
 #pragma unroll
-      for (int p4 = 0; p4 < B4; p4++) { fm_n[p4] = nt_load4(row + frow[p4]); fi_n[p4] = nt_load4(row + Q4 + frow[p4]); }
+      for (int p4 = 0; p4 < B4; p4++) { fm_n[p4] = nt_load4(row + frow[p4]); fi_n[p4] = nt_load4(row + (SG ? Q4 * kWave : Q4) + frow[p4]); }
     }
   };
   request_row(Ld, true);

@@ -309,18 +309,30 @@ def score_roofline(M, lens_local, class_ms, kern_ms0, kern_n0, steps, H, stamp, 
     return r
 
 
-def also_block(name, steps, warmup, device, nq=None, note=None):
+def also_block(name, steps, warmup, device, nq=None, note=None, golden=None):
     """Another workload measured in the same run, reported beside <value> (never part of it): one-GPU hot-path rate,
     stage split and the VALU roofline of its dominant launch class.  Used for SURVEY.md 8(d)'s own sketch of config 3
     (dna_100k_x200_m1000: root 1000 nt, 0.2 % indels per branch; models of 996-2996 nodes in five size classes) at full
     size, and for a slice of BASELINE config 5 (aa_50k_x500: ALL 500 protein HMMs x the first <nq> of its 50 000
-    mixed-length queries - a quarter of those pairs go through the multidomain resolver, reported as an entry of its own)."""
+    mixed-length queries - a quarter of those pairs go through the multidomain resolver, reported as an entry of its own).
+    <golden> = (case, rep): instead of a synthetic workload, the model files and query texts of tests/golden/<case> (data the
+    reference's own example run produced; no oracle involved), the queries replicated <rep> times - the reference's example data
+    is the one real-fragment shape in the line (16S fragments of ~400 nt on models of 1 278-2 574 nodes: long-query
+    instantiations of the 20 / 24-cell classes, 28 % multidomain pairs), and the synthetic workloads did not show the round-5
+    regression that this one did."""
     import torch
     from witch_amd.ehmm import EHMM, pack_queries
     wd = tempfile.mkdtemp(prefix="witch_bench_also_")
     try:
-        fam, se, names, seqs, k = make_workload(name, wd, nq)
-        e = EHMM(se.paths, hmm_index=se.index, nseq=se.nseq, device=device)
+        if golden:
+            from tests.conftest import load_case
+            case = load_case(golden[0])
+            k = int(case.k)
+            e = EHMM(case.hmm_paths, hmm_index=case.hmm_index, nseq=case.nseq, device=device)
+            seqs = [e.digitize(t) for t in case.qseqs] * int(golden[1])
+        else:
+            fam, se, names, seqs, k = make_workload(name, wd, nq)
+            e = EHMM(se.paths, hmm_index=se.index, nseq=se.nseq, device=device)
         res, offs = pack_queries([s_.astype(np.uint8) for s_ in seqs])
         maxlen = int(np.max(np.diff(offs)))
         res_t, off_t = torch.from_numpy(res).cuda(), torch.from_numpy(offs).cuda()
@@ -353,8 +365,9 @@ def also_block(name, steps, warmup, device, nq=None, note=None):
                "roofline": score_roofline(M, lens, class_ms, kern_ms[0], kern_n[0], steps, e.H, None, "not profiled"),
                "pairs_multidomain": hot_path_step.multidomain,
                "note": note or "SURVEY.md 8(d) config 3 as sketched there (root 1000 nt, 0.2 % indels per branch), same timed region as <value>, one GPU"}
-        if nq:
+        if nq and not golden:
             out["n_queries_of_config"] = WORKLOADS[name][7]
+        if nq or golden:
             out["query_len_min_max"] = [int(lens.min()), int(lens.max())]
         if kern_ms[4] > 0 and hot_path_step.multidomain:
             # the resolver is a latency machine: one wavefront per queued pair, 200 stochastic traces whose
@@ -384,7 +397,7 @@ def main():
     ap.add_argument("--nh", type=int, default=0, help="override the HMM count (development only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-level1", action="store_true", help="skip the level-1 end-to-end stage (reported beside the hot-path value)")
-    ap.add_argument("--no-also", action="store_true", help="skip the two workloads reported beside the headline (dna_100k_x200_m1000 in full, a 3 000-query slice of aa_50k_x500)")
+    ap.add_argument("--no-also", action="store_true", help="skip the workloads reported beside the headline (dna_100k_x200_m1000 in full, a 3 000-query slice of aa_50k_x500, the reference's example data x 4)")
     args = ap.parse_args()
     if os.environ.get("WITCH_BENCH_WATCHDOG"):      # tests: a run that stops says where (every thread's stack on stderr), then goes on
         import faulthandler
@@ -563,11 +576,15 @@ def main():
                     line["level1_e2e"] = {"failed": "%s: %s" % (type(ex).__name__, ex)}
             if not args.no_also and world == 1 and args.workload == "dna_100k_x200" and not args.nq and not args.nh:
                 line["also"] = []
-                for wl_, steps_, nq_, note_ in (("dna_100k_x200_m1000", 2, None, None),
-                                                ("aa_50k_x500", 1, 3000, "BASELINE.json configs[4] (SURVEY.md 8(d) config 5) as a SLICE: all 500 protein HMMs x its first 3 000 "
-                                                                         "mixed-length queries (50-2 000 aa), one warm-up + one step, same timed region as <value>, one GPU")):
+                for wl_, steps_, nq_, note_, golden_ in (
+                        ("dna_100k_x200_m1000", 2, None, None, None),
+                        ("aa_50k_x500", 1, 3000, "BASELINE.json configs[4] (SURVEY.md 8(d) config 5) as a SLICE: all 500 protein HMMs x its first 3 000 "
+                                                 "mixed-length queries (50-2 000 aa), one warm-up + one step, same timed region as <value>, one GPU", None),
+                        ("example_e2e_x4", 3, None, "the reference's own example data (tests/golden/example_e2e: 500 16S fragments x 15 HMMs of 1 278-2 574 nodes) "
+                                                    "replicated 4 x, one warm-up + three steps, same timed region as <value>, one GPU; a launch-latency-sized batch: "
+                                                    "read stage_ms_per_step, not <value>", ("example_e2e", 4))):
                     try:
-                        line["also"].append(also_block(wl_, steps_, 1, local_rank, nq_, note_))
+                        line["also"].append(also_block(wl_, steps_, 1, local_rank, nq_, note_, golden_))
                     except Exception as ex:       # an extra workload must never take the bench line down
                         line["also"].append({"workload": wl_, "failed": "%s: %s" % (type(ex).__name__, ex)})
             if not args.no_cpu_baseline:
